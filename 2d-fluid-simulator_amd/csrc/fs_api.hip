@@ -1,0 +1,911 @@
+// fs_api.hip - C-ABI entry points (include/fs_hip.h): contexts, fields, scene upload, kernel launches.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <unordered_map>
+
+#include "fs_host.h"
+
+namespace fs {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_err = buf;
+    return FS_ERR_HIP;
+}
+
+// ---- launch helper: optional HIP-event pair around every launch (fs_prof_*) --------------------
+static hipEvent_t prof_event(fs_ctx *c)
+{
+    hipEvent_t e;
+    if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); return e; }
+    hipEventCreate(&e);
+    return e;
+}
+
+template <typename F>
+static int launch(fs_ctx *c, const char *name, F &&f)
+{
+    const bool prof = c->prof_on && !c->capturing;
+    ProfRec rec{};
+    if (prof) {
+        auto it = c->prof_ids.find(name);
+        if (it == c->prof_ids.end()) {
+            it = c->prof_ids.emplace(name, (int)c->prof_names.size()).first;
+            c->prof_names.push_back(name);
+            c->prof_launches.push_back(0);
+            c->prof_ms.push_back(0.0);
+        }
+        rec.name_id = it->second;
+        rec.start = prof_event(c);
+        rec.stop = prof_event(c);
+        (void)hipEventRecord(rec.start, c->stream);
+    }
+    f();
+    if (prof) {
+        (void)hipEventRecord(rec.stop, c->stream);
+        c->prof_recs.push_back(rec);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, name, __FILE__, __LINE__);
+    return FS_OK;
+}
+
+static int prof_drain(fs_ctx *c)
+{
+    if (c->prof_recs.empty()) return FS_OK;
+    FS_HIP(hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof_recs) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.start, r.stop);
+        c->prof_launches[r.name_id] += 1;
+        c->prof_ms[r.name_id] += ms;
+        c->prof_pool.push_back(r.start);
+        c->prof_pool.push_back(r.stop);
+    }
+    c->prof_recs.clear();
+    return FS_OK;
+}
+
+static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
+
+static int check_rows(const fs_ctx *c, int jb, int je)
+{
+    if (!(0 <= jb && jb <= je && je <= c->rows)) {
+        set_error("row range outside the local slab");
+        return FS_ERR_ARG;
+    }
+    return FS_OK;
+}
+
+static int check_field(const fs_ctx *c, const fs_field *f, int C, const char *what)
+{
+    if (!f || f->ctx != c || f->C != C) {
+        set_error(std::string("field argument '") + what + "' is null, from another context, or has the wrong channel count");
+        return FS_ERR_ARG;
+    }
+    return FS_OK;
+}
+
+#define FS_FIELD(f, C)                                             \
+    do {                                                           \
+        int rc__ = fs::check_field(ctx, f, C, #f);                 \
+        if (rc__) return rc__;                                     \
+    } while (0)
+#define FS_ROWS()                                                  \
+    do {                                                           \
+        int rc__ = fs::check_rows(ctx, row_begin, row_end);        \
+        if (rc__) return rc__;                                     \
+        if (!ctx->mask_set) { fs::set_error("mask not uploaded"); return FS_ERR_STATE; } \
+        if (row_begin == row_end) return FS_OK;                    \
+    } while (0)
+
+// dispatch on ctx dtype: BODY sees `T`
+#define FS_DISPATCH(ctx, ...)                                      \
+    if ((ctx)->dtype == 0) { using T = float; __VA_ARGS__ }        \
+    else { using T = double; __VA_ARGS__ }
+
+static int ensure_stage(fs_ctx *c, size_t bytes)
+{
+    if (c->stage_bytes >= bytes) return FS_OK;
+    if (c->d_stage) { FS_HIP(hipStreamSynchronize(c->stream)); FS_HIP(hipFree(c->d_stage)); c->d_stage = nullptr; c->stage_bytes = 0; }
+    FS_HIP(hipMalloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return FS_OK;
+}
+
+// ---- boundary-condition op lists (host analysis of the global mask) ----------------------------
+struct HostOp { int kind; long long t, s1, s2; };  // cells as global (i*Y + j) ids
+
+struct DSU {
+    std::vector<int> p;
+    explicit DSU(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0); }
+    int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+    void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[std::max(a, b)] = std::min(a, b); }
+};
+
+static void free_ops(BcOpsDev &o)
+{
+    int **ptrs[] = {&o.comp_begin, &o.comp_rlo, &o.comp_rhi, &o.kind, &o.tgt, &o.s1, &o.s2};
+    for (auto pp : ptrs) { if (*pp) hipFree(*pp); *pp = nullptr; }
+    o.ncomp = o.nops = 0;
+}
+
+// Group the serial-order op list into hazard components and upload it in local cell offsets.
+static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, int &reach)
+{
+    free_ops(out);
+    const int n = (int)ops.size();
+    const int Y = c->Y;
+    DSU dsu(n);
+    {
+        std::unordered_map<long long, int> last_writer;
+        std::unordered_map<long long, std::vector<int>> readers;
+        last_writer.reserve(n * 2);
+        readers.reserve(n * 2);
+        for (int o = 0; o < n; ++o) {
+            const long long srcs[2] = {ops[o].s1, ops[o].s2};
+            for (long long s : srcs) {
+                if (s < 0) continue;
+                auto w = last_writer.find(s);
+                if (w != last_writer.end()) dsu.unite(o, w->second);   // read after write
+                readers[s].push_back(o);
+            }
+            const long long t = ops[o].t;
+            auto w = last_writer.find(t);
+            if (w != last_writer.end()) dsu.unite(o, w->second);       // write after write
+            auto r = readers.find(t);
+            if (r != readers.end())
+                for (int q : r->second) if (q != o) dsu.unite(o, q);  // write after read
+            last_writer[t] = o;
+        }
+    }
+    // components in order of their first op; ops inside a component keep serial order
+    std::vector<int> root(n), order(n);
+    for (int o = 0; o < n; ++o) root[o] = dsu.find(o);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return root[a] < root[b]; });
+
+    auto local_row = [&](long long cell) { return (int)(cell % Y) - c->y0 + c->halo; };
+    auto local_off = [&](long long cell) { return local_row(cell) * c->P + (int)(cell / Y); };
+
+    std::vector<int> h_begin, h_rlo, h_rhi, h_kind, h_tgt, h_s1, h_s2;
+    int pos = 0;
+    while (pos < n) {
+        int end = pos;
+        while (end < n && root[order[end]] == root[order[pos]]) ++end;
+        int tlo = INT32_MAX, thi = INT32_MIN, clo = INT32_MAX, chi = INT32_MIN;
+        for (int q = pos; q < end; ++q) {
+            const HostOp &op = ops[order[q]];
+            int tr = local_row(op.t);
+            tlo = std::min(tlo, tr); thi = std::max(thi, tr);
+            clo = std::min(clo, tr); chi = std::max(chi, tr);
+            const long long srcs[2] = {op.s1, op.s2};
+            for (long long s : srcs) if (s >= 0) { int sr = local_row(s); clo = std::min(clo, sr); chi = std::max(chi, sr); }
+        }
+        if (end - pos > 1) reach = std::max(reach, chi - clo);
+        const bool inside = clo >= 0 && chi < c->rows;
+        if (inside) {
+            h_begin.push_back((int)h_kind.size());
+            h_rlo.push_back(tlo);
+            h_rhi.push_back(thi);
+            for (int q = pos; q < end; ++q) {
+                const HostOp &op = ops[order[q]];
+                h_kind.push_back(op.kind);
+                h_tgt.push_back(local_off(op.t));
+                h_s1.push_back(op.s1 >= 0 ? local_off(op.s1) : -1);
+                h_s2.push_back(op.s2 >= 0 ? local_off(op.s2) : -1);
+            }
+        } else if (thi >= c->halo && tlo < c->halo + c->nyl) {
+            c->bc_incomplete = true;  // a hazard chain reaches past this slab's ghost rows
+        }
+        pos = end;
+    }
+    h_begin.push_back((int)h_kind.size());
+    out.ncomp = (int)h_rlo.size();
+    out.nops = (int)h_kind.size();
+    auto up = [&](int *&d, const std::vector<int> &h) -> int {
+        FS_HIP(hipMalloc(&d, std::max<size_t>(h.size(), 1) * sizeof(int)));
+        if (!h.empty()) FS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+        return FS_OK;
+    };
+    int rc;
+    if ((rc = up(out.comp_begin, h_begin))) return rc;
+    if ((rc = up(out.comp_rlo, h_rlo))) return rc;
+    if ((rc = up(out.comp_rhi, h_rhi))) return rc;
+    if ((rc = up(out.kind, h_kind))) return rc;
+    if ((rc = up(out.tgt, h_tgt))) return rc;
+    if ((rc = up(out.s1, h_s1))) return rc;
+    if ((rc = up(out.s2, h_s2))) return rc;
+    return FS_OK;
+}
+
+// Enumerate the assignments of the three BC kernels in the reference's serial (i-major, j-minor) order.
+// Only cells whose row lies within `margin` rows of this slab are examined.
+static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
+{
+    const int X = c->X, Y = c->Y;
+    auto M = [&](int i, int j) -> int { return mask[(size_t)i * Y + j]; };
+    auto MO = [&](int i, int j) -> int { return (i < 0 || i >= X || j < 0 || j >= Y) ? 1 : mask[(size_t)i * Y + j]; };  // H3: outside = wall
+    auto id = [&](int i, int j) -> long long { return (long long)i * Y + j; };
+    auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const int margin = c->halo + 4;
+    const int jlo = std::max(0, c->y0 - margin), jhi = std::min(Y, c->y0 + c->nyl + margin);
+
+    std::vector<HostOp> vel, prs, dye;
+    for (int i = 0; i < X; ++i)
+        for (int j = jlo; j < jhi; ++j) {
+            const int m = M(i, j);
+            if (m == 0) continue;
+            if (m == 1) {
+                // fs/boundary_condition.py:20-33 (velocity mirror, interior wall cells only)
+                if (1 <= i && i < X - 1 && 1 <= j && j < Y - 1) {
+                    if (M(i - 1, j) == 0 && M(i, j - 1) == 1 && M(i, j + 1) == 1) vel.push_back({0, id(i + 1, j), id(i - 1, j), -1});
+                    else if (M(i + 1, j) == 0 && M(i, j - 1) == 1 && M(i, j + 1) == 1) vel.push_back({0, id(i - 1, j), id(i + 1, j), -1});
+                    else if (M(i, j - 1) == 0 && M(i - 1, j) == 1 && M(i + 1, j) == 1) vel.push_back({0, id(i, j + 1), id(i, j - 1), -1});
+                    else if (M(i, j + 1) == 0 && M(i - 1, j) == 1 && M(i + 1, j) == 1) vel.push_back({0, id(i, j - 1), id(i, j + 1), -1});
+                }
+                // fs/boundary_condition.py:45-61 (pressure: 4 face cases then 4 corner cases); sample() clamps
+                const int iw = cl(i - 1, 0, X - 1), ie = cl(i + 1, 0, X - 1), js = cl(j - 1, 0, Y - 1), jn = cl(j + 1, 0, Y - 1);
+                if (MO(i - 1, j) == 0 && MO(i, j - 1) == 1 && MO(i, j + 1) == 1) prs.push_back({0, id(i, j), id(iw, j), -1});
+                else if (MO(i + 1, j) == 0 && MO(i, j - 1) == 1 && MO(i, j + 1) == 1) prs.push_back({0, id(i, j), id(ie, j), -1});
+                else if (MO(i, j - 1) == 0 && MO(i - 1, j) == 1 && MO(i + 1, j) == 1) prs.push_back({0, id(i, j), id(i, js), -1});
+                else if (MO(i, j + 1) == 0 && MO(i - 1, j) == 1 && MO(i + 1, j) == 1) prs.push_back({0, id(i, j), id(i, jn), -1});
+                else if (MO(i - 1, j) == 0 && MO(i, j + 1) == 0) prs.push_back({1, id(i, j), id(iw, j), id(i, jn)});
+                else if (MO(i + 1, j) == 0 && MO(i, j + 1) == 0) prs.push_back({1, id(i, j), id(ie, j), id(i, jn)});
+                else if (MO(i - 1, j) == 0 && MO(i, j - 1) == 0) prs.push_back({1, id(i, j), id(iw, j), id(i, js)});
+                else if (MO(i + 1, j) == 0 && MO(i, j - 1) == 0) prs.push_back({1, id(i, j), id(ie, j), id(i, js)});
+            } else if (m == 2) {
+                vel.push_back({1, id(i, j), -1, -1});                              // :34-35  v = bc_const
+                prs.push_back({0, id(i, j), id(cl(i + 1, 0, X - 1), j), -1});      // :62-63  p = p[i+1, j]
+                dye.push_back({0, id(i, j), -1, -1});                              // :97-99  dye = bc_dye
+            } else if (m == 3) {
+                vel.push_back({2, id(i, j), id(cl(i - 1, 0, X - 1), j), -1});      // :36-39  v.x = max(v[i-1].x, 0.05)
+                prs.push_back({2, id(i, j), -1, -1});                              // :64-65  p = 0
+            }
+        }
+    c->bc_incomplete = false;
+    c->bc_reach = 0;
+    int rc;
+    if ((rc = upload_ops(c, vel, c->ops_vel, c->bc_reach))) return rc;
+    if ((rc = upload_ops(c, prs, c->ops_prs, c->bc_reach))) return rc;
+    if ((rc = upload_ops(c, dye, c->ops_dye, c->bc_reach))) return rc;
+    return FS_OK;
+}
+
+}  // namespace fs
+
+using namespace fs;
+
+extern "C" {
+
+int fs_abi_version(void) { return FS_ABI_VERSION; }
+const char *fs_last_error(void) { return g_err.c_str(); }
+
+int fs_device_count(int *count)
+{
+    FS_REQUIRE(count, "count is null");
+    FS_HIP(hipGetDeviceCount(count));
+    return FS_OK;
+}
+
+int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int ny_local, int halo)
+{
+    FS_REQUIRE(out, "out is null");
+    FS_REQUIRE(nx >= 4 && ny >= 4, "grid must be at least 4x4");
+    FS_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (f32) or 1 (f64)");
+    FS_REQUIRE(halo >= 0 && ny_local >= 1 && y0 >= 0 && y0 + ny_local <= ny, "bad slab (y0, ny_local, halo)");
+    FS_REQUIRE((long long)(ny_local + 2 * halo) * (((long long)nx + 63) / 64 * 64) < (1LL << 31), "slab too large for 32-bit cell offsets");
+    FS_HIP(hipSetDevice(device));
+    fs_ctx *c = new fs_ctx();
+    c->device = device; c->X = nx; c->Y = ny; c->dtype = dtype; c->y0 = y0; c->nyl = ny_local; c->halo = halo;
+    c->rows = ny_local + 2 * halo;
+    c->P = (nx + 63) / 64 * 64;
+    c->Pm = (nx + 63) / 64 * 64;
+    c->esize = dtype == 0 ? 4 : 8;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    e = hipMalloc(&c->d_mask, (size_t)c->rows * c->Pm);
+    if (e == hipSuccess) e = hipMemset(c->d_mask, 1, (size_t)c->rows * c->Pm);
+    if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
+    if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
+    *out = c;
+    return FS_OK;
+}
+
+int fs_destroy(fs_ctx *ctx)
+{
+    if (!ctx) return FS_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    fs_comm_destroy(ctx);
+    for (auto g : ctx->graphs) if (g) hipGraphExecDestroy(g);
+    for (auto &r : ctx->prof_recs) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
+    for (auto e : ctx->prof_pool) hipEventDestroy(e);
+    free_ops(ctx->ops_vel); free_ops(ctx->ops_prs); free_ops(ctx->ops_dye);
+    for (fs_field *f : ctx->fields) { if (f->d) hipFree(f->d); delete f; }
+    ctx->fields.clear();
+    if (ctx->d_mask) hipFree(ctx->d_mask);
+    if (ctx->d_bc_const) hipFree(ctx->d_bc_const);
+    if (ctx->d_bc_dye) hipFree(ctx->d_bc_dye);
+    if (ctx->d_stage) hipFree(ctx->d_stage);
+    if (ctx->d_acc) hipFree(ctx->d_acc);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FS_OK;
+}
+
+int fs_sync(fs_ctx *ctx)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+int fs_ctx_info(const fs_ctx *ctx, int *nx, int *ny, int *dtype, int *y0, int *ny_local, int *halo, int *pitch)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    if (nx) *nx = ctx->X;
+    if (ny) *ny = ctx->Y;
+    if (dtype) *dtype = ctx->dtype;
+    if (y0) *y0 = ctx->y0;
+    if (ny_local) *ny_local = ctx->nyl;
+    if (halo) *halo = ctx->halo;
+    if (pitch) *pitch = ctx->P;
+    return FS_OK;
+}
+
+// ---- window upload / download -------------------------------------------------------------------
+// rows [row_begin, row_begin + nrows) that fall outside the global domain are skipped on upload.
+static int upload_window(fs_ctx *ctx, void *dev, int C, size_t esize, const void *host, int row_begin, int nrows, int pitch)
+{
+    FS_REQUIRE(host, "host pointer is null");
+    FS_REQUIRE(row_begin >= 0 && nrows >= 0 && row_begin + nrows <= ctx->rows, "row window outside the slab");
+    if (nrows == 0) return FS_OK;
+    FS_REQUIRE(!ctx->capturing, "upload during graph capture");
+    const size_t bytes = (size_t)ctx->X * nrows * C * esize;
+    int rc = ensure_stage(ctx, bytes);
+    if (rc) return rc;
+    FS_HIP(hipMemcpyAsync(ctx->d_stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const int Q = nrows * C;
+    dim3 grid((ctx->X + 63) / 64, (Q + 63) / 64);
+    if (esize == 1) hipLaunchKernelGGL(k_to_device<uint8_t>, grid, dim3(256), 0, ctx->stream, (const uint8_t *)ctx->d_stage, (uint8_t *)dev, ctx->X, Q, pitch, row_begin * C);
+    else if (esize == 4) hipLaunchKernelGGL(k_to_device<float>, grid, dim3(256), 0, ctx->stream, (const float *)ctx->d_stage, (float *)dev, ctx->X, Q, pitch, row_begin * C);
+    else hipLaunchKernelGGL(k_to_device<double>, grid, dim3(256), 0, ctx->stream, (const double *)ctx->d_stage, (double *)dev, ctx->X, Q, pitch, row_begin * C);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+// Slice rows [g0, g0 + n) of a GLOBAL (X, Y, C) host array into a contiguous (X, n, C) buffer.
+static std::vector<uint8_t> slice_rows(const void *src, int X, int Y, int C, size_t esize, int g0, int n)
+{
+    std::vector<uint8_t> out((size_t)X * n * C * esize);
+    const uint8_t *s = (const uint8_t *)src;
+    const size_t rowb = (size_t)C * esize;
+    for (int i = 0; i < X; ++i)
+        memcpy(out.data() + (size_t)i * n * rowb, s + ((size_t)i * Y + g0) * rowb, (size_t)n * rowb);
+    return out;
+}
+
+static int upload_global(fs_ctx *ctx, void *dev, int C, size_t esize, const void *host_global, int pitch)
+{
+    // local rows that map inside the global domain
+    const int g_lo = std::max(0, ctx->y0 - ctx->halo), g_hi = std::min(ctx->Y, ctx->y0 + ctx->nyl + ctx->halo);
+    const int r0 = g_lo - (ctx->y0 - ctx->halo), n = g_hi - g_lo;
+    if (g_lo == 0 && n == ctx->Y) return upload_window(ctx, dev, C, esize, host_global, r0, n, pitch);
+    std::vector<uint8_t> tmp = slice_rows(host_global, ctx->X, ctx->Y, C, esize, g_lo, n);
+    return upload_window(ctx, dev, C, esize, tmp.data(), r0, n, pitch);
+}
+
+int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
+{
+    FS_REQUIRE(ctx && mask_xy, "null argument");
+    FS_HIP(hipSetDevice(ctx->device));
+    FS_HIP(hipMemsetAsync(ctx->d_mask, 1, (size_t)ctx->rows * ctx->Pm, ctx->stream));
+    int rc = upload_global(ctx, ctx->d_mask, 1, 1, mask_xy, ctx->Pm);
+    if (rc) return rc;
+    rc = build_bc_ops(ctx, mask_xy);
+    if (rc) return rc;
+    ctx->mask_set = true;
+    return FS_OK;
+}
+
+static int upload_const(fs_ctx *ctx, void **slot, int C, const void *host)
+{
+    FS_REQUIRE(ctx && host, "null argument");
+    FS_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->rows * C * ctx->P * ctx->esize;
+    if (!*slot) FS_HIP(hipMalloc(slot, bytes));
+    FS_HIP(hipMemsetAsync(*slot, 0, bytes, ctx->stream));
+    return upload_global(ctx, *slot, C, ctx->esize, host, ctx->P);
+}
+
+int fs_upload_bc_const(fs_ctx *ctx, const void *bc_xy2) { return upload_const(ctx, ctx ? &ctx->d_bc_const : nullptr, 2, bc_xy2); }
+int fs_upload_bc_dye(fs_ctx *ctx, const void *bc_xy3) { return upload_const(ctx, ctx ? &ctx->d_bc_dye : nullptr, 3, bc_xy3); }
+
+int fs_bc_reach(const fs_ctx *ctx, int *rows)
+{
+    FS_REQUIRE(ctx && rows, "null argument");
+    *rows = ctx->bc_reach;
+    return FS_OK;
+}
+
+// ---- fields ---------------------------------------------------------------------------------------
+int fs_field_alloc(fs_ctx *ctx, int nchan, fs_field **out)
+{
+    FS_REQUIRE(ctx && out, "null argument");
+    FS_REQUIRE(nchan >= 1 && nchan <= 3, "nchan must be 1, 2 or 3");
+    FS_HIP(hipSetDevice(ctx->device));
+    fs_field *f = new fs_field();
+    f->ctx = ctx; f->C = nchan;
+    f->bytes = (size_t)ctx->rows * nchan * ctx->P * ctx->esize;
+    hipError_t e = hipMalloc(&f->d, f->bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(f->d, 0, f->bytes, ctx->stream);
+    if (e != hipSuccess) { delete f; return hip_fail(e, "hipMalloc(field)", __FILE__, __LINE__); }
+    ctx->fields.insert(f);
+    *out = f;
+    return FS_OK;
+}
+
+int fs_field_free(fs_field *f)
+{
+    if (!f) return FS_OK;
+    hipSetDevice(f->ctx->device);
+    hipStreamSynchronize(f->ctx->stream);
+    f->ctx->fields.erase(f);
+    if (f->d) hipFree(f->d);
+    delete f;
+    return FS_OK;
+}
+
+int fs_field_nchan(const fs_field *f) { return f ? f->C : FS_ERR_ARG; }
+
+int fs_field_fill(fs_field *f, double value)
+{
+    FS_REQUIRE(f, "field is null");
+    fs_ctx *ctx = f->ctx;
+    const size_t n = f->bytes / ctx->esize;
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "fill", [&] { hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value); });
+    })
+}
+
+int fs_field_upload(fs_field *f, const void *host_xrc, int row_begin, int nrows)
+{
+    FS_REQUIRE(f, "field is null");
+    FS_HIP(hipSetDevice(f->ctx->device));
+    return upload_window(f->ctx, f->d, f->C, f->ctx->esize, host_xrc, row_begin, nrows, f->ctx->P);
+}
+
+int fs_field_download(const fs_field *f, void *host_xrc, int row_begin, int nrows)
+{
+    FS_REQUIRE(f && host_xrc, "null argument");
+    fs_ctx *ctx = f->ctx;
+    FS_REQUIRE(row_begin >= 0 && nrows >= 0 && row_begin + nrows <= ctx->rows, "row window outside the slab");
+    FS_REQUIRE(!ctx->capturing, "download during graph capture");
+    if (nrows == 0) return FS_OK;
+    FS_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->X * nrows * f->C * ctx->esize;
+    int rc = ensure_stage(ctx, bytes);
+    if (rc) return rc;
+    const int Q = nrows * f->C;
+    dim3 grid((ctx->X + 63) / 64, (Q + 63) / 64);
+    FS_DISPATCH(ctx, {
+        hipLaunchKernelGGL(k_to_host<T>, grid, dim3(256), 0, ctx->stream, (T *)ctx->d_stage, (const T *)f->d, ctx->X, Q, ctx->P, row_begin * f->C);
+    })
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipMemcpyAsync(host_xrc, ctx->d_stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+int fs_field_copy(fs_field *dst, const fs_field *src)
+{
+    FS_REQUIRE(dst && src && dst->ctx == src->ctx && dst->C == src->C, "copy needs two fields of one context and shape");
+    FS_HIP(hipMemcpyAsync(dst->d, src->d, src->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
+    return FS_OK;
+}
+
+int fs_field_devptr(const fs_field *f, void **ptr, size_t *bytes)
+{
+    FS_REQUIRE(f, "field is null");
+    if (ptr) *ptr = f->d;
+    if (bytes) *bytes = f->bytes;
+    return FS_OK;
+}
+
+// ---- boundary-condition kernels ----------------------------------------------------------------------
+static int bc_guard(fs_ctx *ctx)
+{
+    if (ctx->bc_incomplete) {
+        set_error("boundary-condition hazard chain extends beyond this slab's ghost rows (thin walls at a slab cut); increase halo");
+        return FS_ERR_UNSUPPORTED;
+    }
+    return FS_OK;
+}
+
+int fs_velocity_bc(fs_ctx *ctx, fs_field *v, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(v, 2);
+    FS_ROWS();
+    if (!ctx->d_bc_const) { set_error("bc_const not uploaded"); return FS_ERR_STATE; }
+    int rc = bc_guard(ctx); if (rc) return rc;
+    if (ctx->ops_vel.ncomp == 0) return FS_OK;
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "velocity_bc", [&] {
+            hipLaunchKernelGGL(k_velocity_bc<T>, dim3((ctx->ops_vel.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, (T *)v->d, (const T *)ctx->d_bc_const);
+        });
+    })
+}
+
+int fs_pressure_bc(fs_ctx *ctx, fs_field *p, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(p, 1);
+    FS_ROWS();
+    int rc = bc_guard(ctx); if (rc) return rc;
+    if (ctx->ops_prs.ncomp == 0) return FS_OK;
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "pressure_bc", [&] {
+            hipLaunchKernelGGL(k_pressure_bc<T>, dim3((ctx->ops_prs.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->grid(), ctx->ops_prs.view(), row_begin, row_end, (T *)p->d);
+        });
+    })
+}
+
+int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(dye, 3);
+    FS_ROWS();
+    if (!ctx->d_bc_dye) { set_error("bc_dye not uploaded"); return FS_ERR_STATE; }
+    if (ctx->ops_dye.ncomp == 0) return FS_OK;
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "dye_bc", [&] {
+            hipLaunchKernelGGL(k_dye_bc<T>, dim3((ctx->ops_dye.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T *)dye->d, (const T *)ctx->d_bc_dye);
+        });
+    })
+}
+
+// ---- transport -----------------------------------------------------------------------------------------
+#define FS_LAUNCH_CELLS(name, kern, ...)                                                                   \
+    return launch(ctx, name, [&] {                                                                         \
+        hipLaunchKernelGGL(kern, cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, __VA_ARGS__); \
+    });
+
+int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_field *vn, const fs_field *vc,
+                  const fs_field *pc, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(scheme == FS_UPWIND || scheme == FS_KK, "unknown advection scheme");
+    FS_FIELD(vn, 2); FS_FIELD(vc, 2); FS_FIELD(pc, 1);
+    FS_REQUIRE(vn != vc, "vn must not alias vc");
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, re);
+        if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_update_upwind", (k_mac_update<0, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d) }
+        else { FS_LAUNCH_CELLS("mac_update_kk", (k_mac_update<1, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d) }
+    })
+}
+
+int fs_mac_dye(fs_ctx *ctx, int scheme, double dt, double dx, fs_field *dn, const fs_field *dc, const fs_field *vc,
+               int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(scheme == FS_UPWIND || scheme == FS_KK, "unknown advection scheme");
+    FS_FIELD(dn, 3); FS_FIELD(dc, 3); FS_FIELD(vc, 2);
+    FS_REQUIRE(dn != dc, "dn must not alias dc");
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0);
+        if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_dye_upwind", (k_mac_dye<0, T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d, (const T *)vc->d) }
+        else { FS_LAUNCH_CELLS("mac_dye_kk", (k_mac_dye<1, T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d, (const T *)vc->d) }
+    })
+}
+
+int fs_cip_set_grad(fs_ctx *ctx, double dx, fs_field *fx, fs_field *fy, const fs_field *f, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx && f, "null argument");
+    const int C = f->C;
+    FS_REQUIRE(C == 2 || C == 3, "set_grad needs a 2- or 3-channel field");
+    FS_FIELD(fx, C); FS_FIELD(fy, C); FS_FIELD(f, C);
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(1.0, dx, 1.0);
+        if (C == 2) { FS_LAUNCH_CELLS("cip_set_grad", (k_cip_set_grad<2, T>), ctx->grid(), k, row_begin, (T *)fx->d, (T *)fy->d, (const T *)f->d) }
+        else { FS_LAUNCH_CELLS("cip_set_grad_c3", (k_cip_set_grad<3, T>), ctx->grid(), k, row_begin, (T *)fx->d, (T *)fy->d, (const T *)f->d) }
+    })
+}
+
+int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, const fs_field *fc, const fs_field *pc,
+                  int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(fn, 2); FS_FIELD(fc, 2); FS_FIELD(pc, 1);
+    FS_REQUIRE(fn != fc, "fn must not alias fc");
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, re);
+        FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d)
+    })
+}
+
+int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn, const fs_field *dc, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(dn, 3); FS_FIELD(dc, 3);
+    FS_REQUIRE(dn != dc, "dn must not alias dc");
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, re);
+        FS_LAUNCH_CELLS("cip_nonadv_dye", (k_cip_nonadv_dye<T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d)
+    })
+}
+
+int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, const fs_field *fxc, const fs_field *fyc,
+                       const fs_field *fc, const fs_field *fn, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx && fc, "null argument");
+    const int C = fc->C;
+    FS_REQUIRE(C == 2 || C == 3, "nonadv_grad needs 2- or 3-channel fields");
+    FS_FIELD(fxn, C); FS_FIELD(fyn, C); FS_FIELD(fxc, C); FS_FIELD(fyc, C); FS_FIELD(fc, C); FS_FIELD(fn, C);
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(1.0, dx, 1.0);
+        if (C == 2) { FS_LAUNCH_CELLS("cip_nonadv_grad", (k_cip_nonadv_grad<2, T>), ctx->grid(), k, row_begin, (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d) }
+        else { FS_LAUNCH_CELLS("cip_nonadv_grad_c3", (k_cip_nonadv_grad<3, T>), ctx->grid(), k, row_begin, (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d) }
+    })
+}
+
+int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
+                  const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx && fc, "null argument");
+    const int C = fc->C;
+    FS_REQUIRE(C == 2 || C == 3, "cip_advect needs 2- or 3-channel fields");
+    FS_FIELD(fn, C); FS_FIELD(fxn, C); FS_FIELD(fyn, C); FS_FIELD(fc, C); FS_FIELD(fxc, C); FS_FIELD(fyc, C); FS_FIELD(v, 2);
+    FS_REQUIRE(fn != fc && fxn != fxc && fyn != fyc, "outputs must not alias inputs");
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0);
+        if (C == 2) { FS_LAUNCH_CELLS("cip_advect", (k_cip_advect<2, T>), ctx->grid(), k, row_begin, (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d) }
+        else { FS_LAUNCH_CELLS("cip_advect_c3", (k_cip_advect<3, T>), ctx->grid(), k, row_begin, (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d) }
+    })
+}
+
+// ---- vorticity confinement -------------------------------------------------------------------------------
+int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, const fs_field *vc, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1); FS_FIELD(vc, 2);
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(1.0, dx, 1.0);
+        FS_LAUNCH_CELLS("vort_calc", (k_vort_calc<T>), ctx->grid(), k, row_begin, (T *)vort->d, (T *)vort_abs->d, (const T *)vc->d)
+    })
+}
+
+int fs_vort_add(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, const fs_field *vc, const fs_field *vort,
+                const fs_field *vort_abs, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(vn, 2); FS_FIELD(vc, 2); FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1);
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0, weight);
+        FS_LAUNCH_CELLS("vort_add", (k_vort_add<T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)vort->d, (const T *)vort_abs->d)
+    })
+}
+
+// ---- pressure ------------------------------------------------------------------------------------------------
+int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_field *pc, const fs_field *vc, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(vc, 2);
+    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0);
+        FS_LAUNCH_CELLS("jacobi_sweep", (k_jacobi<false, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
+    })
+}
+
+int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
+    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(1.0, 1.0, 1.0);
+        FS_LAUNCH_CELLS("jacobi_sweep_src", (k_jacobi<true, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
+    })
+}
+
+static inline dim3 rb_grid(const fs_ctx *c, int jb, int je) { return dim3(((c->X + 1) / 2 + 255) / 256, je - jb, 1); }
+
+int fs_rbsor_halfsweep(fs_ctx *ctx, double dt, double dx, double omega, int parity, fs_field *pn, const fs_field *pc,
+                       const fs_field *vc, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(parity == 0 || parity == 1, "parity must be 0 or 1");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(vc, 2);
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0, 0.0, omega);
+        return launch(ctx, parity ? "rbsor_odd" : "rbsor_even", [&] {
+            hipLaunchKernelGGL((k_rbsor<false, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
+                               row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
+        });
+    })
+}
+
+int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc, const fs_field *src,
+                           int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(parity == 0 || parity == 1, "parity must be 0 or 1");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(1.0, 1.0, 1.0, 0.0, omega);
+        return launch(ctx, parity ? "rbsor_odd_src" : "rbsor_even_src", [&] {
+            hipLaunchKernelGGL((k_rbsor<true, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
+                               row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
+        });
+    })
+}
+
+int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs_field *vc, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(src, 2); FS_FIELD(vc, 2);
+    FS_REQUIRE(src != vc, "src must not alias vc");
+    FS_ROWS();
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0);
+        FS_LAUNCH_CELLS("poisson_source", (k_poisson_source<T>), ctx->grid(), k, row_begin, (T *)src->d, (const T *)vc->d)
+    })
+}
+
+int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, const fs_field *vc, double *sum_sq, double *count)
+{
+    FS_REQUIRE(ctx && sum_sq && count, "null argument");
+    FS_FIELD(p, 1); FS_FIELD(vc, 2);
+    FS_REQUIRE(!ctx->capturing, "residual during graph capture");
+    if (!ctx->mask_set) { set_error("mask not uploaded"); return FS_ERR_STATE; }
+    const int row_begin = ctx->halo, row_end = ctx->halo + ctx->nyl;
+    FS_HIP(hipMemsetAsync(ctx->d_acc, 0, 2 * sizeof(double), ctx->stream));
+    int rc;
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0);
+        rc = launch(ctx, "poisson_residual", [&] {
+            hipLaunchKernelGGL((k_residual<T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
+                               row_begin, (const T *)p->d, (const T *)vc->d, ctx->d_acc);
+        });
+    })
+    if (rc) return rc;
+    double h[2];
+    FS_HIP(hipMemcpyAsync(h, ctx->d_acc, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    *sum_sq = h[0];
+    *count = h[1];
+    return FS_OK;
+}
+
+// ---- pointwise -----------------------------------------------------------------------------------------------
+int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(v, 2);
+    FS_ROWS();
+    FS_DISPATCH(ctx, { FS_LAUNCH_CELLS("limit_field", (k_limit<T>), ctx->grid(), row_begin, (T)limit, (T *)v->d) })
+}
+
+int fs_clamp_field(fs_ctx *ctx, double low, double high, fs_field *f, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx && f, "null argument");
+    FS_REQUIRE(f->ctx == ctx, "field from another context");
+    FS_ROWS();
+    const int C = f->C;
+    FS_DISPATCH(ctx, {
+        if (C == 1) { FS_LAUNCH_CELLS("clamp_field_c1", (k_clamp<1, T>), ctx->grid(), row_begin, (T)low, (T)high, (T *)f->d) }
+        else if (C == 2) { FS_LAUNCH_CELLS("clamp_field_c2", (k_clamp<2, T>), ctx->grid(), row_begin, (T)low, (T)high, (T *)f->d) }
+        else { FS_LAUNCH_CELLS("clamp_field", (k_clamp<3, T>), ctx->grid(), row_begin, (T)low, (T)high, (T *)f->d) }
+    })
+}
+
+// ---- hipGraph capture ---------------------------------------------------------------------------------------
+int fs_graph_begin(fs_ctx *ctx)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(!ctx->capturing, "already capturing");
+    FS_REQUIRE(!ctx->comm, "graph capture is single-GPU only");
+    int rc = prof_drain(ctx); if (rc) return rc;
+    FS_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return FS_OK;
+}
+
+int fs_graph_end(fs_ctx *ctx, int *graph_id)
+{
+    FS_REQUIRE(ctx && graph_id, "null argument");
+    FS_REQUIRE(ctx->capturing, "not capturing");
+    hipGraph_t g = nullptr;
+    ctx->capturing = false;
+    FS_HIP(hipStreamEndCapture(ctx->stream, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
+    ctx->graphs.push_back(ex);
+    *graph_id = (int)ctx->graphs.size() - 1;
+    return FS_OK;
+}
+
+int fs_graph_launch(fs_ctx *ctx, int graph_id, int times)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(graph_id >= 0 && graph_id < (int)ctx->graphs.size() && ctx->graphs[graph_id], "bad graph id");
+    for (int t = 0; t < times; ++t) FS_HIP(hipGraphLaunch(ctx->graphs[graph_id], ctx->stream));
+    return FS_OK;
+}
+
+int fs_graph_free(fs_ctx *ctx, int graph_id)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(graph_id >= 0 && graph_id < (int)ctx->graphs.size(), "bad graph id");
+    if (ctx->graphs[graph_id]) {
+        FS_HIP(hipStreamSynchronize(ctx->stream));
+        FS_HIP(hipGraphExecDestroy(ctx->graphs[graph_id]));
+        ctx->graphs[graph_id] = nullptr;
+    }
+    return FS_OK;
+}
+
+// ---- profiling --------------------------------------------------------------------------------------------------
+int fs_prof_enable(fs_ctx *ctx, int on)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    int rc = prof_drain(ctx); if (rc) return rc;
+    ctx->prof_on = on != 0;
+    return FS_OK;
+}
+
+int fs_prof_reset(fs_ctx *ctx)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    int rc = prof_drain(ctx); if (rc) return rc;
+    std::fill(ctx->prof_launches.begin(), ctx->prof_launches.end(), 0);
+    std::fill(ctx->prof_ms.begin(), ctx->prof_ms.end(), 0.0);
+    return FS_OK;
+}
+
+int fs_prof_count(fs_ctx *ctx, int *n)
+{
+    FS_REQUIRE(ctx && n, "null argument");
+    int rc = prof_drain(ctx); if (rc) return rc;
+    *n = (int)ctx->prof_names.size();
+    return FS_OK;
+}
+
+int fs_prof_get(fs_ctx *ctx, int idx, char *name, int name_cap, int *launches, double *total_ms)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(idx >= 0 && idx < (int)ctx->prof_names.size(), "bad profile index");
+    if (name && name_cap > 0) { strncpy(name, ctx->prof_names[idx].c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = ctx->prof_launches[idx];
+    if (total_ms) *total_ms = ctx->prof_ms[idx];
+    return FS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+// fs_comm.hip - y-slab halo exchange over RCCL (xGMI on an MI355X node).
+//
+// New relative to the reference (which is single-device): the grid is cut along y into one slab per GPU
+// / process; a field's ghost rows are refreshed from the slab neighbours with one grouped
+// ncclSend/ncclRecv pair per neighbour.  A y-halo of `depth` rows is ONE contiguous block of
+// depth*C*P elements in the [row][channel][x] device layout, so no packing kernels are needed.
+// Each rank talks to at most two peers (its slab neighbours), i.e. point-to-point traffic on dedicated
+// xGMI links; messages are 64 KiB - a few MiB, so the exchange is latency- rather than link-bound.
+//
+// librccl is dlopen()ed on first use so that single-GPU users never pay for loading it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "fs_host.h"
+
+namespace fs {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi g_rccl;
+
+static int load_rccl()
+{
+    if (g_rccl.handle) return FS_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { set_error(std::string("cannot load librccl: ") + dlerror()); return FS_ERR_COMM; }
+#define SYM(field, name)                                                                   \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                                            \
+    if (!g_rccl.field) { set_error("librccl lacks symbol " name); dlclose(h); return FS_ERR_COMM; }
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.handle = h;
+    return FS_OK;
+}
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    double *d_red = nullptr;
+};
+
+static int nccl_fail(ncclResult_t r, const char *what)
+{
+    set_error(std::string("RCCL error in ") + what + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    return FS_ERR_COMM;
+}
+#define FS_NCCL(call)                                               \
+    do {                                                            \
+        ncclResult_t r__ = (call);                                  \
+        if (r__ != ncclSuccess) return fs::nccl_fail(r__, #call);   \
+    } while (0)
+
+}  // namespace fs
+
+using namespace fs;
+
+extern "C" {
+
+int fs_comm_unique_id(void *out_128_bytes)
+{
+    FS_REQUIRE(out_128_bytes, "null argument");
+    static_assert(sizeof(ncclUniqueId) == FS_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    int rc = load_rccl(); if (rc) return rc;
+    ncclUniqueId id;
+    FS_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(out_128_bytes, &id, sizeof id);
+    return FS_OK;
+}
+
+int fs_comm_init(fs_ctx *ctx, int rank, int nranks, const void *unique_id_128_bytes)
+{
+    FS_REQUIRE(ctx && unique_id_128_bytes, "null argument");
+    FS_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    FS_REQUIRE(!ctx->comm, "communicator already initialised");
+    int rc = load_rccl(); if (rc) return rc;
+    FS_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128_bytes, sizeof id);
+    Comm *cm = new Comm();
+    cm->rank = rank; cm->nranks = nranks;
+    ncclResult_t r = g_rccl.CommInitRank(&cm->comm, nranks, id, rank);
+    if (r != ncclSuccess) { delete cm; return nccl_fail(r, "ncclCommInitRank"); }
+    hipError_t e = hipMalloc(&cm->d_red, 16 * sizeof(double));
+    if (e != hipSuccess) { g_rccl.CommDestroy(cm->comm); delete cm; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    ctx->comm = cm;
+    return FS_OK;
+}
+
+int fs_comm_destroy(fs_ctx *ctx)
+{
+    if (!ctx || !ctx->comm) return FS_OK;
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->comm->d_red) hipFree(ctx->comm->d_red);
+    if (ctx->comm->comm) g_rccl.CommDestroy(ctx->comm->comm);
+    delete ctx->comm;
+    ctx->comm = nullptr;
+    return FS_OK;
+}
+
+// Refresh `depth` ghost rows on each side of the owned rows [halo, halo + nyl).
+//   to the lower neighbour (rank - 1): my first `depth` owned rows  -> their upper ghost rows
+//   to the upper neighbour (rank + 1): my last  `depth` owned rows  -> their lower ghost rows
+int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth)
+{
+    FS_REQUIRE(ctx && f && f->ctx == ctx, "null argument / foreign field");
+    FS_REQUIRE(depth >= 0 && depth <= ctx->halo && depth <= ctx->nyl, "halo depth exceeds the slab's ghost rows or owned rows");
+    if (depth == 0) return FS_OK;
+    Comm *cm = ctx->comm;
+    if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
+    if (cm->nranks == 1) return FS_OK;
+    const size_t row_elems = (size_t)f->C * ctx->P;
+    const size_t count = (size_t)depth * row_elems;
+    const ncclDataType_t dt = ctx->dtype == 0 ? ncclFloat32 : ncclFloat64;
+    char *base = (char *)f->d;
+    auto rowp = [&](int r) { return base + (size_t)r * row_elems * ctx->esize; };
+    const int H = ctx->halo, n = ctx->nyl;
+    FS_NCCL(g_rccl.GroupStart());
+    if (cm->rank > 0) {
+        FS_NCCL(g_rccl.Send(rowp(H), count, dt, cm->rank - 1, cm->comm, ctx->stream));
+        FS_NCCL(g_rccl.Recv(rowp(H - depth), count, dt, cm->rank - 1, cm->comm, ctx->stream));
+    }
+    if (cm->rank < cm->nranks - 1) {
+        FS_NCCL(g_rccl.Send(rowp(H + n - depth), count, dt, cm->rank + 1, cm->comm, ctx->stream));
+        FS_NCCL(g_rccl.Recv(rowp(H + n), count, dt, cm->rank + 1, cm->comm, ctx->stream));
+    }
+    FS_NCCL(g_rccl.GroupEnd());
+    return FS_OK;
+}
+
+int fs_allreduce_sum(fs_ctx *ctx, double *values, int n)
+{
+    FS_REQUIRE(ctx && values && n >= 0 && n <= 16, "bad argument (n <= 16)");
+    Comm *cm = ctx->comm;
+    if (!cm || cm->nranks == 1 || n == 0) return FS_OK;
+    FS_HIP(hipMemcpyAsync(cm->d_red, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FS_NCCL(g_rccl.AllReduce(cm->d_red, cm->d_red, n, ncclFloat64, ncclSum, cm->comm, ctx->stream));
+    FS_HIP(hipMemcpyAsync(values, cm->d_red, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+}  // extern "C"

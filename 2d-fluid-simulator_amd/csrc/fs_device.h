@@ -1,0 +1,91 @@
+// fs_device.h - device-side geometry, constants and stencil primitives shared by all kernels.
+//
+// Device layout (private to the library): a C-channel field over a slab of `rows`
+// local rows is stored as [row][channel][P] with x contiguous and P = row pitch (X rounded up to
+// 64 elements), i.e. element (i, r, c) lives at ((r*C + c)*P + i).  Rows are the y index, so a
+// y-halo is a contiguous block and wave lanes walk x (coalesced 256 B .. 1 KiB per wave access).
+//
+// Arithmetic follows the reference's operation order literally; the file is compiled with
+// -ffp-contract=off (no FMA fusion) and HIP's default correctly-rounded f32 divide/sqrt so that the
+// results are bit-identical to an IEEE evaluation of the same expression tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fs {
+
+struct Grid {
+    int X;        // cells per row (2*res)
+    int P;        // field row pitch in elements
+    int Pm;       // mask row pitch in bytes
+    int rows;     // local rows allocated (ny_local + 2*halo)
+    int jlo, jhi; // local rows of global y = 0 and y = Y-1 (clamp range of sample())
+    int ybase;    // global y of local row 0 (red-black parity)
+    const uint8_t *mask;  // [rows][Pm]; rows outside the global domain hold 1 (wall)
+};
+
+// Kernel constants with Taichi's typing rules; filled on the host by make_konst().
+template <typename T>
+struct Konst {
+    T dt, dx, re;
+    T two_dx;     // 2.0*dx      folded in double   (fs/solver.py:257,260)
+    T dx2_fold;   // dx**2       folded in double   (fs/solver.py:311-313)
+    T dx3_fold;   // dx**3       folded in double   (fs/solver.py:304-305)
+    T dx_sq;      // dx*dx in T                     (fs/differentiation.py:55,60)
+    T six_dx;     // 6*dx  in T                     (fs/advection.py:46,58)
+    T eight_dt;   // 8*dt  in T                     (fs/pressure_updater.py:37)
+    T dtw;        // dt*weight   folded in double   (fs/vorticity_confinement.py:42)
+    T om, om1;    // omega, 1.0-omega folded        (fs/pressure_updater.py:112)
+};
+
+template <typename T> __device__ __forceinline__ T tmin(T a, T b);
+template <typename T> __device__ __forceinline__ T tmax(T a, T b);
+template <> __device__ __forceinline__ float tmin<float>(float a, float b) { return fminf(a, b); }
+template <> __device__ __forceinline__ float tmax<float>(float a, float b) { return fmaxf(a, b); }
+template <> __device__ __forceinline__ double tmin<double>(double a, double b) { return fmin(a, b); }
+template <> __device__ __forceinline__ double tmax<double>(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float tsqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ double tsqrt(double a) { return sqrt(a); }
+__device__ __forceinline__ float tabs(float a) { return fabsf(a); }
+__device__ __forceinline__ double tabs(double a) { return fabs(a); }
+
+__device__ __forceinline__ int clampx(const Grid &g, int i) { return i < 0 ? 0 : (i > g.X - 1 ? g.X - 1 : i); }
+__device__ __forceinline__ int clampy(const Grid &g, int j) { return j < g.jlo ? g.jlo : (j > g.jhi ? g.jhi : j); }
+
+template <int C, typename T>
+__device__ __forceinline__ size_t idx(const Grid &g, int c, int i, int j) { return ((size_t)j * C + c) * g.P + i; }
+
+// direct read / write of an in-range cell
+template <int C, typename T>
+__device__ __forceinline__ T at(const T *f, const Grid &g, int c, int i, int j) { return f[idx<C, T>(g, c, i, j)]; }
+
+// fs/differentiation.py:4-9  sample(): clamp-to-edge read
+template <int C, typename T>
+__device__ __forceinline__ T smp(const T *f, const Grid &g, int c, int i, int j)
+{ return f[idx<C, T>(g, c, clampx(g, i), clampy(g, j))]; }
+
+__device__ __forceinline__ uint8_t mask_at(const Grid &g, int i, int j) { return g.mask[(size_t)j * g.Pm + i]; }
+
+// fs/differentiation.py:41-50  central differences
+template <int C, typename T>
+__device__ __forceinline__ T diff_x(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
+{ return ((T)0.5 * (smp<C>(f, g, c, i + 1, j) - smp<C>(f, g, c, i - 1, j))) / k.dx; }
+template <int C, typename T>
+__device__ __forceinline__ T diff_y(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
+{ return ((T)0.5 * (smp<C>(f, g, c, i, j + 1) - smp<C>(f, g, c, i, j - 1))) / k.dx; }
+// fs/differentiation.py:53-60  second differences
+template <int C, typename T>
+__device__ __forceinline__ T diff2_x(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
+{ return ((smp<C>(f, g, c, i + 1, j) - (T)2.0 * smp<C>(f, g, c, i, j)) + smp<C>(f, g, c, i - 1, j)) / k.dx_sq; }
+template <int C, typename T>
+__device__ __forceinline__ T diff2_y(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
+{ return ((smp<C>(f, g, c, i, j + 1) - (T)2.0 * smp<C>(f, g, c, i, j)) + smp<C>(f, g, c, i, j - 1)) / k.dx_sq; }
+// fs/differentiation.py:17-26  forward differences
+template <int C, typename T>
+__device__ __forceinline__ T fdiff_x(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
+{ return (smp<C>(f, g, c, i + 1, j) - smp<C>(f, g, c, i, j)) / k.dx; }
+template <int C, typename T>
+__device__ __forceinline__ T fdiff_y(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
+{ return (smp<C>(f, g, c, i, j + 1) - smp<C>(f, g, c, i, j)) / k.dx; }
+
+}  // namespace fs

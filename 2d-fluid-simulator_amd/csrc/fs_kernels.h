@@ -1,0 +1,462 @@
+// fs_kernels.h - the step() kernels, one cell per lane, lanes along x (coalesced rows).
+//
+// Every kernel covers local rows [jb, je) x columns [0, X): blockIdx.y = row, blockIdx.x*256 + tid = x.
+// Masked kernels leave the cells they do not own untouched (the reference's DoubleBuffer "stale cell"
+// behaviour, SURVEY.md H5, is part of the algorithm).  Reference citations are per kernel.
+#pragma once
+#include "fs_device.h"
+
+namespace fs {
+
+#define FS_CELL_PROLOGUE                                   \
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   \
+    const int j = jb + blockIdx.y;                         \
+    if (i >= g.X) return;
+
+// ------------------------------------------------------------------------------------------------
+// advection terms (fs/advection.py)
+// ------------------------------------------------------------------------------------------------
+// advect_upwind, fs/advection.py:12-24
+template <int C, typename T>
+__device__ __forceinline__ T adv_upwind(const T *phi, const Grid &g, const Konst<T> &k, T ux, T uy, int c, int i, int j)
+{
+    int kx = ux < (T)0.0 ? i : i - 1;
+    T a = ux * fdiff_x<C>(phi, g, k, c, kx, j);
+    int ky = uy < (T)0.0 ? j : j - 1;
+    T b = uy * fdiff_y<C>(phi, g, k, c, i, ky);
+    return a + b;
+}
+
+// advect_kk_scheme, fs/advection.py:27-60: 5-point one-sided stencils, coefficients dotted left to right
+template <int C, typename T>
+__device__ __forceinline__ T adv_kk(const T *phi, const Grid &g, const Konst<T> &k, T ux, T uy, int c, int i, int j)
+{
+    // u < 0: coef = [-2, 10, -9, 2, -1];  u >= 0: -coef[::-1] = [1, -2, 9, -10, 2]   (over phi[+2], [+1], [0], [-1], [-2])
+    const bool nx = ux < (T)0;
+    T w0 = nx ? (T)-2 : (T)1, w1 = nx ? (T)10 : (T)-2, w2 = nx ? (T)-9 : (T)9, w3 = nx ? (T)2 : (T)-10, w4 = nx ? (T)-1 : (T)2;
+    T acc = smp<C>(phi, g, c, i + 2, j) * w0;
+    acc = acc + smp<C>(phi, g, c, i + 1, j) * w1;
+    acc = acc + smp<C>(phi, g, c, i, j) * w2;
+    acc = acc + smp<C>(phi, g, c, i - 1, j) * w3;
+    acc = acc + smp<C>(phi, g, c, i - 2, j) * w4;
+    T a = acc / k.six_dx;
+    const bool ny = uy < (T)0;
+    w0 = ny ? (T)-2 : (T)1; w1 = ny ? (T)10 : (T)-2; w2 = ny ? (T)-9 : (T)9; w3 = ny ? (T)2 : (T)-10; w4 = ny ? (T)-1 : (T)2;
+    acc = smp<C>(phi, g, c, i, j + 2) * w0;
+    acc = acc + smp<C>(phi, g, c, i, j + 1) * w1;
+    acc = acc + smp<C>(phi, g, c, i, j) * w2;
+    acc = acc + smp<C>(phi, g, c, i, j - 1) * w3;
+    acc = acc + smp<C>(phi, g, c, i, j - 2) * w4;
+    T b = acc / k.six_dx;
+    return ux * a + uy * b;
+}
+
+template <int SCHEME, int C, typename T>
+__device__ __forceinline__ T advect(const T *phi, const Grid &g, const Konst<T> &k, T ux, T uy, int c, int i, int j)
+{
+    if (SCHEME == 0) return adv_upwind<C>(phi, g, k, ux, uy, c, i, j);
+    return adv_kk<C>(phi, g, k, ux, uy, c, i, j);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2'  MacSolver._update_velocities, fs/solver.py:94-107  (fluid cells)
+// ------------------------------------------------------------------------------------------------
+template <int SCHEME, typename T>
+__global__ __launch_bounds__(256) void k_mac_update(Grid g, Konst<T> k, int jb, T *vn, const T *vc, const T *pc)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) != 0) return;
+    const T ux = at<2>(vc, g, 0, i, j), uy = at<2>(vc, g, 1, i, j);
+    const T gp[2] = {diff_x<1>(pc, g, k, 0, i, j), diff_y<1>(pc, g, k, 0, i, j)};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        T a = advect<SCHEME, 2>(vc, g, k, ux, uy, c, i, j);
+        T lap = (diff2_x<2>(vc, g, k, c, i, j) + diff2_y<2>(vc, g, k, c, i, j)) / k.re;
+        vn[idx<2, T>(g, c, i, j)] = (c == 0 ? ux : uy) + k.dt * (((-a) - gp[c]) + lap);
+    }
+}
+
+// K11  DyeMacSolver._update_dye, fs/solver.py:157-161
+template <int SCHEME, typename T>
+__global__ __launch_bounds__(256) void k_mac_dye(Grid g, Konst<T> k, int jb, T *dn, const T *dc, const T *vc)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) != 0) return;
+    const T ux = at<2>(vc, g, 0, i, j), uy = at<2>(vc, g, 1, i, j);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        dn[idx<3, T>(g, c, i, j)] = at<3>(dc, g, c, i, j) - k.dt * advect<SCHEME, 3>(dc, g, k, ux, uy, c, i, j);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0  CipMacSolver._set_grad, fs/solver.py:207-211  (all cells)
+// ------------------------------------------------------------------------------------------------
+template <int C, typename T>
+__global__ __launch_bounds__(256) void k_cip_set_grad(Grid g, Konst<T> k, int jb, T *fx, T *fy, const T *f)
+{
+    FS_CELL_PROLOGUE
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        fx[idx<C, T>(g, c, i, j)] = diff_x<C>(f, g, k, c, i, j);
+        fy[idx<C, T>(g, c, i, j)] = diff_y<C>(f, g, k, c, i, j);
+    }
+}
+
+// K2  CipMacSolver._non_advection_phase (+ _calc_diffusion), fs/solver.py:229-240, 263-265  (not-wall cells)
+template <typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv(Grid g, Konst<T> k, int jb, T *fn, const T *fc, const T *pc)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) == 1) return;
+    const T gp[2] = {diff_x<1>(pc, g, k, 0, i, j), diff_y<1>(pc, g, k, 0, i, j)};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        T dif = (diff2_x<2>(fc, g, k, c, i, j) + diff2_y<2>(fc, g, k, c, i, j)) / k.re;
+        T gg = (-gp[c]) + dif;
+        fn[idx<2, T>(g, c, i, j)] = at<2>(fc, g, c, i, j) + gg * k.dt;
+    }
+}
+
+// K12  DyeCipMacSolver._non_advection_phase_dye, fs/solver.py:378-383
+template <typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_dye(Grid g, Konst<T> k, int jb, T *dn, const T *dc)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) == 1) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        T dif = (diff2_x<3>(dc, g, k, c, i, j) + diff2_y<3>(dc, g, k, c, i, j)) / k.re;
+        dn[idx<3, T>(g, c, i, j)] = at<3>(dc, g, c, i, j) + dif * k.dt;
+    }
+}
+
+// K3  _non_advection_phase_grad, fs/solver.py:242-261  (not-wall cells).  The reference indexes fn/fc
+// without sample(); its out-of-range reads at i = 0 / X-1 are defined here as clamped.
+template <int C, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_grad(Grid g, Konst<T> k, int jb, T *fxn, T *fyn,
+                                                         const T *fxc, const T *fyc, const T *fc, const T *fn)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) == 1) return;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        T sx = ((smp<C>(fn, g, c, i + 1, j) - smp<C>(fc, g, c, i + 1, j)) - smp<C>(fn, g, c, i - 1, j)) + smp<C>(fc, g, c, i - 1, j);
+        T sy = ((smp<C>(fn, g, c, i, j + 1) - smp<C>(fc, g, c, i, j + 1)) - smp<C>(fn, g, c, i, j - 1)) + smp<C>(fc, g, c, i, j - 1);
+        fxn[idx<C, T>(g, c, i, j)] = at<C>(fxc, g, c, i, j) + sx / k.two_dx;
+        fyn[idx<C, T>(g, c, i, j)] = at<C>(fyc, g, c, i, j) + sy / k.two_dx;
+    }
+}
+
+// K4  _advection_phase / _cip_advect, fs/solver.py:267-332  (fluid cells; C channels advected by v)
+template <int C, typename T>
+__global__ __launch_bounds__(256) void k_cip_advect(Grid g, Konst<T> k, int jb, T *fn, T *fxn, T *fyn,
+                                                    const T *fc, const T *fxc, const T *fyc, const T *v)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) != 0) return;
+    const T vx = at<2>(v, g, 0, i, j), vy = at<2>(v, g, 1, i, j);
+    const int i_s = vx < (T)0.0 ? -1 : 1;   // sign(0) = +1, fs/differentiation.py:12-14
+    const int j_s = vy < (T)0.0 ? -1 : 1;
+    const int im = i - i_s, jm = j - j_s;
+    const T is = (T)i_s, js = (T)j_s;
+    const T i_s_denom = is * k.dx3_fold, j_s_denom = js * k.dx3_fold, is_dx = is * k.dx;
+    const T Xd = (-vx) * k.dt, Yd = (-vy) * k.dt;
+    const T dxx = diff_x<2>(v, g, k, 0, i, j), dxy = diff_x<2>(v, g, k, 1, i, j);
+    const T dyx = diff_y<2>(v, g, k, 0, i, j), dyy = diff_y<2>(v, g, k, 1, i, j);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const T f00 = at<C>(fc, g, c, i, j), f0m = smp<C>(fc, g, c, i, jm), fm0 = smp<C>(fc, g, c, im, j), fmm = smp<C>(fc, g, c, im, jm);
+        const T fx00 = at<C>(fxc, g, c, i, j), fxm0 = smp<C>(fxc, g, c, im, j), fx0m = smp<C>(fxc, g, c, i, jm);
+        const T fy00 = at<C>(fyc, g, c, i, j), fy0m = smp<C>(fyc, g, c, i, jm), fym0 = smp<C>(fyc, g, c, im, j);
+        const T tmp1 = ((f00 - f0m) - fm0) + fmm;
+        const T tmp2 = fm0 - f00;
+        const T tmp3 = f0m - f00;
+        const T a = ((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2)) / i_s_denom;
+        const T b = ((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3)) / j_s_denom;
+        const T cc = ((-tmp1) - (is * (fx0m - fx00)) * k.dx) / j_s_denom;
+        const T d = ((-tmp1) - (js * (fym0 - fy00)) * k.dx) / i_s_denom;
+        const T e = ((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx) / k.dx2_fold;
+        const T f = ((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx) / k.dx2_fold;
+        const T gq = ((-(fym0 - fy00)) + cc * k.dx2_fold) / is_dx;
+        fn[idx<C, T>(g, c, i, j)] =
+            (((((a * Xd + cc * Yd) + e) * Xd + gq * Yd) + fx00) * Xd + (((b * Yd + d * Xd) + f) * Yd + fy00) * Yd) + f00;
+        const T Fx = ((((T)3.0 * a) * Xd + ((T)2.0 * cc) * Yd) + (T)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
+        const T Fy = ((((T)3.0 * b) * Yd + ((T)2.0 * d) * Xd) + (T)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;
+        fxn[idx<C, T>(g, c, i, j)] = Fx - (k.dt * (Fx * dxx + Fy * dxy)) / (T)2.0;
+        fyn[idx<C, T>(g, c, i, j)] = Fy - (k.dt * (Fx * dyx + Fy * dyy)) / (T)2.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  VorticityConfinement._calc_vorticity, fs/vorticity_confinement.py:27-32  (fluid cells)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_vort_calc(Grid g, Konst<T> k, int jb, T *vort, T *vort_abs, const T *vc)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) != 0) return;
+    T w = diff_x<2>(vc, g, k, 1, i, j) - diff_y<2>(vc, g, k, 0, i, j);
+    vort[idx<1, T>(g, 0, i, j)] = w;
+    vort_abs[idx<1, T>(g, 0, i, j)] = tabs(w);
+}
+
+// K6  _add_vorticity + _vorticity_vec, fs/vorticity_confinement.py:34-55.  |grad| == 0 gives 0/0 = NaN and the
+// NaN-ignoring min/max (fminf/fmaxf) turn it into +0.1 on both components.
+template <typename T>
+__global__ __launch_bounds__(256) void k_vort_add(Grid g, Konst<T> k, int jb, T *vn, const T *vc, const T *vort, const T *vort_abs)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) != 0) return;
+    T gx = diff_x<1>(vort_abs, g, k, 0, i, j), gy = diff_y<1>(vort_abs, g, k, 0, i, j);
+    T nrm = tsqrt(gx * gx + gy * gy);
+    gx = gx / nrm;
+    gy = gy / nrm;
+    T w = at<1>(vort, g, 0, i, j);
+    T f0 = gy * w, f1 = (-gx) * w;
+    f0 = tmax(tmin(f0, (T)0.1), (T)-0.1);
+    f1 = tmax(tmin(f1, (T)0.1), (T)-0.1);
+    vn[idx<2, T>(g, 0, i, j)] = at<2>(vc, g, 0, i, j) + k.dtw * f0;
+    vn[idx<2, T>(g, 1, i, j)] = at<2>(vc, g, 1, i, j) + k.dtw * f1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F1  predict_p, fs/pressure_updater.py:23-38:  (0.25*(pE + pW + pN + pS) + s2) - s3
+//     s2 = (sxx^2 + syy^2 + syx*sxy) / 8,  s3 = dx*(sxx + syy) / (8*dt),  sub_x/sub_y = clamped velocity differences
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void poisson_source(const T *vc, const Grid &g, const Konst<T> &k, int i, int j, T &s2, T &s3)
+{
+    T sxx = smp<2>(vc, g, 0, i + 1, j) - smp<2>(vc, g, 0, i - 1, j);
+    T sxy = smp<2>(vc, g, 1, i + 1, j) - smp<2>(vc, g, 1, i - 1, j);
+    T syx = smp<2>(vc, g, 0, i, j + 1) - smp<2>(vc, g, 0, i, j - 1);
+    T syy = smp<2>(vc, g, 1, i, j + 1) - smp<2>(vc, g, 1, i, j - 1);
+    s2 = ((sxx * sxx + syy * syy) + (syx * sxy)) / (T)8.0;
+    s3 = (k.dx * (sxx + syy)) / k.eight_dt;
+}
+
+template <typename T>
+__device__ __forceinline__ T p_avg(const T *pc, const Grid &g, int i, int j)
+{
+    return (T)0.25 * (((smp<1>(pc, g, 0, i + 1, j) + smp<1>(pc, g, 0, i - 1, j)) + smp<1>(pc, g, 0, i, j + 1)) + smp<1>(pc, g, 0, i, j - 1));
+}
+
+// K8J  JacobiPressureUpdater._update, fs/pressure_updater.py:62-66  (not-wall cells)
+template <bool SRC, typename T>
+__global__ __launch_bounds__(256) void k_jacobi(Grid g, Konst<T> k, int jb, T *pn, const T *pc, const T *vs)
+{
+    FS_CELL_PROLOGUE
+    if (mask_at(g, i, j) == 1) return;
+    T s2, s3;
+    if (SRC) { s2 = at<2>(vs, g, 0, i, j); s3 = at<2>(vs, g, 1, i, j); }
+    else poisson_source(vs, g, k, i, j, s2, s3);
+    pn[idx<1, T>(g, 0, i, j)] = (p_avg(pc, g, i, j) + s2) - s3;
+}
+
+// K8R  RedBlackSorPressureUpdater._update_pressures_odd/_even + _pn_ij, fs/pressure_updater.py:98-114.
+// Lanes map to every second cell of the row so that a wave is fully active.  pn may alias pc (even pass).
+template <bool SRC, typename T>
+__global__ __launch_bounds__(256) void k_rbsor(Grid g, Konst<T> k, int jb, int parity, T *pn, const T *pc, const T *vs)
+{
+    const int j = jb + blockIdx.y;
+    const int gy = g.ybase + j;
+    const int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x) + ((gy + parity) & 1);
+    if (i >= g.X) return;
+    if (mask_at(g, i, j) != 0) return;
+    T s2, s3;
+    if (SRC) { s2 = at<2>(vs, g, 0, i, j); s3 = at<2>(vs, g, 1, i, j); }
+    else poisson_source(vs, g, k, i, j, s2, s3);
+    T pred = (p_avg(pc, g, i, j) + s2) - s3;
+    pn[idx<1, T>(g, 0, i, j)] = k.om1 * at<1>(pc, g, 0, i, j) + k.om * pred;
+}
+
+// source precompute (all cells of the row range; build-side optimisation, see fs_hip.h)
+template <typename T>
+__global__ __launch_bounds__(256) void k_poisson_source(Grid g, Konst<T> k, int jb, T *src, const T *vc)
+{
+    FS_CELL_PROLOGUE
+    T s2, s3;
+    poisson_source(vc, g, k, i, j, s2, s3);
+    src[idx<2, T>(g, 0, i, j)] = s2;
+    src[idx<2, T>(g, 1, i, j)] = s3;
+}
+
+// residual diagnostic: sum over not-wall cells of (predict_p(p) - p)^2, wave-reduced, one atomic per wave
+template <typename T>
+__global__ __launch_bounds__(256) void k_residual(Grid g, Konst<T> k, int jb, const T *p, const T *vc, double *acc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = jb + blockIdx.y;
+    double r2 = 0.0, n = 0.0;
+    if (i < g.X && mask_at(g, i, j) != 1) {
+        T s2, s3;
+        poisson_source(vc, g, k, i, j, s2, s3);
+        T r = ((p_avg(p, g, i, j) + s2) - s3) - at<1>(p, g, 0, i, j);
+        r2 = (double)r * (double)r;
+        n = 1.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r2 += __shfl_down(r2, off, 64);
+        n += __shfl_down(n, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && n > 0.0) {
+        atomicAdd(&acc[0], r2);
+        atomicAdd(&acc[1], n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9  limit_field, fs/solver.py:38-43 ;  K13  clamp_field, fs/solver.py:46-49   (all cells)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_limit(Grid g, int jb, T lim, T *v)
+{
+    FS_CELL_PROLOGUE
+    T x = at<2>(v, g, 0, i, j), y = at<2>(v, g, 1, i, j);
+    T nrm = tsqrt(x * x + y * y);
+    if (nrm > lim) {
+        v[idx<2, T>(g, 0, i, j)] = lim * (x / nrm);
+        v[idx<2, T>(g, 1, i, j)] = lim * (y / nrm);
+    }
+}
+
+template <int C, typename T>
+__global__ __launch_bounds__(256) void k_clamp(Grid g, int jb, T lo, T hi, T *f)
+{
+    FS_CELL_PROLOGUE
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        size_t o = idx<C, T>(g, c, i, j);
+        f[o] = tmin(tmax(f[o], lo), hi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Boundary-condition kernels as op lists.
+//
+// The reference's BC kernels (fs/boundary_condition.py:16-65, 94-99) touch only boundary cells, but do so
+// with in-kernel read/write hazards whose outcome depends on Taichi's loop order.  The
+// library fixes the serial (i-major, j-minor) order as THE semantics: when the mask is uploaded the host
+// enumerates the kernel's assignments in that order, groups assignments that touch a common cell (with at
+// least one write) into a component, and the device runs one lane per component, executing its
+// assignments in serial order.  Independent assignments (nearly all) run in parallel; the result is
+// exactly the serial one for any mask.
+// ------------------------------------------------------------------------------------------------
+struct BcOps {
+    int ncomp;
+    const int *comp_begin;  // [ncomp + 1] into the op arrays
+    const int *comp_rlo;    // [ncomp] min / max local target row of the component
+    const int *comp_rhi;
+    const int *kind;        // per op
+    const int *tgt;         // per op: cell offset j*P + i (channel 0 of a C=1 field; scaled by the kernels)
+    const int *s1, *s2;     // per op: source cell offsets (or -1)
+};
+
+__device__ __forceinline__ size_t cell_off(const Grid &g, int cell, int C, int c)
+{
+    int j = cell / g.P, i = cell - j * g.P;
+    return ((size_t)j * C + c) * g.P + i;
+}
+
+// K1  set_velocity_boundary_condition, fs/boundary_condition.py:16-39
+//   kind 0: v[t] = -v[s1] (mirror into the 2nd wall layer), 1: v[t] = bc_const[t], 2: v[t].x = max(v[s1].x, 0.05)
+template <typename T>
+__global__ __launch_bounds__(256) void k_velocity_bc(Grid g, BcOps ops, int jb, int je, T *v, const T *bc_const)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= ops.ncomp) return;
+    if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
+    for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {
+        const int kind = ops.kind[o], t = ops.tgt[o], s = ops.s1[o];
+        if (kind == 0) {
+            v[cell_off(g, t, 2, 0)] = -v[cell_off(g, s, 2, 0)];
+            v[cell_off(g, t, 2, 1)] = -v[cell_off(g, s, 2, 1)];
+        } else if (kind == 1) {
+            v[cell_off(g, t, 2, 0)] = bc_const[cell_off(g, t, 2, 0)];
+            v[cell_off(g, t, 2, 1)] = bc_const[cell_off(g, t, 2, 1)];
+        } else {
+            v[cell_off(g, t, 2, 0)] = tmax(v[cell_off(g, s, 2, 0)], (T)0.05);
+        }
+    }
+}
+
+// K7  set_pressure_boundary_condition, fs/boundary_condition.py:41-65
+//   kind 0: p[t] = p[s1], 1: p[t] = (p[s1] + p[s2]) / 2, 2: p[t] = 0
+template <typename T>
+__global__ __launch_bounds__(256) void k_pressure_bc(Grid g, BcOps ops, int jb, int je, T *p)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= ops.ncomp) return;
+    if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
+    for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {
+        const int kind = ops.kind[o], t = ops.tgt[o];
+        T val;
+        if (kind == 0) val = p[ops.s1[o]];
+        else if (kind == 1) val = (p[ops.s1[o]] + p[ops.s2[o]]) / (T)2.0;
+        else val = (T)0.0;
+        p[t] = val;
+    }
+}
+
+// K10  set_dye_boundary_condition, fs/boundary_condition.py:94-99:  dye[t] = bc_dye[t] on inflow cells
+template <typename T>
+__global__ __launch_bounds__(256) void k_dye_bc(Grid g, BcOps ops, int jb, int je, T *dye, const T *bc_dye)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= ops.ncomp) return;
+    if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
+    for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {
+        const int t = ops.tgt[o];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dye[cell_off(g, t, 3, c)] = bc_dye[cell_off(g, t, 3, c)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion: host (X, nrows, C) window [y contiguous, channels innermost]  <->  device [row][c][P]
+// Viewed as a 2-D transpose of A[i][q] (q = r*C + c, Q = nrows*C columns) into B[q + r0*C][i].
+// 64x64 tiles through LDS (pad 1) keep both sides coalesced.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_to_device(const T *__restrict__ A, T *__restrict__ B, int X, int Q, int P, int q0)
+{
+    __shared__ T tile[64][65];
+    const int i0 = blockIdx.x * 64, qb = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {          // read A rows i0+r, columns qb+tx  (contiguous in q)
+        int i = i0 + r, q = qb + tx;
+        if (i < X && q < Q) tile[r][tx] = A[(size_t)i * Q + q];
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {          // write B rows q0+qb+r, columns i0+tx  (contiguous in i)
+        int q = qb + r, i = i0 + tx;
+        if (i < X && q < Q) B[(size_t)(q0 + q) * P + i] = tile[tx][r];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_to_host(T *__restrict__ A, const T *__restrict__ B, int X, int Q, int P, int q0)
+{
+    __shared__ T tile[64][65];
+    const int i0 = blockIdx.x * 64, qb = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        int q = qb + r, i = i0 + tx;
+        if (i < X && q < Q) tile[r][tx] = B[(size_t)(q0 + q) * P + i];
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        int i = i0 + r, q = qb + tx;
+        if (i < X && q < Q) A[(size_t)i * Q + q] = tile[tx][r];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill(T *p, size_t n, T v)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; t < n; t += stride) p[t] = v;
+}
+
+}  // namespace fs

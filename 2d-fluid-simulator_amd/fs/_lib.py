@@ -1,0 +1,109 @@
+"""ctypes binding of libfs_hip.so (include/fs_hip.h).  No PyTorch, no Taichi: numpy + ctypes only.
+
+The library is REQUIRED: there is no CPU or eager fallback in the product path.  If the shared
+object is missing (or was built for another ABI) importing a kernel entry point raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfs_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+_c_int, _c_dbl, _c_vp, _c_sz = ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+_P = ctypes.POINTER
+
+# name -> argtypes (restype is int unless stated); mirrors include/fs_hip.h declaration by declaration
+_ROWS = [_c_int, _c_int]
+_PROTOS = {
+    "fs_abi_version": [],
+    "fs_device_count": [_P(_c_int)],
+    "fs_create": [_P(_c_vp), _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
+    "fs_destroy": [_c_vp],
+    "fs_sync": [_c_vp],
+    "fs_ctx_info": [_c_vp] + [_P(_c_int)] * 7,
+    "fs_upload_mask": [_c_vp, _c_vp],
+    "fs_upload_bc_const": [_c_vp, _c_vp],
+    "fs_upload_bc_dye": [_c_vp, _c_vp],
+    "fs_bc_reach": [_c_vp, _P(_c_int)],
+    "fs_field_alloc": [_c_vp, _c_int, _P(_c_vp)],
+    "fs_field_free": [_c_vp],
+    "fs_field_fill": [_c_vp, _c_dbl],
+    "fs_field_nchan": [_c_vp],
+    "fs_field_upload": [_c_vp, _c_vp, _c_int, _c_int],
+    "fs_field_download": [_c_vp, _c_vp, _c_int, _c_int],
+    "fs_field_copy": [_c_vp, _c_vp],
+    "fs_field_devptr": [_c_vp, _P(_c_vp), _P(_c_sz)],
+    "fs_velocity_bc": [_c_vp, _c_vp] + _ROWS,
+    "fs_pressure_bc": [_c_vp, _c_vp] + _ROWS,
+    "fs_dye_bc": [_c_vp, _c_vp] + _ROWS,
+    "fs_mac_update": [_c_vp, _c_int, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_mac_dye": [_c_vp, _c_int, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_cip_set_grad": [_c_vp, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_cip_nonadv": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_cip_nonadv_dye": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp] + _ROWS,
+    "fs_cip_nonadv_grad": [_c_vp, _c_dbl] + [_c_vp] * 6 + _ROWS,
+    "fs_cip_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
+    "fs_vort_calc": [_c_vp, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_vort_add": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_jacobi_sweep": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_rbsor_halfsweep": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_int, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_poisson_source": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp] + _ROWS,
+    "fs_jacobi_sweep_src": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_rbsor_halfsweep_src": [_c_vp, _c_dbl, _c_int, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_poisson_residual": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _P(_c_dbl), _P(_c_dbl)],
+    "fs_limit_field": [_c_vp, _c_dbl, _c_vp] + _ROWS,
+    "fs_clamp_field": [_c_vp, _c_dbl, _c_dbl, _c_vp] + _ROWS,
+    "fs_comm_unique_id": [_c_vp],
+    "fs_comm_init": [_c_vp, _c_int, _c_int, _c_vp],
+    "fs_comm_destroy": [_c_vp],
+    "fs_halo_exchange": [_c_vp, _c_vp, _c_int],
+    "fs_allreduce_sum": [_c_vp, _P(_c_dbl), _c_int],
+    "fs_graph_begin": [_c_vp],
+    "fs_graph_end": [_c_vp, _P(_c_int)],
+    "fs_graph_launch": [_c_vp, _c_int, _c_int],
+    "fs_graph_free": [_c_vp, _c_int],
+    "fs_prof_enable": [_c_vp, _c_int],
+    "fs_prof_reset": [_c_vp],
+    "fs_prof_count": [_c_vp, _P(_c_int)],
+    "fs_prof_get": [_c_vp, _c_int, ctypes.c_char_p, _c_int, _P(_c_int), _P(_c_dbl)],
+}
+EXPORTS = sorted(list(_PROTOS) + ["fs_last_error"])
+
+
+class FsError(RuntimeError):
+    """Raised for any non-zero status of a libfs_hip call (HIP / RCCL errors included)."""
+
+
+def load():
+    """Load libfs_hip.so (once) and attach prototypes.  Fails loudly when the extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FsError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C 2d-fluid-simulator_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    lib.fs_last_error.argtypes = []
+    lib.fs_last_error.restype = ctypes.c_char_p
+    if lib.fs_abi_version() != ABI_VERSION:
+        raise FsError(f"libfs_hip ABI {lib.fs_abi_version()} != expected {ABI_VERSION}; rebuild the extension")
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().fs_last_error()
+        raise FsError(f"libfs_hip status {status}: {msg.decode() if msg else '?'}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

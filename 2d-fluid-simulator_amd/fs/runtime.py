@@ -1,0 +1,375 @@
+"""Device runtime: what `ti.init()` + Taichi's field allocator are to the reference (main.py:65-69).
+
+A `Device` owns one libfs_hip context = one y-slab of the grid on one MI355X.  `Field` is the
+subset of the Taichi field API the reference uses (`shape`, `to_numpy`, `from_numpy`, `fill`;
+fs/fluid_simulator.py:36, fs/boundary_condition.py:81-83, fs/double_buffer.py:17-18).
+
+Multi-GPU (new - the reference is single-device): one process per GPU, the grid is cut along y into
+`nranks` slabs with `halo` ghost rows on each side.  Ghost-row validity is tracked per field: every
+kernel wrapper declares the stencil radius it reads each input with and which fields it writes; a
+halo exchange (RCCL send/recv inside libfs_hip) is issued only when an input's ghost rows are stale.
+With nranks == 1 all of this is a no-op and the launches are exactly the reference's sequence.
+
+`DeviceBase` holds that host logic and is backend-agnostic (the CPU test-suite drives it with a
+numpy/gloo stand-in to check the slab logic without a GPU); `Device` binds it to libfs_hip.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_DTYPES = {"f32": np.float32, "f64": np.float64, np.float32: np.float32, np.float64: np.float64,
+           np.dtype("float32"): np.float32, np.dtype("float64"): np.float64}
+
+# process-wide configuration, set by init() (the analogue of ti.init)
+_config = {
+    "gpu": 0, "dtype": np.float32, "rank": 0, "nranks": 1, "halo": None,
+    "bcast": None,        # bcast(bytes | None) -> bytes : rank 0's payload on every rank (rendezvous only)
+    "allgather": None,    # allgather(obj) -> list[obj]  : host-side gather for Field.to_numpy() on slabs
+    "device_cls": None,   # test hook: a DeviceBase subclass
+}
+_devices = []
+
+
+def init(gpu=0, dtype="f32", rank=0, nranks=1, halo=None, bcast=None, allgather=None, device_cls=None):
+    """Select GPU / precision / slab decomposition for the contexts created afterwards."""
+    if dtype not in _DTYPES:
+        raise ValueError(f"dtype must be 'f32' or 'f64', got {dtype!r}")
+    if nranks > 1 and bcast is None and device_cls is None:
+        raise ValueError("nranks > 1 needs a `bcast` callable to share the RCCL unique id")
+    _config.update(gpu=gpu, dtype=_DTYPES[dtype], rank=rank, nranks=nranks, halo=halo, bcast=bcast,
+                   allgather=allgather, device_cls=device_cls)
+
+
+def config():
+    return dict(_config)
+
+
+def slab_rows(ny, rank, nranks):
+    """Rows [y0, y0 + n) owned by `rank`: as even as possible, lower ranks take the remainder."""
+    base, rem = divmod(ny, nranks)
+    n = base + (1 if rank < rem else 0)
+    y0 = rank * base + min(rank, rem)
+    return y0, n
+
+
+def create_device(resolution):
+    cls = _config["device_cls"] or Device
+    dev = cls(resolution[0], resolution[1], _config["dtype"], gpu=_config["gpu"], rank=_config["rank"],
+              nranks=_config["nranks"], halo=_config["halo"], bcast=_config["bcast"],
+              allgather=_config["allgather"])
+    _devices.append(dev)
+    return dev
+
+
+def current_device(resolution=None):
+    """Most recently created device (optionally: with this (X, Y) resolution)."""
+    for dev in reversed(_devices):
+        if resolution is None or tuple(resolution) == (dev.nx, dev.ny):
+            return dev
+    raise RuntimeError(
+        "no device context for this resolution yet: construct the BoundaryCondition first "
+        "(it creates the context, like the reference's boundary condition is the first object built)")
+
+
+class Field:
+    """Device-resident field of shape (X, Y) with `nchan` channels."""
+
+    def __init__(self, dev, nchan):
+        self.dev = dev
+        self.nchan = nchan
+        self._h = dev._p_alloc(nchan)
+        self.valid = dev.halo          # ghost rows valid to this depth (zero-filled == consistent everywhere)
+
+    @property
+    def shape(self):
+        return (self.dev.nx, self.dev.ny)
+
+    def _full_shape(self, nrows):
+        return (self.dev.nx, nrows) if self.nchan == 1 else (self.dev.nx, nrows, self.nchan)
+
+    def fill(self, value):
+        self.dev._p_fill(self._h, float(value))
+        self.valid = self.dev.halo
+
+    def from_numpy(self, arr):
+        """Upload a GLOBAL (X, Y[, C]) array; each slab keeps its rows (ghost rows included)."""
+        dev = self.dev
+        arr = np.asarray(arr)
+        if arr.shape != self._full_shape(dev.ny):
+            raise ValueError(f"expected array of shape {self._full_shape(dev.ny)}, got {arr.shape}")
+        win = np.ascontiguousarray(arr[:, dev.g_lo:dev.g_hi], dtype=dev.dtype)
+        dev._p_upload(self._h, self.nchan, win, dev.g_lo - (dev.y0 - dev.halo), dev.g_hi - dev.g_lo)
+        self.valid = dev.halo
+
+    def to_numpy(self, local=False):
+        """Global (X, Y[, C]) array (gathered over slabs) or, with local=True, this slab's owned rows."""
+        dev = self.dev
+        mine = dev._p_download(self._h, self.nchan, dev.halo, dev.nyl).reshape(self._full_shape(dev.nyl))
+        if local or dev.nranks == 1:
+            return mine
+        if dev.allgather is None:
+            raise RuntimeError("to_numpy() on a slab needs runtime.init(allgather=...) or local=True")
+        return np.concatenate(dev.allgather(mine), axis=1)
+
+    def local_window(self):
+        """All local rows that lie inside the global domain (ghost rows included) - diagnostics/tests."""
+        dev = self.dev
+        r0, n = dev.g_lo - (dev.y0 - dev.halo), dev.g_hi - dev.g_lo
+        return dev._p_download(self._h, self.nchan, r0, n).reshape(self._full_shape(n))
+
+    def __del__(self):
+        try:
+            self.dev._p_free(self._h)
+        except Exception:
+            pass
+
+
+class DeviceBase:
+    """Slab geometry + ghost-row bookkeeping + one method per reference kernel (backend-agnostic)."""
+
+    MIN_HALO = 2   # deepest stencil on the path: Kawamura-Kuwahara / velocity-BC mirror (fs/advection.py:39-55)
+
+    def __init__(self, nx, ny, dtype, gpu=0, rank=0, nranks=1, halo=None, bcast=None, allgather=None):
+        self.nx, self.ny = int(nx), int(ny)
+        self.dtype = np.dtype(_DTYPES[dtype])
+        self.gpu, self.rank, self.nranks = gpu, rank, nranks
+        self.bcast, self.allgather = bcast, allgather
+        self.y0, self.nyl = slab_rows(self.ny, rank, nranks)
+        self.halo = (0 if nranks == 1 else self.MIN_HALO) if halo is None else int(halo)
+        if nranks > 1 and self.halo < self.MIN_HALO:
+            raise ValueError(f"slab decomposition needs halo >= {self.MIN_HALO}")
+        if nranks > 1 and self.nyl < self.halo:
+            raise ValueError("slab thinner than its halo: use fewer ranks or a larger grid")
+        self.rows = self.nyl + 2 * self.halo
+        # global rows covered by local rows (ghost rows included), clipped to the domain
+        self.g_lo = max(0, self.y0 - self.halo)
+        self.g_hi = min(self.ny, self.y0 + self.nyl + self.halo)
+        self.bc_reach = 0
+        self.n_exchanges = 0
+
+    # ---- ghost-row bookkeeping --------------------------------------------------------------------
+    def exchange(self, field, depth=None):
+        depth = self.halo if depth is None else depth
+        self._p_exchange(field._h, field.nchan, depth)
+        field.valid = depth
+        self.n_exchanges += 1
+
+    def _run(self, name, args, reads=(), writes=(), pointwise=False):
+        multi = self.nranks > 1
+        if multi:
+            for f, radius in reads:
+                if radius > self.halo:
+                    raise RuntimeError(f"{name}: stencil radius {radius} exceeds halo {self.halo}")
+                if f.valid < radius:
+                    self.exchange(f)
+        if pointwise:      # all local in-domain rows, ghost rows included: validity is preserved
+            lo, hi = self.g_lo - (self.y0 - self.halo), self.g_hi - (self.y0 - self.halo)
+        else:
+            lo, hi = self.halo, self.halo + self.nyl
+        self._p_kernel(name, *args, lo, hi)
+        if multi and not pointwise:
+            for f in writes:
+                f.valid = 0
+
+    def alloc(self, nchan):
+        return Field(self, nchan)
+
+    # ---- scene --------------------------------------------------------------------------------------
+    def upload_scene(self, bc_mask, bc_const, bc_dye=None):
+        shape = (self.nx, self.ny)
+        bc_mask = np.ascontiguousarray(bc_mask, dtype=np.uint8)
+        bc_const = np.ascontiguousarray(bc_const, dtype=self.dtype)
+        if bc_mask.shape != shape or bc_const.shape != shape + (2,):
+            raise ValueError("bc_mask must be (X, Y) and bc_const (X, Y, 2)")
+        if bc_dye is not None:
+            bc_dye = np.ascontiguousarray(bc_dye, dtype=self.dtype)
+            if bc_dye.shape != shape + (3,):
+                raise ValueError("bc_dye must be (X, Y, 3)")
+        self.bc_reach = self._p_upload_scene(bc_mask, bc_const, bc_dye)
+        if self.nranks > 1 and 2 + self.bc_reach > self.halo:
+            raise RuntimeError(
+                f"mask couples boundary cells {self.bc_reach} rows apart (thin walls); slab runs need halo >= "
+                f"{2 + self.bc_reach}, have {self.halo}")
+
+    # ---- one wrapper per reference kernel: (C-ABI name, scalars + fields, reads with radius, writes) ----
+    def velocity_bc(self, v):                                   # fs/boundary_condition.py:16-39
+        self._run("velocity_bc", (v._h,), reads=[(v, 2 + self.bc_reach)], writes=[v])
+
+    def pressure_bc(self, p):                                   # fs/boundary_condition.py:41-65
+        self._run("pressure_bc", (p._h,), reads=[(p, 1 + self.bc_reach)], writes=[p])
+
+    def dye_bc(self, dye):                                      # fs/boundary_condition.py:94-99
+        self._run("dye_bc", (dye._h,), reads=[], writes=[dye])
+
+    def mac_update(self, scheme, dt, dx, re, vn, vc, pc):       # fs/solver.py:94-107
+        r = 1 if scheme == 0 else 2
+        self._run("mac_update", (scheme, dt, dx, re, vn._h, vc._h, pc._h), reads=[(vc, r), (pc, 1)], writes=[vn])
+
+    def mac_dye(self, scheme, dt, dx, dn, dc, vc):              # fs/solver.py:157-161
+        r = 1 if scheme == 0 else 2
+        self._run("mac_dye", (scheme, dt, dx, dn._h, dc._h, vc._h), reads=[(dc, r), (vc, 0)], writes=[dn])
+
+    def cip_set_grad(self, dx, fx, fy, f):                      # fs/solver.py:207-211
+        self._run("cip_set_grad", (dx, fx._h, fy._h, f._h), reads=[(f, 1)], writes=[fx, fy])
+
+    def cip_nonadv(self, dt, dx, re, fn, fc, pc):               # fs/solver.py:229-240
+        self._run("cip_nonadv", (dt, dx, re, fn._h, fc._h, pc._h), reads=[(fc, 1), (pc, 1)], writes=[fn])
+
+    def cip_nonadv_dye(self, dt, dx, re, dn, dc):               # fs/solver.py:378-383
+        self._run("cip_nonadv_dye", (dt, dx, re, dn._h, dc._h), reads=[(dc, 1)], writes=[dn])
+
+    def cip_nonadv_grad(self, dx, fxn, fyn, fxc, fyc, fc, fn):  # fs/solver.py:242-261
+        self._run("cip_nonadv_grad", (dx, fxn._h, fyn._h, fxc._h, fyc._h, fc._h, fn._h),
+                  reads=[(fc, 1), (fn, 1), (fxc, 0), (fyc, 0)], writes=[fxn, fyn])
+
+    def cip_advect(self, dt, dx, fn, fxn, fyn, fc, fxc, fyc, v):  # fs/solver.py:267-332
+        self._run("cip_advect", (dt, dx, fn._h, fxn._h, fyn._h, fc._h, fxc._h, fyc._h, v._h),
+                  reads=[(fc, 1), (fxc, 1), (fyc, 1), (v, 1)], writes=[fn, fxn, fyn])
+
+    def vort_calc(self, dx, vort, vort_abs, vc):                # fs/vorticity_confinement.py:27-32
+        self._run("vort_calc", (dx, vort._h, vort_abs._h, vc._h), reads=[(vc, 1)], writes=[vort, vort_abs])
+
+    def vort_add(self, dt, dx, weight, vn, vc, vort, vort_abs):  # fs/vorticity_confinement.py:34-55
+        self._run("vort_add", (dt, dx, weight, vn._h, vc._h, vort._h, vort_abs._h),
+                  reads=[(vort_abs, 1), (vort, 0), (vc, 0)], writes=[vn])
+
+    def jacobi_sweep(self, dt, dx, pn, pc, vc):                 # fs/pressure_updater.py:62-66
+        self._run("jacobi_sweep", (dt, dx, pn._h, pc._h, vc._h), reads=[(pc, 1), (vc, 1)], writes=[pn])
+
+    def rbsor_halfsweep(self, dt, dx, omega, parity, pn, pc, vc):  # fs/pressure_updater.py:98-114
+        self._run("rbsor_halfsweep", (dt, dx, omega, parity, pn._h, pc._h, vc._h),
+                  reads=[(pc, 1), (vc, 1)], writes=[pn])
+
+    def poisson_source(self, dt, dx, src, vc):                  # build-side: source of predict_p, once per step
+        self._run("poisson_source", (dt, dx, src._h, vc._h), reads=[(vc, 1)], writes=[src])
+
+    def jacobi_sweep_src(self, pn, pc, src):
+        self._run("jacobi_sweep_src", (pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
+
+    def rbsor_halfsweep_src(self, omega, parity, pn, pc, src):
+        self._run("rbsor_halfsweep_src", (omega, parity, pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
+
+    def limit_field(self, limit, v):                            # fs/solver.py:38-43
+        self._run("limit_field", (limit, v._h), pointwise=True)
+
+    def clamp_field(self, low, high, f):                        # fs/solver.py:46-49
+        self._run("clamp_field", (low, high, f._h), pointwise=True)
+
+    def poisson_residual(self, dt, dx, p, vc):
+        """(sum of squared Jacobi residuals, cell count) over all not-wall cells of the GLOBAL grid."""
+        if self.nranks > 1:
+            for f in (p, vc):
+                if f.valid < 1:
+                    self.exchange(f)
+        s, n = self._p_residual(dt, dx, p._h, vc._h)
+        return self._p_allreduce([s, n]) if self.nranks > 1 else (s, n)
+
+
+class Device(DeviceBase):
+    """DeviceBase bound to libfs_hip.so (HIP kernels on one MI355X; RCCL for the ghost rows)."""
+
+    def __init__(self, nx, ny, dtype, gpu=0, rank=0, nranks=1, halo=None, bcast=None, allgather=None):
+        super().__init__(nx, ny, dtype, gpu, rank, nranks, halo, bcast, allgather)
+        self._lib = _lib.load()
+        ctx = ctypes.c_void_p()
+        _lib.call("fs_create", ctypes.byref(ctx), gpu, self.nx, self.ny, 0 if self.dtype == np.float32 else 1,
+                  self.y0, self.nyl, self.halo)
+        self._ctx = ctx
+        self._graphs = []
+        if nranks > 1:
+            uid = None
+            if rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                _lib.call("fs_comm_unique_id", buf)
+                uid = buf.raw
+            uid = bcast(uid)
+            _lib.call("fs_comm_init", self._ctx, rank, nranks, ctypes.c_char_p(uid))
+
+    # -- primitives -------------------------------------------------------------------------------------
+    def _p_alloc(self, nchan):
+        h = ctypes.c_void_p()
+        _lib.call("fs_field_alloc", self._ctx, nchan, ctypes.byref(h))
+        return h
+
+    def _p_free(self, h):
+        if self._ctx is not None and h:
+            self._lib.fs_field_free(h)
+
+    def _p_fill(self, h, value):
+        _lib.call("fs_field_fill", h, value)
+
+    def _p_upload(self, h, nchan, window, row_begin, nrows):
+        _lib.call("fs_field_upload", h, window.ctypes.data_as(ctypes.c_void_p), row_begin, nrows)
+
+    def _p_download(self, h, nchan, row_begin, nrows):
+        out = np.empty((self.nx, nrows, nchan), dtype=self.dtype)
+        _lib.call("fs_field_download", h, out.ctypes.data_as(ctypes.c_void_p), row_begin, nrows)
+        return out
+
+    def _p_upload_scene(self, bc_mask, bc_const, bc_dye):
+        _lib.call("fs_upload_mask", self._ctx, bc_mask.ctypes.data_as(ctypes.c_void_p))
+        _lib.call("fs_upload_bc_const", self._ctx, bc_const.ctypes.data_as(ctypes.c_void_p))
+        if bc_dye is not None:
+            _lib.call("fs_upload_bc_dye", self._ctx, bc_dye.ctypes.data_as(ctypes.c_void_p))
+        reach = ctypes.c_int()
+        _lib.call("fs_bc_reach", self._ctx, ctypes.byref(reach))
+        return reach.value
+
+    def _p_kernel(self, name, *args):
+        _lib.check(getattr(self._lib, "fs_" + name)(self._ctx, *args))
+
+    def _p_exchange(self, h, nchan, depth):
+        _lib.call("fs_halo_exchange", self._ctx, h, depth)
+
+    def _p_residual(self, dt, dx, ph, vh):
+        s, n = ctypes.c_double(), ctypes.c_double()
+        _lib.call("fs_poisson_residual", self._ctx, dt, dx, ph, vh, ctypes.byref(s), ctypes.byref(n))
+        return s.value, n.value
+
+    def _p_allreduce(self, values):
+        arr = (ctypes.c_double * len(values))(*values)
+        _lib.call("fs_allreduce_sum", self._ctx, arr, len(values))
+        return tuple(arr)
+
+    def sync(self):
+        _lib.call("fs_sync", self._ctx)
+
+    # -- hipGraph capture of a launch sequence (single GPU) ---------------------------------------------
+    def capture(self, fn):
+        """Run fn() once in stream-capture mode and return a graph id replayable with replay()."""
+        _lib.call("fs_graph_begin", self._ctx)
+        try:
+            fn()
+        finally:
+            gid = ctypes.c_int(-1)
+            _lib.call("fs_graph_end", self._ctx, ctypes.byref(gid))
+        return gid.value
+
+    def replay(self, graph_id, times=1):
+        _lib.call("fs_graph_launch", self._ctx, graph_id, times)
+
+    # -- per-kernel HIP-event timing ---------------------------------------------------------------------
+    def profile(self, on=True):
+        _lib.call("fs_prof_enable", self._ctx, 1 if on else 0)
+
+    def profile_reset(self):
+        _lib.call("fs_prof_reset", self._ctx)
+
+    def profile_report(self):
+        """{kernel name: (launches, total_ms)} accumulated since the last reset."""
+        n = ctypes.c_int()
+        _lib.call("fs_prof_count", self._ctx, ctypes.byref(n))
+        out = {}
+        for k in range(n.value):
+            name = ctypes.create_string_buffer(64)
+            launches, ms = ctypes.c_int(), ctypes.c_double()
+            _lib.call("fs_prof_get", self._ctx, k, name, 64, ctypes.byref(launches), ctypes.byref(ms))
+            out[name.value.decode()] = (launches.value, ms.value)
+        return out
+
+    def close(self):
+        if self._ctx is not None:
+            ctx, self._ctx = self._ctx, None
+            self._lib.fs_destroy(ctx)

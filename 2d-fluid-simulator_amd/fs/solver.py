@@ -1,0 +1,184 @@
+"""Per-step orchestration (reference: fs/solver.py).
+
+Each `update()` issues the same kernel sequence, on the same physical buffers, with the same
+DoubleBuffer swaps as the reference - that choreography is part of the algorithm.
+The kernels themselves are HIP (csrc/fs_kernels.h); launches are asynchronous on the device stream.
+"""
+from abc import ABCMeta, abstractmethod
+
+from .double_buffer import DoubleBuffer
+
+VELOCITY_LIMIT = 10.0
+
+
+class Solver(metaclass=ABCMeta):
+    def __init__(self, boundary_condition):
+        self._bc = boundary_condition
+        self._dev = boundary_condition.device
+        self.resolution = boundary_condition.get_resolution()
+
+    @abstractmethod
+    def update(self):
+        pass
+
+    @abstractmethod
+    def get_fields(self):
+        pass
+
+    def is_wall(self, i, j):
+        return self._bc.is_wall(i, j)
+
+    def is_fluid_domain(self, i, j):
+        return self._bc.is_fluid_domain(i, j)
+
+
+def limit_field(field, limit):
+    """Cap the velocity magnitude (fs/solver.py:38-43)."""
+    field.dev.limit_field(limit, field)
+
+
+def clamp_field(field, low, high):
+    """Clamp every channel (fs/solver.py:46-49)."""
+    field.dev.clamp_field(low, high, field)
+
+
+class MacSolver(Solver):
+    """Explicit-Euler MAC-style solver with upwind or Kawamura-Kuwahara advection (fs/solver.py:53-107)."""
+
+    def __init__(self, boundary_condition, pressure_updater, advect_function, dt, dx, re, vorticity_confinement=None):
+        super().__init__(boundary_condition)
+        self._advect = advect_function
+        self.dt = dt
+        self.dx = dx
+        self.re = re
+        self.pressure_updater = pressure_updater
+        self.vorticity_confinement = vorticity_confinement
+        self.v = DoubleBuffer(self.resolution, 2, self._dev)
+        self.p = DoubleBuffer(self.resolution, 1, self._dev)
+
+    def _flow_step(self):
+        self._bc.set_velocity_boundary_condition(self.v.current)
+        self._update_velocities(self.v.next, self.v.current, self.p.current)
+        self.v.swap()
+        if self.vorticity_confinement is not None:
+            self.vorticity_confinement.apply(self.v)
+            self.v.swap()
+        self.pressure_updater.update(self.p, self.v.current)
+        limit_field(self.v.current, VELOCITY_LIMIT)
+
+    def update(self):
+        self._flow_step()
+
+    def get_fields(self):
+        return self.v.current, self.p.current
+
+    def _update_velocities(self, vn, vc, pc):
+        self._dev.mac_update(self._advect.code, self.dt, self.dx, self.re, vn, vc, pc)
+
+
+class DyeMacSolver(MacSolver):
+    """MacSolver + passive dye transport (fs/solver.py:110-161)."""
+
+    def __init__(self, boundary_condition, pressure_updater, advect_function, dt, dx, re, vorticity_confinement=None):
+        super().__init__(boundary_condition, pressure_updater, advect_function, dt, dx, re, vorticity_confinement)
+        self.dye = DoubleBuffer(self.resolution, 3, self._dev)
+
+    def update(self):
+        self._flow_step()
+        self._bc.set_dye_boundary_condition(self.dye.current)
+        self._update_dye(self.dye.next, self.dye.current, self.v.current)
+        self.dye.swap()
+        clamp_field(self.dye.current, 0.0, 1.0)
+
+    def get_fields(self):
+        return self.v.current, self.p.current, self.dye.current
+
+    def _update_dye(self, dn, dc, vc):
+        self._dev.mac_dye(self._advect.code, self.dt, self.dx, dn, dc, vc)
+
+
+class CipMacSolver(Solver):
+    """Two-phase CIP solver: non-advection phase (pressure gradient + diffusion, with the gradient fields
+    updated alongside), then CIP advection of value and gradients (fs/solver.py:165-332)."""
+
+    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None):
+        super().__init__(boundary_condition)
+        self.dt = dt
+        self.dx = dx
+        self.re = re
+        self.pressure_updater = pressure_updater
+        self.vorticity_confinement = vorticity_confinement
+        self.v = DoubleBuffer(self.resolution, 2, self._dev)
+        self.vx = DoubleBuffer(self.resolution, 2, self._dev)
+        self.vy = DoubleBuffer(self.resolution, 2, self._dev)
+        self.p = DoubleBuffer(self.resolution, 1, self._dev)
+        self._set_grad(self.vx.current, self.vy.current, self.v.current)
+
+    def _flow_step(self):
+        self._bc.set_velocity_boundary_condition(self.v.current)
+        self._update_velocities(self.v, self.vx, self.vy, self.p)
+        if self.vorticity_confinement is not None:
+            self.vorticity_confinement.apply(self.v)
+            self.v.swap()
+        self.pressure_updater.update(self.p, self.v.current)
+        limit_field(self.v.current, VELOCITY_LIMIT)
+
+    def update(self):
+        self._flow_step()
+
+    def get_fields(self):
+        return self.v.current, self.p.current
+
+    def _set_grad(self, fx, fy, f):
+        self._dev.cip_set_grad(self.dx, fx, fy, f)
+
+    def _update_velocities(self, v, vx, vy, p):
+        self._non_advection_phase(v.next, v.current, p.current)
+        self._non_advection_phase_grad(vx.next, vy.next, vx.current, vy.current, v.current, v.next)
+        for buf in (v, vx, vy):
+            buf.swap()
+        self._advection_phase(v.next, vx.next, vy.next, v.current, vx.current, vy.current, v.current)
+        for buf in (v, vx, vy):
+            buf.swap()
+
+    def _non_advection_phase(self, fn, fc, pc):
+        self._dev.cip_nonadv(self.dt, self.dx, self.re, fn, fc, pc)
+
+    def _non_advection_phase_grad(self, fxn, fyn, fxc, fyc, fc, fn):
+        self._dev.cip_nonadv_grad(self.dx, fxn, fyn, fxc, fyc, fc, fn)
+
+    def _advection_phase(self, fn, fxn, fyn, fc, fxc, fyc, v):
+        self._dev.cip_advect(self.dt, self.dx, fn, fxn, fyn, fc, fxc, fyc, v)
+
+
+class DyeCipMacSolver(CipMacSolver):
+    """CipMacSolver + CIP-advected dye with its own gradient fields (fs/solver.py:335-401)."""
+
+    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None):
+        super().__init__(boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement)
+        res = boundary_condition.get_resolution()
+        self.dye = DoubleBuffer(res, 3, self._dev)
+        self.dyex = DoubleBuffer(res, 3, self._dev)
+        self.dyey = DoubleBuffer(res, 3, self._dev)
+        self._set_grad(self.dyex.current, self.dyey.current, self.dye.current)
+
+    def update(self):
+        self._flow_step()
+        self._bc.set_dye_boundary_condition(self.dye.current)
+        self._update_dye(self.dye, self.dyex, self.dyey, self.v)
+        clamp_field(self.dye.current, 0.0, 1.0)
+
+    def get_fields(self):
+        return self.v.current, self.p.current, self.dye.current
+
+    def _non_advection_phase_dye(self, dn, dc):
+        self._dev.cip_nonadv_dye(self.dt, self.dx, self.re, dn, dc)
+
+    def _update_dye(self, dye, dyex, dyey, v):
+        self._non_advection_phase_dye(dye.next, dye.current)
+        self._non_advection_phase_grad(dyex.next, dyey.next, dyex.current, dyey.current, dye.current, dye.next)
+        for buf in (dye, dyex, dyey):
+            buf.swap()
+        self._advection_phase(dye.next, dyex.next, dyey.next, dye.current, dyex.current, dyey.current, v.current)
+        for buf in (dye, dyex, dyey):
+            buf.swap()

@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py - steps/sec of FluidSimulator.step() on MI355X (+ Poisson-sweep HBM roofline fraction).
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): scene 5, res 4096
+(8192 x 4096 cells, f32), CIP advection + vorticity confinement 5.0, red-black SOR(1.3, 2 iterations),
+Re 1e6, dt 0.05/res - exactly what `FluidSimulator.create(5, 4096, ...)` builds in the reference.
+Synthetic: the scene comes from the NumPy scene builder, the state starts at zero.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--res R] [--no-cpu] [--sweeps S]
+
+N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per
+GPU; the grid is cut into N y-slabs (strong scaling: same res 4096 grid), ghost rows travel over RCCL inside
+libfs_hip.  torch.distributed (gloo, CPU) is used only as the launcher's rendezvous: to share the RCCL unique id,
+for the barriers around the timed region and for the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--res", type=int, default=4096)
+    ap.add_argument("--bc", type=int, default=5)
+    ap.add_argument("--scheme", default="cip")
+    ap.add_argument("--vc", type=float, default=5.0)
+    ap.add_argument("--sweeps", type=int, default=200, help="isolated Jacobi sweeps for the roofline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step as a hipGraph (N=1)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(mask, esize=4):
+    """Algorithmic HBM bytes per launch of each kernel: every distinct array element touched once, no
+    stencil re-reads, no write-allocate.  N = cells, nw = not-wall, fl = fluid."""
+    import numpy as np
+    n = mask.size
+    fl = int((mask == 0).sum())
+    nw = int((mask != 1).sum())
+    e = esize
+    return {
+        "cip_nonadv": n + nw * (2 * e + e + 2 * e),                      # v, p -> v'
+        "cip_nonadv_grad": n + nw * (4 * e + 4 * e + 4 * e),             # vx,vy,v,v' -> vx',vy'  (8+8+8+8+16 B)
+        "cip_advect": n + fl * (6 * e + 6 * e),                          # v,vx,vy -> v',vx',vy'
+        "vort_calc": n + fl * (2 * e + 2 * e),                           # v -> w, |w|
+        "vort_add": n + fl * (2 * e + 2 * e + 2 * e),                    # w,|w|,v -> v'
+        "rbsor_odd": n // 2 + fl * e + (fl // 2) * (2 * e) + (fl // 2) * e,   # p (both colours), v of the other colour, write half
+        "rbsor_even": n // 2 + fl * e + (fl // 2) * (2 * e) + (fl // 2) * e,
+        "jacobi_sweep": n + nw * (e + 2 * e + e),                        # p, v -> p'   (S = 8: reads v like the reference)
+        "jacobi_sweep_src": n + nw * (e + 2 * e + e),                    # p, (s2, s3) -> p'
+        "mac_update_upwind": n + fl * (2 * e + e + 2 * e),
+        "mac_update_kk": n + fl * (2 * e + e + 2 * e),
+        "limit_field": n * 2 * e,                                        # read v (writes only where |v| > 10)
+        "poisson_source": n * 4 * e,
+    }, {"cells": n, "fluid": fl, "not_wall": nw}
+
+
+def cpu_baseline(args, scene):
+    """The CPU oracle (C restatement of the reference algorithm, OpenMP) on this host's cores: same workload,
+    zero initial state, as many steps as fit in ~cpu_seconds (>= 2)."""
+    import numpy as np
+    from oracle import oracle as O
+    const, mask, _ = scene
+    res = args.res
+    sim = O.make_simulator(const, mask, None, scheme=args.scheme, dt=0.05 / res, dx=1.0 / res, re=1.0e6,
+                           vor_eps=args.vc if args.vc else None)
+    sim.update()   # first touch of every buffer (page faults) is not timed
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0) < args.cpu_seconds:
+        sim.update()
+        n += 1
+        if n >= args.steps:
+            break
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or len(os.sched_getaffinity(0))
+    return {"value": n / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the same workload (bc{args.bc} res{res} {args.scheme}) from the zero state, "
+                      f"{dt:.1f} s, OpenMP C oracle"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    importlib.import_module("2d-fluid-simulator_amd")
+    import numpy as np
+    import fs
+    from fs import _lib
+    from fs.boundary_condition import create_scene_arrays
+    _lib.load()   # ROCm's HIP runtime is resolved before anything else can bring its own copy
+
+    dist = None
+    bcast = allgather = None
+    if world > 1:
+        try:    # bind ROCm's RCCL before torch is imported (torch ships its own copy under the same soname)
+            ctypes.CDLL("/opt/rocm/lib/librccl.so.1", mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        def bcast(payload):
+            box = [payload]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        def allgather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    res = args.res
+    dt, dx, re = 0.05 / res, 1.0 / res, 1.0e6
+    vc = args.vc if args.vc else None
+    fs.runtime.init(gpu=local_rank, dtype="f32", rank=rank, nranks=world, bcast=bcast, allgather=allgather)
+    sim = fs.FluidSimulator.create(args.bc, res, dt, dx, re, vc, args.scheme)
+    dev = sim._solver._bc.device
+    mask = sim._solver._bc.mask
+
+    # ---- warm-up, then EXACTLY K timed steps between barrier + device sync --------------------------------
+    use_graph = world == 1 and not args.no_graph and args.steps % 2 == 0 and args.warmup % 2 == 0
+    for _ in range(args.warmup):
+        sim.step()
+    graph = None
+    if use_graph:
+        # two consecutive steps return every DoubleBuffer to its starting parity, so the captured pair replays
+        graph = dev.capture(lambda: (sim.step(), sim.step()))
+        dev.replay(graph, 1)   # capture does not execute: run the pair once so the state advances like eager
+    dev.sync()
+    barrier()
+    t0 = time.perf_counter()
+    if graph is not None:
+        dev.replay(graph, args.steps // 2)
+    else:
+        for _ in range(args.steps):
+            sim.step()
+    dev.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    steps_per_s = args.steps / elapsed
+
+    # ---- per-kernel durations with HIP events on the kernels' own stream (same K steps again) -------------
+    dev.profile(True)
+    dev.profile_reset()
+    prof_steps = min(args.steps, 50)
+    for _ in range(prof_steps):
+        sim.step()
+    rep = dev.profile_report()
+    dev.profile(False)
+    abytes, counts = algorithmic_bytes(mask)
+    frac_rows = dev.nyl / dev.ny
+    kernels = {}
+    for name, (launches, ms) in rep.items():
+        if launches == 0:
+            continue
+        avg_ms = ms / launches
+        entry = {"launches_per_step": launches / prof_steps, "avg_us": round(avg_ms * 1e3, 2),
+                 "share": round(ms / max(sum(m for _, m in rep.values()), 1e-12), 4)}
+        if name in abytes:
+            entry["alg_MB"] = round(abytes[name] * frac_rows / 1e6, 2)
+            entry["GBps"] = round(abytes[name] * frac_rows / (avg_ms * 1e-3) / 1e9, 1)
+        kernels[name] = entry
+    dominant = max((k for k in kernels if "GBps" in kernels[k]), key=lambda k: kernels[k]["share"] * 1.0, default=None)
+
+    # ---- isolated Poisson Jacobi sweep (the roofline-graded kernel): S sweeps ping-ponging two p buffers ---
+    jac = None
+    if world == 1 and args.sweeps > 0:
+        v, p = sim._solver.get_fields()
+        pa, pb = dev.alloc(1), dev.alloc(1)
+        pa.from_numpy(p.to_numpy())
+        dev.profile_reset()
+        dev.profile(True)
+        for _ in range(args.sweeps // 2):
+            dev.jacobi_sweep(dt, dx, pb, pa, v)
+            dev.jacobi_sweep(dt, dx, pa, pb, v)
+        r = dev.profile_report()["jacobi_sweep"]
+        dev.profile(False)
+        avg_s = r[1] / r[0] * 1e-3
+        jac = {"kernel": "jacobi_sweep (reads v: S=8)", "sweeps": r[0], "avg_us": round(avg_s * 1e6, 2),
+               "alg_MB": round(abytes["jacobi_sweep"] / 1e6, 2), "achieved": round(abytes["jacobi_sweep"] / avg_s / 1e9, 1),
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(abytes["jacobi_sweep"] / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
+
+    out = {
+        "metric": "simulation steps/sec (FluidSimulator.step, bc5 res 4096 CIP+VC)" if (res, args.bc) == (4096, 5)
+                  else f"simulation steps/sec (bc{args.bc} res {res} {args.scheme})",
+        "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 / steps_per_s, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"bc={args.bc} res={res} ({2 * res}x{res} cells) scheme={args.scheme} vc={vc} "
+                               f"RB-SOR(1.3, 2 iters) Re=1e6 dt=0.05/res; BASELINE.json configs[2]",
+                   "cells": counts["cells"], "fluid_cells": counts["fluid"], "parallelism": f"y-slab x{world}",
+                   "launch": "hipGraph replay of 2-step pairs" if graph is not None else "eager (python per step)"},
+        "halo_exchanges_per_step": None if world == 1 else round(dev.n_exchanges / max(args.warmup + args.steps + prof_steps, 1), 2),
+    }
+    if dominant:
+        kd = kernels[dominant]
+        out["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": kd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(kd["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                           "alg_bytes_per_launch": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"]}
+    if jac:
+        out["poisson_jacobi_sweep"] = jac
+    out["kernels"] = kernels
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args, create_scene_arrays(args.bc, res))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/*
+ * fs_hip.h - C-ABI of libfs_hip.so: the MI355X (gfx950) implementation of the
+ * FluidSimulator.step() hot path of takah29/2d-fluid-simulator.
+ *
+ * The reference has no FFI: its hot path is a set of Taichi kernels behind plain Python classes
+ * (SURVEY.md 8b).  This header is the boundary a maintainer would bind instead of Taichi: one entry
+ * point per reference kernel, taking opaque device-field handles, so that the Python classes keep
+ * the reference's own orchestration (and its DoubleBuffer swap semantics).  Each declaration cites
+ * the reference code it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative fs_status on failure; fs_last_error() gives text.
+ *   - all launches are asynchronous on the context's HIP stream; fs_sync()/downloads synchronise.
+ *   - host arrays use the reference layout: shape (X, rows[, C]), y contiguous, channels innermost
+ *     (what Taichi's to_numpy()/from_numpy() exchange: fs/fluid_simulator.py:34-36,
+ *     fs/boundary_condition.py:78-85).  Device layout is private (row-major in x).
+ *   - dtype: 0 = f32 (the reference's only precision, fs/double_buffer.py:7-11), 1 = f64.
+ *   - a context owns one slab of the grid: global rows [y0, y0 + ny_local) plus `halo` ghost rows on
+ *     each side (single GPU: y0 = 0, ny_local = ny).  "local row" r maps to global y = y0 - halo + r.
+ *   - kernels take a local row range [row_begin, row_end) to compute on; reads reach up to 2 rows
+ *     outside it (clamped at the global domain edge like fs/differentiation.py:4-9 sample()).
+ */
+#ifndef FS_HIP_H
+#define FS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_ABI_VERSION 1
+
+typedef struct fs_ctx fs_ctx;
+typedef struct fs_field fs_field;
+
+enum fs_status {
+    FS_OK = 0,
+    FS_ERR_ARG = -1,      /* bad argument / shape / dtype mismatch        */
+    FS_ERR_HIP = -2,      /* HIP runtime error (text in fs_last_error)    */
+    FS_ERR_STATE = -3,    /* call order (e.g. kernel before mask upload)  */
+    FS_ERR_COMM = -4,     /* RCCL error / communicator not initialised    */
+    FS_ERR_UNSUPPORTED = -5
+};
+
+enum fs_scheme { FS_UPWIND = 0, FS_KK = 1 };   /* fs/advection.py:12-24 / :27-60 */
+
+int fs_abi_version(void);
+const char *fs_last_error(void);
+int fs_device_count(int *count);
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* replaces ti.init(...) + Taichi's field allocator (main.py:65-69). */
+int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int ny_local, int halo);
+int fs_destroy(fs_ctx *ctx);
+int fs_sync(fs_ctx *ctx);
+int fs_ctx_info(const fs_ctx *ctx, int *nx, int *ny, int *dtype, int *y0, int *ny_local, int *halo, int *pitch);
+
+/* ---- scene (BoundaryCondition.to_field, fs/boundary_condition.py:78-85, :101-112) ----------- */
+/* Arrays are GLOBAL: mask (X, Y) u8; bc_const (X, Y, 2); bc_dye (X, Y, 3) of the ctx dtype.      */
+int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy);
+int fs_upload_bc_const(fs_ctx *ctx, const void *bc_xy2);
+int fs_upload_bc_dye(fs_ctx *ctx, const void *bc_xy3);
+/* Max distance in rows between cells coupled by the boundary kernels' in-kernel read/write
+ * hazards (0 for every reference scene except thin-walled masks); slab runs need halo >= 2 + it. */
+int fs_bc_reach(const fs_ctx *ctx, int *rows);
+
+/* ---- fields (ti.field / ti.Vector.field + DoubleBuffer members, fs/double_buffer.py:4-18) ---- */
+int fs_field_alloc(fs_ctx *ctx, int nchan, fs_field **out);           /* zero-initialised */
+int fs_field_free(fs_field *f);
+int fs_field_fill(fs_field *f, double value);                          /* field.fill()     */
+int fs_field_nchan(const fs_field *f);
+/* from_numpy / to_numpy on a window of local rows: host shape (X, nrows, C). */
+int fs_field_upload(fs_field *f, const void *host_xrc, int row_begin, int nrows);
+int fs_field_download(const fs_field *f, void *host_xrc, int row_begin, int nrows);
+int fs_field_copy(fs_field *dst, const fs_field *src);
+/* raw device pointer + geometry, for zero-copy interop (hipMemcpy peers, profilers). */
+int fs_field_devptr(const fs_field *f, void **ptr, size_t *bytes);
+
+/* ---- boundary-condition kernels -------------------------------------------------------------- */
+/* BoundaryCondition.set_velocity_boundary_condition   fs/boundary_condition.py:16-39  (in place) */
+int fs_velocity_bc(fs_ctx *ctx, fs_field *v, int row_begin, int row_end);
+/* BoundaryCondition.set_pressure_boundary_condition   fs/boundary_condition.py:41-65  (in place) */
+int fs_pressure_bc(fs_ctx *ctx, fs_field *p, int row_begin, int row_end);
+/* DyeBoundaryCondition.set_dye_boundary_condition     fs/boundary_condition.py:94-99  (in place) */
+int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end);
+
+/* ---- velocity / dye transport ----------------------------------------------------------------- */
+/* MacSolver._update_velocities        fs/solver.py:94-107   (fluid cells; scheme = fs_scheme)   */
+int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re,
+                  fs_field *vn, const fs_field *vc, const fs_field *pc, int row_begin, int row_end);
+/* DyeMacSolver._update_dye            fs/solver.py:157-161                                      */
+int fs_mac_dye(fs_ctx *ctx, int scheme, double dt, double dx,
+               fs_field *dn, const fs_field *dc, const fs_field *vc, int row_begin, int row_end);
+/* CipMacSolver._set_grad              fs/solver.py:207-211  (all cells)                         */
+int fs_cip_set_grad(fs_ctx *ctx, double dx, fs_field *fx, fs_field *fy, const fs_field *f,
+                    int row_begin, int row_end);
+/* CipMacSolver._non_advection_phase   fs/solver.py:229-240  (not-wall cells)                    */
+int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re,
+                  fs_field *fn, const fs_field *fc, const fs_field *pc, int row_begin, int row_end);
+/* DyeCipMacSolver._non_advection_phase_dye  fs/solver.py:378-383                                */
+int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re,
+                      fs_field *dn, const fs_field *dc, int row_begin, int row_end);
+/* CipMacSolver._non_advection_phase_grad    fs/solver.py:242-261  (C = 2 or 3 channels)         */
+int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn,
+                       const fs_field *fxc, const fs_field *fyc, const fs_field *fc, const fs_field *fn,
+                       int row_begin, int row_end);
+/* CipMacSolver._advection_phase / _cip_advect  fs/solver.py:267-332  (v = advecting velocity)   */
+int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn,
+                  const fs_field *fc, const fs_field *fxc, const fs_field *fyc, const fs_field *v,
+                  int row_begin, int row_end);
+
+/* ---- vorticity confinement -------------------------------------------------------------------- */
+/* VorticityConfinement._calc_vorticity    fs/vorticity_confinement.py:27-32                     */
+int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, const fs_field *vc,
+                 int row_begin, int row_end);
+/* VorticityConfinement._add_vorticity     fs/vorticity_confinement.py:34-55                     */
+int fs_vort_add(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, const fs_field *vc,
+                const fs_field *vort, const fs_field *vort_abs, int row_begin, int row_end);
+
+/* ---- pressure Poisson relaxation (predict_p, fs/pressure_updater.py:23-38) -------------------- */
+/* JacobiPressureUpdater._update           fs/pressure_updater.py:62-66   (not-wall cells)       */
+int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_field *pc,
+                    const fs_field *vc, int row_begin, int row_end);
+/* RedBlackSorPressureUpdater._update_pressures_odd/_even  fs/pressure_updater.py:98-114.
+ * parity 1 = odd cells ((i + j) % 2 == 1), 0 = even; pn may be the same field as pc (even pass).  */
+int fs_rbsor_halfsweep(fs_ctx *ctx, double dt, double dx, double omega, int parity,
+                       fs_field *pn, const fs_field *pc, const fs_field *vc, int row_begin, int row_end);
+/* Source-term precompute (build-side optimisation; the source of predict_p depends only on v and is
+ * constant over the sweeps of one step).  src has 2 channels: (s2, s3) with predict_p = (0.25*sum + s2) - s3,
+ * i.e. the reference's operation order is kept and results stay bit-identical to the v-reading kernels. */
+int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs_field *vc,
+                      int row_begin, int row_end);
+int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src,
+                        int row_begin, int row_end);
+int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc,
+                           const fs_field *src, int row_begin, int row_end);
+/* Residual diagnostic (new; the reference never measures convergence): sum over owned not-wall cells of
+ * (predict_p(p) - p)^2 and the cell count, accumulated in double.  Does not alter any field.       */
+int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, const fs_field *vc,
+                        double *sum_sq, double *count);
+
+/* ---- pointwise -------------------------------------------------------------------------------- */
+/* limit_field   fs/solver.py:38-43 ;  clamp_field   fs/solver.py:46-49                           */
+int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int row_end);
+int fs_clamp_field(fs_ctx *ctx, double low, double high, fs_field *f, int row_begin, int row_end);
+
+/* ---- multi-GPU: y-slab halo exchange over RCCL (new; the reference is single-device) ---------- */
+#define FS_UNIQUE_ID_BYTES 128
+int fs_comm_unique_id(void *out_128_bytes);
+int fs_comm_init(fs_ctx *ctx, int rank, int nranks, const void *unique_id_128_bytes);
+int fs_comm_destroy(fs_ctx *ctx);
+/* Fill `depth` ghost rows on each side from the slab neighbours (ncclSend/ncclRecv pairs).       */
+int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth);
+int fs_allreduce_sum(fs_ctx *ctx, double *values, int n);
+
+/* ---- launch-overhead removal: capture the launches issued between begin/end into a hipGraph ---- */
+int fs_graph_begin(fs_ctx *ctx);
+int fs_graph_end(fs_ctx *ctx, int *graph_id);
+int fs_graph_launch(fs_ctx *ctx, int graph_id, int times);
+int fs_graph_free(fs_ctx *ctx, int graph_id);
+
+/* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) --------------- */
+int fs_prof_enable(fs_ctx *ctx, int on);          /* record an event pair around every launch      */
+int fs_prof_reset(fs_ctx *ctx);
+int fs_prof_count(fs_ctx *ctx, int *n);           /* number of distinct kernels seen (syncs)       */
+int fs_prof_get(fs_ctx *ctx, int idx, char *name, int name_cap, int *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FS_HIP_H */

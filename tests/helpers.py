@@ -1,0 +1,39 @@
+"""Shared helpers for the parity tests: build oracle / product simulators from a golden trajectory file."""
+import numpy as np
+
+
+def traj_config(g):
+    bcn, res, dt, dx, re, vc = [float(x) for x in g["params"]]
+    upd = [str(x) for x in g["updater"]]
+    updater = ("rbsor", float(upd[1]), int(upd[2])) if upd[0] == "rbsor" else ("jacobi", int(upd[1]))
+    return dict(bc=int(bcn), res=int(res), dt=dt, dx=dx, re=re, vor_eps=None if vc < 0 else vc,
+                scheme=str(g["scheme"]), updater=updater, dye=bool(g["dye"]), fp64=bool(g["fp64"]),
+                snaps=[int(s) for s in g["snaps"]])
+
+
+def make_oracle(g, cfg=None):
+    from oracle import oracle as O
+    cfg = cfg or traj_config(g)
+    return O.make_simulator(g["bc_const"], g["bc_mask"], g["bc_dye"] if cfg["dye"] else None, scheme=cfg["scheme"],
+                            dt=cfg["dt"], dx=cfg["dx"], re=cfg["re"], vor_eps=cfg["vor_eps"], updater=cfg["updater"],
+                            dtype=np.float64 if cfg["fp64"] else np.float32)
+
+
+def make_product(g, cfg=None, precompute_source=False):
+    """Compose the product classes by hand from the scene arrays stored in the fixture (constructor-level API)."""
+    import fs
+    from fs.boundary_condition import BoundaryCondition, DyeBoundaryCondition
+    cfg = cfg or traj_config(g)
+    dt, dx, re = cfg["dt"], cfg["dx"], cfg["re"]
+    bc = (DyeBoundaryCondition(g["bc_const"], g["bc_dye"], g["bc_mask"]) if cfg["dye"]
+          else BoundaryCondition(g["bc_const"], g["bc_mask"]))
+    vc = fs.VorticityConfinement(bc, dt, dx, cfg["vor_eps"]) if cfg["vor_eps"] is not None else None
+    u = cfg["updater"]
+    pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, u[1], u[2], precompute_source=precompute_source) if u[0] == "rbsor"
+          else fs.JacobiPressureUpdater(bc, dt, dx, u[1], precompute_source=precompute_source))
+    if cfg["scheme"] == "cip":
+        solver = (fs.DyeCipMacSolver if cfg["dye"] else fs.CipMacSolver)(bc, pu, dt, dx, re, vc)
+    else:
+        adv = fs.advect_upwind if cfg["scheme"] == "upwind" else fs.advect_kk_scheme
+        solver = (fs.DyeMacSolver if cfg["dye"] else fs.MacSolver)(bc, pu, adv, dt, dx, re, vc)
+    return (fs.DyeFluidSimulator if cfg["dye"] else fs.FluidSimulator)(solver)
