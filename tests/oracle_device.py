@@ -1,0 +1,140 @@
+"""CPU stand-in for fs.runtime.Device, for testing the HOST logic of the y-slab decomposition without a GPU.
+
+TEST INFRASTRUCTURE: implements the primitive hooks of fs.runtime.DeviceBase with NumPy arrays, the CPU
+oracle as the kernel provider and torch.distributed (gloo) as the ghost-row transport.  Everything above the
+primitives - slab geometry, ghost-row validity tracking, which exchange happens when, the reference's solver
+orchestration - is the product's own Python code, exercised unchanged.
+
+After every kernel the ghost rows of the fields it wrote are POISONED with NaN: if the host logic ever lets a
+stencil read a stale ghost row, the NaN reaches the owned rows and the comparison with the single-domain
+result fails.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+from fs.runtime import DeviceBase
+from oracle import oracle as O
+
+
+class _Arr:
+    def __init__(self, a):
+        self.a = a
+
+
+class OracleSlabDevice(DeviceBase):
+    def __init__(self, nx, ny, dtype, gpu=0, rank=0, nranks=1, halo=None, bcast=None, allgather=None):
+        super().__init__(nx, ny, dtype, gpu, rank, nranks, halo, bcast, allgather)
+        self.r_off = self.g_lo - (self.y0 - self.halo)     # local row of the first in-domain row
+        self.nloc = self.g_hi - self.g_lo                  # rows actually stored (in-domain only)
+        self.poison = nranks > 1
+
+    # ---- primitives -------------------------------------------------------------------------------
+    def _shape(self, nchan):
+        return (self.nx, self.nloc) if nchan == 1 else (self.nx, self.nloc, nchan)
+
+    def _p_alloc(self, nchan):
+        return _Arr(np.zeros(self._shape(nchan), self.dtype))
+
+    def _p_free(self, h):
+        pass
+
+    def _p_fill(self, h, value):
+        h.a[...] = value
+
+    def _p_upload(self, h, nchan, window, row_begin, nrows):
+        a0 = row_begin - self.r_off
+        h.a[:, a0:a0 + nrows] = window.reshape(self._shape(nchan)[:1] + (nrows,) + self._shape(nchan)[2:])
+
+    def _p_download(self, h, nchan, row_begin, nrows):
+        a0 = row_begin - self.r_off
+        return np.ascontiguousarray(h.a[:, a0:a0 + nrows]).reshape(self.nx, nrows, nchan)
+
+    def _p_upload_scene(self, bc_mask, bc_const, bc_dye):
+        sl = slice(self.g_lo, self.g_hi)
+        self.obc = O.OracleBC(bc_const[:, sl], bc_mask[:, sl], None if bc_dye is None else bc_dye[:, sl], self.dtype)
+        return 0
+
+    def _p_exchange(self, h, nchan, depth):
+        a = h.a
+        lo = self.halo - self.r_off                # array row of the first owned row
+        hi = lo + self.nyl
+        ops, recvs = [], []
+
+        def rows(s):
+            return torch.from_numpy(np.ascontiguousarray(a[:, s]))
+
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.isend, rows(slice(lo, lo + depth)), self.rank - 1))
+            t = rows(slice(lo - depth, lo)); recvs.append((slice(lo - depth, lo), t))
+            ops.append(dist.P2POp(dist.irecv, t, self.rank - 1))
+        if self.rank < self.nranks - 1:
+            ops.append(dist.P2POp(dist.isend, rows(slice(hi - depth, hi)), self.rank + 1))
+            t = rows(slice(hi, hi + depth)); recvs.append((slice(hi, hi + depth), t))
+            ops.append(dist.P2POp(dist.irecv, t, self.rank + 1))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        for s, t in recvs:
+            a[:, s] = t.numpy()
+
+    # ---- kernels: same argument order as the C-ABI (include/fs_hip.h) --------------------------------
+    def _p_kernel(self, name, *args):
+        *args, lo, hi = args
+        b, X, Y, dt_ = self.obc, self.nx, self.nloc, self.dtype
+        A = [x.a if isinstance(x, _Arr) else x for x in args]
+        written = []
+        if name == "velocity_bc":
+            b.set_velocity_boundary_condition(A[0]); written = [A[0]]
+        elif name == "pressure_bc":
+            b.set_pressure_boundary_condition(A[0]); written = [A[0]]
+        elif name == "dye_bc":
+            b.set_dye_boundary_condition(A[0]); written = [A[0]]
+        elif name == "mac_update":
+            scheme, dt, dx, re, vn, vc, pc = A
+            O._call("oracle_mac_update", dt_, X, Y, dt, dx, re, scheme, b.mask, vn, vc, pc); written = [vn]
+        elif name == "mac_dye":
+            scheme, dt, dx, dn, dc, vc = A
+            O._call("oracle_mac_dye", dt_, X, Y, dt, dx, 1.0, scheme, b.mask, dn, dc, vc); written = [dn]
+        elif name == "cip_set_grad":
+            dx, fx, fy, f = A
+            O._call("oracle_cip_set_grad", dt_, X, Y, dx, f.shape[2], fx, fy, f); written = [fx, fy]
+        elif name == "cip_nonadv":
+            dt, dx, re, fn, fc, pc = A
+            O._call("oracle_cip_nonadv", dt_, X, Y, dt, dx, re, b.mask, fn, fc, pc); written = [fn]
+        elif name == "cip_nonadv_dye":
+            dt, dx, re, dn, dc = A
+            O._call("oracle_cip_nonadv_dye", dt_, X, Y, dt, dx, re, b.mask, dn, dc); written = [dn]
+        elif name == "cip_nonadv_grad":
+            dx, fxn, fyn, fxc, fyc, fc, fn = A
+            O._call("oracle_cip_nonadv_grad", dt_, X, Y, dx, fc.shape[2], b.mask, fxn, fyn, fxc, fyc, fc, fn); written = [fxn, fyn]
+        elif name == "cip_advect":
+            dt, dx, fn, fxn, fyn, fc, fxc, fyc, v = A
+            O._call("oracle_cip_advect", dt_, X, Y, dt, dx, fc.shape[2], b.mask, fn, fxn, fyn, fc, fxc, fyc, v); written = [fn, fxn, fyn]
+        elif name == "vort_calc":
+            dx, w, wa, vc = A
+            O._call("oracle_vort_calc", dt_, X, Y, dx, b.mask, w, wa, vc); written = [w, wa]
+        elif name == "vort_add":
+            dt, dx, weight, vn, vc, w, wa = A
+            O._call("oracle_vort_add", dt_, X, Y, dt, dx, weight, b.mask, vn, vc, w, wa); written = [vn]
+        elif name == "jacobi_sweep":
+            dt, dx, pn, pc, vc = A
+            O._call("oracle_jacobi_sweep", dt_, X, Y, dt, dx, b.mask, pn, pc, vc); written = [pn]
+        elif name == "rbsor_halfsweep":
+            dt, dx, omega, parity, pn, pc, vc = A
+            O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, parity ^ (self.g_lo & 1), b.mask, pn, pc, vc); written = [pn]
+        elif name == "limit_field":
+            O.limit_field(A[1], A[0])
+        elif name == "clamp_field":
+            O.clamp_field(A[2], A[0], A[1])
+        else:
+            raise NotImplementedError(name)
+        if self.poison and written:
+            a_lo, a_hi = lo - self.r_off, hi - self.r_off
+            for w in written:
+                w[:, :a_lo] = np.nan
+                w[:, a_hi:] = np.nan
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass

@@ -1,0 +1,67 @@
+"""N > 1 path on CPU: world_size 2 and 3 over gloo.  The product's slab logic (fs.runtime.DeviceBase: slab
+geometry, ghost-row validity tracking, exchange scheduling) drives the CPU stand-in device of
+tests/oracle_device.py; results must be bit-identical to the single-domain golden trajectories, including
+every internal buffer.  Ghost rows are NaN-poisoned after each write, so one missing exchange fails the test."""
+import os
+import socket
+
+import pytest
+import torch.multiprocessing as mp
+from fs.runtime import slab_rows
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+CASES = [
+    ("traj_bc5_cip_vc5.npz", 2, 2),
+    ("traj_bc2_cip_jacobi4_vc5.npz", 2, 2),
+    ("traj_bc1_upwind_vc0.npz", 2, 2),
+    ("traj_bc3_kk_vc5.npz", 2, 2),                # KK: +-2 stencil; res-32 bc3 has thin walls (serial-order stress)
+    ("traj_dye_bc2_cip_vc5.npz", 2, 2),
+    ("traj_dye_bc5_kk_vc5.npz", 3, 2),            # uneven slabs 11 / 11 / 10 rows
+    ("traj_bc4_cip_vc0.npz", 3, 3),               # deeper halo than needed
+    ("traj_f64_bc1_cip_vc0.npz", 2, 2),
+]
+
+
+@pytest.mark.parametrize("fname,world,halo", CASES)
+def test_slab_run_is_bit_identical(fname, world, halo, tmp_path):
+    from slab_worker import run
+    mp.spawn(run, args=(world, _free_port(), fname, halo, str(tmp_path)), nprocs=world, join=True)
+    nbad, per_step, *names = open(os.path.join(tmp_path, "result.txt")).read().split()
+    assert int(nbad) == 0, f"{fname}: slabs differ from the single-domain result in {names}"
+    assert 0 < float(per_step) <= 24.0
+
+
+def test_slab_rows_partition():
+    for ny in (32, 33, 4096, 100):
+        for n in (1, 2, 3, 7, 8):
+            rows = [slab_rows(ny, r, n) for r in range(n)]
+            assert rows[0][0] == 0 and sum(c for _, c in rows) == ny
+            for (a0, c0), (a1, _) in zip(rows, rows[1:]):
+                assert a0 + c0 == a1
+            assert max(c for _, c in rows) - min(c for _, c in rows) <= 1
+
+
+def test_single_rank_never_exchanges():
+    import numpy as np
+    from fs.runtime import DeviceBase
+
+    class Null(DeviceBase):
+        def _p_alloc(self, n): return object()
+        def _p_free(self, h): pass
+        def _p_kernel(self, name, *a): self.calls.append((name, a[-2:]))
+        def _p_exchange(self, *a): raise AssertionError("exchange on a single rank")
+
+    d = Null(64, 32, np.float32)
+    d.calls = []
+    v, p = d.alloc(2), d.alloc(1)
+    d.velocity_bc(v); d.cip_nonadv(0.1, 0.1, 1.0, d.alloc(2), v, p); d.limit_field(10.0, v)
+    assert d.halo == 0 and d.n_exchanges == 0
+    assert [c[1] for c in d.calls] == [(0, 32)] * 3
