@@ -1,6 +1,7 @@
 // fs_api.hip - C-ABI entry points (include/fs_hip.h): contexts, fields, scene upload, kernel launches.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <unordered_map>
@@ -73,6 +74,21 @@ static int prof_drain(fs_ctx *c)
 }
 
 static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
+// row-marching kernels: x = 1024-cell stripes (256 lanes x 4 cells), y = strips of c->strip rows
+static inline dim3 march_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X / 4 + 255) / 256, (je - jb + c->strip - 1) / c->strip, 1); }
+
+template <bool SRC, typename T>
+static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
+{
+    const int v = ctx->jacobi_variant;
+    auto tile_grid = [&](int rt) { return dim3((ctx->X / 4 + 255) / 256, (je - jb + rt - 1) / rt, 1); };
+    return launch(ctx, name, [&] {
+        if (v == 2) hipLaunchKernelGGL((k_jacobi_tile<SRC, 2, T>), tile_grid(2), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
+        else if (v == 4) hipLaunchKernelGGL((k_jacobi_tile<SRC, 4, T>), tile_grid(4), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
+        else if (v == 8) hipLaunchKernelGGL((k_jacobi_tile<SRC, 8, T>), tile_grid(8), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
+        else hipLaunchKernelGGL((k_jacobi_march<SRC, T>), march_grid(ctx, jb, je), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, ctx->strip, pn, pc, vs);
+    });
+}
 
 static int check_rows(const fs_ctx *c, int jb, int je)
 {
@@ -314,6 +330,10 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e == hipSuccess) e = hipMemset(c->d_mask, 1, (size_t)c->rows * c->Pm);
     if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
+    if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
+    if (const char *s = getenv("FS_STRIP")) { int r = atoi(s); if (r >= 1) c->strip = r; }
+    if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
+    if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows
     *out = c;
     return FS_OK;
 }
@@ -706,6 +726,37 @@ int fs_vort_add(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, 
     })
 }
 
+int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, const fs_field *vc, fs_field *vort,
+                    fs_field *vort_abs, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(vn, 2); FS_FIELD(vc, 2);
+    FS_REQUIRE(vn != vc, "vn must not alias vc");
+    FS_REQUIRE((vort == nullptr) == (vort_abs == nullptr), "pass both vort and vort_abs or neither");
+    if (vort) { FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1); }
+    FS_ROWS();
+    if (!ctx->use_march) {   // rows not 16-byte aligned (odd res): the unfused pair
+        if (!vort) { set_error("fused vorticity confinement needs X % 4 == 0 or explicit vort fields"); return FS_ERR_UNSUPPORTED; }
+        int rc = fs_vort_calc(ctx, dx, vort, vort_abs, vc, std::max(row_begin - 1, 0), std::min(row_end + 1, ctx->rows));
+        if (rc) return rc;
+        return fs_vort_add(ctx, dt, dx, weight, vn, vc, vort, vort_abs, row_begin, row_end);
+    }
+    constexpr int RT = 4;
+    const int nq = ctx->X / 4, waves = (nq + 61) / 62;
+    const dim3 grid((waves + 3) / 4, (row_end - row_begin + RT - 1) / RT, 1);
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0, weight);
+        const bool p2 = is_pow2(k.dx);
+        T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
+        return launch(ctx, "vort_confine", [&] {
+            if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+            else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+            else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+            else hipLaunchKernelGGL((k_vort_fused<RT, false, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+        });
+    })
+}
+
 // ---- pressure ------------------------------------------------------------------------------------------------
 int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_field *pc, const fs_field *vc, int row_begin, int row_end)
 {
@@ -715,6 +766,7 @@ int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_fi
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0);
+        if (ctx->use_march) return launch_jacobi<false, T>(ctx, "jacobi_sweep", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
         FS_LAUNCH_CELLS("jacobi_sweep", (k_jacobi<false, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
     })
 }
@@ -727,6 +779,7 @@ int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(1.0, 1.0, 1.0);
+        if (ctx->use_march) return launch_jacobi<true, T>(ctx, "jacobi_sweep_src", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
         FS_LAUNCH_CELLS("jacobi_sweep_src", (k_jacobi<true, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
     })
 }

@@ -36,6 +36,7 @@ struct Konst {
     T eight_dt;   // 8*dt  in T                     (fs/pressure_updater.py:37)
     T dtw;        // dt*weight   folded in double   (fs/vorticity_confinement.py:42)
     T om, om1;    // omega, 1.0-omega folded        (fs/pressure_updater.py:112)
+    T inv_dx;     // 1/dx, used only when dx is a power of two (then x*inv_dx == x/dx bit for bit)
 };
 
 template <typename T> __device__ __forceinline__ T tmin(T a, T b);

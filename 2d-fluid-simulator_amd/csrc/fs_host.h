@@ -12,6 +12,7 @@
 #include "../../include/fs_hip.h"
 #include "fs_device.h"
 #include "fs_kernels.h"
+#include "fs_march.h"
 
 namespace fs {
 
@@ -76,6 +77,10 @@ struct fs_ctx {
     // comm
     fs::Comm *comm = nullptr;
     std::set<fs_field *> fields;  // live fields, released with the context
+    // tuning knobs (env FS_MARCH=0 disables the row-marching kernels, FS_STRIP=<rows per strip>)
+    bool use_march = true;
+    int strip = 32;
+    int jacobi_variant = 2;   // 0: marching strips, 2/4/8: register tile of that many rows (env FS_JACOBI)
 
     fs::Grid grid() const
     {
@@ -113,9 +118,16 @@ inline Konst<T> make_konst(double dt, double dx, double re, double weight = 0.0,
     k.dtw = (T)(dt * weight);
     k.om = (T)omega;
     k.om1 = (T)(1.0 - omega);
+    k.inv_dx = (T)1 / k.dx;
     return k;
 }
 
-int comm_halo_exchange(fs_ctx *ctx, fs_field *f, int depth);
+// dx (as rounded to T) is an exact power of two: division by it may be replaced by multiplication
+template <typename T>
+inline bool is_pow2(T x)
+{
+    int e;
+    return x > 0 && std::frexp(x, &e) == (T)0.5;
+}
 
 }  // namespace fs

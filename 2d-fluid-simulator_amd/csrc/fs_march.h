@@ -1,0 +1,353 @@
+// fs_march.h - row-marching stencil kernels for gfx950 (the fast path of the Poisson sweeps).
+//
+// Mapping (CDNA4): a lane owns a QUAD of 4 consecutive x cells (one 16-byte global_load_dwordx4 per
+// field row: a wave moves a full 1 KiB row segment per instruction, perfectly coalesced) and marches down
+// a strip of R rows keeping the rows j-1, j, j+1 of every stencilled field in registers, so each row is
+// fetched from HBM/L2 once per strip instead of once per neighbour.  The x-neighbours of a quad come from
+// the adjacent lanes through DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1 - no LDS, no barrier);
+// only lane 0 / lane 63 of a wave fetch their outer neighbour from memory (an L1/L2 hit: the line is the
+// neighbouring wave's).  No LDS tile is needed for a 5-point stencil in this form; LDS stays free.
+//
+// Work skipping: the mask quad (one u32 per lane and row) tells a wave whether any of its 256 cells in a
+// row is active; rows that are all wall neither load nor compute (scene 5 is one third wall).
+//
+// blockIdx.x -> 1024-cell column stripe, blockIdx.y -> strip.  With a stripe count that is a multiple of 8
+// the round-robin block->XCD dispatch keeps vertically adjacent strips of a stripe on one XCD, so the two
+// halo rows a strip shares with its neighbours are L2 hits.
+//
+// Arithmetic: identical expression trees / operation order as the one-cell-per-lane kernels in
+// fs_kernels.h (and the reference); results are bit-identical.
+#pragma once
+#include "fs_device.h"
+
+namespace fs {
+
+template <typename T> struct Quad;
+template <> struct Quad<float> { using type = float4; };
+template <> struct Quad<double> { using type = double4; };
+
+// value of the previous / next lane (undefined in lane 0 / lane 63: the caller patches those)
+__device__ __forceinline__ float lane_prev(float x)
+{ return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, false)); }   // wave_shr:1
+__device__ __forceinline__ float lane_next(float x)
+{ return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, false)); }   // wave_shl:1
+__device__ __forceinline__ double lane_prev(double x) { return __shfl_up(x, 1, 64); }
+__device__ __forceinline__ double lane_next(double x) { return __shfl_down(x, 1, 64); }
+
+template <int C, typename T>
+__device__ __forceinline__ typename Quad<T>::type load_quad(const T *f, const Grid &g, int c, int i0, int j)
+{ return *reinterpret_cast<const typename Quad<T>::type *>(f + idx<C, T>(g, c, i0, j)); }
+
+// left neighbour of q.x and right neighbour of q.w in row j of channel c (clamped at the domain edge)
+template <int C, typename T>
+__device__ __forceinline__ void quad_sides(const T *f, const Grid &g, int c, int i0, int j, int lane,
+                                           const typename Quad<T>::type &q, T &left, T &right)
+{
+    left = lane_prev(q.w);
+    right = lane_next(q.x);
+    if (lane == 0) left = i0 > 0 ? f[idx<C, T>(g, c, i0 - 1, j)] : q.x;
+    if (lane == 63 || i0 + 4 >= g.X) right = i0 + 4 < g.X ? f[idx<C, T>(g, c, i0 + 4, j)] : q.w;
+}
+
+__device__ __forceinline__ uint32_t mask_quad(const Grid &g, int i0, int j)
+{ return *reinterpret_cast<const uint32_t *>(g.mask + (size_t)j * g.Pm + i0); }
+
+// store the components of `v` whose mask byte satisfies the predicate encoded in `sel` (bit k = cell k)
+template <typename T>
+__device__ __forceinline__ void store_quad_sel(T *dst, const typename Quad<T>::type &v, unsigned sel)
+{
+    if (sel == 0xfu) { *reinterpret_cast<typename Quad<T>::type *>(dst) = v; return; }
+    if (sel & 1u) dst[0] = v.x;
+    if (sel & 2u) dst[1] = v.y;
+    if (sel & 4u) dst[2] = v.z;
+    if (sel & 8u) dst[3] = v.w;
+}
+
+// bit k set when byte k of m4 != 1 (not wall) / == 0 (fluid)
+__device__ __forceinline__ unsigned sel_not_wall(uint32_t m4)
+{
+    return ((m4 & 0xffu) != 1u ? 1u : 0u) | (((m4 >> 8) & 0xffu) != 1u ? 2u : 0u) |
+           (((m4 >> 16) & 0xffu) != 1u ? 4u : 0u) | (((m4 >> 24) & 0xffu) != 1u ? 8u : 0u);
+}
+__device__ __forceinline__ unsigned sel_fluid(uint32_t m4)
+{
+    return ((m4 & 0xffu) == 0u ? 1u : 0u) | (((m4 >> 8) & 0xffu) == 0u ? 2u : 0u) |
+           (((m4 >> 16) & 0xffu) == 0u ? 4u : 0u) | (((m4 >> 24) & 0xffu) == 0u ? 8u : 0u);
+}
+
+// predict_p on one cell from already-gathered neighbours (fs/pressure_updater.py:23-38, literal order)
+template <typename T>
+__device__ __forceinline__ T predict_from(T pE, T pW, T pN, T pS, T s2, T s3)
+{ return ((T)0.25 * (((pE + pW) + pN) + pS) + s2) - s3; }
+
+template <typename T>
+__device__ __forceinline__ void source_from(const Konst<T> &k, T vxE, T vxW, T vyE, T vyW, T vxN, T vxS, T vyN, T vyS, T &s2, T &s3)
+{
+    T sxx = vxE - vxW, sxy = vyE - vyW, syx = vxN - vxS, syy = vyN - vyS;
+    s2 = ((sxx * sxx + syy * syy) + (syx * sxy)) / (T)8.0;
+    s3 = (k.dx * (sxx + syy)) / k.eight_dt;
+}
+
+// three rolling rows of one scalar plane
+template <typename T>
+struct Rows3 {
+    typename Quad<T>::type m, c, p;
+};
+
+// ------------------------------------------------------------------------------------------------
+// K8J  JacobiPressureUpdater._update (fs/pressure_updater.py:62-66), marching form.
+//   SRC = false: reads v like the reference (S = 8 B/cell);  SRC = true: reads the precomputed (s2, s3) pair.
+// ------------------------------------------------------------------------------------------------
+template <bool SRC, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_march(Grid g, Konst<T> k, int jb, int je, int R, T *pn, const T *pc, const T *vs)
+{
+    using V = typename Quad<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= g.X) return;
+    const int j0 = jb + blockIdx.y * R;
+    const int j1 = j0 + R < je ? j0 + R : je;
+
+    Rows3<T> P, VX, VY;
+    bool hm = false, hc = false, hp = false;   // rows j-1, j, j+1 resident? (wave-uniform)
+
+    for (int j = j0; j < j1; ++j) {
+        const uint32_t m4 = mask_quad(g, i0, j);
+        const unsigned sel = sel_not_wall(m4);
+        if (__any(sel != 0u)) {
+            const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
+            if (!hm) { P.m = load_quad<1>(pc, g, 0, i0, jm); if (!SRC) { VX.m = load_quad<2>(vs, g, 0, i0, jm); VY.m = load_quad<2>(vs, g, 1, i0, jm); } }
+            if (!hc) { P.c = load_quad<1>(pc, g, 0, i0, j); if (!SRC) { VX.c = load_quad<2>(vs, g, 0, i0, j); VY.c = load_quad<2>(vs, g, 1, i0, j); } }
+            if (!hp) { P.p = load_quad<1>(pc, g, 0, i0, jp); if (!SRC) { VX.p = load_quad<2>(vs, g, 0, i0, jp); VY.p = load_quad<2>(vs, g, 1, i0, jp); } }
+            hm = hc = hp = true;
+            T pl, pr;
+            quad_sides<1>(pc, g, 0, i0, j, lane, P.c, pl, pr);
+            V s2, s3;
+            if (SRC) {
+                s2 = load_quad<2>(vs, g, 0, i0, j);
+                s3 = load_quad<2>(vs, g, 1, i0, j);
+            } else {
+                T xl, xr, yl, yr;
+                quad_sides<2>(vs, g, 0, i0, j, lane, VX.c, xl, xr);
+                quad_sides<2>(vs, g, 1, i0, j, lane, VY.c, yl, yr);
+                source_from(k, VX.c.y, xl, VY.c.y, yl, VX.p.x, VX.m.x, VY.p.x, VY.m.x, s2.x, s3.x);
+                source_from(k, VX.c.z, VX.c.x, VY.c.z, VY.c.x, VX.p.y, VX.m.y, VY.p.y, VY.m.y, s2.y, s3.y);
+                source_from(k, VX.c.w, VX.c.y, VY.c.w, VY.c.y, VX.p.z, VX.m.z, VY.p.z, VY.m.z, s2.z, s3.z);
+                source_from(k, xr, VX.c.z, yr, VY.c.z, VX.p.w, VX.m.w, VY.p.w, VY.m.w, s2.w, s3.w);
+            }
+            V o;
+            o.x = predict_from(P.c.y, pl, P.p.x, P.m.x, s2.x, s3.x);
+            o.y = predict_from(P.c.z, P.c.x, P.p.y, P.m.y, s2.y, s3.y);
+            o.z = predict_from(P.c.w, P.c.y, P.p.z, P.m.z, s2.z, s3.z);
+            o.w = predict_from(pr, P.c.z, P.p.w, P.m.w, s2.w, s3.w);
+            store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o, sel);
+        }
+        // rotate: row j becomes j-1, row j+1 becomes j
+        P.m = P.c; P.c = P.p;
+        if (!SRC) { VX.m = VX.c; VX.c = VX.p; VY.m = VY.c; VY.c = VY.p; }
+        hm = hc; hc = hp; hp = false;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K8J, register-tile form: a lane owns a quad x RT rows.  All (RT+2) rows of p (and of v.x, v.y unless SRC)
+// are requested up front - 3*(RT+2) independent 16-byte loads per lane, i.e. tens of KiB in flight per
+// wave - which is what keeps HBM busy at a few waves per SIMD (Little: ~60 KiB in flight per CU needed).
+// The two halo rows are re-read by the vertically adjacent tiles (same column stripe => same XCD => L2 hit).
+// ------------------------------------------------------------------------------------------------
+template <bool SRC, int RT, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_tile(Grid g, Konst<T> k, int jb, int je, T *pn, const T *pc, const T *vs)
+{
+    using V = typename Quad<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= g.X) return;
+    const int j0 = jb + blockIdx.y * RT;
+
+    unsigned sel[RT];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        sel[r] = j0 + r < je ? sel_not_wall(mask_quad(g, i0, j0 + r)) : 0u;
+        any |= sel[r] != 0u;
+    }
+    if (!__any(any)) return;
+
+    V P[RT + 2], VX[RT + 2], VY[RT + 2];
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        const int j = clampy(g, j0 - 1 + r);
+        P[r] = load_quad<1>(pc, g, 0, i0, j);
+        if (!SRC) { VX[r] = load_quad<2>(vs, g, 0, i0, j); VY[r] = load_quad<2>(vs, g, 1, i0, j); }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int j = j0 + r;
+        if (j >= je) break;
+        const int jc = clampy(g, j);
+        T pl, pr;
+        quad_sides<1>(pc, g, 0, i0, jc, lane, P[r + 1], pl, pr);
+        V s2, s3;
+        if (SRC) {
+            s2 = load_quad<2>(vs, g, 0, i0, jc);
+            s3 = load_quad<2>(vs, g, 1, i0, jc);
+        } else {
+            T xl, xr, yl, yr;
+            quad_sides<2>(vs, g, 0, i0, jc, lane, VX[r + 1], xl, xr);
+            quad_sides<2>(vs, g, 1, i0, jc, lane, VY[r + 1], yl, yr);
+            const V &xc = VX[r + 1], &yc = VY[r + 1], &xp = VX[r + 2], &xm = VX[r], &yp = VY[r + 2], &ym = VY[r];
+            source_from(k, xc.y, xl, yc.y, yl, xp.x, xm.x, yp.x, ym.x, s2.x, s3.x);
+            source_from(k, xc.z, xc.x, yc.z, yc.x, xp.y, xm.y, yp.y, ym.y, s2.y, s3.y);
+            source_from(k, xc.w, xc.y, yc.w, yc.y, xp.z, xm.z, yp.z, ym.z, s2.z, s3.z);
+            source_from(k, xr, xc.z, yr, yc.z, xp.w, xm.w, yp.w, ym.w, s2.w, s3.w);
+        }
+        const V &c = P[r + 1], &n = P[r + 2], &m = P[r];
+        V o;
+        o.x = predict_from(c.y, pl, n.x, m.x, s2.x, s3.x);
+        o.y = predict_from(c.z, c.x, n.y, m.y, s2.y, s3.y);
+        o.z = predict_from(c.w, c.y, n.z, m.z, s2.z, s3.z);
+        o.w = predict_from(pr, c.z, n.w, m.w, s2.w, s3.w);
+        if (sel[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o, sel[r]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Overlapped-wave column mapping for multi-stage stencils: a wave covers 64 consecutive quads of which the
+// inner 62 produce output; lanes 0 and 63 are x-halo lanes (they load and compute so that their inner
+// neighbour can read a valid value through DPP, but never store).  3 % redundant loads (L1/L2 hits) buy a
+// kernel with no edge loads, no LDS and no barriers, for any number of fused radius-1 stages up to 4.
+// ------------------------------------------------------------------------------------------------
+struct LaneMap {
+    int i0;        // first cell of this lane's quad (clamped into the row)
+    bool owner;    // lane produces output
+    bool at_lo;    // quad starts at i = 0  (left neighbour of .x is .x itself: sample() clamp)
+    bool at_hi;    // quad ends at i = X-1
+};
+__device__ __forceinline__ LaneMap lane_map(const Grid &g)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nq = g.X >> 2;
+    int q = wave * 62 - 1 + lane;
+    LaneMap m;
+    m.owner = lane >= 1 && lane <= 62 && q >= 0 && q < nq;
+    q = q < 0 ? 0 : (q > nq - 1 ? nq - 1 : q);
+    m.i0 = q << 2;
+    m.at_lo = q == 0;
+    m.at_hi = q == nq - 1;
+    return m;
+}
+__device__ __forceinline__ bool wave_in_range(const Grid &g)
+{
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    return wave * 62 < (g.X >> 2);
+}
+
+template <typename T>
+__device__ __forceinline__ T quad_left(const LaneMap &m, const typename Quad<T>::type &q)
+{ T l = lane_prev(q.w); return m.at_lo ? q.x : l; }
+template <typename T>
+__device__ __forceinline__ T quad_right(const LaneMap &m, const typename Quad<T>::type &q)
+{ T r = lane_next(q.x); return m.at_hi ? q.w : r; }
+
+// x / dx for the central differences: a true IEEE division unless dx is a power of two, where the
+// (exact) multiplication by 1/dx gives the same bits for a fraction of the instructions.
+template <bool P2, typename T>
+__device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return P2 ? x * k.inv_dx : x / k.dx; }
+
+// ------------------------------------------------------------------------------------------------
+// K5 + K6 fused: vorticity confinement in one pass (fs/vorticity_confinement.py:27-55).
+//   w(i,j)  = fluid ? diff_x(v).y - diff_y(v).x : 0          (the reference's vorticity field is zero-initialised
+//                                                              and only ever written on fluid cells)
+//   vn(i,j) = v + dt*weight * clamp((n.y, -n.x) * w, +-0.1),  n = grad|w| / |grad|w||       on fluid cells
+// A lane computes w for RT+2 rows of its quad from RT+4 rows of v, takes the x-neighbours of |w| from the adjacent
+// lanes (DPP) and writes RT rows of vn.  w / |w| never touch HBM unless STORE_W (they are public attributes of
+// VorticityConfinement; the unfused pair of kernels remains available and is what parity tests compare with).
+// ------------------------------------------------------------------------------------------------
+template <int RT, bool P2, bool STORE_W, typename T>
+__global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs)
+{
+    using V = typename Quad<T>::type;
+    if (!wave_in_range(g)) return;
+    const LaneMap lm = lane_map(g);
+    const int i0 = lm.i0;
+    const int j0 = jb + blockIdx.y * RT;
+
+    unsigned fl[RT + 2];   // fluid selectors of rows j0-1 .. j0+RT (clamped rows repeat)
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        const int j = clampy(g, j0 - 1 + r);
+        fl[r] = sel_fluid(mask_quad(g, i0, j));
+        if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
+    }
+    if (!__any(any)) return;
+
+    V VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1
+#pragma unroll
+    for (int r = 0; r < RT + 4; ++r) {
+        const int j = clampy(g, j0 - 2 + r);
+        VX[r] = load_quad<2>(vc, g, 0, i0, j);
+        VY[r] = load_quad<2>(vc, g, 1, i0, j);
+    }
+    // vorticity of rows j0-1 .. j0+RT  (index r <-> v slot r+1)
+    V W[RT + 2];
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        // rows were loaded with clamped indices, so for an in-domain row j0-1+r the slots r, r+1, r+2 hold exactly
+        // sample()'s rows clamp(j-1), j, clamp(j+1); out-of-domain virtual rows are never consumed (see wm / wp).
+        const V &yc = VY[r + 1], &xm = VX[r], &xp = VX[r + 2];
+        const T yl = quad_left<T>(lm, yc), yr = quad_right<T>(lm, yc);
+        V w;
+        w.x = div_dx<P2>((T)0.5 * (yc.y - yl), k) - div_dx<P2>((T)0.5 * (xp.x - xm.x), k);
+        w.y = div_dx<P2>((T)0.5 * (yc.z - yc.x), k) - div_dx<P2>((T)0.5 * (xp.y - xm.y), k);
+        w.z = div_dx<P2>((T)0.5 * (yc.w - yc.y), k) - div_dx<P2>((T)0.5 * (xp.z - xm.z), k);
+        w.w = div_dx<P2>((T)0.5 * (yr - yc.z), k) - div_dx<P2>((T)0.5 * (xp.w - xm.w), k);
+        const unsigned f = fl[r];
+        w.x = (f & 1u) ? w.x : (T)0; w.y = (f & 2u) ? w.y : (T)0; w.z = (f & 4u) ? w.z : (T)0; w.w = (f & 8u) ? w.w : (T)0;
+        W[r] = w;
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int j = j0 + r;
+        if (j >= je) break;
+        const unsigned f = fl[r + 1];
+        const V &wc = W[r + 1];
+        // |w| of the clamped neighbour rows: for the first / last domain row the neighbour is the row itself
+        const V &wm = (j - 1 < g.jlo) ? W[r + 1] : W[r];
+        const V &wp = (j + 1 > g.jhi) ? W[r + 1] : W[r + 2];
+        V a; a.x = tabs(wc.x); a.y = tabs(wc.y); a.z = tabs(wc.z); a.w = tabs(wc.w);
+        const T al = quad_left<T>(lm, a), ar = quad_right<T>(lm, a);
+        if (STORE_W && lm.owner && f) {
+            store_quad_sel<T>(vort + idx<1, T>(g, 0, i0, j), wc, f);
+            store_quad_sel<T>(vort_abs + idx<1, T>(g, 0, i0, j), a, f);
+        }
+        V ox, oy;
+        const V &cx = VX[r + 2], &cy = VY[r + 2];
+#define FS_VC_CELL(comp, aE, aW)                                                              \
+        {                                                                                     \
+            T gx = div_dx<P2>((T)0.5 * ((aE) - (aW)), k);                                     \
+            T gy = div_dx<P2>((T)0.5 * (tabs(wp.comp) - tabs(wm.comp)), k);                   \
+            T nrm = tsqrt(gx * gx + gy * gy);                                                 \
+            gx = gx / nrm; gy = gy / nrm;                                                     \
+            T f0 = gy * wc.comp, f1 = (-gx) * wc.comp;                                        \
+            f0 = tmax(tmin(f0, (T)0.1), (T)-0.1);                                             \
+            f1 = tmax(tmin(f1, (T)0.1), (T)-0.1);                                             \
+            ox.comp = cx.comp + k.dtw * f0;                                                   \
+            oy.comp = cy.comp + k.dtw * f1;                                                   \
+        }
+        FS_VC_CELL(x, a.y, al)
+        FS_VC_CELL(y, a.z, a.x)
+        FS_VC_CELL(z, a.w, a.y)
+        FS_VC_CELL(w, ar, a.z)
+#undef FS_VC_CELL
+        if (lm.owner && f) {
+            store_quad_sel<T>(vn + idx<2, T>(g, 0, i0, j), ox, f);
+            store_quad_sel<T>(vn + idx<2, T>(g, 1, i0, j), oy, f);
+        }
+    }
+}
+
+}  // namespace fs

@@ -48,6 +48,7 @@ _PROTOS = {
     "fs_cip_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
     "fs_vort_calc": [_c_vp, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_vort_add": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_vort_confine": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_jacobi_sweep": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_rbsor_halfsweep": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_int, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_poisson_source": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp] + _ROWS,

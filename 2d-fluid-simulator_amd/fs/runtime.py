@@ -235,6 +235,12 @@ class DeviceBase:
         self._run("vort_add", (dt, dx, weight, vn._h, vc._h, vort._h, vort_abs._h),
                   reads=[(vort_abs, 1), (vort, 0), (vc, 0)], writes=[vn])
 
+    def vort_confine(self, dt, dx, weight, vn, vc, vort=None, vort_abs=None):
+        """K5 + K6 in one pass (build-side fusion, same bits); vort / vort_abs are written only when given."""
+        store = vort is not None
+        self._run("vort_confine", (dt, dx, weight, vn._h, vc._h, vort._h if store else None, vort_abs._h if store else None),
+                  reads=[(vc, 2)], writes=[vn] + ([vort, vort_abs] if store else []))
+
     def jacobi_sweep(self, dt, dx, pn, pc, vc):                 # fs/pressure_updater.py:62-66
         self._run("jacobi_sweep", (dt, dx, pn._h, pc._h, vc._h), reads=[(pc, 1), (vc, 1)], writes=[pn])
 

@@ -1,13 +1,21 @@
-"""Vorticity confinement (reference: fs/vorticity_confinement.py:9-59)."""
+"""Vorticity confinement (reference: fs/vorticity_confinement.py:9-59).
+
+`apply()` runs the reference's two kernels (_calc_vorticity, _add_vorticity) as ONE fused HIP pass by
+default: the vorticity is consumed where it is produced instead of round-tripping through HBM
+(17 instead of 42 B/cell), with bit-identical velocities.  The public `vorticity` / `vorticity_abs`
+fields are then only refreshed when `store_fields=True`; `fused=False` restores the two-kernel form.
+"""
 
 
 class VorticityConfinement:
-    def __init__(self, boundary_condition, dt, dx, weight):
+    def __init__(self, boundary_condition, dt, dx, weight, fused=True, store_fields=False):
         self._bc = boundary_condition
         self._dev = boundary_condition.device
         self.dt = dt
         self.dx = dx
         self.weight = weight
+        self._fused = fused
+        self._store_fields = store_fields
         self._resolution = boundary_condition.get_resolution()
         self.vorticity = self._dev.alloc(1)
         self.vorticity_abs = self._dev.alloc(1)
@@ -20,5 +28,11 @@ class VorticityConfinement:
 
     def apply(self, v):
         """Writes v.next only; the caller swaps (fs/vorticity_confinement.py:57-59, fs/solver.py:84-86)."""
+        if self._fused and self._resolution[0] % 4 == 0:
+            if self._store_fields:
+                self._dev.vort_confine(self.dt, self.dx, self.weight, v.next, v.current, self.vorticity, self.vorticity_abs)
+            else:
+                self._dev.vort_confine(self.dt, self.dx, self.weight, v.next, v.current)
+            return
         self._calc_vorticity(v.current)
         self._add_vorticity(v.next, v.current)

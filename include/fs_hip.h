@@ -119,6 +119,11 @@ int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, con
 int fs_vort_add(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, const fs_field *vc,
                 const fs_field *vort, const fs_field *vort_abs, int row_begin, int row_end);
 
+/* _calc_vorticity + _add_vorticity fused into one pass (build-side optimisation, same bits): the vorticity never
+ * goes through HBM.  vort / vort_abs may be NULL; when given they are also written (fluid cells), like K5 does. */
+int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, const fs_field *vc,
+                    fs_field *vort, fs_field *vort_abs, int row_begin, int row_end);
+
 /* ---- pressure Poisson relaxation (predict_p, fs/pressure_updater.py:23-38) -------------------- */
 /* JacobiPressureUpdater._update           fs/pressure_updater.py:62-66   (not-wall cells)       */
 int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_field *pc,

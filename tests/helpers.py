@@ -19,7 +19,7 @@ def make_oracle(g, cfg=None):
                             dtype=np.float64 if cfg["fp64"] else np.float32)
 
 
-def make_product(g, cfg=None, precompute_source=False):
+def make_product(g, cfg=None, precompute_source=False, vc_kwargs=None):
     """Compose the product classes by hand from the scene arrays stored in the fixture (constructor-level API)."""
     import fs
     from fs.boundary_condition import BoundaryCondition, DyeBoundaryCondition
@@ -27,7 +27,7 @@ def make_product(g, cfg=None, precompute_source=False):
     dt, dx, re = cfg["dt"], cfg["dx"], cfg["re"]
     bc = (DyeBoundaryCondition(g["bc_const"], g["bc_dye"], g["bc_mask"]) if cfg["dye"]
           else BoundaryCondition(g["bc_const"], g["bc_mask"]))
-    vc = fs.VorticityConfinement(bc, dt, dx, cfg["vor_eps"]) if cfg["vor_eps"] is not None else None
+    vc = fs.VorticityConfinement(bc, dt, dx, cfg["vor_eps"], **(vc_kwargs or {})) if cfg["vor_eps"] is not None else None
     u = cfg["updater"]
     pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, u[1], u[2], precompute_source=precompute_source) if u[0] == "rbsor"
           else fs.JacobiPressureUpdater(bc, dt, dx, u[1], precompute_source=precompute_source))

@@ -115,6 +115,14 @@ class OracleSlabDevice(DeviceBase):
         elif name == "vort_add":
             dt, dx, weight, vn, vc, w, wa = A
             O._call("oracle_vort_add", dt_, X, Y, dt, dx, weight, b.mask, vn, vc, w, wa); written = [vn]
+        elif name == "vort_confine":
+            dt, dx, weight, vn, vc, w, wa = A
+            if w is None:
+                w, wa = np.zeros((X, Y), dt_), np.zeros((X, Y), dt_)
+            else:
+                written = [w, wa]
+            O._call("oracle_vort_calc", dt_, X, Y, dx, b.mask, w, wa, vc)
+            O._call("oracle_vort_add", dt_, X, Y, dt, dx, weight, b.mask, vn, vc, w, wa); written = written + [vn]
         elif name == "jacobi_sweep":
             dt, dx, pn, pc, vc = A
             O._call("oracle_jacobi_sweep", dt_, X, Y, dt, dx, b.mask, pn, pc, vc); written = [pn]

@@ -25,7 +25,7 @@ def test_trajectory_bitwise(fname, hip_lib):
     g = np.load(os.path.join(GOLDEN, fname))
     cfg = traj_config(g)
     fs.runtime.init(gpu=0, dtype="f64" if cfg["fp64"] else "f32")
-    sim = make_product(g, cfg)
+    sim = make_product(g, cfg, vc_kwargs={"store_fields": True})   # fused K5+K6 pass that also writes w, |w|
     try:
         for step in range(1, max(cfg["snaps"]) + 1):
             sim.step()
@@ -62,6 +62,26 @@ def test_precomputed_source_is_bit_identical(fname, hip_lib):
             sim.step()
         for k, a in sim.field_to_numpy().items():
             assert np.array_equal(a, g[f"step{last}.{k}"])
+    finally:
+        sim._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("vc_kwargs", [{"fused": False}, {"fused": True, "store_fields": False}])
+@pytest.mark.parametrize("fname", ["traj_bc5_cip_vc5.npz", "traj_cfg5_bc3_res96_kk_vc10_re1e8.npz", "traj_bc1_upwind_vc5.npz",
+                                   "traj_dye_bc2_cip_vc5.npz", "traj_bc6_cip_vc5.npz"])
+def test_vorticity_confinement_forms_agree(fname, vc_kwargs, hip_lib):
+    """Two-kernel form (as the reference) and the fused single pass give the same bits."""
+    import fs
+    g = np.load(os.path.join(GOLDEN, fname))
+    cfg = traj_config(g)
+    fs.runtime.init(gpu=0, dtype="f32")
+    sim = make_product(g, cfg, vc_kwargs=vc_kwargs)
+    try:
+        last = max(cfg["snaps"])
+        for _ in range(last):
+            sim.step()
+        for k, a in sim.field_to_numpy().items():
+            assert np.array_equal(a, g[f"step{last}.{k}"]), (fname, k)
     finally:
         sim._solver._bc.device.close()
 

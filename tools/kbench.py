@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench on the BASELINE grid (bc5 res 4096): per-kernel avg time / algorithmic GB/s via HIP events.
+    python tools/kbench.py [--res 4096] [--bc 5] [--steps 20] [--sweeps 100]
+Env: FS_MARCH=0/1, FS_STRIP=<rows>."""
+import argparse, importlib, json, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+importlib.import_module("2d-fluid-simulator_amd")
+import fs
+from bench import algorithmic_bytes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--res", type=int, default=4096); ap.add_argument("--bc", type=int, default=5)
+ap.add_argument("--steps", type=int, default=20); ap.add_argument("--sweeps", type=int, default=100)
+ap.add_argument("--scheme", default="cip"); ap.add_argument("--vc", type=float, default=5.0)
+ap.add_argument("--warm", type=int, default=20)
+a = ap.parse_args()
+res = a.res; dt, dx = 0.05 / res, 1.0 / res
+fs.runtime.init(gpu=0)
+sim = fs.FluidSimulator.create(a.bc, res, dt, dx, 1e6, a.vc or None, a.scheme)
+dev = sim._solver._bc.device
+for _ in range(a.warm): sim.step()
+dev.sync()
+ab, counts = algorithmic_bytes(sim._solver._bc.mask)
+dev.profile(True); dev.profile_reset()
+for _ in range(a.steps): sim.step()
+v, p = sim._solver.get_fields()
+pa, pb, src = dev.alloc(1), dev.alloc(1), dev.alloc(2)
+pa.from_numpy(p.to_numpy())
+for _ in range(a.sweeps // 2):
+    dev.jacobi_sweep(dt, dx, pb, pa, v); dev.jacobi_sweep(dt, dx, pa, pb, v)
+dev.poisson_source(dt, dx, src, v)
+for _ in range(a.sweeps // 2):
+    dev.jacobi_sweep_src(pb, pa, src); dev.jacobi_sweep_src(pa, pb, src)
+rep = dev.profile_report()
+tot = 0.0
+print(f"# FS_MARCH={os.environ.get('FS_MARCH','1')} FS_STRIP={os.environ.get('FS_STRIP','32')} res={res} bc={a.bc}")
+for name, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1] / max(kv[1][0], 1)):
+    if n == 0: continue
+    us = ms / n * 1e3
+    gb = f"{ab[name] / (us * 1e-6) / 1e9:8.1f} GB/s ({ab[name] / (us * 1e-6) / 8e12 * 100:5.1f}% of 8 TB/s)" if name in ab else ""
+    print(f"{name:22s} n={n:5d} avg={us:9.2f} us {gb}")
+dev.close()
