@@ -802,6 +802,30 @@ int fs_rbsor_halfsweep(fs_ctx *ctx, double dt, double dx, double omega, int pari
     })
 }
 
+int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pn, const fs_field *pc, const fs_field *vc,
+                       int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(vc, 2);
+    FS_REQUIRE(pn != pc, "the fused iteration needs distinct p.next / p.current");
+    FS_ROWS();
+    if (!ctx->use_march) {
+        int rc = fs_rbsor_halfsweep(ctx, dt, dx, omega, 1, pn, pc, vc, std::max(row_begin - 1, 0), std::min(row_end + 1, ctx->rows));
+        if (rc) return rc;
+        return fs_rbsor_halfsweep(ctx, dt, dx, omega, 0, pn, pn, vc, row_begin, row_end);
+    }
+    constexpr int RT = 2;
+    const int nq = ctx->X / 4, waves = (nq + 61) / 62;
+    const dim3 grid((waves + 3) / 4, (row_end - row_begin + RT - 1) / RT, 1);
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0, 0.0, omega);
+        return launch(ctx, "rbsor_iteration", [&] {
+            hipLaunchKernelGGL((k_rbsor_fused<RT, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end,
+                               (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
+        });
+    })
+}
+
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc, const fs_field *src,
                            int row_begin, int row_end)
 {

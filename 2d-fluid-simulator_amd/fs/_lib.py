@@ -51,6 +51,7 @@ _PROTOS = {
     "fs_vort_confine": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_jacobi_sweep": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_rbsor_halfsweep": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_int, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_rbsor_iteration": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_poisson_source": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp] + _ROWS,
     "fs_jacobi_sweep_src": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_rbsor_halfsweep_src": [_c_vp, _c_dbl, _c_int, _c_vp, _c_vp, _c_vp] + _ROWS,

@@ -51,10 +51,12 @@ class RedBlackSorPressureUpdater(PressureUpdater):
     into p.next, then the even cells are relaxed IN PLACE on p.next (blending with that buffer's stale
     value), then the buffers swap.  Not a textbook single-buffer SOR - reproduced literally."""
 
-    def __init__(self, boundary_condition, dt, dx, relaxation_factor, n_iter, precompute_source=False):
+    def __init__(self, boundary_condition, dt, dx, relaxation_factor, n_iter, precompute_source=False, fused=True):
         super().__init__(boundary_condition, dt, dx)
         self._n_iter = n_iter
         self._relaxation_factor = relaxation_factor
+        # fused: odd + even pass of one iteration in a single kernel (same bits, fewer bytes)
+        self._fused = fused and not precompute_source and boundary_condition.get_resolution()[0] % 4 == 0
         self._precompute = bool(precompute_source)
         self._src = self._dev.alloc(2) if self._precompute else None
 
@@ -67,6 +69,9 @@ class RedBlackSorPressureUpdater(PressureUpdater):
             p.swap()
 
     def _update(self, p_next, p_current, v_current):
+        if self._fused:
+            self._dev.rbsor_iteration(self.dt, self.dx, self._relaxation_factor, p_next, p_current, v_current)
+            return
         self._update_pressures_odd(p_next, p_current, v_current)
         self._update_pressures_even(p_next, p_next, v_current)
 

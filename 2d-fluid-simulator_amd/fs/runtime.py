@@ -248,6 +248,10 @@ class DeviceBase:
         self._run("rbsor_halfsweep", (dt, dx, omega, parity, pn._h, pc._h, vc._h),
                   reads=[(pc, 1), (vc, 1)], writes=[pn])
 
+    def rbsor_iteration(self, dt, dx, omega, pn, pc, vc):
+        """Odd pass (pc -> pn) + even pass (in place on pn) fused into one kernel; same bits as the two half-sweeps."""
+        self._run("rbsor_iteration", (dt, dx, omega, pn._h, pc._h, vc._h), reads=[(pc, 2), (pn, 1), (vc, 2)], writes=[pn])
+
     def poisson_source(self, dt, dx, src, vc):                  # build-side: source of predict_p, once per step
         self._run("poisson_source", (dt, dx, src._h, vc._h), reads=[(vc, 1)], writes=[src])
 

@@ -129,6 +129,11 @@ class OracleSlabDevice(DeviceBase):
         elif name == "rbsor_halfsweep":
             dt, dx, omega, parity, pn, pc, vc = A
             O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, parity ^ (self.g_lo & 1), b.mask, pn, pc, vc); written = [pn]
+        elif name == "rbsor_iteration":
+            dt, dx, omega, pn, pc, vc = A
+            par = self.g_lo & 1
+            O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, 1 ^ par, b.mask, pn, pc, vc)
+            O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, 0 ^ par, b.mask, pn, pn, vc); written = [pn]
         elif name == "limit_field":
             O.limit_field(A[1], A[0])
         elif name == "clamp_field":

@@ -153,6 +153,21 @@ def test_pressure_update_choreography(cx, tag, src):
     cx.expect(n, "p_current", p.current); cx.expect(n, "p_next", p.next)
 
 
+def test_rbsor_fused_iteration_matches_two_half_sweeps(cx):
+    """odd golden input -> odd pass -> even pass, in one fused launch, against the oracle's two half-sweeps."""
+    from oracle import oracle as O
+    n = "rbsor_odd"
+    pn0, pc0, v0 = cx.g[f"{n}.in.pn"], cx.g[f"{n}.in.pc"], cx.g[f"{n}.in.vc"]
+    ob = O.OracleBC(cx.g["bc_const"], cx.g["bc_mask"])
+    sor = O.OracleRedBlackSor(ob, cx.dt, cx.dx, cx.omega, 1)
+    ref = pn0.copy()
+    sor.half(1, ref, pc0, v0); sor.half(0, ref, ref, v0)
+    pn = cx.field(n, "pn")
+    cx.dev.rbsor_iteration(cx.dt, cx.dx, cx.omega, pn, cx.field(n, "pc"), cx.field(n, "vc"))
+    got = pn.to_numpy()
+    assert np.array_equal(got, ref), f"max|d| = {np.abs(got - ref).max()}"
+
+
 def test_limit_and_clamp(cx):
     from fs.solver import VELOCITY_LIMIT, clamp_field, limit_field
     v = cx.field("limit_field", "v"); limit_field(v, VELOCITY_LIMIT); cx.expect("limit_field", "v", v)

@@ -86,6 +86,26 @@ def test_vorticity_confinement_forms_agree(fname, vc_kwargs, hip_lib):
         sim._solver._bc.device.close()
 
 
+@pytest.mark.parametrize("fname", ["traj_bc5_cip_vc5.npz", "traj_bc3_kk_vc5.npz", "traj_bc2_upwind_vc0.npz", "traj_bc4_cip_vc0.npz"])
+def test_rbsor_two_half_sweeps_agree_with_fused_iteration(fname, hip_lib):
+    """The reference's two half-sweep launches (fused=False) and the fused single-kernel iteration: same bits."""
+    import fs
+    g = np.load(os.path.join(GOLDEN, fname))
+    cfg = traj_config(g)
+    fs.runtime.init(gpu=0, dtype="f32")
+    sim = make_product(g, cfg, rb_fused=False)
+    try:
+        last = max(cfg["snaps"])
+        for _ in range(last):
+            sim.step()
+        for k, a in sim.field_to_numpy().items():
+            assert np.array_equal(a, g[f"step{last}.{k}"]), (fname, k)
+        for which in ("current", "next"):
+            assert np.array_equal(getattr(sim._solver.p, which).to_numpy(), g[f"final.p.{which}"])
+    finally:
+        sim._solver._bc.device.close()
+
+
 @pytest.mark.parametrize("bc,scheme,vc", [(5, "cip", 5.0), (2, "cip", None), (3, "kk", 10.0), (1, "upwind", None)])
 def test_create_vs_oracle_res128(bc, scheme, vc, hip_lib):
     """FluidSimulator.create(...) (scene built by the product's own builders) vs the oracle at a size the
