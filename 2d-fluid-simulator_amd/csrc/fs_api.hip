@@ -77,6 +77,20 @@ static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c-
 // row-marching kernels: x = 1024-cell stripes (256 lanes x 4 cells), y = strips of c->strip rows
 static inline dim3 march_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X / 4 + 255) / 256, (je - jb + c->strip - 1) / c->strip, 1); }
 
+// overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
+struct OvGrid { int nbx, nby; dim3 grid; };
+enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16 };
+static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroups, int family)
+{
+    OvGrid o;
+    const int nq = c->X / 4, waves = (nq + 61) / 62;
+    o.nbx = (waves + 3) / 4;
+    o.nby = (je - jb + rt - 1) / rt;
+    if (c->xcd_mask & family) o.grid = dim3(band_blocks(o.nbx, o.nby), zgroups, 1);
+    else { o.grid = dim3(o.nbx * o.nby, zgroups, 1); o.nbx = -o.nbx; }   // negative nbx = row-major decode
+    return o;
+}
+
 template <bool SRC, typename T>
 static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
 {
@@ -333,6 +347,8 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_STRIP")) { int r = atoi(s); if (r >= 1) c->strip = r; }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
+    c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD;
+    if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);
     if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows
     *out = c;
     return FS_OK;
@@ -655,7 +671,15 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, re);
-        FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d)
+        if (ctx->use_march) {
+            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
+            return launch(ctx, "cip_nonadv", [&] {
+                if (k.p2) hipLaunchKernelGGL((k_cip_nonadv_quad<true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d);
+                else hipLaunchKernelGGL((k_cip_nonadv_quad<false, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d);
+            });
+        }
+        if (k.p2) { FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<true, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d) }
+        FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<false, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d)
     })
 }
 
@@ -671,6 +695,9 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
     })
 }
 
+#define FS_K3Q(CC, NC, PP) hipLaunchKernelGGL((k_cip_nonadv_grad_quad<CC, NC, PP, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+            (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d)
+#define FS_K3(CC, PP, NAME) { FS_LAUNCH_CELLS(NAME, (k_cip_nonadv_grad<CC, PP, T>), ctx->grid(), k, row_begin, (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d) }
 int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, const fs_field *fxc, const fs_field *fyc,
                        const fs_field *fc, const fs_field *fn, int row_begin, int row_end)
 {
@@ -681,11 +708,24 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(1.0, dx, 1.0);
-        if (C == 2) { FS_LAUNCH_CELLS("cip_nonadv_grad", (k_cip_nonadv_grad<2, T>), ctx->grid(), k, row_begin, (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d) }
-        else { FS_LAUNCH_CELLS("cip_nonadv_grad_c3", (k_cip_nonadv_grad<3, T>), ctx->grid(), k, row_begin, (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d) }
+        if (ctx->use_march) {
+            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, C == 2 ? 1 : 3, XCD_GRAD);
+            return launch(ctx, C == 2 ? "cip_nonadv_grad" : "cip_nonadv_grad_c3", [&] {
+                if (C == 2) { if (k.p2) FS_K3Q(2, 2, true); else FS_K3Q(2, 2, false); }
+                else { if (k.p2) FS_K3Q(3, 1, true); else FS_K3Q(3, 1, false); }
+            });
+        }
+        if (C == 2 && k.p2) FS_K3(2, true, "cip_nonadv_grad")
+        else if (C == 2) FS_K3(2, false, "cip_nonadv_grad")
+        else if (k.p2) FS_K3(3, true, "cip_nonadv_grad_c3")
+        else FS_K3(3, false, "cip_nonadv_grad_c3")
     })
 }
 
+#define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
+#define FS_K4N(CC, PP) hipLaunchKernelGGL((k_cip_advect<CC, PP, T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, \
+        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
 int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
                   const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
 {
@@ -697,8 +737,19 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0);
-        if (C == 2) { FS_LAUNCH_CELLS("cip_advect", (k_cip_advect<2, T>), ctx->grid(), k, row_begin, (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d) }
-        else { FS_LAUNCH_CELLS("cip_advect_c3", (k_cip_advect<3, T>), ctx->grid(), k, row_begin, (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d) }
+        const bool self = (v == fc);
+        const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, (C == 2 && self) ? 1 : C, XCD_ADVECT);
+        const dim3 qgrid = og.grid;
+        return launch(ctx, C == 2 ? "cip_advect" : "cip_advect_c3", [&] {
+            if (ctx->use_march) {
+                if (C == 2 && self) { if (k.p2) FS_K4Q(2, 2, true, true); else FS_K4Q(2, 2, true, false); }
+                else if (C == 2) { if (k.p2) FS_K4Q(2, 1, false, true); else FS_K4Q(2, 1, false, false); }
+                else { if (k.p2) FS_K4Q(3, 1, false, true); else FS_K4Q(3, 1, false, false); }
+            } else {
+                if (C == 2) { if (k.p2) FS_K4N(2, true); else FS_K4N(2, false); }
+                else { if (k.p2) FS_K4N(3, true); else FS_K4N(3, false); }
+            }
+        });
     })
 }
 
@@ -742,17 +793,17 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
         return fs_vort_add(ctx, dt, dx, weight, vn, vc, vort, vort_abs, row_begin, row_end);
     }
     constexpr int RT = 4;
-    const int nq = ctx->X / 4, waves = (nq + 61) / 62;
-    const dim3 grid((waves + 3) / 4, (row_end - row_begin + RT - 1) / RT, 1);
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 1, XCD_VORT);
+    const dim3 grid = og.grid;
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0, weight);
-        const bool p2 = is_pow2(k.dx);
+        const bool p2 = k.p2 != 0;
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
         return launch(ctx, "vort_confine", [&] {
-            if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
-            else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
-            else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
-            else hipLaunchKernelGGL((k_vort_fused<RT, false, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+            if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+            else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+            else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+            else hipLaunchKernelGGL((k_vort_fused<RT, false, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
         });
     })
 }
@@ -815,12 +866,11 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
         return fs_rbsor_halfsweep(ctx, dt, dx, omega, 0, pn, pn, vc, row_begin, row_end);
     }
     constexpr int RT = 2;
-    const int nq = ctx->X / 4, waves = (nq + 61) / 62;
-    const dim3 grid((waves + 3) / 4, (row_end - row_begin + RT - 1) / RT, 1);
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 1, XCD_RBSOR);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0, 0.0, omega);
         return launch(ctx, "rbsor_iteration", [&] {
-            hipLaunchKernelGGL((k_rbsor_fused<RT, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end,
+            hipLaunchKernelGGL((k_rbsor_fused<RT, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
                                (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
         });
     })

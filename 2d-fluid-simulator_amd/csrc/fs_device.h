@@ -36,7 +36,10 @@ struct Konst {
     T eight_dt;   // 8*dt  in T                     (fs/pressure_updater.py:37)
     T dtw;        // dt*weight   folded in double   (fs/vorticity_confinement.py:42)
     T om, om1;    // omega, 1.0-omega folded        (fs/pressure_updater.py:112)
-    T inv_dx;     // 1/dx, used only when dx is a power of two (then x*inv_dx == x/dx bit for bit)
+    // When dx is an exact power of two (res = 1024, 4096, 8192 ...) every dx-derived divisor below is one too and
+    // x / d == x * (1/d) bit for bit (exact scaling); p2 switches those divisions to multiplications.
+    int p2;
+    T inv_dx, inv_two_dx, inv_dx_sq, inv_dx2_fold, inv_dx3_fold;
 };
 
 template <typename T> __device__ __forceinline__ T tmin(T a, T b);
@@ -49,6 +52,12 @@ __device__ __forceinline__ float tsqrt(float a) { return sqrtf(a); }
 __device__ __forceinline__ double tsqrt(double a) { return sqrt(a); }
 __device__ __forceinline__ float tabs(float a) { return fabsf(a); }
 __device__ __forceinline__ double tabs(double a) { return fabs(a); }
+
+// x / d with the exact-reciprocal shortcut (see Konst::p2)
+// P2 is a COMPILE-TIME switch: a run-time branch per division splits the kernel into basic blocks and
+// serialises its loads (measured: K2 192 -> 302 us).
+template <bool P2, typename T>
+__device__ __forceinline__ T qdiv(T x, T d, T inv_d) { return P2 ? x * inv_d : x / d; }
 
 __device__ __forceinline__ int clampx(const Grid &g, int i) { return i < 0 ? 0 : (i > g.X - 1 ? g.X - 1 : i); }
 __device__ __forceinline__ int clampy(const Grid &g, int j) { return j < g.jlo ? g.jlo : (j > g.jhi ? g.jhi : j); }
@@ -68,25 +77,25 @@ __device__ __forceinline__ T smp(const T *f, const Grid &g, int c, int i, int j)
 __device__ __forceinline__ uint8_t mask_at(const Grid &g, int i, int j) { return g.mask[(size_t)j * g.Pm + i]; }
 
 // fs/differentiation.py:41-50  central differences
-template <int C, typename T>
+template <int C, bool P2 = false, typename T>
 __device__ __forceinline__ T diff_x(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
-{ return ((T)0.5 * (smp<C>(f, g, c, i + 1, j) - smp<C>(f, g, c, i - 1, j))) / k.dx; }
-template <int C, typename T>
+{ return qdiv<P2>((T)0.5 * (smp<C>(f, g, c, i + 1, j) - smp<C>(f, g, c, i - 1, j)), k.dx, k.inv_dx); }
+template <int C, bool P2 = false, typename T>
 __device__ __forceinline__ T diff_y(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
-{ return ((T)0.5 * (smp<C>(f, g, c, i, j + 1) - smp<C>(f, g, c, i, j - 1))) / k.dx; }
+{ return qdiv<P2>((T)0.5 * (smp<C>(f, g, c, i, j + 1) - smp<C>(f, g, c, i, j - 1)), k.dx, k.inv_dx); }
 // fs/differentiation.py:53-60  second differences
-template <int C, typename T>
+template <int C, bool P2 = false, typename T>
 __device__ __forceinline__ T diff2_x(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
-{ return ((smp<C>(f, g, c, i + 1, j) - (T)2.0 * smp<C>(f, g, c, i, j)) + smp<C>(f, g, c, i - 1, j)) / k.dx_sq; }
-template <int C, typename T>
+{ return qdiv<P2>((smp<C>(f, g, c, i + 1, j) - (T)2.0 * smp<C>(f, g, c, i, j)) + smp<C>(f, g, c, i - 1, j), k.dx_sq, k.inv_dx_sq); }
+template <int C, bool P2 = false, typename T>
 __device__ __forceinline__ T diff2_y(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
-{ return ((smp<C>(f, g, c, i, j + 1) - (T)2.0 * smp<C>(f, g, c, i, j)) + smp<C>(f, g, c, i, j - 1)) / k.dx_sq; }
+{ return qdiv<P2>((smp<C>(f, g, c, i, j + 1) - (T)2.0 * smp<C>(f, g, c, i, j)) + smp<C>(f, g, c, i, j - 1), k.dx_sq, k.inv_dx_sq); }
 // fs/differentiation.py:17-26  forward differences
-template <int C, typename T>
+template <int C, bool P2 = false, typename T>
 __device__ __forceinline__ T fdiff_x(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
-{ return (smp<C>(f, g, c, i + 1, j) - smp<C>(f, g, c, i, j)) / k.dx; }
-template <int C, typename T>
+{ return qdiv<P2>(smp<C>(f, g, c, i + 1, j) - smp<C>(f, g, c, i, j), k.dx, k.inv_dx); }
+template <int C, bool P2 = false, typename T>
 __device__ __forceinline__ T fdiff_y(const T *f, const Grid &g, const Konst<T> &k, int c, int i, int j)
-{ return (smp<C>(f, g, c, i, j + 1) - smp<C>(f, g, c, i, j)) / k.dx; }
+{ return qdiv<P2>(smp<C>(f, g, c, i, j + 1) - smp<C>(f, g, c, i, j), k.dx, k.inv_dx); }
 
 }  // namespace fs

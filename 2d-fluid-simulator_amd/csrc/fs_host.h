@@ -79,6 +79,7 @@ struct fs_ctx {
     std::set<fs_field *> fields;  // live fields, released with the context
     // tuning knobs (env FS_MARCH=0 disables the row-marching kernels, FS_STRIP=<rows per strip>)
     bool use_march = true;
+    int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int strip = 32;
     int jacobi_variant = 2;   // 0: marching strips, 2/4/8: register tile of that many rows (env FS_JACOBI)
 
@@ -104,6 +105,14 @@ struct fs_field {
 
 namespace fs {
 
+// dx (as rounded to T) is an exact power of two: division by it may be replaced by multiplication
+template <typename T>
+inline bool is_pow2(T x)
+{
+    int e;
+    return x > 0 && std::frexp(x, &e) == (T)0.5;
+}
+
 template <typename T>
 inline Konst<T> make_konst(double dt, double dx, double re, double weight = 0.0, double omega = 0.0)
 {
@@ -118,16 +127,15 @@ inline Konst<T> make_konst(double dt, double dx, double re, double weight = 0.0,
     k.dtw = (T)(dt * weight);
     k.om = (T)omega;
     k.om1 = (T)(1.0 - omega);
+    // exact-reciprocal shortcut: only when every dx-derived divisor is a power of two and its inverse is finite
+    k.p2 = is_pow2(k.dx) && is_pow2(k.dx2_fold) && is_pow2(k.dx3_fold) && std::isfinite((double)((T)1 / k.dx3_fold)) ? 1 : 0;
     k.inv_dx = (T)1 / k.dx;
+    k.inv_two_dx = (T)1 / k.two_dx;
+    k.inv_dx_sq = (T)1 / k.dx_sq;
+    k.inv_dx2_fold = (T)1 / k.dx2_fold;
+    k.inv_dx3_fold = (T)1 / k.dx3_fold;
     return k;
 }
 
-// dx (as rounded to T) is an exact power of two: division by it may be replaced by multiplication
-template <typename T>
-inline bool is_pow2(T x)
-{
-    int e;
-    return x > 0 && std::frexp(x, &e) == (T)0.5;
-}
 
 }  // namespace fs

@@ -103,15 +103,15 @@ __global__ __launch_bounds__(256) void k_cip_set_grad(Grid g, Konst<T> k, int jb
 }
 
 // K2  CipMacSolver._non_advection_phase (+ _calc_diffusion), fs/solver.py:229-240, 263-265  (not-wall cells)
-template <typename T>
+template <bool P2, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv(Grid g, Konst<T> k, int jb, T *fn, const T *fc, const T *pc)
 {
     FS_CELL_PROLOGUE
     if (mask_at(g, i, j) == 1) return;
-    const T gp[2] = {diff_x<1>(pc, g, k, 0, i, j), diff_y<1>(pc, g, k, 0, i, j)};
+    const T gp[2] = {diff_x<1, P2>(pc, g, k, 0, i, j), diff_y<1, P2>(pc, g, k, 0, i, j)};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        T dif = (diff2_x<2>(fc, g, k, c, i, j) + diff2_y<2>(fc, g, k, c, i, j)) / k.re;
+        T dif = (diff2_x<2, P2>(fc, g, k, c, i, j) + diff2_y<2, P2>(fc, g, k, c, i, j)) / k.re;
         T gg = (-gp[c]) + dif;
         fn[idx<2, T>(g, c, i, j)] = at<2>(fc, g, c, i, j) + gg * k.dt;
     }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_dye(Grid g, Konst<T> k, int 
 
 // K3  _non_advection_phase_grad, fs/solver.py:242-261  (not-wall cells).  The reference indexes fn/fc
 // without sample(); its out-of-range reads at i = 0 / X-1 are defined here as clamped.
-template <int C, typename T>
+template <int C, bool P2, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv_grad(Grid g, Konst<T> k, int jb, T *fxn, T *fyn,
                                                          const T *fxc, const T *fyc, const T *fc, const T *fn)
 {
@@ -142,48 +142,62 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad(Grid g, Konst<T> k, int
     for (int c = 0; c < C; ++c) {
         T sx = ((smp<C>(fn, g, c, i + 1, j) - smp<C>(fc, g, c, i + 1, j)) - smp<C>(fn, g, c, i - 1, j)) + smp<C>(fc, g, c, i - 1, j);
         T sy = ((smp<C>(fn, g, c, i, j + 1) - smp<C>(fc, g, c, i, j + 1)) - smp<C>(fn, g, c, i, j - 1)) + smp<C>(fc, g, c, i, j - 1);
-        fxn[idx<C, T>(g, c, i, j)] = at<C>(fxc, g, c, i, j) + sx / k.two_dx;
-        fyn[idx<C, T>(g, c, i, j)] = at<C>(fyc, g, c, i, j) + sy / k.two_dx;
+        fxn[idx<C, T>(g, c, i, j)] = at<C>(fxc, g, c, i, j) + qdiv<P2>(sx, k.two_dx, k.inv_two_dx);
+        fyn[idx<C, T>(g, c, i, j)] = at<C>(fyc, g, c, i, j) + qdiv<P2>(sy, k.two_dx, k.inv_two_dx);
     }
 }
 
-// K4  _advection_phase / _cip_advect, fs/solver.py:267-332  (fluid cells; C channels advected by v)
-template <int C, typename T>
+// _cip_advect for one cell and one channel, fs/solver.py:282-332, on already-gathered values:
+//   f00 = f[i,j], f0m = f[i,j_m], fm0 = f[i_m,j], fmm = f[i_m,j_m]  with the upwind cell (i_m, j_m) = (i - sign(u), j - sign(v));
+//   likewise the x- / y-gradient fields; (vx, vy) the advecting velocity, d?? its central differences.
+template <bool P2, typename T>
+__device__ __forceinline__ void cip_point(const Konst<T> &k, T vx, T vy, T dxx, T dxy, T dyx, T dyy,
+                                          T f00, T f0m, T fm0, T fmm, T fx00, T fxm0, T fx0m, T fy00, T fy0m, T fym0,
+                                          T &out_f, T &out_fx, T &out_fy)
+{
+    const T is = vx < (T)0.0 ? (T)-1 : (T)1;   // sign(0) = +1, fs/differentiation.py:12-14
+    const T js = vy < (T)0.0 ? (T)-1 : (T)1;
+    const T i_s_denom = is * k.dx3_fold, j_s_denom = js * k.dx3_fold, is_dx = is * k.dx;
+    const T i_s_inv = is * k.inv_dx3_fold, j_s_inv = js * k.inv_dx3_fold, is_dx_inv = is * k.inv_dx;   // exact when p2
+    const T Xd = (-vx) * k.dt, Yd = (-vy) * k.dt;
+    const T tmp1 = ((f00 - f0m) - fm0) + fmm;
+    const T tmp2 = fm0 - f00;
+    const T tmp3 = f0m - f00;
+    const T a = qdiv<P2>((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2), i_s_denom, i_s_inv);
+    const T b = qdiv<P2>((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3), j_s_denom, j_s_inv);
+    const T cc = qdiv<P2>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv);
+    const T d = qdiv<P2>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv);
+    const T e = qdiv<P2>((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold);
+    const T f = qdiv<P2>((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold);
+    const T gq = qdiv<P2>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv);
+    out_f = (((((a * Xd + cc * Yd) + e) * Xd + gq * Yd) + fx00) * Xd + (((b * Yd + d * Xd) + f) * Yd + fy00) * Yd) + f00;
+    const T Fx = ((((T)3.0 * a) * Xd + ((T)2.0 * cc) * Yd) + (T)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
+    const T Fy = ((((T)3.0 * b) * Yd + ((T)2.0 * d) * Xd) + (T)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;
+    out_fx = Fx - (k.dt * (Fx * dxx + Fy * dxy)) / (T)2.0;
+    out_fy = Fy - (k.dt * (Fx * dyx + Fy * dyy)) / (T)2.0;
+}
+
+// K4  _advection_phase / _cip_advect, fs/solver.py:267-332  (fluid cells; C channels advected by v), one cell per lane
+template <int C, bool P2, typename T>
 __global__ __launch_bounds__(256) void k_cip_advect(Grid g, Konst<T> k, int jb, T *fn, T *fxn, T *fyn,
                                                     const T *fc, const T *fxc, const T *fyc, const T *v)
 {
     FS_CELL_PROLOGUE
     if (mask_at(g, i, j) != 0) return;
     const T vx = at<2>(v, g, 0, i, j), vy = at<2>(v, g, 1, i, j);
-    const int i_s = vx < (T)0.0 ? -1 : 1;   // sign(0) = +1, fs/differentiation.py:12-14
-    const int j_s = vy < (T)0.0 ? -1 : 1;
-    const int im = i - i_s, jm = j - j_s;
-    const T is = (T)i_s, js = (T)j_s;
-    const T i_s_denom = is * k.dx3_fold, j_s_denom = js * k.dx3_fold, is_dx = is * k.dx;
-    const T Xd = (-vx) * k.dt, Yd = (-vy) * k.dt;
-    const T dxx = diff_x<2>(v, g, k, 0, i, j), dxy = diff_x<2>(v, g, k, 1, i, j);
-    const T dyx = diff_y<2>(v, g, k, 0, i, j), dyy = diff_y<2>(v, g, k, 1, i, j);
+    const int im = i - (vx < (T)0.0 ? -1 : 1), jm = j - (vy < (T)0.0 ? -1 : 1);
+    const T dxx = diff_x<2, P2>(v, g, k, 0, i, j), dxy = diff_x<2, P2>(v, g, k, 1, i, j);
+    const T dyx = diff_y<2, P2>(v, g, k, 0, i, j), dyy = diff_y<2, P2>(v, g, k, 1, i, j);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const T f00 = at<C>(fc, g, c, i, j), f0m = smp<C>(fc, g, c, i, jm), fm0 = smp<C>(fc, g, c, im, j), fmm = smp<C>(fc, g, c, im, jm);
-        const T fx00 = at<C>(fxc, g, c, i, j), fxm0 = smp<C>(fxc, g, c, im, j), fx0m = smp<C>(fxc, g, c, i, jm);
-        const T fy00 = at<C>(fyc, g, c, i, j), fy0m = smp<C>(fyc, g, c, i, jm), fym0 = smp<C>(fyc, g, c, im, j);
-        const T tmp1 = ((f00 - f0m) - fm0) + fmm;
-        const T tmp2 = fm0 - f00;
-        const T tmp3 = f0m - f00;
-        const T a = ((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2)) / i_s_denom;
-        const T b = ((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3)) / j_s_denom;
-        const T cc = ((-tmp1) - (is * (fx0m - fx00)) * k.dx) / j_s_denom;
-        const T d = ((-tmp1) - (js * (fym0 - fy00)) * k.dx) / i_s_denom;
-        const T e = ((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx) / k.dx2_fold;
-        const T f = ((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx) / k.dx2_fold;
-        const T gq = ((-(fym0 - fy00)) + cc * k.dx2_fold) / is_dx;
-        fn[idx<C, T>(g, c, i, j)] =
-            (((((a * Xd + cc * Yd) + e) * Xd + gq * Yd) + fx00) * Xd + (((b * Yd + d * Xd) + f) * Yd + fy00) * Yd) + f00;
-        const T Fx = ((((T)3.0 * a) * Xd + ((T)2.0 * cc) * Yd) + (T)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
-        const T Fy = ((((T)3.0 * b) * Yd + ((T)2.0 * d) * Xd) + (T)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;
-        fxn[idx<C, T>(g, c, i, j)] = Fx - (k.dt * (Fx * dxx + Fy * dxy)) / (T)2.0;
-        fyn[idx<C, T>(g, c, i, j)] = Fy - (k.dt * (Fx * dyx + Fy * dyy)) / (T)2.0;
+        T of, ofx, ofy;
+        cip_point<P2>(k, vx, vy, dxx, dxy, dyx, dyy,
+                  at<C>(fc, g, c, i, j), smp<C>(fc, g, c, i, jm), smp<C>(fc, g, c, im, j), smp<C>(fc, g, c, im, jm),
+                  at<C>(fxc, g, c, i, j), smp<C>(fxc, g, c, im, j), smp<C>(fxc, g, c, i, jm),
+                  at<C>(fyc, g, c, i, j), smp<C>(fyc, g, c, i, jm), smp<C>(fyc, g, c, im, j), of, ofx, ofy);
+        fn[idx<C, T>(g, c, i, j)] = of;
+        fxn[idx<C, T>(g, c, i, j)] = ofx;
+        fyn[idx<C, T>(g, c, i, j)] = ofy;
     }
 }
 

@@ -19,6 +19,7 @@
 // fs_kernels.h (and the reference); results are bit-identical.
 #pragma once
 #include "fs_device.h"
+#include "fs_kernels.h"
 
 namespace fs {
 
@@ -225,10 +226,39 @@ struct LaneMap {
     bool at_lo;    // quad starts at i = 0  (left neighbour of .x is .x itself: sample() clamp)
     bool at_hi;    // quad ends at i = X-1
 };
-__device__ __forceinline__ LaneMap lane_map(const Grid &g)
+// XCD-aware block mapping for the tile kernels.  Workgroups are dispatched round-robin over the 8 XCDs
+// (block b -> XCD b % 8), each with a private 4 MiB L2.  A 1-D launch is decoded so that groups of FS_XCD_GROUP
+// consecutive tile rows (x-blocks innermost) stay on one XCD: vertically adjacent tiles, which re-read each
+// other's halo rows, then run on the same XCD close in time and the re-read is a local L2 hit.  Groups are dealt
+// to the XCDs cyclically, so regions with little work (solid walls) are spread evenly - one contiguous band per
+// XCD measured 15 % slower on scene 5 because the dispatcher does not rebalance.  Placement only affects speed.
+#define FS_XCD_GROUP 8
+__device__ __forceinline__ bool band_coords(int nbx, int nby, int &bx, int &by)
+{
+    if (nbx < 0) {   // plain row-major decode (rows of one tile row spread over the XCDs)
+        nbx = -nbx;
+        by = blockIdx.x / nbx;
+        bx = blockIdx.x - by * nbx;
+        return by < nby;
+    }
+    const int id = blockIdx.x, xcd = id & 7, t = id >> 3;
+    const int per_group = FS_XCD_GROUP * nbx;
+    const int lg = t / per_group, rem = t - lg * per_group;
+    const int ly = rem / nbx;
+    bx = rem - ly * nbx;
+    by = (lg * 8 + xcd) * FS_XCD_GROUP + ly;
+    return by < nby;
+}
+static inline int band_blocks(int nbx, int nby)
+{
+    const int groups = (nby + FS_XCD_GROUP - 1) / FS_XCD_GROUP;
+    return 8 * ((groups + 7) / 8) * FS_XCD_GROUP * nbx;
+}
+
+__device__ __forceinline__ LaneMap lane_map(const Grid &g, int bx)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wave = bx * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nq = g.X >> 2;
     int q = wave * 62 - 1 + lane;
     LaneMap m;
@@ -239,9 +269,9 @@ __device__ __forceinline__ LaneMap lane_map(const Grid &g)
     m.at_hi = q == nq - 1;
     return m;
 }
-__device__ __forceinline__ bool wave_in_range(const Grid &g)
+__device__ __forceinline__ bool wave_in_range(const Grid &g, int bx)
 {
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wave = bx * (blockDim.x >> 6) + (threadIdx.x >> 6);
     return wave * 62 < (g.X >> 2);
 }
 
@@ -255,7 +285,7 @@ __device__ __forceinline__ T quad_right(const LaneMap &m, const typename Quad<T>
 // x / dx for the central differences: a true IEEE division unless dx is a power of two, where the
 // (exact) multiplication by 1/dx gives the same bits for a fraction of the instructions.
 template <bool P2, typename T>
-__device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return P2 ? x * k.inv_dx : x / k.dx; }
+__device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return P2 ? x * k.inv_dx : x / k.dx; }   // P2 only when k.p2
 
 // ------------------------------------------------------------------------------------------------
 // K5 + K6 fused: vorticity confinement in one pass (fs/vorticity_confinement.py:27-55).
@@ -267,13 +297,14 @@ __device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return P2 ? x * k.
 // VorticityConfinement; the unfused pair of kernels remains available and is what parity tests compare with).
 // ------------------------------------------------------------------------------------------------
 template <int RT, bool P2, bool STORE_W, typename T>
-__global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs)
+__global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs)
 {
     using V = typename Quad<T>::type;
-    if (!wave_in_range(g)) return;
-    const LaneMap lm = lane_map(g);
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
     const int i0 = lm.i0;
-    const int j0 = jb + blockIdx.y * RT;
+    const int j0 = jb + by * RT;
 
     unsigned fl[RT + 2];   // fluid selectors of rows j0-1 .. j0+RT (clamped rows repeat)
     bool any = false;
@@ -399,12 +430,13 @@ __device__ __forceinline__ void rb_relax_row(const Konst<T> &k, const LaneMap &l
 }
 
 template <int RT, typename T>
-__global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int jb, int je, T *pn, const T *pc, const T *vc)
+__global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
 {
-    if (!wave_in_range(g)) return;
-    const LaneMap lm = lane_map(g);
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
     const int i0 = lm.i0;
-    const int j0 = jb + blockIdx.y * RT;
+    const int j0 = jb + by * RT;
 
     unsigned fl[RT + 2];   // rows j0-1 .. j0+RT
     bool any = false;
@@ -449,6 +481,185 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int jb,
         if (par) rb_relax_row<1, 0>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
         else     rb_relax_row<0, 0>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
         if (lm.owner && fl[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), out.quad(), fl[r]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K4  CIP advection (fs/solver.py:267-332), quad form.  A lane advects NC channels [c0, c0+NC) of a C-channel
+// field for its 4 cells of one row: rows j-1, j, j+1 of the value field and of both gradient fields are
+// requested up front as 16-byte loads (9*NC + 6 independent loads per lane), the x-neighbours come from the
+// adjacent lanes (DPP; overlapped-wave mapping, no edge loads), and the data-dependent upwind cell
+// (i - sign(u), j - sign(v)) becomes a per-cell select among the 3x3 gathered values.  blockIdx.z selects the
+// channel group (dye: 3 single-channel passes sharing the advecting velocity).
+// ------------------------------------------------------------------------------------------------
+template <int C, int NC, bool SELF, bool P2, typename T>
+__global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+                                                         const T *fc, const T *fxc, const T *fyc, const T *v)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0;
+    const int j = jb + by;
+    const int c0 = blockIdx.y * NC;
+    const unsigned fl = sel_fluid(mask_quad(g, i0, j));
+    if (!__any(fl != 0u)) return;
+    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
+
+    Q4<T> F[NC][3], FX[NC][3], FY[NC][3];      // rows j-1, j, j+1
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        F[c][0] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jm)); F[c][1] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, j)); F[c][2] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jp));
+        FX[c][0] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, jm)); FX[c][1] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, j)); FX[c][2] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, jp));
+        FY[c][0] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, jm)); FY[c][1] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, j)); FY[c][2] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, jp));
+    }
+    Q4<T> VX[3], VY[3];
+    if (SELF) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { VX[r] = F[0][r]; VY[r] = F[1][r]; }
+    } else {
+        VX[0] = Q4<T>(load_quad<2>(v, g, 0, i0, jm)); VX[1] = Q4<T>(load_quad<2>(v, g, 0, i0, j)); VX[2] = Q4<T>(load_quad<2>(v, g, 0, i0, jp));
+        VY[0] = Q4<T>(load_quad<2>(v, g, 1, i0, jm)); VY[1] = Q4<T>(load_quad<2>(v, g, 1, i0, j)); VY[2] = Q4<T>(load_quad<2>(v, g, 1, i0, jp));
+    }
+    // x-neighbours (left of cell 0 / right of cell 3)
+    const T vxl = quad_left<T>(lm, VX[1].quad()), vxr = quad_right<T>(lm, VX[1].quad());
+    const T vyl = quad_left<T>(lm, VY[1].quad()), vyr = quad_right<T>(lm, VY[1].quad());
+    T fl_[NC][3], fr_[NC][3], fxl[NC], fxr[NC], fyl[NC], fyr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { fl_[c][r] = quad_left<T>(lm, F[c][r].quad()); fr_[c][r] = quad_right<T>(lm, F[c][r].quad()); }
+        fxl[c] = quad_left<T>(lm, FX[c][1].quad()); fxr[c] = quad_right<T>(lm, FX[c][1].quad());
+        fyl[c] = quad_left<T>(lm, FY[c][1].quad()); fyr[c] = quad_right<T>(lm, FY[c][1].quad());
+    }
+    Q4<T> OF[NC], OFX[NC], OFY[NC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const T vx = VX[1].a[q], vy = VY[1].a[q];
+        const bool nx = vx < (T)0.0, ny = vy < (T)0.0;       // upwind cell is E / N when the velocity is negative
+        const T vxE = q == 3 ? vxr : VX[1].a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VX[1].a[q == 0 ? 0 : q - 1];
+        const T vyE = q == 3 ? vyr : VY[1].a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VY[1].a[q == 0 ? 0 : q - 1];
+        const T dxx = qdiv<P2>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx), dxy = qdiv<P2>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx);
+        const T dyx = qdiv<P2>((T)0.5 * (VX[2].a[q] - VX[0].a[q]), k.dx, k.inv_dx), dyy = qdiv<P2>((T)0.5 * (VY[2].a[q] - VY[0].a[q]), k.dx, k.inv_dx);
+        const int ru = ny ? 2 : 0;                             // row of the upwind cell
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const T fE1 = q == 3 ? fr_[c][1] : F[c][1].a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl_[c][1] : F[c][1].a[q == 0 ? 0 : q - 1];
+            const T fE0 = q == 3 ? fr_[c][0] : F[c][0].a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl_[c][0] : F[c][0].a[q == 0 ? 0 : q - 1];
+            const T fE2 = q == 3 ? fr_[c][2] : F[c][2].a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl_[c][2] : F[c][2].a[q == 0 ? 0 : q - 1];
+            const T fxE = q == 3 ? fxr[c] : FX[c][1].a[q == 3 ? 3 : q + 1], fxW = q == 0 ? fxl[c] : FX[c][1].a[q == 0 ? 0 : q - 1];
+            const T fyE = q == 3 ? fyr[c] : FY[c][1].a[q == 3 ? 3 : q + 1], fyW = q == 0 ? fyl[c] : FY[c][1].a[q == 0 ? 0 : q - 1];
+            const T f00 = F[c][1].a[q];
+            const T f0m = ny ? F[c][2].a[q] : F[c][0].a[q];
+            const T fm0 = nx ? fE1 : fW1;
+            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
+            const T fx00 = FX[c][1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? FX[c][2].a[q] : FX[c][0].a[q];
+            const T fy00 = FY[c][1].a[q], fy0m = ny ? FY[c][2].a[q] : FY[c][0].a[q], fym0 = nx ? fyE : fyW;
+            (void)ru;
+            cip_point<P2>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
+                      OF[c].a[q], OFX[c].a[q], OFY[c].a[q]);
+        }
+    }
+    if (lm.owner && fl) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            store_quad_sel<T>(fn + idx<C, T>(g, c0 + c, i0, j), OF[c].quad(), fl);
+            store_quad_sel<T>(fxn + idx<C, T>(g, c0 + c, i0, j), OFX[c].quad(), fl);
+            store_quad_sel<T>(fyn + idx<C, T>(g, c0 + c, i0, j), OFY[c].quad(), fl);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K2  CipMacSolver._non_advection_phase (fs/solver.py:229-240, 263-265), quad form: rows j-1, j, j+1 of v (2 planes)
+// and p are requested up front; not-wall cells get  fn = fc + ((-grad p) + lap(fc)/re) * dt.
+// ------------------------------------------------------------------------------------------------
+template <bool P2, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0, j = jb + by;
+    const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
+    if (!__any(nw != 0u)) return;
+    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
+    Q4<T> F[2][3], P[3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { F[c][0] = Q4<T>(load_quad<2>(fc, g, c, i0, jm)); F[c][1] = Q4<T>(load_quad<2>(fc, g, c, i0, j)); F[c][2] = Q4<T>(load_quad<2>(fc, g, c, i0, jp)); }
+    P[0] = Q4<T>(load_quad<1>(pc, g, 0, i0, jm)); P[1] = Q4<T>(load_quad<1>(pc, g, 0, i0, j)); P[2] = Q4<T>(load_quad<1>(pc, g, 0, i0, jp));
+    const T pl = quad_left<T>(lm, P[1].quad()), pr = quad_right<T>(lm, P[1].quad());
+    Q4<T> O[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const T l = quad_left<T>(lm, F[c][1].quad()), r = quad_right<T>(lm, F[c][1].quad());
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T fE = q == 3 ? r : F[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : F[c][1].a[q == 0 ? 0 : q - 1];
+            const T f0 = F[c][1].a[q];
+            const T d2x = qdiv<P2>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq);
+            const T d2y = qdiv<P2>((F[c][2].a[q] - (T)2.0 * f0) + F[c][0].a[q], k.dx_sq, k.inv_dx_sq);
+            const T dif = (d2x + d2y) / k.re;
+            T gp;
+            if (c == 0) {
+                const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
+                gp = qdiv<P2>((T)0.5 * (pE - pW), k.dx, k.inv_dx);
+            } else {
+                gp = qdiv<P2>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx);
+            }
+            const T gg = (-gp) + dif;
+            O[c].a[q] = f0 + gg * k.dt;
+        }
+    }
+    if (lm.owner && nw) {
+        store_quad_sel<T>(fn + idx<2, T>(g, 0, i0, j), O[0].quad(), nw);
+        store_quad_sel<T>(fn + idx<2, T>(g, 1, i0, j), O[1].quad(), nw);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  _non_advection_phase_grad (fs/solver.py:242-261), quad form, NC channels [c0, c0+NC) per lane (blockIdx.y = group).
+// Out-of-range neighbours are clamped (SURVEY.md H2 policy), as in the one-cell-per-lane kernel.
+// ------------------------------------------------------------------------------------------------
+template <int C, int NC, bool P2, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
+                                                              const T *fxc, const T *fyc, const T *fc, const T *fn)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0, j = jb + by, c0 = blockIdx.y * NC;
+    const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
+    if (!__any(nw != 0u)) return;
+    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
+    Q4<T> N[NC][3], Fc[NC][3], GX[NC], GY[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        N[c][0] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, jm)); N[c][1] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, j)); N[c][2] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, jp));
+        Fc[c][0] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jm)); Fc[c][1] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, j)); Fc[c][2] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jp));
+        GX[c] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, j));
+        GY[c] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, j));
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const T nl = quad_left<T>(lm, N[c][1].quad()), nr = quad_right<T>(lm, N[c][1].quad());
+        const T cl = quad_left<T>(lm, Fc[c][1].quad()), cr = quad_right<T>(lm, Fc[c][1].quad());
+        Q4<T> OX, OY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T nE = q == 3 ? nr : N[c][1].a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : N[c][1].a[q == 0 ? 0 : q - 1];
+            const T cE = q == 3 ? cr : Fc[c][1].a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : Fc[c][1].a[q == 0 ? 0 : q - 1];
+            const T sx = ((nE - cE) - nW) + cW;
+            const T sy = ((N[c][2].a[q] - Fc[c][2].a[q]) - N[c][0].a[q]) + Fc[c][0].a[q];
+            OX.a[q] = GX[c].a[q] + qdiv<P2>(sx, k.two_dx, k.inv_two_dx);
+            OY.a[q] = GY[c].a[q] + qdiv<P2>(sy, k.two_dx, k.inv_two_dx);
+        }
+        if (lm.owner && nw) {
+            store_quad_sel<T>(fxn + idx<C, T>(g, c0 + c, i0, j), OX.quad(), nw);
+            store_quad_sel<T>(fyn + idx<C, T>(g, c0 + c, i0, j), OY.quad(), nw);
+        }
     }
 }
 

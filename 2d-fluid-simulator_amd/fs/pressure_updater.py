@@ -6,6 +6,7 @@ source term depends only on v, which is constant over the sweeps of one step).  
 reference's operation order and give bit-identical pressures; `precompute_source` only trades one
 extra pass per step for cheaper sweeps.
 """
+import os
 from abc import ABCMeta, abstractmethod
 
 
@@ -56,7 +57,8 @@ class RedBlackSorPressureUpdater(PressureUpdater):
         self._n_iter = n_iter
         self._relaxation_factor = relaxation_factor
         # fused: odd + even pass of one iteration in a single kernel (same bits, fewer bytes)
-        self._fused = fused and not precompute_source and boundary_condition.get_resolution()[0] % 4 == 0
+        self._fused = (fused and not precompute_source and boundary_condition.get_resolution()[0] % 4 == 0
+                       and os.environ.get("FS_MARCH", "1") != "0")
         self._precompute = bool(precompute_source)
         self._src = self._dev.alloc(2) if self._precompute else None
 

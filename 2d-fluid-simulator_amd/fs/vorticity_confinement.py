@@ -5,6 +5,7 @@ default: the vorticity is consumed where it is produced instead of round-trippin
 (17 instead of 42 B/cell), with bit-identical velocities.  The public `vorticity` / `vorticity_abs`
 fields are then only refreshed when `store_fields=True`; `fused=False` restores the two-kernel form.
 """
+import os
 
 
 class VorticityConfinement:
@@ -14,7 +15,7 @@ class VorticityConfinement:
         self.dt = dt
         self.dx = dx
         self.weight = weight
-        self._fused = fused
+        self._fused = fused and os.environ.get("FS_MARCH", "1") != "0"   # FS_MARCH=0: debugging knob, one-cell-per-lane kernels only
         self._store_fields = store_fields
         self._resolution = boundary_condition.get_resolution()
         self.vorticity = self._dev.alloc(1)
