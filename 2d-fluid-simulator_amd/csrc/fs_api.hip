@@ -86,7 +86,7 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
     const int nq = c->X / 4, waves = (nq + 61) / 62;
     o.nbx = (waves + 3) / 4;
     o.nby = (je - jb + rt - 1) / rt;
-    if (c->xcd_mask & family) o.grid = dim3(band_blocks(o.nbx, o.nby), zgroups, 1);
+    if (c->xcd_mask & family) { o.grid = dim3(band_blocks(o.nbx, o.nby, c->xcd_group), zgroups, 1); o.nby |= (c->xcd_group - 1) << 24; }
     else { o.grid = dim3(o.nbx * o.nby, zgroups, 1); o.nbx = -o.nbx; }   // negative nbx = row-major decode
     return o;
 }
@@ -349,6 +349,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD;
     if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);
+    if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
     if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows
     *out = c;
     return FS_OK;

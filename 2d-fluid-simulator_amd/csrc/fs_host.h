@@ -79,6 +79,7 @@ struct fs_ctx {
     std::set<fs_field *> fields;  // live fields, released with the context
     // tuning knobs (env FS_MARCH=0 disables the row-marching kernels, FS_STRIP=<rows per strip>)
     bool use_march = true;
+    int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int strip = 32;
     int jacobi_variant = 2;   // 0: marching strips, 2/4/8: register tile of that many rows (env FS_JACOBI)

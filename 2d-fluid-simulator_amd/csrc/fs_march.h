@@ -39,6 +39,21 @@ template <int C, typename T>
 __device__ __forceinline__ typename Quad<T>::type load_quad(const T *f, const Grid &g, int c, int i0, int j)
 { return *reinterpret_cast<const typename Quad<T>::type *>(f + idx<C, T>(g, c, i0, j)); }
 
+// predicated load: lanes whose quad (and whose neighbours' quads) are solid wall fetch nothing
+template <int C, typename T>
+__device__ __forceinline__ typename Quad<T>::type load_quad_if(bool need, const T *f, const Grid &g, int c, int i0, int j)
+{
+    typename Quad<T>::type q;
+    q.x = q.y = q.z = q.w = (T)0;
+    if (need) q = *reinterpret_cast<const typename Quad<T>::type *>(f + idx<C, T>(g, c, i0, j));
+    return q;
+}
+
+__device__ __forceinline__ unsigned lane_prev_u(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned lane_next_u(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false); }
+// does this lane, or a lane next to it, have any active cell?  (its loads feed the neighbours through DPP)
+__device__ __forceinline__ bool lane_needed(unsigned active) { return (active | lane_prev_u(active) | lane_next_u(active)) != 0u; }
+
 // left neighbour of q.x and right neighbour of q.w in row j of channel c (clamped at the domain edge)
 template <int C, typename T>
 __device__ __forceinline__ void quad_sides(const T *f, const Grid &g, int c, int i0, int j, int lane,
@@ -174,13 +189,14 @@ __global__ __launch_bounds__(256) void k_jacobi_tile(Grid g, Konst<T> k, int jb,
         any |= sel[r] != 0u;
     }
     if (!__any(any)) return;
+    const bool need = lane_needed(any ? 1u : 0u);
 
     V P[RT + 2], VX[RT + 2], VY[RT + 2];
 #pragma unroll
     for (int r = 0; r < RT + 2; ++r) {
         const int j = clampy(g, j0 - 1 + r);
-        P[r] = load_quad<1>(pc, g, 0, i0, j);
-        if (!SRC) { VX[r] = load_quad<2>(vs, g, 0, i0, j); VY[r] = load_quad<2>(vs, g, 1, i0, j); }
+        P[r] = load_quad_if<1>(need, pc, g, 0, i0, j);
+        if (!SRC) { VX[r] = load_quad_if<2>(need, vs, g, 0, i0, j); VY[r] = load_quad_if<2>(need, vs, g, 1, i0, j); }
     }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
@@ -191,8 +207,8 @@ __global__ __launch_bounds__(256) void k_jacobi_tile(Grid g, Konst<T> k, int jb,
         quad_sides<1>(pc, g, 0, i0, jc, lane, P[r + 1], pl, pr);
         V s2, s3;
         if (SRC) {
-            s2 = load_quad<2>(vs, g, 0, i0, jc);
-            s3 = load_quad<2>(vs, g, 1, i0, jc);
+            s2 = load_quad_if<2>(sel[r] != 0u, vs, g, 0, i0, jc);
+            s3 = load_quad_if<2>(sel[r] != 0u, vs, g, 1, i0, jc);
         } else {
             T xl, xr, yl, yr;
             quad_sides<2>(vs, g, 0, i0, jc, lane, VX[r + 1], xl, xr);
@@ -232,9 +248,9 @@ struct LaneMap {
 // other's halo rows, then run on the same XCD close in time and the re-read is a local L2 hit.  Groups are dealt
 // to the XCDs cyclically, so regions with little work (solid walls) are spread evenly - one contiguous band per
 // XCD measured 15 % slower on scene 5 because the dispatcher does not rebalance.  Placement only affects speed.
-#define FS_XCD_GROUP 8
-__device__ __forceinline__ bool band_coords(int nbx, int nby, int &bx, int &by)
+__device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by)
 {
+    const int nby = nby_packed & 0xffffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte
     if (nbx < 0) {   // plain row-major decode (rows of one tile row spread over the XCDs)
         nbx = -nbx;
         by = blockIdx.x / nbx;
@@ -249,7 +265,7 @@ __device__ __forceinline__ bool band_coords(int nbx, int nby, int &bx, int &by)
     by = (lg * 8 + xcd) * FS_XCD_GROUP + ly;
     return by < nby;
 }
-static inline int band_blocks(int nbx, int nby)
+static inline int band_blocks(int nbx, int nby, int FS_XCD_GROUP)
 {
     const int groups = (nby + FS_XCD_GROUP - 1) / FS_XCD_GROUP;
     return 8 * ((groups + 7) / 8) * FS_XCD_GROUP * nbx;
@@ -315,13 +331,14 @@ __global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx,
         if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
     }
     if (!__any(any)) return;
+    const bool need = lane_needed(any ? 1u : 0u);
 
     V VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1
 #pragma unroll
     for (int r = 0; r < RT + 4; ++r) {
         const int j = clampy(g, j0 - 2 + r);
-        VX[r] = load_quad<2>(vc, g, 0, i0, j);
-        VY[r] = load_quad<2>(vc, g, 1, i0, j);
+        VX[r] = load_quad_if<2>(need, vc, g, 0, i0, j);
+        VY[r] = load_quad_if<2>(need, vc, g, 1, i0, j);
     }
     // vorticity of rows j0-1 .. j0+RT  (index r <-> v slot r+1)
     V W[RT + 2];
@@ -446,18 +463,19 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx
         if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
     }
     if (!__any(any)) return;
+    const bool need = lane_needed(any ? 1u : 0u);
 
     Q4<T> PC[RT + 4], VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1 (clamped)
 #pragma unroll
     for (int r = 0; r < RT + 4; ++r) {
         const int j = clampy(g, j0 - 2 + r);
-        PC[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, j));
-        VX[r] = Q4<T>(load_quad<2>(vc, g, 0, i0, j));
-        VY[r] = Q4<T>(load_quad<2>(vc, g, 1, i0, j));
+        PC[r] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, j));
+        VX[r] = Q4<T>(load_quad_if<2>(need, vc, g, 0, i0, j));
+        VY[r] = Q4<T>(load_quad_if<2>(need, vc, g, 1, i0, j));
     }
     Q4<T> PO[RT + 2];                            // p.next after the odd pass, rows j0-1 .. j0+RT
 #pragma unroll
-    for (int r = 0; r < RT + 2; ++r) PO[r] = Q4<T>(load_quad<1>(pn, g, 0, i0, clampy(g, j0 - 1 + r)));
+    for (int r = 0; r < RT + 2; ++r) PO[r] = Q4<T>(load_quad_if<1>(need, pn, g, 0, i0, clampy(g, j0 - 1 + r)));
 
     // odd pass on rows j0-1 .. j0+RT (slot r <-> field slot r+1)
 #pragma unroll
@@ -505,22 +523,23 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
     const int c0 = blockIdx.y * NC;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
     if (!__any(fl != 0u)) return;
+    const bool need = lane_needed(fl);
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
 
     Q4<T> F[NC][3], FX[NC][3], FY[NC][3];      // rows j-1, j, j+1
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        F[c][0] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jm)); F[c][1] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, j)); F[c][2] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jp));
-        FX[c][0] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, jm)); FX[c][1] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, j)); FX[c][2] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, jp));
-        FY[c][0] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, jm)); FY[c][1] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, j)); FY[c][2] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, jp));
+        F[c][0] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, jm)); F[c][1] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, j)); F[c][2] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, jp));
+        FX[c][0] = Q4<T>(load_quad_if<C>(need, fxc, g, c0 + c, i0, jm)); FX[c][1] = Q4<T>(load_quad_if<C>(need, fxc, g, c0 + c, i0, j)); FX[c][2] = Q4<T>(load_quad_if<C>(need, fxc, g, c0 + c, i0, jp));
+        FY[c][0] = Q4<T>(load_quad_if<C>(need, fyc, g, c0 + c, i0, jm)); FY[c][1] = Q4<T>(load_quad_if<C>(need, fyc, g, c0 + c, i0, j)); FY[c][2] = Q4<T>(load_quad_if<C>(need, fyc, g, c0 + c, i0, jp));
     }
     Q4<T> VX[3], VY[3];
     if (SELF) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) { VX[r] = F[0][r]; VY[r] = F[1][r]; }
     } else {
-        VX[0] = Q4<T>(load_quad<2>(v, g, 0, i0, jm)); VX[1] = Q4<T>(load_quad<2>(v, g, 0, i0, j)); VX[2] = Q4<T>(load_quad<2>(v, g, 0, i0, jp));
-        VY[0] = Q4<T>(load_quad<2>(v, g, 1, i0, jm)); VY[1] = Q4<T>(load_quad<2>(v, g, 1, i0, j)); VY[2] = Q4<T>(load_quad<2>(v, g, 1, i0, jp));
+        VX[0] = Q4<T>(load_quad_if<2>(need, v, g, 0, i0, jm)); VX[1] = Q4<T>(load_quad_if<2>(need, v, g, 0, i0, j)); VX[2] = Q4<T>(load_quad_if<2>(need, v, g, 0, i0, jp));
+        VY[0] = Q4<T>(load_quad_if<2>(need, v, g, 1, i0, jm)); VY[1] = Q4<T>(load_quad_if<2>(need, v, g, 1, i0, j)); VY[2] = Q4<T>(load_quad_if<2>(need, v, g, 1, i0, jp));
     }
     // x-neighbours (left of cell 0 / right of cell 3)
     const T vxl = quad_left<T>(lm, VX[1].quad()), vxr = quad_right<T>(lm, VX[1].quad());
@@ -585,11 +604,12 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return;
+    const bool need = lane_needed(nw);
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> F[2][3], P[3];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { F[c][0] = Q4<T>(load_quad<2>(fc, g, c, i0, jm)); F[c][1] = Q4<T>(load_quad<2>(fc, g, c, i0, j)); F[c][2] = Q4<T>(load_quad<2>(fc, g, c, i0, jp)); }
-    P[0] = Q4<T>(load_quad<1>(pc, g, 0, i0, jm)); P[1] = Q4<T>(load_quad<1>(pc, g, 0, i0, j)); P[2] = Q4<T>(load_quad<1>(pc, g, 0, i0, jp));
+    for (int c = 0; c < 2; ++c) { F[c][0] = Q4<T>(load_quad_if<2>(need, fc, g, c, i0, jm)); F[c][1] = Q4<T>(load_quad_if<2>(need, fc, g, c, i0, j)); F[c][2] = Q4<T>(load_quad_if<2>(need, fc, g, c, i0, jp)); }
+    P[0] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, jm)); P[1] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, j)); P[2] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, jp));
     const T pl = quad_left<T>(lm, P[1].quad()), pr = quad_right<T>(lm, P[1].quad());
     Q4<T> O[2];
 #pragma unroll
@@ -633,14 +653,15 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k
     const int i0 = lm.i0, j = jb + by, c0 = blockIdx.y * NC;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return;
+    const bool need = lane_needed(nw);
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> N[NC][3], Fc[NC][3], GX[NC], GY[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        N[c][0] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, jm)); N[c][1] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, j)); N[c][2] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, jp));
-        Fc[c][0] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jm)); Fc[c][1] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, j)); Fc[c][2] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jp));
-        GX[c] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, j));
-        GY[c] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, j));
+        N[c][0] = Q4<T>(load_quad_if<C>(need, fn, g, c0 + c, i0, jm)); N[c][1] = Q4<T>(load_quad_if<C>(need, fn, g, c0 + c, i0, j)); N[c][2] = Q4<T>(load_quad_if<C>(need, fn, g, c0 + c, i0, jp));
+        Fc[c][0] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, jm)); Fc[c][1] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, j)); Fc[c][2] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, jp));
+        GX[c] = Q4<T>(load_quad_if<C>(need, fxc, g, c0 + c, i0, j));
+        GY[c] = Q4<T>(load_quad_if<C>(need, fyc, g, c0 + c, i0, j));
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {

@@ -26,10 +26,11 @@ class JacobiPressureUpdater(PressureUpdater):
     """Jacobi method: n_iter x { pressure BC on p.current; p.next <- predict_p(p.current) on not-wall cells; swap }
     (fs/pressure_updater.py:41-66)."""
 
-    def __init__(self, boundary_condition, dt, dx, n_iter, precompute_source=False):
+    def __init__(self, boundary_condition, dt, dx, n_iter, precompute_source=None):
         super().__init__(boundary_condition, dt, dx)
         self._n_iter = n_iter
-        self._precompute = bool(precompute_source)
+        # one extra pass per step buys ~25 % cheaper sweeps (82 vs 106 us at res 4096): worth it from 5 sweeps on
+        self._precompute = (n_iter >= 5) if precompute_source is None else bool(precompute_source)
         self._src = self._dev.alloc(2) if self._precompute else None
 
     def update(self, p, v_current):

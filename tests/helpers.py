@@ -19,7 +19,7 @@ def make_oracle(g, cfg=None):
                             dtype=np.float64 if cfg["fp64"] else np.float32)
 
 
-def make_product(g, cfg=None, precompute_source=False, vc_kwargs=None, rb_fused=True):
+def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=True):
     """Compose the product classes by hand from the scene arrays stored in the fixture (constructor-level API)."""
     import fs
     from fs.boundary_condition import BoundaryCondition, DyeBoundaryCondition
@@ -29,7 +29,7 @@ def make_product(g, cfg=None, precompute_source=False, vc_kwargs=None, rb_fused=
           else BoundaryCondition(g["bc_const"], g["bc_mask"]))
     vc = fs.VorticityConfinement(bc, dt, dx, cfg["vor_eps"], **(vc_kwargs or {})) if cfg["vor_eps"] is not None else None
     u = cfg["updater"]
-    pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, u[1], u[2], precompute_source=precompute_source, fused=rb_fused) if u[0] == "rbsor"
+    pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, u[1], u[2], precompute_source=bool(precompute_source), fused=rb_fused) if u[0] == "rbsor"
           else fs.JacobiPressureUpdater(bc, dt, dx, u[1], precompute_source=precompute_source))
     if cfg["scheme"] == "cip":
         solver = (fs.DyeCipMacSolver if cfg["dye"] else fs.CipMacSolver)(bc, pu, dt, dx, re, vc)

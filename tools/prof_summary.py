@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into one table per kernel.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 B for wide (16 B/lane)
+streaming reads (MI355X_MICROARCH.md, HBM section), so the read side is doubled: hbm_read = 2 * FETCH_SIZE * 1024."""
+import csv, glob, os, re, sys, collections
+out = sys.argv[1]
+def short(n):
+    n = re.sub(r"^void ", "", n); n = re.sub(r"\(.*", "", n); n = re.sub(r"fs::", "", n)
+    return re.sub(r"<.*", "", n)
+stats = {}
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Name"])
+        s = stats.setdefault(k, [0, 0.0])
+        s[0] += int(r["Calls"]); s[1] += float(r["TotalDurationNs"])
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("pmc_fetch", "pmc_write"):
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json
+traffic = {}
+NAMES = {"k_cip_advect_quad": "cip_advect", "k_rbsor_fused": "rbsor_iteration", "k_cip_nonadv_grad_quad": "cip_nonadv_grad",
+         "k_cip_nonadv_quad": "cip_nonadv", "k_vort_fused": "vort_confine", "k_limit": "limit_field"}
+print(f"{'kernel':28s} {'calls':>6s} {'avg_us':>9s} {'fetch_MB(x2)':>13s} {'write_MB':>9s} {'L2hit%':>7s} {'HBM GB/s':>9s}")
+for k, (calls, tot) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
+    avg = tot / calls / 1e3
+    c = pmc.get(k, {})
+    mean = lambda name: (sum(c[name]) / len(c[name])) if c.get(name) else None
+    fe, wr, hit, miss = mean("FETCH_SIZE"), mean("WRITE_SIZE"), mean("TCC_HIT_sum"), mean("TCC_MISS_sum")
+    fe_mb = None if fe is None else 2 * fe * 1024 / 1e6
+    wr_mb = None if wr is None else wr * 1024 / 1e6
+    hr = None if hit is None or miss is None or hit + miss == 0 else 100 * hit / (hit + miss)
+    bw = None if fe_mb is None or wr_mb is None else (fe_mb + wr_mb) * 1e6 / (avg * 1e-6) / 1e9
+    if fe_mb is not None and wr_mb is not None and k in NAMES:
+        traffic[NAMES[k]] = int((fe_mb + wr_mb) * 1e6)
+    f = lambda x, w, p=1: (f"{x:{w}.{p}f}" if x is not None else " " * (w - 1) + "-")
+    print(f"{k:28s} {calls:6d} {avg:9.2f} {f(fe_mb,13)} {f(wr_mb,9)} {f(hr,7)} {f(bw,9,0)}")
+
+# jacobi_tile is launched in two forms by bench.py (v-reading first, then source-pair): split by launch order
+rows = []
+for sub in ("pmc_fetch", "pmc_write"):
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if short(r["Kernel_Name"]) == "k_jacobi_tile":
+                rows.append((r["Counter_Name"], "SRC" if "ILb1E" in r["Kernel_Name"] or "<true" in r["Kernel_Name"] else "V", float(r["Counter_Value"])))
+for form, key in (("V", "jacobi_sweep"), ("SRC", "jacobi_sweep_src")):
+    fe = [v for n, fo, v in rows if n == "FETCH_SIZE" and fo == form]
+    wr = [v for n, fo, v in rows if n == "WRITE_SIZE" and fo == form]
+    if fe and wr:
+        traffic[key] = int((2 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024)
+json.dump({"note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from rocprofv3 --pmc passes (gfx950 FETCH_SIZE correction x2), "
+                   "workload bc5 res4096 cip+vc, see tools/profile.sh", "bytes_per_launch": traffic},
+          open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
