@@ -123,32 +123,38 @@ int fs_comm_destroy(fs_ctx *ctx)
 // Refresh `depth` ghost rows on each side of the owned rows [halo, halo + nyl).
 //   to the lower neighbour (rank - 1): my first `depth` owned rows  -> their upper ghost rows
 //   to the upper neighbour (rank + 1): my last  `depth` owned rows  -> their lower ghost rows
-int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth)
+int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
 {
-    FS_REQUIRE(ctx && f && f->ctx == ctx, "null argument / foreign field");
+    FS_REQUIRE(ctx && fields && nfields >= 0, "null argument");
     FS_REQUIRE(depth >= 0 && depth <= ctx->halo && depth <= ctx->nyl, "halo depth exceeds the slab's ghost rows or owned rows");
-    if (depth == 0) return FS_OK;
+    for (int n = 0; n < nfields; ++n) FS_REQUIRE(fields[n] && fields[n]->ctx == ctx, "null / foreign field");
+    if (depth == 0 || nfields == 0) return FS_OK;
     Comm *cm = ctx->comm;
     if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
     if (cm->nranks == 1) return FS_OK;
-    const size_t row_elems = (size_t)f->C * ctx->P;
-    const size_t count = (size_t)depth * row_elems;
     const ncclDataType_t dt = ctx->dtype == 0 ? ncclFloat32 : ncclFloat64;
-    char *base = (char *)f->d;
-    auto rowp = [&](int r) { return base + (size_t)r * row_elems * ctx->esize; };
     const int H = ctx->halo, n = ctx->nyl;
     FS_NCCL(g_rccl.GroupStart());
-    if (cm->rank > 0) {
-        FS_NCCL(g_rccl.Send(rowp(H), count, dt, cm->rank - 1, cm->comm, ctx->stream));
-        FS_NCCL(g_rccl.Recv(rowp(H - depth), count, dt, cm->rank - 1, cm->comm, ctx->stream));
-    }
-    if (cm->rank < cm->nranks - 1) {
-        FS_NCCL(g_rccl.Send(rowp(H + n - depth), count, dt, cm->rank + 1, cm->comm, ctx->stream));
-        FS_NCCL(g_rccl.Recv(rowp(H + n), count, dt, cm->rank + 1, cm->comm, ctx->stream));
+    for (int k = 0; k < nfields; ++k) {
+        fs_field *f = fields[k];
+        const size_t row_elems = (size_t)f->C * ctx->P;
+        const size_t count = (size_t)depth * row_elems;
+        char *base = (char *)f->d;
+        auto rowp = [&](int r) { return base + (size_t)r * row_elems * ctx->esize; };
+        if (cm->rank > 0) {
+            FS_NCCL(g_rccl.Send(rowp(H), count, dt, cm->rank - 1, cm->comm, ctx->stream));
+            FS_NCCL(g_rccl.Recv(rowp(H - depth), count, dt, cm->rank - 1, cm->comm, ctx->stream));
+        }
+        if (cm->rank < cm->nranks - 1) {
+            FS_NCCL(g_rccl.Send(rowp(H + n - depth), count, dt, cm->rank + 1, cm->comm, ctx->stream));
+            FS_NCCL(g_rccl.Recv(rowp(H + n), count, dt, cm->rank + 1, cm->comm, ctx->stream));
+        }
     }
     FS_NCCL(g_rccl.GroupEnd());
     return FS_OK;
 }
+
+int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth) { return fs_halo_exchange_multi(ctx, &f, 1, depth); }
 
 int fs_allreduce_sum(fs_ctx *ctx, double *values, int n)
 {

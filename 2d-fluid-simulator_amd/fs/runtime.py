@@ -14,6 +14,7 @@ With nranks == 1 all of this is a no-op and the launches are exactly the referen
 numpy/gloo stand-in to check the slab logic without a GPU); `Device` binds it to libfs_hip.so.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -147,23 +148,40 @@ class DeviceBase:
         self.g_lo = max(0, self.y0 - self.halo)
         self.g_hi = min(self.ny, self.y0 + self.nyl + self.halo)
         self.bc_reach = 0
-        self.n_exchanges = 0
+        self.n_exchanges = 0          # grouped send/recv launches issued
+        self.n_exchanged_fields = 0   # fields refreshed by them
 
     # ---- ghost-row bookkeeping --------------------------------------------------------------------
     def exchange(self, field, depth=None):
+        self.exchange_many([field], depth)
+
+    def exchange_many(self, fields, depth=None):
+        """Refresh the ghost rows of several fields with ONE grouped send/recv (one launch, one latency)."""
         depth = self.halo if depth is None else depth
-        self._p_exchange(field._h, field.nchan, depth)
-        field.valid = depth
+        if len(fields) == 1:
+            self._p_exchange(fields[0]._h, fields[0].nchan, depth)
+        else:
+            self._p_exchange_many([(f._h, f.nchan) for f in fields], depth)
+        for f in fields:
+            f.valid = depth
         self.n_exchanges += 1
+        self.n_exchanged_fields += len(fields)
+
+    def _p_exchange_many(self, handles, depth):     # backends without a grouped primitive: one by one
+        for h, nchan in handles:
+            self._p_exchange(h, nchan, depth)
 
     def _run(self, name, args, reads=(), writes=(), pointwise=False):
         multi = self.nranks > 1
         if multi:
+            stale = []
             for f, radius in reads:
                 if radius > self.halo:
                     raise RuntimeError(f"{name}: stencil radius {radius} exceeds halo {self.halo}")
-                if f.valid < radius:
-                    self.exchange(f)
+                if f.valid < radius and not any(f is s for s in stale):
+                    stale.append(f)
+            if stale:
+                self.exchange_many(stale)
         if pointwise:      # all local in-domain rows, ghost rows included: validity is preserved
             lo, hi = self.g_lo - (self.y0 - self.halo), self.g_hi - (self.y0 - self.halo)
         else:
@@ -270,9 +288,9 @@ class DeviceBase:
     def poisson_residual(self, dt, dx, p, vc):
         """(sum of squared Jacobi residuals, cell count) over all not-wall cells of the GLOBAL grid."""
         if self.nranks > 1:
-            for f in (p, vc):
-                if f.valid < 1:
-                    self.exchange(f)
+            stale = [f for f in (p, vc) if f.valid < 1]
+            if stale:
+                self.exchange_many(stale)
         s, n = self._p_residual(dt, dx, p._h, vc._h)
         return self._p_allreduce([s, n]) if self.nranks > 1 else (s, n)
 
@@ -288,7 +306,7 @@ class Device(DeviceBase):
                   self.y0, self.nyl, self.halo)
         self._ctx = ctx
         self._graphs = []
-        if nranks > 1:
+        if nranks > 1 or (os.environ.get("FS_TEST_COMM") == "1" and bcast is not None):   # FS_TEST_COMM: 1-rank communicator (debug)
             uid = None
             if rank == 0:
                 buf = ctypes.create_string_buffer(128)
@@ -333,6 +351,10 @@ class Device(DeviceBase):
     def _p_exchange(self, h, nchan, depth):
         _lib.call("fs_halo_exchange", self._ctx, h, depth)
 
+    def _p_exchange_many(self, handles, depth):
+        arr = (ctypes.c_void_p * len(handles))(*[h for h, _ in handles])
+        _lib.call("fs_halo_exchange_multi", self._ctx, arr, len(handles), depth)
+
     def _p_residual(self, dt, dx, ph, vh):
         s, n = ctypes.c_double(), ctypes.c_double()
         _lib.call("fs_poisson_residual", self._ctx, dt, dx, ph, vh, ctypes.byref(s), ctypes.byref(n))
@@ -345,6 +367,22 @@ class Device(DeviceBase):
 
     def sync(self):
         _lib.call("fs_sync", self._ctx)
+
+    # -- tiny collectives over the RCCL communicator (benchmark plumbing: barrier, max-over-ranks) -------------
+    def allgather_scalars(self, value):
+        """[value of rank 0, value of rank 1, ...] on every rank (one ncclAllReduce of a one-hot vector)."""
+        if self.nranks == 1:
+            return [float(value)]
+        if self.nranks > 16:
+            raise ValueError("allgather_scalars supports up to 16 ranks")
+        slots = [0.0] * self.nranks
+        slots[self.rank] = float(value)
+        return list(self._p_allreduce(slots))
+
+    def barrier(self):
+        """Device sync + rendezvous of all ranks."""
+        self.sync()
+        self.allgather_scalars(0.0)
 
     # -- hipGraph capture of a launch sequence (single GPU) ---------------------------------------------
     def capture(self, fn):

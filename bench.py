@@ -9,14 +9,14 @@ Synthetic: the scene comes from the NumPy scene builder, the state starts at zer
     python bench.py [--gpus N] [--steps K] [--warmup W] [--res R] [--no-cpu] [--sweeps S]
 
 N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per
-GPU; the grid is cut into N y-slabs (strong scaling: same res 4096 grid), ghost rows travel over RCCL inside
-libfs_hip.  torch.distributed (gloo, CPU) is used only as the launcher's rendezvous: to share the RCCL unique id,
-for the barriers around the timed region and for the max-over-ranks of the elapsed time.
+GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the env); the grid is cut into N y-slabs (strong scaling:
+same res 4096 grid), ghost rows travel over RCCL inside libfs_hip.  The bench process itself imports no torch: the
+RCCL unique id is shared through a file keyed by the launcher, and the barriers around the timed region and the
+max-over-ranks of the elapsed time go through the RCCL communicator (Device.barrier / allgather_scalars).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import importlib
 import json
 import os
@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step as a hipGraph (N=1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: take the multi-process code path (gloo rendezvous + RCCL communicator) even with one rank")
     return ap.parse_args()
 
 
@@ -113,41 +115,27 @@ def main():
     from fs.boundary_condition import create_scene_arrays
     _lib.load()   # ROCm's HIP runtime is resolved before anything else can bring its own copy
 
-    dist = None
-    bcast = allgather = None
-    if world > 1:
-        try:    # bind ROCm's RCCL before torch is imported (torch ships its own copy under the same soname)
-            ctypes.CDLL("/opt/rocm/lib/librccl.so.1", mode=ctypes.RTLD_GLOBAL)
-        except OSError:
-            pass
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
-        def bcast(payload):
-            box = [payload]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-
-        def allgather(obj):
-            out = [None] * world
-            dist.all_gather_object(out, obj)
-            return out
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    # N > 1: no torch / MPI in this process.  The only out-of-band datum is the 128-byte RCCL unique id (a file in /tmp
+    # keyed by the launcher's pid and MASTER_PORT); barriers and the max-over-ranks go through the RCCL communicator.
+    rdzv = None
+    bcast = None
+    if world > 1 or args.force_dist:
+        from fs.rendezvous import FileRendezvous
+        rdzv = FileRendezvous(rank, world)
+        bcast = rdzv.bcast
+        if args.force_dist:
+            os.environ["FS_TEST_COMM"] = "1"
 
     res = args.res
     dt, dx, re = 0.05 / res, 1.0 / res, 1.0e6
     vc = args.vc if args.vc else None
-    fs.runtime.init(gpu=local_rank, dtype="f32", rank=rank, nranks=world, bcast=bcast, allgather=allgather)
+    fs.runtime.init(gpu=local_rank, dtype="f32", rank=rank, nranks=world, bcast=bcast)
     sim = fs.FluidSimulator.create(args.bc, res, dt, dx, re, vc, args.scheme)
     dev = sim._solver._bc.device
     mask = sim._solver._bc.mask
 
     # ---- warm-up, then EXACTLY K timed steps between barrier + device sync --------------------------------
-    use_graph = world == 1 and not args.no_graph and args.steps % 2 == 0 and args.warmup % 2 == 0
+    use_graph = world == 1 and not args.force_dist and not args.no_graph and args.steps % 2 == 0 and args.warmup % 2 == 0
     for _ in range(args.warmup):
         sim.step()
     graph = None
@@ -155,22 +143,15 @@ def main():
         # two consecutive steps return every DoubleBuffer to its starting parity, so the captured pair replays
         graph = dev.capture(lambda: (sim.step(), sim.step()))
         dev.replay(graph, 1)   # capture does not execute: run the pair once so the state advances like eager
-    dev.sync()
-    barrier()
+    dev.barrier()                      # device sync + all ranks arrived
     t0 = time.perf_counter()
     if graph is not None:
         dev.replay(graph, args.steps // 2)
     else:
         for _ in range(args.steps):
             sim.step()
-    dev.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    dev.barrier()
+    elapsed = max(dev.allgather_scalars(time.perf_counter() - t0))      # max over ranks
     steps_per_s = args.steps / elapsed
 
     # ---- per-kernel durations with HIP events on the kernels' own stream (same K steps again) -------------
@@ -241,7 +222,9 @@ def main():
                                f"RB-SOR(1.3, 2 iters) Re=1e6 dt=0.05/res; BASELINE.json configs[2]",
                    "cells": counts["cells"], "fluid_cells": counts["fluid"], "parallelism": f"y-slab x{world}",
                    "launch": "hipGraph replay of 2-step pairs" if graph is not None else "eager (python per step)"},
-        "halo_exchanges_per_step": None if world == 1 else round(dev.n_exchanges / max(args.warmup + args.steps + prof_steps, 1), 2),
+        "halo_exchanges_per_step": None if world == 1 else {
+            "grouped_launches": round(dev.n_exchanges / max(args.warmup + args.steps + prof_steps, 1), 2),
+            "fields": round(dev.n_exchanged_fields / max(args.warmup + args.steps + prof_steps, 1), 2)},
     }
     if dominant:
         kd = kernels[dominant]
@@ -255,10 +238,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, create_scene_arrays(args.bc, res))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dev.barrier()
     dev.close()
+    if rdzv is not None:
+        rdzv.cleanup()
 
 
 if __name__ == "__main__":

@@ -162,6 +162,8 @@ int fs_comm_init(fs_ctx *ctx, int rank, int nranks, const void *unique_id_128_by
 int fs_comm_destroy(fs_ctx *ctx);
 /* Fill `depth` ghost rows on each side from the slab neighbours (ncclSend/ncclRecv pairs).       */
 int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth);
+/* Same for several fields in ONE grouped RCCL call (one fused send/recv launch instead of n).     */
+int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth);
 int fs_allreduce_sum(fs_ctx *ctx, double *values, int n);
 
 /* ---- launch-overhead removal: capture the launches issued between begin/end into a hipGraph ---- */
