@@ -313,7 +313,19 @@ class Device(DeviceBase):
                 _lib.call("fs_comm_unique_id", buf)
                 uid = buf.raw
             uid = bcast(uid)
-            _lib.call("fs_comm_init", self._ctx, rank, nranks, ctypes.c_char_p(uid))
+            # RCCL prints a version banner on C stdout while initialising; keep stdout clean for callers that emit
+            # machine-readable output (bench.py's single JSON line): route fd 1 to stderr for the duration.
+            import sys
+            sys.stdout.flush()
+            libc = ctypes.CDLL(None)
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                _lib.call("fs_comm_init", self._ctx, rank, nranks, ctypes.c_char_p(uid))
+            finally:
+                libc.fflush(None)
+                os.dup2(saved, 1)
+                os.close(saved)
 
     # -- primitives -------------------------------------------------------------------------------------
     def _p_alloc(self, nchan):

@@ -236,12 +236,12 @@ def main():
     out["kernels"] = kernels
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, create_scene_arrays(args.bc, res))
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     dev.barrier()
     dev.close()
     if rdzv is not None:
         rdzv.cleanup()
+    if rank == 0:
+        print(json.dumps(out), flush=True)      # the ONE line on stdout, after everything else is torn down
 
 
 if __name__ == "__main__":
