@@ -210,15 +210,30 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
         int end = pos;
         while (end < n && root[order[end]] == root[order[pos]]) ++end;
         int tlo = INT32_MAX, thi = INT32_MIN, clo = INT32_MAX, chi = INT32_MIN;
+        // dependency span: rows of PRE-kernel data each rewritten cell depends on (chains through earlier ops of the
+        // component included).  The largest |target row - dependency row| is the stencil radius a slab needs.
+        std::unordered_map<long long, std::pair<int, int>> dep;
         for (int q = pos; q < end; ++q) {
             const HostOp &op = ops[order[q]];
             int tr = local_row(op.t);
             tlo = std::min(tlo, tr); thi = std::max(thi, tr);
             clo = std::min(clo, tr); chi = std::max(chi, tr);
+            int dlo = INT32_MAX, dhi = INT32_MIN;
             const long long srcs[2] = {op.s1, op.s2};
-            for (long long s : srcs) if (s >= 0) { int sr = local_row(s); clo = std::min(clo, sr); chi = std::max(chi, sr); }
+            for (long long s : srcs) if (s >= 0) {
+                int sr = local_row(s);
+                clo = std::min(clo, sr); chi = std::max(chi, sr);
+                auto d = dep.find(s);
+                if (d != dep.end()) { dlo = std::min(dlo, d->second.first); dhi = std::max(dhi, d->second.second); }
+                else { dlo = std::min(dlo, sr); dhi = std::max(dhi, sr); }
+            }
+            if (dlo <= dhi) {
+                reach = std::max(reach, std::max(tr - dlo, dhi - tr));
+                dep[op.t] = {dlo, dhi};
+            } else {
+                dep[op.t] = {tr, tr};   // constant assignment (inflow value, p = 0)
+            }
         }
-        if (end - pos > 1) reach = std::max(reach, chi - clo);
         const bool inside = clo >= 0 && chi < c->rows;
         if (inside) {
             h_begin.push_back((int)h_kind.size());
@@ -300,11 +315,11 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
             }
         }
     c->bc_incomplete = false;
-    c->bc_reach = 0;
-    int rc;
-    if ((rc = upload_ops(c, vel, c->ops_vel, c->bc_reach))) return rc;
-    if ((rc = upload_ops(c, prs, c->ops_prs, c->bc_reach))) return rc;
-    if ((rc = upload_ops(c, dye, c->ops_dye, c->bc_reach))) return rc;
+    c->bc_radius_vel = c->bc_radius_prs = 0;
+    int rc, dummy = 0;
+    if ((rc = upload_ops(c, vel, c->ops_vel, c->bc_radius_vel))) return rc;
+    if ((rc = upload_ops(c, prs, c->ops_prs, c->bc_radius_prs))) return rc;
+    if ((rc = upload_ops(c, dye, c->ops_dye, dummy))) return rc;
     return FS_OK;
 }
 
@@ -466,10 +481,11 @@ static int upload_const(fs_ctx *ctx, void **slot, int C, const void *host)
 int fs_upload_bc_const(fs_ctx *ctx, const void *bc_xy2) { return upload_const(ctx, ctx ? &ctx->d_bc_const : nullptr, 2, bc_xy2); }
 int fs_upload_bc_dye(fs_ctx *ctx, const void *bc_xy3) { return upload_const(ctx, ctx ? &ctx->d_bc_dye : nullptr, 3, bc_xy3); }
 
-int fs_bc_reach(const fs_ctx *ctx, int *rows)
+int fs_bc_radius(const fs_ctx *ctx, int *velocity_rows, int *pressure_rows)
 {
-    FS_REQUIRE(ctx && rows, "null argument");
-    *rows = ctx->bc_reach;
+    FS_REQUIRE(ctx && velocity_rows && pressure_rows, "null argument");
+    *velocity_rows = ctx->bc_radius_vel;
+    *pressure_rows = ctx->bc_radius_prs;
     return FS_OK;
 }
 

@@ -58,7 +58,7 @@ struct fs_ctx {
     uint8_t *d_mask = nullptr;
     void *d_bc_const = nullptr, *d_bc_dye = nullptr;
     bool mask_set = false, bc_incomplete = false;
-    int bc_reach = 0;
+    int bc_radius_vel = 0, bc_radius_prs = 0;   // rows of pre-kernel data a rewritten boundary cell depends on
     fs::BcOpsDev ops_vel, ops_prs, ops_dye;
     void *d_stage = nullptr;
     size_t stage_bytes = 0;

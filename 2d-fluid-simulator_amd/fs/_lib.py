@@ -27,7 +27,7 @@ _PROTOS = {
     "fs_upload_mask": [_c_vp, _c_vp],
     "fs_upload_bc_const": [_c_vp, _c_vp],
     "fs_upload_bc_dye": [_c_vp, _c_vp],
-    "fs_bc_reach": [_c_vp, _P(_c_int)],
+    "fs_bc_radius": [_c_vp, _P(_c_int), _P(_c_int)],
     "fs_field_alloc": [_c_vp, _c_int, _P(_c_vp)],
     "fs_field_free": [_c_vp],
     "fs_field_fill": [_c_vp, _c_dbl],

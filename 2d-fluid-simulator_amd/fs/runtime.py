@@ -151,7 +151,7 @@ class DeviceBase:
         # global rows covered by local rows (ghost rows included), clipped to the domain
         self.g_lo = max(0, self.y0 - self.halo)
         self.g_hi = min(self.ny, self.y0 + self.nyl + self.halo)
-        self.bc_reach = 0
+        self.bc_radius_v, self.bc_radius_p = 2, 1
         self.n_exchanges = 0          # grouped send/recv launches issued
         self.n_exchanged_fields = 0   # fields refreshed by them
 
@@ -232,18 +232,19 @@ class DeviceBase:
             bc_dye = np.ascontiguousarray(bc_dye, dtype=self.dtype)
             if bc_dye.shape != shape + (3,):
                 raise ValueError("bc_dye must be (X, Y, 3)")
-        self.bc_reach = self._p_upload_scene(bc_mask, bc_const, bc_dye)
-        if self.nranks > 1 and 2 + self.bc_reach > self.halo:
+        rv, rp = self._p_upload_scene(bc_mask, bc_const, bc_dye)
+        self.bc_radius_v, self.bc_radius_p = max(2, rv), max(1, rp)
+        if self.nranks > 1 and max(self.bc_radius_v, self.bc_radius_p) > self.halo:
             raise RuntimeError(
-                f"mask couples boundary cells {self.bc_reach} rows apart (thin walls); slab runs need halo >= "
-                f"{2 + self.bc_reach}, have {self.halo}")
+                f"the boundary kernels reach {max(self.bc_radius_v, self.bc_radius_p)} rows on this mask (chained thin "
+                f"walls); slab runs need at least that many ghost rows, have {self.halo}")
 
     # ---- one wrapper per reference kernel: (C-ABI name, scalars + fields, reads with radius, writes) ----
     def velocity_bc(self, v):                                   # fs/boundary_condition.py:16-39
-        self._run("velocity_bc", (v._h,), reads=[(v, 2 + self.bc_reach)], writes=[v])
+        self._run("velocity_bc", (v._h,), reads=[(v, self.bc_radius_v)], writes=[v])
 
     def pressure_bc(self, p):                                   # fs/boundary_condition.py:41-65
-        self._run("pressure_bc", (p._h,), reads=[(p, 1 + self.bc_reach)], writes=[p])
+        self._run("pressure_bc", (p._h,), reads=[(p, self.bc_radius_p)], writes=[p])
 
     def dye_bc(self, dye):                                      # fs/boundary_condition.py:94-99
         self._run("dye_bc", (dye._h,), reads=[], writes=[dye])
@@ -380,9 +381,9 @@ class Device(DeviceBase):
         _lib.call("fs_upload_bc_const", self._ctx, bc_const.ctypes.data_as(ctypes.c_void_p))
         if bc_dye is not None:
             _lib.call("fs_upload_bc_dye", self._ctx, bc_dye.ctypes.data_as(ctypes.c_void_p))
-        reach = ctypes.c_int()
-        _lib.call("fs_bc_reach", self._ctx, ctypes.byref(reach))
-        return reach.value
+        rv, rp = ctypes.c_int(), ctypes.c_int()
+        _lib.call("fs_bc_radius", self._ctx, ctypes.byref(rv), ctypes.byref(rp))
+        return rv.value, rp.value
 
     def _p_kernel(self, name, *args):
         _lib.check(getattr(self._lib, "fs_" + name)(self._ctx, *args))

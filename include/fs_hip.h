@@ -62,9 +62,10 @@ int fs_ctx_info(const fs_ctx *ctx, int *nx, int *ny, int *dtype, int *y0, int *n
 int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy);
 int fs_upload_bc_const(fs_ctx *ctx, const void *bc_xy2);
 int fs_upload_bc_dye(fs_ctx *ctx, const void *bc_xy3);
-/* Max distance in rows between cells coupled by the boundary kernels' in-kernel read/write
- * hazards (0 for every reference scene except thin-walled masks); slab runs need halo >= 2 + it. */
-int fs_bc_reach(const fs_ctx *ctx, int *rows);
+/* Stencil radius in rows of the velocity / pressure boundary kernels on this mask: how far (chains of the
+ * reference's in-kernel read-after-write hazards included) a rewritten cell depends on pre-kernel data.
+ * 2 and 1 for regular scenes; slab runs need halo >= these.                                            */
+int fs_bc_radius(const fs_ctx *ctx, int *velocity_rows, int *pressure_rows);
 
 /* ---- fields (ti.field / ti.Vector.field + DoubleBuffer members, fs/double_buffer.py:4-18) ---- */
 int fs_field_alloc(fs_ctx *ctx, int nchan, fs_field **out);           /* zero-initialised */

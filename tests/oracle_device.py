@@ -52,7 +52,7 @@ class OracleSlabDevice(DeviceBase):
     def _p_upload_scene(self, bc_mask, bc_const, bc_dye):
         sl = slice(self.g_lo, self.g_hi)
         self.obc = O.OracleBC(bc_const[:, sl], bc_mask[:, sl], None if bc_dye is None else bc_dye[:, sl], self.dtype)
-        return 0
+        return 2, 1
 
     def _p_exchange(self, h, nchan, depth):
         a = h.a

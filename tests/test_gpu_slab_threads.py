@@ -1,0 +1,117 @@
+"""The slab code path of the HIP library on ONE GPU: N slab contexts (y0 > 0, ghost rows, extended row ranges,
+per-slab boundary op lists, red-black parity offset) driven by N host threads, with the ghost rows carried between
+the contexts by host copies instead of RCCL (a single-GPU box cannot form an RCCL communicator of N ranks).
+Everything else - kernels, slab geometry, the validity tracker, the solver orchestration - is the product path.
+Results must be bit-identical to the single-domain golden trajectories."""
+import os
+import threading
+
+import numpy as np
+import pytest
+from conftest import GOLDEN
+from helpers import traj_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_device_cls(world, shared):
+    from fs.runtime import Device
+
+    class ThreadSlabDevice(Device):
+        """Device whose ghost-row exchange goes through host memory shared by the threads of one process."""
+
+        def __init__(self, nx, ny, dtype, rank, halo):
+            super().__init__(nx, ny, dtype, gpu=0, rank=0, nranks=1, halo=0)   # plain context first, replaced below
+            self.close()
+            # re-run DeviceBase geometry as a slab, then create the context by hand (no RCCL communicator)
+            from fs.runtime import DeviceBase
+            import ctypes
+            from fs import _lib
+            DeviceBase.__init__(self, nx, ny, dtype, 0, rank, world, halo, None, None)
+            ctx = ctypes.c_void_p()
+            _lib.call("fs_create", ctypes.byref(ctx), 0, self.nx, self.ny, 0 if self.dtype == np.float32 else 1,
+                      self.y0, self.nyl, self.halo)
+            self._ctx = ctx
+
+        def _p_exchange(self, h, nchan, depth):
+            self._p_exchange_many([(h, nchan)], depth)
+
+        def _p_exchange_many(self, handles, depth):
+            H, n = self.halo, self.nyl
+            mine = [(self._p_download(h, c, H, depth), self._p_download(h, c, H + n - depth, depth)) for h, c in handles]
+            shared["box"][self.rank] = mine
+            shared["barrier"].wait()
+            for k, (h, c) in enumerate(handles):
+                if self.rank > 0:
+                    self._p_upload(h, c, np.ascontiguousarray(shared["box"][self.rank - 1][k][1]), H - depth, depth)
+                if self.rank < world - 1:
+                    self._p_upload(h, c, np.ascontiguousarray(shared["box"][self.rank + 1][k][0]), H + n, depth)
+            shared["barrier"].wait()
+
+    return ThreadSlabDevice
+
+
+def _worker(rank, world, halo, g, cfg, Dev, results, errors):
+    try:
+        import fs
+        from fs.boundary_condition import BoundaryCondition, DyeBoundaryCondition
+        dt, dx, re = cfg["dt"], cfg["dx"], cfg["re"]
+        X, Y = g["bc_mask"].shape
+        dev = Dev(X, Y, np.float64 if cfg["fp64"] else np.float32, rank, halo)
+        bc = (DyeBoundaryCondition(g["bc_const"], g["bc_dye"], g["bc_mask"], device=dev) if cfg["dye"]
+              else BoundaryCondition(g["bc_const"], g["bc_mask"], device=dev))
+        vc = fs.VorticityConfinement(bc, dt, dx, cfg["vor_eps"]) if cfg["vor_eps"] is not None else None
+        u = cfg["updater"]
+        pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, u[1], u[2]) if u[0] == "rbsor" else fs.JacobiPressureUpdater(bc, dt, dx, u[1]))
+        if cfg["scheme"] == "cip":
+            solver = (fs.DyeCipMacSolver if cfg["dye"] else fs.CipMacSolver)(bc, pu, dt, dx, re, vc)
+        else:
+            adv = fs.advect_upwind if cfg["scheme"] == "upwind" else fs.advect_kk_scheme
+            solver = (fs.DyeMacSolver if cfg["dye"] else fs.MacSolver)(bc, pu, adv, dt, dx, re, vc)
+        snaps = {}
+        for step in range(1, max(cfg["snaps"]) + 1):
+            solver.update()
+            if step in cfg["snaps"]:
+                snaps[step] = [f.to_numpy(local=True) for f in solver.get_fields()]
+        results[rank] = (snaps, dev.n_exchanges / max(cfg["snaps"]))
+        dev.close()
+    except BaseException as e:   # noqa: BLE001 - surface in the main thread
+        errors.append((rank, repr(e)))
+        try:
+            shared_abort = threading.current_thread()._fs_shared
+            shared_abort["barrier"].abort()
+        except Exception:
+            pass
+
+
+CASES = [
+    ("traj_bc5_cip_vc5.npz", 2, 2), ("traj_bc5_cip_vc5.npz", 2, 8), ("traj_bc5_cip_vc5.npz", 3, 4),
+    ("traj_cfg5_bc3_res96_kk_vc10_re1e8.npz", 3, 8), ("traj_bc2_cip_jacobi50_vc0.npz", 2, 4),
+    ("traj_dye_bc2_cip_vc5.npz", 2, 8), ("traj_bc1_upwind_vc0.npz", 4, 2), ("traj_bc6_res64_cip_vc5_dye.npz", 2, 8),
+    ("traj_f64_bc1_cip_vc0.npz", 2, 4),
+]
+
+
+@pytest.mark.parametrize("fname,world,halo", CASES)
+def test_slabs_on_one_gpu_are_bit_identical(fname, world, halo, hip_lib):
+    g = np.load(os.path.join(GOLDEN, fname))
+    cfg = traj_config(g)
+    shared = {"barrier": threading.Barrier(world), "box": [None] * world}
+    Dev = _make_device_cls(world, shared)
+    results, errors = [None] * world, []
+    threads = []
+    for r in range(world):
+        t = threading.Thread(target=_worker, args=(r, world, halo, g, cfg, Dev, results, errors))
+        t._fs_shared = shared
+        threads.append(t)
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    names = ["v", "p", "dye"]
+    for step in cfg["snaps"]:
+        for k in range(len(results[0][0][step])):
+            full = np.concatenate([results[r][0][step][k] for r in range(world)], axis=1)
+            assert np.array_equal(full, g[f"step{step}.{names[k]}"]), f"{fname} step {step} {names[k]}"
+    if halo >= 8 and cfg["updater"][0] == "rbsor" and not cfg["dye"]:
+        assert results[0][1] <= 6.0

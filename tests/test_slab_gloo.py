@@ -70,5 +70,5 @@ def test_single_rank_never_exchanges():
     d.calls = []
     v, p = d.alloc(2), d.alloc(1)
     d.velocity_bc(v); d.cip_nonadv(0.1, 0.1, 1.0, d.alloc(2), v, p); d.limit_field(10.0, v)
-    assert d.halo == 0 and d.n_exchanges == 0
+    assert d.halo == 0 and d.n_exchanges == 0 and (d.bc_radius_v, d.bc_radius_p) == (2, 1)
     assert [c[1] for c in d.calls] == [(0, 32)] * 3
