@@ -770,6 +770,36 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
     })
 }
 
+#define FS_K34(PP, EE) hipLaunchKernelGGL((k_cip_grad_advect<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
+                (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d)
+int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
+                       const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(v_out, 2); FS_FIELD(gx_out, 2); FS_FIELD(gy_out, 2); FS_FIELD(fn, 2); FS_FIELD(fc, 2); FS_FIELD(gxc, 2); FS_FIELD(gyc, 2);
+    FS_REQUIRE(v_out != fn && v_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
+    FS_REQUIRE(ctx->use_march, "the fused gradient+advection pass needs X % 4 == 0 (use the two-kernel form)");
+    FS_ROWS();
+    // rows within two rows of the domain's first / last row take the run-time-slot (EDGE) instantiation
+    const Grid gg = ctx->grid();
+    const int in_lo = std::min(std::max(row_begin, gg.jlo + 2), row_end), in_hi = std::max(std::min(row_end, gg.jhi - 1), in_lo);
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0);
+        auto run = [&](int jb, int je, bool edge) -> int {
+            if (jb >= je) return FS_OK;
+            const OvGrid og = ov_grid(ctx, jb, je, 1, 2, XCD_ADVECT);
+            return launch(ctx, edge ? "cip_grad_advect_edge" : "cip_grad_advect", [&] {
+                if (k.p2) { if (edge) FS_K34(true, true); else FS_K34(true, false); }
+                else { if (edge) FS_K34(false, true); else FS_K34(false, false); }
+            });
+        };
+        int rc = run(row_begin, in_lo, true);
+        if (!rc) rc = run(in_lo, in_hi, false);
+        if (!rc) rc = run(in_hi, row_end, true);
+        return rc;
+    })
+}
+
 // ---- vorticity confinement -------------------------------------------------------------------------------
 int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, const fs_field *vc, int row_begin, int row_end)
 {

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_jacobi_tile(Grid g, Konst<T> k, int jb,
         quad_sides<1>(pc, g, 0, i0, jc, lane, P[r + 1], pl, pr);
         V s2, s3;
         if (SRC) {
-            s2 = load_quad_if<2>(sel[r] != 0u, vs, g, 0, i0, jc);
+            s2 = load_quad_if<2>(sel[r] != 0u, vs, g, 0, i0, jc);   // (nontemporal loads / stores measured 1.6x SLOWER here)
             s3 = load_quad_if<2>(sel[r] != 0u, vs, g, 1, i0, jc);
         } else {
             T xl, xr, yl, yr;
@@ -682,6 +682,156 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k
             store_quad_sel<T>(fyn + idx<C, T>(g, c0 + c, i0, j), OY.quad(), nw);
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K3 + K4 fused for the velocity field: gradient update of the non-advection phase (fs/solver.py:242-261) and CIP
+// advection (fs/solver.py:267-332) in ONE pass, one velocity component per launch slice (blockIdx.y = component).
+//
+// In the reference K3 writes the intermediate gradients into vx.next / vy.next, the buffers swap, and K4 reads them
+// back on a 3x3 neighbourhood: 16 B/cell written and 16 B/cell read again, plus the intermediate velocity read twice.
+// Here a lane evaluates K3 for rows j-1, j, j+1 of its quad in registers (halo recompute) and feeds K4 for row j
+// directly: 66 instead of 96 B/cell over the two kernels.  The intermediate gradients are never observable (the
+// buffer that would hold them is overwritten by the next step's K3 before anything reads it), so they are not stored.
+//
+// Buffer choreography (SURVEY.md H5 - contents, not addresses, are what later kernels see): K4's velocity output goes to
+// a THIRD velocity buffer `vo` (the unfused code overwrites the pre-K2 velocity buffer `fc` in place, which a fused
+// kernel still has to read at radius 2 in other tiles), carrying fc's values on non-fluid cells exactly as the in-place
+// update would leave them.  The new gradients go to the buffers the reference would use for the intermediates
+// (gxo/gyo), carrying gxc/gyc on inflow/outflow cells; wall cells of the gradient buffers are never written by any
+// kernel and are identical in both physical buffers (zero) - the host falls back to the unfused pair if a user
+// uploaded gradient data.  The caller rotates (v.cur, v.next, spare) and swaps vx / vy once.
+//   fn = velocity after K2 (v.next), fc = velocity before K2 (v.cur), gxc/gyc = gradients before K3.
+// ------------------------------------------------------------------------------------------------
+// A[u] for a wave-uniform runtime u, as selects over by-value copies (a runtime index or a reference to the array would
+// force the whole register array into scratch)
+template <typename T>
+__device__ __forceinline__ Q4<T> pick5(Q4<T> a0, Q4<T> a1, Q4<T> a2, Q4<T> a3, Q4<T> a4, int u)
+{
+    Q4<T> r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        r.a[q] = u == 0 ? a0.a[q] : (u == 1 ? a1.a[q] : (u == 2 ? a2.a[q] : (u == 3 ? a3.a[q] : a4.a[q])));
+    return r;
+}
+
+template <int c, bool P2, bool EDGE, typename T>
+__device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+                                                     T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                     const T *gxc, const T *gyc)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0, j = jb + by;
+    constexpr int o = 1 - c;                        // c: this pass's component (compile time: runtime selection among the
+                                                    // register arrays below would push them to scratch), o: the other one
+    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1), jmm = clampy(g, j - 2), jpp = clampy(g, j + 2);
+
+    const uint32_t m_m = mask_quad(g, i0, jm), m_c = mask_quad(g, i0, j), m_p = mask_quad(g, i0, jp);
+    const unsigned nw[3] = {sel_not_wall(m_m), sel_not_wall(m_c), sel_not_wall(m_p)};
+    const unsigned fl = sel_fluid(m_c);
+    const bool act = lane_needed(fl);              // some fluid cell here or next door: the full stencil is needed
+
+    // velocity rows: this component j-2..j+2 of fn and fc; the other component of fn for rows j-1..j+1 (advecting velocity)
+    Q4<T> N[5], Fc[5], NO[3], GX[3], GY[3];
+    const int rows5[5] = {jmm, jm, j, jp, jpp};
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        N[r] = Q4<T>(load_quad_if<2>(act, fn, g, c, i0, rows5[r]));
+        Fc[r] = Q4<T>(load_quad_if<2>(act || r == 2, fc, g, c, i0, rows5[r]));     // row j of fc is always needed (carry)
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        NO[r] = Q4<T>(load_quad_if<2>(act, fn, g, o, i0, rows5[r + 1]));
+        GX[r] = Q4<T>(load_quad_if<2>(act || (r == 1 && nw[1] != 0u), gxc, g, c, i0, rows5[r + 1]));
+        GY[r] = Q4<T>(load_quad_if<2>(act || (r == 1 && nw[1] != 0u), gyc, g, c, i0, rows5[r + 1]));
+    }
+
+    Q4<T> OV = Fc[2], OX = GX[1], OY = GY[1];       // carry values; fluid cells are replaced below
+    if (__any(act)) {
+        // ---- K3 on rows j-1, j, j+1 (slot s <-> velocity slot s+1); wall cells keep the stored gradient ----
+        Q4<T> NX[3], NY[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const Q4<T> &n1 = N[s + 1], &c1 = Fc[s + 1];
+            const T nl = quad_left<T>(lm, n1.quad()), nr = quad_right<T>(lm, n1.quad());
+            const T cl = quad_left<T>(lm, c1.quad()), cr = quad_right<T>(lm, c1.quad());
+            // sample()'s row neighbours of the row held in slot s+1.  Slot u holds row clamp(j-2+u); away from the domain's first /
+            // last two rows that is simply slots s and s+2.  Near the edge (clamped duplicates) the slot of row t is t-(j-2).
+            Q4<T> nS, nN, cS, cN;
+            if (!EDGE) { nS = N[s]; nN = N[s + 2]; cS = Fc[s]; cN = Fc[s + 2]; }
+            else {
+                const int jr = rows5[s + 1];
+                const int uS = clampy(g, jr - 1) - (j - 2), uN = clampy(g, jr + 1) - (j - 2);
+                nS = pick5(N[0], N[1], N[2], N[3], N[4], uS); nN = pick5(N[0], N[1], N[2], N[3], N[4], uN);
+                cS = pick5(Fc[0], Fc[1], Fc[2], Fc[3], Fc[4], uS); cN = pick5(Fc[0], Fc[1], Fc[2], Fc[3], Fc[4], uN);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const T nE = q == 3 ? nr : n1.a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : n1.a[q == 0 ? 0 : q - 1];
+                const T cE = q == 3 ? cr : c1.a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : c1.a[q == 0 ? 0 : q - 1];
+                const T sx = ((nE - cE) - nW) + cW;
+                const T sy = ((nN.a[q] - cN.a[q]) - nS.a[q]) + cS.a[q];
+                const bool live = (nw[s] >> q) & 1u;
+                NX[s].a[q] = live ? GX[s].a[q] + qdiv<P2>(sx, k.two_dx, k.inv_two_dx) : GX[s].a[q];
+                NY[s].a[q] = live ? GY[s].a[q] + qdiv<P2>(sy, k.two_dx, k.inv_two_dx) : GY[s].a[q];
+            }
+        }
+        // ---- K4 on row j ----
+        const Q4<T> &VXr = c == 0 ? N[2] : NO[1], &VYr = c == 0 ? NO[1] : N[2];                 // advecting velocity, row j
+        const Q4<T> &VXm = c == 0 ? N[1] : NO[0], &VXp = c == 0 ? N[3] : NO[2];                 // v.x rows j-1 / j+1
+        const Q4<T> &VYm = c == 0 ? NO[0] : N[1], &VYp = c == 0 ? NO[2] : N[3];
+        const T vxl = quad_left<T>(lm, VXr.quad()), vxr = quad_right<T>(lm, VXr.quad());
+        const T vyl = quad_left<T>(lm, VYr.quad()), vyr = quad_right<T>(lm, VYr.quad());
+        T fl_[3], fr_[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { fl_[r] = quad_left<T>(lm, N[r + 1].quad()); fr_[r] = quad_right<T>(lm, N[r + 1].quad()); }
+        const T fxl = quad_left<T>(lm, NX[1].quad()), fxr = quad_right<T>(lm, NX[1].quad());
+        const T fyl = quad_left<T>(lm, NY[1].quad()), fyr = quad_right<T>(lm, NY[1].quad());
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T vx = VXr.a[q], vy = VYr.a[q];
+            const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
+            const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
+            const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
+            const T dxx = qdiv<P2>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx), dxy = qdiv<P2>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx);
+            const T dyx = qdiv<P2>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx), dyy = qdiv<P2>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx);
+            const T fE1 = q == 3 ? fr_[1] : N[2].a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl_[1] : N[2].a[q == 0 ? 0 : q - 1];
+            const T fE0 = q == 3 ? fr_[0] : N[1].a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl_[0] : N[1].a[q == 0 ? 0 : q - 1];
+            const T fE2 = q == 3 ? fr_[2] : N[3].a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl_[2] : N[3].a[q == 0 ? 0 : q - 1];
+            const T fxE = q == 3 ? fxr : NX[1].a[q == 3 ? 3 : q + 1], fxW = q == 0 ? fxl : NX[1].a[q == 0 ? 0 : q - 1];
+            const T fyE = q == 3 ? fyr : NY[1].a[q == 3 ? 3 : q + 1], fyW = q == 0 ? fyl : NY[1].a[q == 0 ? 0 : q - 1];
+            const T f00 = N[2].a[q];
+            const T f0m = ny ? N[3].a[q] : N[1].a[q];
+            const T fm0 = nx ? fE1 : fW1;
+            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
+            const T fx00 = NX[1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[2].a[q] : NX[0].a[q];
+            const T fy00 = NY[1].a[q], fy0m = ny ? NY[2].a[q] : NY[0].a[q], fym0 = nx ? fyE : fyW;
+            T of, ofx, ofy;
+            cip_point<P2>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
+            if ((fl >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
+        }
+    }
+    if (lm.owner) {
+        *reinterpret_cast<typename Quad<T>::type *>(vo + idx<2, T>(g, c, i0, j)) = OV.quad();     // every cell: result or carried value
+        if (nw[1]) {
+            store_quad_sel<T>(gxo + idx<2, T>(g, c, i0, j), OX.quad(), nw[1]);                  // fluid: result, inflow/outflow: carried
+            store_quad_sel<T>(gyo + idx<2, T>(g, c, i0, j), OY.quad(), nw[1]);
+        }
+    }
+}
+
+// EDGE = false: rows at least two rows away from the domain's first / last row (static register slots, branch-free);
+// EDGE = true: the up to four remaining rows, launched separately (run-time slot selection - slow, but 4 rows of 4096).
+template <bool P2, bool EDGE, typename T>
+__global__ __launch_bounds__(256) void k_cip_grad_advect(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+                                                         T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                         const T *gxc, const T *gyc)
+{
+    if (blockIdx.y == 0) cip_grad_advect_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc);
+    else cip_grad_advect_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc);
 }
 
 }  // namespace fs

@@ -82,6 +82,7 @@ class Field:
         self.nchan = nchan
         self._h = dev._p_alloc(nchan)
         self.valid = dev.halo          # ghost rows valid to this depth (zero-filled == consistent everywhere)
+        self.user_data = False         # set once the user uploads / fills data (disables fusions that rely on invariants)
 
     @property
     def shape(self):
@@ -93,6 +94,7 @@ class Field:
     def fill(self, value):
         self.dev._p_fill(self._h, float(value))
         self.valid = self.dev.halo
+        self.user_data = self.user_data or float(value) != 0.0
 
     def from_numpy(self, arr):
         """Upload a GLOBAL (X, Y[, C]) array; each slab keeps its rows (ghost rows included)."""
@@ -103,6 +105,7 @@ class Field:
         win = np.ascontiguousarray(arr[:, dev.g_lo:dev.g_hi], dtype=dev.dtype)
         dev._p_upload(self._h, self.nchan, win, dev.g_lo - (dev.y0 - dev.halo), dev.g_hi - dev.g_lo)
         self.valid = dev.halo
+        self.user_data = True
 
     def to_numpy(self, local=False):
         """Global (X, Y[, C]) array (gathered over slabs) or, with local=True, this slab's owned rows."""
@@ -175,7 +178,7 @@ class DeviceBase:
         for h, nchan in handles:
             self._p_exchange(h, nchan, depth)
 
-    def _run(self, name, args, reads=(), writes=(), pointwise=False):
+    def _run(self, name, args, reads=(), writes=(), pointwise=False, full_writes=()):
         """Launch one kernel on this slab.
 
         Single rank: rows [0, Y), nothing else happens.  Slabs: every field carries `valid` = how many ghost rows are
@@ -215,7 +218,7 @@ class DeviceBase:
         lo = max(H - e, self.g_lo - off)
         hi = min(H + self.nyl + e, self.g_hi - off)
         self._p_kernel(name, *args, lo, hi)
-        for f in writes:
+        for f in list(writes) + list(full_writes):      # full_writes: every cell of the computed rows is overwritten
             f.valid = e
 
     def alloc(self, nchan):
@@ -273,6 +276,11 @@ class DeviceBase:
     def cip_advect(self, dt, dx, fn, fxn, fyn, fc, fxc, fyc, v):  # fs/solver.py:267-332
         self._run("cip_advect", (dt, dx, fn._h, fxn._h, fyn._h, fc._h, fxc._h, fyc._h, v._h),
                   reads=[(fc, 1), (fxc, 1), (fyc, 1), (v, 1)], writes=[fn, fxn, fyn])
+
+    def cip_grad_advect(self, dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc):
+        """K3 + K4 of the velocity field in one pass (build-side fusion): see csrc/fs_march.h k_cip_grad_advect."""
+        self._run("cip_grad_advect", (dt, dx, v_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h),
+                  reads=[(fn, 2), (fc, 2), (gxc, 1), (gyc, 1)], writes=[gx_out, gy_out], full_writes=[v_out])
 
     def vort_calc(self, dx, vort, vort_abs, vc):                # fs/vorticity_confinement.py:27-32
         self._run("vort_calc", (dx, vort._h, vort_abs._h, vc._h), reads=[(vc, 1)], writes=[vort, vort_abs])

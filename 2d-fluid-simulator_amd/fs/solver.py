@@ -4,6 +4,7 @@ Each `update()` issues the same kernel sequence, on the same physical buffers, w
 DoubleBuffer swaps as the reference - that choreography is part of the algorithm.
 The kernels themselves are HIP (csrc/fs_kernels.h); launches are asynchronous on the device stream.
 """
+import os
 from abc import ABCMeta, abstractmethod
 
 from .double_buffer import DoubleBuffer
@@ -101,7 +102,7 @@ class CipMacSolver(Solver):
     """Two-phase CIP solver: non-advection phase (pressure gradient + diffusion, with the gradient fields
     updated alongside), then CIP advection of value and gradients (fs/solver.py:165-332)."""
 
-    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None):
+    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None, fused_transport=None):
         super().__init__(boundary_condition)
         self.dt = dt
         self.dx = dx
@@ -113,6 +114,15 @@ class CipMacSolver(Solver):
         self.vy = DoubleBuffer(self.resolution, 2, self._dev)
         self.p = DoubleBuffer(self.resolution, 1, self._dev)
         self._set_grad(self.vx.current, self.vy.current, self.v.current)
+        # Optional fused gradient-update + advection pass (same observable bits, 66 instead of 96 B/cell of HBM traffic;
+        # needs a third velocity buffer because the reference's in-place result buffer is still an input of neighbouring
+        # tiles).  Measured on MI355X at res 4096: 544 us against 331 + 238 us for the two kernels - the recomputed
+        # gradient rows make it issue-bound, so it is OFF by default (fused_transport=True or FS_FUSE_TRANSPORT=1 enables).
+        if fused_transport is None:
+            fused_transport = os.environ.get("FS_FUSE_TRANSPORT", "0") == "1"
+        self._fused_transport = (bool(fused_transport) and self.resolution[0] % 4 == 0
+                                 and os.environ.get("FS_MARCH", "1") != "0")
+        self._v_spare = self._dev.alloc(2) if self._fused_transport else None
 
     def _flow_step(self):
         self._bc.set_velocity_boundary_condition(self.v.current)
@@ -134,6 +144,15 @@ class CipMacSolver(Solver):
 
     def _update_velocities(self, v, vx, vy, p):
         self._non_advection_phase(v.next, v.current, p.current)
+        grads = (vx.current, vx.next, vy.current, vy.next)
+        if self._fused_transport and not any(f.user_data for f in grads):
+            # one pass instead of K3 + swap + K4 + swap.  End state as in the reference: v.current = advected velocity with the
+            # pre-K2 values on non-fluid cells, v.next = post-K2 velocity, vx/vy.current = new gradients (their .next: dead data)
+            self._dev.cip_grad_advect(self.dt, self.dx, self._v_spare, vx.next, vy.next, v.next, v.current, vx.current, vy.current)
+            v.current, self._v_spare = self._v_spare, v.current
+            vx.swap()
+            vy.swap()
+            return
         self._non_advection_phase_grad(vx.next, vy.next, vx.current, vy.current, v.current, v.next)
         for buf in (v, vx, vy):
             buf.swap()
@@ -154,8 +173,8 @@ class CipMacSolver(Solver):
 class DyeCipMacSolver(CipMacSolver):
     """CipMacSolver + CIP-advected dye with its own gradient fields (fs/solver.py:335-401)."""
 
-    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None):
-        super().__init__(boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement)
+    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None, fused_transport=None):
+        super().__init__(boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement, fused_transport)
         res = boundary_condition.get_resolution()
         self.dye = DoubleBuffer(res, 3, self._dev)
         self.dyex = DoubleBuffer(res, 3, self._dev)

@@ -112,6 +112,15 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
                   const fs_field *fc, const fs_field *fxc, const fs_field *fyc, const fs_field *v,
                   int row_begin, int row_end);
 
+/* _non_advection_phase_grad + _advection_phase of the VELOCITY field fused into one pass (build-side optimisation, same
+ * bits for everything observable): the intermediate gradients never go through HBM.  fn = velocity after
+ * _non_advection_phase, fc = velocity before it, gxc/gyc = gradients before; outputs: v_out (EVERY cell: advected value on
+ * fluid cells, fc carried elsewhere - what the reference's in-place update of fc's buffer leaves), gx_out / gy_out (not-wall
+ * cells).  v_out must be a third buffer distinct from fn and fc; the caller rotates buffers (see fs/solver.py).          */
+int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
+                       const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc,
+                       int row_begin, int row_end);
+
 /* ---- vorticity confinement -------------------------------------------------------------------- */
 /* VorticityConfinement._calc_vorticity    fs/vorticity_confinement.py:27-32                     */
 int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, const fs_field *vc,

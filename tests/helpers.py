@@ -19,7 +19,7 @@ def make_oracle(g, cfg=None):
                             dtype=np.float64 if cfg["fp64"] else np.float32)
 
 
-def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=True):
+def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=True, fused_transport=None):
     """Compose the product classes by hand from the scene arrays stored in the fixture (constructor-level API)."""
     import fs
     from fs.boundary_condition import BoundaryCondition, DyeBoundaryCondition
@@ -32,8 +32,14 @@ def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=T
     pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, u[1], u[2], precompute_source=bool(precompute_source), fused=rb_fused) if u[0] == "rbsor"
           else fs.JacobiPressureUpdater(bc, dt, dx, u[1], precompute_source=precompute_source))
     if cfg["scheme"] == "cip":
-        solver = (fs.DyeCipMacSolver if cfg["dye"] else fs.CipMacSolver)(bc, pu, dt, dx, re, vc)
+        solver = (fs.DyeCipMacSolver if cfg["dye"] else fs.CipMacSolver)(bc, pu, dt, dx, re, vc, fused_transport=fused_transport)
     else:
         adv = fs.advect_upwind if cfg["scheme"] == "upwind" else fs.advect_kk_scheme
         solver = (fs.DyeMacSolver if cfg["dye"] else fs.MacSolver)(bc, pu, adv, dt, dx, re, vc)
     return (fs.DyeFluidSimulator if cfg["dye"] else fs.FluidSimulator)(solver)
+
+
+def dead_buffers(solver):
+    """Internal buffers whose content is unobservable in the run mode of `solver` and therefore not reproduced:
+    with the fused gradient+advection pass the intermediate gradients (vx.next / vy.next) are never stored."""
+    return {"vx.next", "vy.next"} if getattr(solver, "_fused_transport", False) else set()

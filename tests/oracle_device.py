@@ -109,6 +109,15 @@ class OracleSlabDevice(DeviceBase):
         elif name == "cip_advect":
             dt, dx, fn, fxn, fyn, fc, fxc, fyc, v = A
             O._call("oracle_cip_advect", dt_, X, Y, dt, dx, fc.shape[2], b.mask, fn, fxn, fyn, fc, fxc, fyc, v); written = [fn, fxn, fyn]
+        elif name == "cip_grad_advect":
+            dt, dx, vo, gxo, gyo, fn, fc, gxc, gyc = A
+            O._call("oracle_cip_nonadv_grad", dt_, X, Y, dx, 2, b.mask, gxo, gyo, gxc, gyc, fc, fn)     # K3 into the output buffers
+            tx, ty = gxc.copy(), gyc.copy()                                                             # K4 targets: old gradient buffers
+            vo[...] = fc
+            O._call("oracle_cip_advect", dt_, X, Y, dt, dx, 2, b.mask, vo, tx, ty, fn, gxo, gyo, fn)
+            nw = b.mask != 1
+            gxo[nw] = tx[nw]; gyo[nw] = ty[nw]                     # not-wall cells: K4 result (fluid) or carried old gradient
+            written = [vo, gxo, gyo]
         elif name == "vort_calc":
             dx, w, wa, vc = A
             O._call("oracle_vort_calc", dt_, X, Y, dx, b.mask, w, wa, vc); written = [w, wa]

@@ -63,7 +63,10 @@ def test_fast_paths_equal_reference_literal_kernels(cfg, steps, hip_lib):
             fast.step()
             ref.step()
         a, b = _state(fast), _state(ref)
+        from helpers import dead_buffers
         for k in a:
+            if k in dead_buffers(fast._solver):
+                continue
             assert np.array_equal(a[k], b[k], equal_nan=True), f"{k}: rel-L2 {rel_l2(a[k], b[k]):.3e}"
         assert float(np.abs(a["p.current"]).max()) > 0
     finally:

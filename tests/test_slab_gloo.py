@@ -33,6 +33,7 @@ CASES = [
     ("traj_dye_bc2_cip_vc5.npz", 2, 8),
     ("traj_cfg5_bc3_res96_kk_vc10_re1e8.npz", 3, 12),
 ]
+FUSED_TRANSPORT_CASES = [("traj_bc5_cip_vc5.npz", 2, 4), ("traj_dye_bc2_cip_vc5.npz", 2, 8)]
 
 
 @pytest.mark.parametrize("fname,world,halo", CASES)
@@ -44,6 +45,16 @@ def test_slab_run_is_bit_identical(fname, world, halo, tmp_path):
     assert 0 < float(per_step) <= 24.0
     if halo >= 8 and "jacobi" not in fname and "dye" not in fname:
         assert float(per_step) <= 6.0, f"deep halo should need few grouped exchanges per step, got {per_step}"
+
+
+@pytest.mark.parametrize("fname,world,halo", FUSED_TRANSPORT_CASES)
+def test_slab_run_with_fused_transport(fname, world, halo, tmp_path, monkeypatch):
+    """Opt-in fused gradient+advection pass (third velocity buffer, single gradient swap) across slabs."""
+    from slab_worker import run
+    monkeypatch.setenv("FS_FUSE_TRANSPORT", "1")
+    mp.spawn(run, args=(world, _free_port(), fname, halo, str(tmp_path)), nprocs=world, join=True)
+    nbad, per_step, *names = open(os.path.join(tmp_path, "result.txt")).read().split()
+    assert int(nbad) == 0, names
 
 
 def test_slab_rows_partition():
