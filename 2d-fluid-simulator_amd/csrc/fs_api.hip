@@ -79,7 +79,7 @@ static inline dim3 march_grid(const fs_ctx *c, int jb, int je) { return dim3((c-
 
 // overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
 struct OvGrid { int nbx, nby; dim3 grid; };
-enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16 };
+enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16, XCD_JACOBI = 32 };
 static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroups, int family)
 {
     OvGrid o;
@@ -96,6 +96,15 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
 {
     const int v = ctx->jacobi_variant;
     auto tile_grid = [&](int rt) { return dim3((ctx->X / 4 + 255) / 256, (je - jb + rt - 1) / rt, 1); };
+    if (v == 22 || v == 24 || v == 21) {   // overlapped-wave tiles (DPP halo lanes, XCD-group dispatch)
+        const int rt = v == 22 ? 2 : (v == 24 ? 4 : 1);
+        const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
+        return launch(ctx, name, [&] {
+            if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
+            else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
+            else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
+        });
+    }
     return launch(ctx, name, [&] {
         if (v == 2) hipLaunchKernelGGL((k_jacobi_tile<SRC, 2, T>), tile_grid(2), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
         else if (v == 4) hipLaunchKernelGGL((k_jacobi_tile<SRC, 4, T>), tile_grid(4), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
@@ -362,7 +371,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_STRIP")) { int r = atoi(s); if (r >= 1) c->strip = r; }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
-    c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD;
+    c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
     if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);
     if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
     if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows

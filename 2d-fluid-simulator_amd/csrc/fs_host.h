@@ -82,7 +82,7 @@ struct fs_ctx {
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int strip = 32;
-    int jacobi_variant = 2;   // 0: marching strips, 2/4/8: register tile of that many rows (env FS_JACOBI)
+    int jacobi_variant = 22;  // env FS_JACOBI: 22/24/21 overlapped-wave tiles of 2/4/1 rows (default 22), 2/4/8 plain tiles, 0 marching strips
 
     fs::Grid grid() const
     {

@@ -834,4 +834,72 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect(Grid g, Konst<T> k, int
     else cip_grad_advect_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K8J, overlapped-wave register tile: same arithmetic as k_jacobi_tile, but x-neighbours of the wave-edge quads come
+// from halo lanes (DPP) instead of per-row edge loads, and blocks are dealt to the XCDs in groups of tile rows.
+// ------------------------------------------------------------------------------------------------
+template <bool SRC, int RT, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0;
+    const int j0 = jb + by * RT;
+
+    unsigned sel[RT];
+    unsigned any = 0u;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        sel[r] = j0 + r < je ? sel_not_wall(mask_quad(g, i0, j0 + r)) : 0u;
+        any |= sel[r];
+    }
+    if (!__any(any != 0u)) return;
+    const bool need = lane_needed(any);
+
+    Q4<T> P[RT + 2], VX[RT + 2], VY[RT + 2], S2[RT], S3[RT];
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        const int j = clampy(g, j0 - 1 + r);
+        P[r] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, j));
+        if (!SRC) { VX[r] = Q4<T>(load_quad_if<2>(need, vs, g, 0, i0, j)); VY[r] = Q4<T>(load_quad_if<2>(need, vs, g, 1, i0, j)); }
+    }
+    if (SRC) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int j = clampy(g, j0 + r);
+            S2[r] = Q4<T>(load_quad_if<2>(sel[r] != 0u, vs, g, 0, i0, j));
+            S3[r] = Q4<T>(load_quad_if<2>(sel[r] != 0u, vs, g, 1, i0, j));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int j = j0 + r;
+        if (j >= je) break;
+        const Q4<T> &c = P[r + 1], &n = P[r + 2], &m = P[r];
+        const T pl = quad_left<T>(lm, c.quad()), pr = quad_right<T>(lm, c.quad());
+        T xl = 0, xr = 0, yl = 0, yr = 0;
+        if (!SRC) {
+            xl = quad_left<T>(lm, VX[r + 1].quad()); xr = quad_right<T>(lm, VX[r + 1].quad());
+            yl = quad_left<T>(lm, VY[r + 1].quad()); yr = quad_right<T>(lm, VY[r + 1].quad());
+        }
+        Q4<T> o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            T s2, s3;
+            if (SRC) { s2 = S2[r].a[q]; s3 = S3[r].a[q]; }
+            else {
+                const Q4<T> &xc = VX[r + 1], &yc = VY[r + 1];
+                const T xE = q == 3 ? xr : xc.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : xc.a[q == 0 ? 0 : q - 1];
+                const T yE = q == 3 ? yr : yc.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : yc.a[q == 0 ? 0 : q - 1];
+                source_from(k, xE, xW, yE, yW, VX[r + 2].a[q], VX[r].a[q], VY[r + 2].a[q], VY[r].a[q], s2, s3);
+            }
+            const T pE = q == 3 ? pr : c.a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : c.a[q == 0 ? 0 : q - 1];
+            o.a[q] = predict_from(pE, pW, n.a[q], m.a[q], s2, s3);
+        }
+        if (lm.owner && sel[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o.quad(), sel[r]);
+    }
+}
+
 }  // namespace fs

@@ -209,8 +209,8 @@ def main():
             return {"kernel": label, "sweeps": n_, "avg_us": round(avg_s * 1e6, 2), "alg_MB": round(abytes[name] / 1e6, 2),
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "traffic": pmc_traffic.get(name)}
-        jac = leg("jacobi_sweep_src", "jacobi_sweep_src (k_jacobi_tile<SRC>: p + precomputed source pair, S=8)")
-        jac["reads_v_like_reference"] = leg("jacobi_sweep", "jacobi_sweep (k_jacobi_tile: p + v, S=8)")
+        jac = leg("jacobi_sweep_src", "jacobi_sweep_src (k_jacobi_ov<SRC>: p + precomputed source pair, S=8)")
+        jac["reads_v_like_reference"] = leg("jacobi_sweep", "jacobi_sweep (k_jacobi_ov: p + v, S=8)")
 
     out = {
         "metric": "simulation steps/sec (FluidSimulator.step, bc5 res 4096 CIP+VC)" if (res, args.bc) == (4096, 5)

@@ -42,7 +42,7 @@ rows = []
 for sub in ("pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if short(r["Kernel_Name"]) == "k_jacobi_tile":
+            if short(r["Kernel_Name"]) in ("k_jacobi_tile", "k_jacobi_ov"):
                 rows.append((r["Counter_Name"], "SRC" if "ILb1E" in r["Kernel_Name"] or "<true" in r["Kernel_Name"] else "V", float(r["Counter_Value"])))
 for form, key in (("V", "jacobi_sweep"), ("SRC", "jacobi_sweep_src")):
     fe = [v for n, fo, v in rows if n == "FETCH_SIZE" and fo == form]
