@@ -644,6 +644,8 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
         hipLaunchKernelGGL(kern, cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, __VA_ARGS__); \
     });
 
+#define FS_K2M(SS, PP) hipLaunchKernelGGL((k_mac_update_quad<SS, PP, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+            (T *)vn->d, (const T *)vc->d, (const T *)pc->d)
 int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_field *vn, const fs_field *vc,
                   const fs_field *pc, int row_begin, int row_end)
 {
@@ -654,6 +656,13 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, re);
+        if (ctx->use_march) {
+            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
+            return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [&] {
+                if (scheme == FS_UPWIND) { if (k.p2) FS_K2M(0, true); else FS_K2M(0, false); }
+                else { if (k.p2) FS_K2M(1, true); else FS_K2M(1, false); }
+            });
+        }
         if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_update_upwind", (k_mac_update<0, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d) }
         else { FS_LAUNCH_CELLS("mac_update_kk", (k_mac_update<1, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d) }
     })

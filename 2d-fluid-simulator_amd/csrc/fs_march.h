@@ -902,4 +902,87 @@ __global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K2'  MacSolver._update_velocities (fs/solver.py:94-107), quad form: upwind (fs/advection.py:12-24, +-1 stencil) or
+// Kawamura-Kuwahara (fs/advection.py:27-60, +-2 stencil: two DPP hops give the cells i0-2 .. i0+5 of a row).
+// ------------------------------------------------------------------------------------------------
+template <int SCHEME, bool P2, typename T>
+__global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc)
+{
+    constexpr int R = SCHEME == 0 ? 1 : 2;          // stencil radius
+    constexpr int NR = 2 * R + 1;
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0, j = jb + by;
+    const unsigned fl = sel_fluid(mask_quad(g, i0, j));
+    if (!__any(fl != 0u)) return;
+    const bool need = lane_needed(fl);
+    Q4<T> V[2][NR], P[3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) V[c][r] = Q4<T>(load_quad_if<2>(need, vc, g, c, i0, clampy(g, j - R + r)));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) P[r] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, clampy(g, j - 1 + r)));
+    const T pl = quad_left<T>(lm, P[1].quad()), pr = quad_right<T>(lm, P[1].quad());
+    Q4<T> O[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const Q4<T> &row = V[c][R];
+        // row[-2], row[-1], row[4], row[5]: the two cells left / right of the quad (sample()-clamped at the domain edge)
+        const T l1 = quad_left<T>(lm, row.quad()), r1 = quad_right<T>(lm, row.quad());
+        T l2 = l1, r2 = r1;
+        if (SCHEME == 1) {
+            l2 = lane_prev(row.a[2]); if (lm.at_lo) l2 = row.a[0];
+            r2 = lane_next(row.a[1]); if (lm.at_hi) r2 = row.a[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T ux = V[0][R].a[q], uy = V[1][R].a[q];
+            const T f0 = row.a[q];
+            const T fE = q == 3 ? r1 : row.a[q == 3 ? 3 : q + 1], fW = q == 0 ? l1 : row.a[q == 0 ? 0 : q - 1];
+            const T fN = V[c][R + 1].a[q], fS = V[c][R - 1].a[q];
+            T adv;
+            if (SCHEME == 0) {
+                const T ax = ux * qdiv<P2>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx);
+                const T ay = uy * qdiv<P2>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx);
+                adv = ax + ay;
+            } else {
+                // cells i+2 / i-2 of the row: inside the quad, or one of the two DPP'd neighbours; at the domain edge sample() clamps
+                // BOTH i-1 and i-2 (resp. i+1, i+2) onto the edge cell, which quad_left / l2 already return
+                const T fEE = q <= 1 ? row.a[q <= 1 ? q + 2 : 3] : (q == 2 ? r1 : r2);
+                const T fWW = q >= 2 ? row.a[q >= 2 ? q - 2 : 0] : (q == 1 ? l1 : l2);
+                const bool nx = ux < (T)0;
+                T w0 = nx ? (T)-2 : (T)1, w1 = nx ? (T)10 : (T)-2, w2 = nx ? (T)-9 : (T)9, w3 = nx ? (T)2 : (T)-10, w4 = nx ? (T)-1 : (T)2;
+                T acc = fEE * w0;
+                acc = acc + fE * w1; acc = acc + f0 * w2; acc = acc + fW * w3; acc = acc + fWW * w4;
+                const T a = acc / k.six_dx;
+                const bool ny = uy < (T)0;
+                w0 = ny ? (T)-2 : (T)1; w1 = ny ? (T)10 : (T)-2; w2 = ny ? (T)-9 : (T)9; w3 = ny ? (T)2 : (T)-10; w4 = ny ? (T)-1 : (T)2;
+                acc = V[c][R + 2 > NR - 1 ? NR - 1 : R + 2].a[q] * w0;
+                acc = acc + fN * w1; acc = acc + f0 * w2; acc = acc + fS * w3; acc = acc + V[c][R - 2 < 0 ? 0 : R - 2].a[q] * w4;
+                const T b = acc / k.six_dx;
+                adv = ux * a + uy * b;
+            }
+            T gp;
+            if (c == 0) {
+                const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
+                gp = qdiv<P2>((T)0.5 * (pE - pW), k.dx, k.inv_dx);
+            } else {
+                gp = qdiv<P2>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx);
+            }
+            const T d2x = qdiv<P2>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq);
+            const T d2y = qdiv<P2>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq);
+            const T lap = (d2x + d2y) / k.re;
+            O[c].a[q] = f0 + k.dt * (((-adv) - gp) + lap);
+        }
+    }
+    if (lm.owner && fl) {
+        store_quad_sel<T>(vn + idx<2, T>(g, 0, i0, j), O[0].quad(), fl);
+        store_quad_sel<T>(vn + idx<2, T>(g, 1, i0, j), O[1].quad(), fl);
+    }
+}
+
 }  // namespace fs

@@ -29,8 +29,8 @@ class JacobiPressureUpdater(PressureUpdater):
     def __init__(self, boundary_condition, dt, dx, n_iter, precompute_source=None):
         super().__init__(boundary_condition, dt, dx)
         self._n_iter = n_iter
-        # one extra pass per step buys ~25 % cheaper sweeps (82 vs 106 us at res 4096): worth it from 5 sweeps on
-        self._precompute = (n_iter >= 5) if precompute_source is None else bool(precompute_source)
+        # one extra pass per step (~112 us at res 4096) buys cheaper sweeps (74 vs 87 us): worth it from 9 sweeps on
+        self._precompute = (n_iter >= 9) if precompute_source is None else bool(precompute_source)
         self._src = self._dev.alloc(2) if self._precompute else None
 
     def update(self, p, v_current):

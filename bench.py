@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--bc", type=int, default=5)
     ap.add_argument("--scheme", default="cip")
     ap.add_argument("--vc", type=float, default=5.0)
+    ap.add_argument("--re", type=float, default=1.0e6)
+    ap.add_argument("--jacobi", type=int, default=0, help="use JacobiPressureUpdater with this many sweeps/step (BASELINE configs[1])")
     ap.add_argument("--sweeps", type=int, default=200, help="isolated Jacobi sweeps for the roofline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step as a hipGraph (N=1)")
@@ -127,10 +129,11 @@ def main():
             os.environ["FS_TEST_COMM"] = "1"
 
     res = args.res
-    dt, dx, re = 0.05 / res, 1.0 / res, 1.0e6
+    dt, dx, re = 0.05 / res, 1.0 / res, args.re
     vc = args.vc if args.vc else None
     fs.runtime.init(gpu=local_rank, dtype="f32", rank=rank, nranks=world, bcast=bcast)
-    sim = fs.FluidSimulator.create(args.bc, res, dt, dx, re, vc, args.scheme)
+    sim = fs.FluidSimulator.create(args.bc, res, dt, dx, re, vc, args.scheme,
+                                   pressure_updater=("jacobi", args.jacobi) if args.jacobi else None)
     dev = sim._solver._bc.device
     mask = sim._solver._bc.mask
 
@@ -214,12 +217,13 @@ def main():
 
     out = {
         "metric": "simulation steps/sec (FluidSimulator.step, bc5 res 4096 CIP+VC)" if (res, args.bc) == (4096, 5)
-                  else f"simulation steps/sec (bc{args.bc} res {res} {args.scheme})",
+                  else f"simulation steps/sec (bc{args.bc} res {res} {args.scheme}{' jacobi' + str(args.jacobi) if args.jacobi else ''})",
         "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 / steps_per_s, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"bc={args.bc} res={res} ({2 * res}x{res} cells) scheme={args.scheme} vc={vc} "
-                               f"RB-SOR(1.3, 2 iters) Re=1e6 dt=0.05/res; BASELINE.json configs[2]",
+                               f"{'Jacobi(' + str(args.jacobi) + ')' if args.jacobi else 'RB-SOR(1.3, 2 iters)'} Re={re:g} dt=0.05/res"
+                               + ("; BASELINE.json configs[2]" if (res, args.bc, args.scheme, args.jacobi) == (4096, 5, "cip", 0) else ""),
                    "cells": counts["cells"], "fluid_cells": counts["fluid"], "parallelism": f"y-slab x{world}",
                    "launch": "hipGraph replay of 2-step pairs" if graph is not None else "eager (python per step)"},
         "halo_exchanges_per_step": None if world == 1 else {
