@@ -790,6 +790,35 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
 
 #define FS_K34(PP, EE) hipLaunchKernelGGL((k_cip_grad_advect<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d)
+#define FS_K23(PP, EE) hipLaunchKernelGGL((k_cip_nonadv_fused<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
+                (T *)fn->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d)
+int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, fs_field *gx_out, fs_field *gy_out,
+                        const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(fn, 2); FS_FIELD(gx_out, 2); FS_FIELD(gy_out, 2); FS_FIELD(fc, 2); FS_FIELD(pc, 1); FS_FIELD(gxc, 2); FS_FIELD(gyc, 2);
+    FS_REQUIRE(fn != fc && gx_out != gxc && gy_out != gyc, "outputs must not alias inputs");
+    FS_REQUIRE(ctx->use_march, "the fused non-advection pass needs X % 4 == 0 (use the two-kernel form)");
+    FS_ROWS();
+    const Grid gg = ctx->grid();
+    const int in_lo = std::min(std::max(row_begin, gg.jlo + 2), row_end), in_hi = std::max(std::min(row_end, gg.jhi - 1), in_lo);
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, re);
+        auto run = [&](int jb, int je, bool edge) -> int {
+            if (jb >= je) return FS_OK;
+            const OvGrid og = ov_grid(ctx, jb, je, 1, 2, XCD_NONADV);
+            return launch(ctx, edge ? "cip_nonadv_fused_edge" : "cip_nonadv_fused", [&] {
+                if (k.p2) { if (edge) FS_K23(true, true); else FS_K23(true, false); }
+                else { if (edge) FS_K23(false, true); else FS_K23(false, false); }
+            });
+        };
+        int rc = run(row_begin, in_lo, true);
+        if (!rc) rc = run(in_lo, in_hi, false);
+        if (!rc) rc = run(in_hi, row_end, true);
+        return rc;
+    })
+}
+
 int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
                        const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, int row_begin, int row_end)
 {

@@ -985,4 +985,103 @@ __global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K2 + K3 fused for the velocity field: non-advection phase (fs/solver.py:229-240) and the gradient update that consumes its
+// result on a 5-point stencil (fs/solver.py:242-261) in one pass, one component per launch slice (blockIdx.y).
+//   fn(cell) = not-wall ? fc + ((-grad p) + lap(fc)/re) dt : <stored fn>      (K2 leaves wall cells of the fn buffer untouched
+//                                                                              and K3 reads them as they are, H5)
+// is evaluated for rows j-1, j, j+1 of the lane's quad (halo recompute, 3x the cheap K2 arithmetic), row j is stored, and the
+// gradients of row j are updated from fn / fc of the four neighbours.  Saves K3's re-read of fn and fc: 56 instead of 70 B/cell.
+// Wall cells of fn are read-only here and not-wall cells are only written, so concurrent tiles never conflict.
+// ------------------------------------------------------------------------------------------------
+template <int c, bool P2, bool EDGE, typename T>
+__device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+                                                      T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0, j = jb + by;
+    const int rows5[5] = {clampy(g, j - 2), clampy(g, j - 1), j, clampy(g, j + 1), clampy(g, j + 2)};
+    const uint32_t m4[3] = {mask_quad(g, i0, rows5[1]), mask_quad(g, i0, rows5[2]), mask_quad(g, i0, rows5[3])};
+    const unsigned nw[3] = {sel_not_wall(m4[0]), sel_not_wall(m4[1]), sel_not_wall(m4[2])};
+    if (!__any(nw[1] != 0u)) return;
+    const bool need = lane_needed(nw[1]);
+
+    Q4<T> F[5], P[5], GX, GY, FNold[3];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        F[r] = Q4<T>(load_quad_if<2>(need, fc, g, c, i0, rows5[r]));
+        if (c == 1 || (r >= 1 && r <= 3)) P[r] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, rows5[r]));
+    }
+    GX = Q4<T>(load_quad_if<2>(nw[1] != 0u, gxc, g, c, i0, j));
+    GY = Q4<T>(load_quad_if<2>(nw[1] != 0u, gyc, g, c, i0, j));
+#pragma unroll
+    for (int s = 0; s < 3; ++s)      // stored fn only where this lane's quad has a wall cell in that row
+        FNold[s] = Q4<T>(load_quad_if<2>(need && nw[s] != 0xfu, fn, g, c, i0, rows5[s + 1]));
+
+    // ---- K2 on rows j-1, j, j+1 (slot s <-> row slot s+1) ----
+    Q4<T> N[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const Q4<T> &row = F[s + 1];
+        Q4<T> fS, fN, pS, pN;
+        if (!EDGE) { fS = F[s]; fN = F[s + 2]; if (c == 1) { pS = P[s]; pN = P[s + 2]; } }
+        else {
+            const int jr = rows5[s + 1];
+            const int uS = clampy(g, jr - 1) - (j - 2), uN = clampy(g, jr + 1) - (j - 2);
+            fS = pick5(F[0], F[1], F[2], F[3], F[4], uS); fN = pick5(F[0], F[1], F[2], F[3], F[4], uN);
+            if (c == 1) { pS = pick5(P[0], P[1], P[2], P[3], P[4], uS); pN = pick5(P[0], P[1], P[2], P[3], P[4], uN); }
+        }
+        const T l = quad_left<T>(lm, row.quad()), r = quad_right<T>(lm, row.quad());
+        T pl = 0, pr = 0;
+        if (c == 0) { pl = quad_left<T>(lm, P[s + 1].quad()); pr = quad_right<T>(lm, P[s + 1].quad()); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T f0 = row.a[q];
+            const T fE = q == 3 ? r : row.a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : row.a[q == 0 ? 0 : q - 1];
+            const T d2x = qdiv<P2>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq);
+            const T d2y = qdiv<P2>((fN.a[q] - (T)2.0 * f0) + fS.a[q], k.dx_sq, k.inv_dx_sq);
+            const T dif = (d2x + d2y) / k.re;
+            T gp;
+            if (c == 0) {
+                const T pE = q == 3 ? pr : P[s + 1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[s + 1].a[q == 0 ? 0 : q - 1];
+                gp = qdiv<P2>((T)0.5 * (pE - pW), k.dx, k.inv_dx);
+            } else {
+                gp = qdiv<P2>((T)0.5 * (pN.a[q] - pS.a[q]), k.dx, k.inv_dx);
+            }
+            const T gg = (-gp) + dif;
+            const T val = f0 + gg * k.dt;
+            N[s].a[q] = ((nw[s] >> q) & 1u) ? val : FNold[s].a[q];
+        }
+    }
+    // ---- K3 on row j ----
+    const T nl = quad_left<T>(lm, N[1].quad()), nr = quad_right<T>(lm, N[1].quad());
+    const T cl = quad_left<T>(lm, F[2].quad()), cr = quad_right<T>(lm, F[2].quad());
+    Q4<T> OX, OY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const T nE = q == 3 ? nr : N[1].a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : N[1].a[q == 0 ? 0 : q - 1];
+        const T cE = q == 3 ? cr : F[2].a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : F[2].a[q == 0 ? 0 : q - 1];
+        const T sx = ((nE - cE) - nW) + cW;
+        const T sy = ((N[2].a[q] - F[3].a[q]) - N[0].a[q]) + F[1].a[q];
+        OX.a[q] = GX.a[q] + qdiv<P2>(sx, k.two_dx, k.inv_two_dx);
+        OY.a[q] = GY.a[q] + qdiv<P2>(sy, k.two_dx, k.inv_two_dx);
+    }
+    if (lm.owner && nw[1]) {
+        store_quad_sel<T>(fn + idx<2, T>(g, c, i0, j), N[1].quad(), nw[1]);
+        store_quad_sel<T>(gxn + idx<2, T>(g, c, i0, j), OX.quad(), nw[1]);
+        store_quad_sel<T>(gyn + idx<2, T>(g, c, i0, j), OY.quad(), nw[1]);
+    }
+}
+
+template <bool P2, bool EDGE, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+                                                          T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc)
+{
+    if (blockIdx.y == 0) cip_nonadv_fused_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc);
+    else cip_nonadv_fused_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc);
+}
+
 }  // namespace fs
