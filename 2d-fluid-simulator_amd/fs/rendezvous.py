@@ -17,6 +17,7 @@ class FileRendezvous:
             key = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         self.base = os.path.join(os.environ.get("FS_RDZV_DIR", "/tmp"), f"fs_rdzv_{key}")
         self.calls = 0
+        self.t_start = time.time()
 
     def bcast(self, payload):
         """Rank 0's bytes on every rank.  Collective: every rank must call it the same number of times."""
@@ -29,7 +30,12 @@ class FileRendezvous:
             os.replace(tmp, path)
             return payload
         t0 = time.time()
-        while not os.path.exists(path):
+        while True:
+            try:    # a leftover file of an earlier job with a recycled key is older than this process: ignore it
+                if os.path.getmtime(path) >= self.t_start - 120.0:
+                    break
+            except OSError:
+                pass
             if time.time() - t0 > self.timeout:
                 raise TimeoutError(f"rendezvous file {path} did not appear within {self.timeout} s")
             time.sleep(0.01)
