@@ -4,6 +4,9 @@ import sys
 import numpy as np
 import pytest
 
+# the oracle's OpenMP regions run on tiny grids here: a team of hundreds of threads costs far more than the work
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(REPO, "tests", "golden")
 for p in (REPO, os.path.join(REPO, "2d-fluid-simulator_amd"), os.path.join(REPO, "tests")):
