@@ -1,7 +1,7 @@
 /*
  * fs_oracle.c - CPU oracle for the FluidSimulator.step() hot path: TEST INFRASTRUCTURE ONLY.
  *
- * Plain-C restatement of the reference's Taichi kernels (fs/*.py of takah29/2d-fluid-simulator);
+ * Plain-C restatement of the reference's Taichi kernels (the fs/ package of takah29/2d-fluid-simulator);
  * every function cites the reference lines it follows (see fs_oracle_impl.h).  Pinned against golden
  * vectors produced by running the reference's own kernel source under oracle/shim (tests/golden/).
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.

@@ -3,7 +3,7 @@
  * REAL=float / SUF=f32 and REAL=double / SUF=f64).
  *
  * TEST INFRASTRUCTURE.  A plain-C restatement of the reference algorithm
- * (takah29/2d-fluid-simulator, fs/*.py) used only as the parity checker by tests/,
+ * (takah29/2d-fluid-simulator, package fs/) used only as the parity checker by tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Never linked into the product.
  *
  * Layout = the reference's own: field[i, j] with i = x in [0, X), j = y in [0, Y), j contiguous,
