@@ -74,8 +74,6 @@ static int prof_drain(fs_ctx *c)
 }
 
 static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
-// row-marching kernels: x = 1024-cell stripes (256 lanes x 4 cells), y = strips of c->strip rows
-static inline dim3 march_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X / 4 + 255) / 256, (je - jb + c->strip - 1) / c->strip, 1); }
 
 // overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
 struct OvGrid { int nbx, nby; dim3 grid; };
@@ -94,22 +92,13 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
 template <bool SRC, typename T>
 static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
 {
-    const int v = ctx->jacobi_variant;
-    auto tile_grid = [&](int rt) { return dim3((ctx->X / 4 + 255) / 256, (je - jb + rt - 1) / rt, 1); };
-    if (v == 22 || v == 24 || v == 21) {   // overlapped-wave tiles (DPP halo lanes, XCD-group dispatch)
-        const int rt = v == 22 ? 2 : (v == 24 ? 4 : 1);
-        const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
-        return launch(ctx, name, [&] {
-            if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
-            else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
-            else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
-        });
-    }
+    const int v = ctx->jacobi_variant;               // overlapped-wave tiles of 2 (default), 4 or 1 rows
+    const int rt = v == 24 ? 4 : (v == 21 ? 1 : 2);
+    const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
     return launch(ctx, name, [&] {
-        if (v == 2) hipLaunchKernelGGL((k_jacobi_tile<SRC, 2, T>), tile_grid(2), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
-        else if (v == 4) hipLaunchKernelGGL((k_jacobi_tile<SRC, 4, T>), tile_grid(4), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
-        else if (v == 8) hipLaunchKernelGGL((k_jacobi_tile<SRC, 8, T>), tile_grid(8), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
-        else hipLaunchKernelGGL((k_jacobi_march<SRC, T>), march_grid(ctx, jb, je), dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, ctx->strip, pn, pc, vs);
+        if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
+        else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
+        else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
     });
 }
 
@@ -369,7 +358,6 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
-    if (const char *s = getenv("FS_STRIP")) { int r = atoi(s); if (r >= 1) c->strip = r; }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
     if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);

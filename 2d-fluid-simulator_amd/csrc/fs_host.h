@@ -77,12 +77,11 @@ struct fs_ctx {
     // comm
     fs::Comm *comm = nullptr;
     std::set<fs_field *> fields;  // live fields, released with the context
-    // tuning knobs (env FS_MARCH=0 disables the row-marching kernels, FS_STRIP=<rows per strip>)
+    // tuning knobs (env FS_MARCH=0: one-cell-per-lane kernels only)
     bool use_march = true;
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
-    int strip = 32;
-    int jacobi_variant = 22;  // env FS_JACOBI: 22/24/21 overlapped-wave tiles of 2/4/1 rows (default 22), 2/4/8 plain tiles, 0 marching strips
+    int jacobi_variant = 22;  // env FS_JACOBI: 22 / 24 / 21 = overlapped-wave tiles of 2 / 4 / 1 rows
 
     fs::Grid grid() const
     {

@@ -1,19 +1,16 @@
-// fs_march.h - row-marching stencil kernels for gfx950 (the fast path of the Poisson sweeps).
+// fs_march.h - register-tile stencil kernels for gfx950 (the fast paths of the step() kernels).
 //
-// Mapping (CDNA4): a lane owns a QUAD of 4 consecutive x cells (one 16-byte global_load_dwordx4 per
-// field row: a wave moves a full 1 KiB row segment per instruction, perfectly coalesced) and marches down
-// a strip of R rows keeping the rows j-1, j, j+1 of every stencilled field in registers, so each row is
-// fetched from HBM/L2 once per strip instead of once per neighbour.  The x-neighbours of a quad come from
-// the adjacent lanes through DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1 - no LDS, no barrier);
-// only lane 0 / lane 63 of a wave fetch their outer neighbour from memory (an L1/L2 hit: the line is the
-// neighbouring wave's).  No LDS tile is needed for a 5-point stencil in this form; LDS stays free.
+// Mapping (CDNA4): a lane owns a QUAD of 4 consecutive x cells (one 16-byte global_load_dwordx4 per field row: a wave moves
+// a full 1 KiB row segment per instruction, perfectly coalesced) times RT rows; all RT + 2*radius rows of every input are
+// requested up front (tens of KiB in flight per wave - the memory-level parallelism that saturates HBM at 4-6 waves/SIMD;
+// an earlier row-MARCHING variant with three rolling rows was latency-bound and is gone: 100 us vs 74 us per Jacobi sweep).
+// The x-neighbours of a quad come from the adjacent lanes through DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1 -
+// no LDS, no barrier); a wave covers 64 quads of which the inner 62 store ("overlapped waves", see lane_map).
 //
-// Work skipping: the mask quad (one u32 per lane and row) tells a wave whether any of its 256 cells in a
-// row is active; rows that are all wall neither load nor compute (scene 5 is one third wall).
+// Work skipping: the mask quad (one u32 per lane and row) tells a wave whether any of its cells is active; tiles that are
+// all wall neither load nor compute, wall lanes issue no loads (scene 5 is one third wall).
 //
-// blockIdx.x -> 1024-cell column stripe, blockIdx.y -> strip.  With a stripe count that is a multiple of 8
-// the round-robin block->XCD dispatch keeps vertically adjacent strips of a stripe on one XCD, so the two
-// halo rows a strip shares with its neighbours are L2 hits.
+// Blocks are dealt to the 8 XCDs in groups of tile rows (band_coords) so that halo rows are re-read from the local L2.
 //
 // Arithmetic: identical expression trees / operation order as the one-cell-per-lane kernels in
 // fs_kernels.h (and the reference); results are bit-identical.
@@ -54,17 +51,6 @@ __device__ __forceinline__ unsigned lane_next_u(unsigned x) { return (unsigned)_
 // does this lane, or a lane next to it, have any active cell?  (its loads feed the neighbours through DPP)
 __device__ __forceinline__ bool lane_needed(unsigned active) { return (active | lane_prev_u(active) | lane_next_u(active)) != 0u; }
 
-// left neighbour of q.x and right neighbour of q.w in row j of channel c (clamped at the domain edge)
-template <int C, typename T>
-__device__ __forceinline__ void quad_sides(const T *f, const Grid &g, int c, int i0, int j, int lane,
-                                           const typename Quad<T>::type &q, T &left, T &right)
-{
-    left = lane_prev(q.w);
-    right = lane_next(q.x);
-    if (lane == 0) left = i0 > 0 ? f[idx<C, T>(g, c, i0 - 1, j)] : q.x;
-    if (lane == 63 || i0 + 4 >= g.X) right = i0 + 4 < g.X ? f[idx<C, T>(g, c, i0 + 4, j)] : q.w;
-}
-
 __device__ __forceinline__ uint32_t mask_quad(const Grid &g, int i0, int j)
 { return *reinterpret_cast<const uint32_t *>(g.mask + (size_t)j * g.Pm + i0); }
 
@@ -103,132 +89,6 @@ __device__ __forceinline__ void source_from(const Konst<T> &k, T vxE, T vxW, T v
     s2 = ((sxx * sxx + syy * syy) + (syx * sxy)) / (T)8.0;
     s3 = (k.dx * (sxx + syy)) / k.eight_dt;
 }
-
-// three rolling rows of one scalar plane
-template <typename T>
-struct Rows3 {
-    typename Quad<T>::type m, c, p;
-};
-
-// ------------------------------------------------------------------------------------------------
-// K8J  JacobiPressureUpdater._update (fs/pressure_updater.py:62-66), marching form.
-//   SRC = false: reads v like the reference (S = 8 B/cell);  SRC = true: reads the precomputed (s2, s3) pair.
-// ------------------------------------------------------------------------------------------------
-template <bool SRC, typename T>
-__global__ __launch_bounds__(256) void k_jacobi_march(Grid g, Konst<T> k, int jb, int je, int R, T *pn, const T *pc, const T *vs)
-{
-    using V = typename Quad<T>::type;
-    const int lane = threadIdx.x & 63;
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= g.X) return;
-    const int j0 = jb + blockIdx.y * R;
-    const int j1 = j0 + R < je ? j0 + R : je;
-
-    Rows3<T> P, VX, VY;
-    bool hm = false, hc = false, hp = false;   // rows j-1, j, j+1 resident? (wave-uniform)
-
-    for (int j = j0; j < j1; ++j) {
-        const uint32_t m4 = mask_quad(g, i0, j);
-        const unsigned sel = sel_not_wall(m4);
-        if (__any(sel != 0u)) {
-            const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
-            if (!hm) { P.m = load_quad<1>(pc, g, 0, i0, jm); if (!SRC) { VX.m = load_quad<2>(vs, g, 0, i0, jm); VY.m = load_quad<2>(vs, g, 1, i0, jm); } }
-            if (!hc) { P.c = load_quad<1>(pc, g, 0, i0, j); if (!SRC) { VX.c = load_quad<2>(vs, g, 0, i0, j); VY.c = load_quad<2>(vs, g, 1, i0, j); } }
-            if (!hp) { P.p = load_quad<1>(pc, g, 0, i0, jp); if (!SRC) { VX.p = load_quad<2>(vs, g, 0, i0, jp); VY.p = load_quad<2>(vs, g, 1, i0, jp); } }
-            hm = hc = hp = true;
-            T pl, pr;
-            quad_sides<1>(pc, g, 0, i0, j, lane, P.c, pl, pr);
-            V s2, s3;
-            if (SRC) {
-                s2 = load_quad<2>(vs, g, 0, i0, j);
-                s3 = load_quad<2>(vs, g, 1, i0, j);
-            } else {
-                T xl, xr, yl, yr;
-                quad_sides<2>(vs, g, 0, i0, j, lane, VX.c, xl, xr);
-                quad_sides<2>(vs, g, 1, i0, j, lane, VY.c, yl, yr);
-                source_from(k, VX.c.y, xl, VY.c.y, yl, VX.p.x, VX.m.x, VY.p.x, VY.m.x, s2.x, s3.x);
-                source_from(k, VX.c.z, VX.c.x, VY.c.z, VY.c.x, VX.p.y, VX.m.y, VY.p.y, VY.m.y, s2.y, s3.y);
-                source_from(k, VX.c.w, VX.c.y, VY.c.w, VY.c.y, VX.p.z, VX.m.z, VY.p.z, VY.m.z, s2.z, s3.z);
-                source_from(k, xr, VX.c.z, yr, VY.c.z, VX.p.w, VX.m.w, VY.p.w, VY.m.w, s2.w, s3.w);
-            }
-            V o;
-            o.x = predict_from(P.c.y, pl, P.p.x, P.m.x, s2.x, s3.x);
-            o.y = predict_from(P.c.z, P.c.x, P.p.y, P.m.y, s2.y, s3.y);
-            o.z = predict_from(P.c.w, P.c.y, P.p.z, P.m.z, s2.z, s3.z);
-            o.w = predict_from(pr, P.c.z, P.p.w, P.m.w, s2.w, s3.w);
-            store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o, sel);
-        }
-        // rotate: row j becomes j-1, row j+1 becomes j
-        P.m = P.c; P.c = P.p;
-        if (!SRC) { VX.m = VX.c; VX.c = VX.p; VY.m = VY.c; VY.c = VY.p; }
-        hm = hc; hc = hp; hp = false;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// K8J, register-tile form: a lane owns a quad x RT rows.  All (RT+2) rows of p (and of v.x, v.y unless SRC)
-// are requested up front - 3*(RT+2) independent 16-byte loads per lane, i.e. tens of KiB in flight per
-// wave - which is what keeps HBM busy at a few waves per SIMD (Little: ~60 KiB in flight per CU needed).
-// The two halo rows are re-read by the vertically adjacent tiles (same column stripe => same XCD => L2 hit).
-// ------------------------------------------------------------------------------------------------
-template <bool SRC, int RT, typename T>
-__global__ __launch_bounds__(256) void k_jacobi_tile(Grid g, Konst<T> k, int jb, int je, T *pn, const T *pc, const T *vs)
-{
-    using V = typename Quad<T>::type;
-    const int lane = threadIdx.x & 63;
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= g.X) return;
-    const int j0 = jb + blockIdx.y * RT;
-
-    unsigned sel[RT];
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        sel[r] = j0 + r < je ? sel_not_wall(mask_quad(g, i0, j0 + r)) : 0u;
-        any |= sel[r] != 0u;
-    }
-    if (!__any(any)) return;
-    const bool need = lane_needed(any ? 1u : 0u);
-
-    V P[RT + 2], VX[RT + 2], VY[RT + 2];
-#pragma unroll
-    for (int r = 0; r < RT + 2; ++r) {
-        const int j = clampy(g, j0 - 1 + r);
-        P[r] = load_quad_if<1>(need, pc, g, 0, i0, j);
-        if (!SRC) { VX[r] = load_quad_if<2>(need, vs, g, 0, i0, j); VY[r] = load_quad_if<2>(need, vs, g, 1, i0, j); }
-    }
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int j = j0 + r;
-        if (j >= je) break;
-        const int jc = clampy(g, j);
-        T pl, pr;
-        quad_sides<1>(pc, g, 0, i0, jc, lane, P[r + 1], pl, pr);
-        V s2, s3;
-        if (SRC) {
-            s2 = load_quad_if<2>(sel[r] != 0u, vs, g, 0, i0, jc);   // (nontemporal loads / stores measured 1.6x SLOWER here)
-            s3 = load_quad_if<2>(sel[r] != 0u, vs, g, 1, i0, jc);
-        } else {
-            T xl, xr, yl, yr;
-            quad_sides<2>(vs, g, 0, i0, jc, lane, VX[r + 1], xl, xr);
-            quad_sides<2>(vs, g, 1, i0, jc, lane, VY[r + 1], yl, yr);
-            const V &xc = VX[r + 1], &yc = VY[r + 1], &xp = VX[r + 2], &xm = VX[r], &yp = VY[r + 2], &ym = VY[r];
-            source_from(k, xc.y, xl, yc.y, yl, xp.x, xm.x, yp.x, ym.x, s2.x, s3.x);
-            source_from(k, xc.z, xc.x, yc.z, yc.x, xp.y, xm.y, yp.y, ym.y, s2.y, s3.y);
-            source_from(k, xc.w, xc.y, yc.w, yc.y, xp.z, xm.z, yp.z, ym.z, s2.z, s3.z);
-            source_from(k, xr, xc.z, yr, yc.z, xp.w, xm.w, yp.w, ym.w, s2.w, s3.w);
-        }
-        const V &c = P[r + 1], &n = P[r + 2], &m = P[r];
-        V o;
-        o.x = predict_from(c.y, pl, n.x, m.x, s2.x, s3.x);
-        o.y = predict_from(c.z, c.x, n.y, m.y, s2.y, s3.y);
-        o.z = predict_from(c.w, c.y, n.z, m.z, s2.z, s3.z);
-        o.w = predict_from(pr, c.z, n.w, m.w, s2.w, s3.w);
-        if (sel[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o, sel[r]);
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Overlapped-wave column mapping for multi-stage stencils: a wave covers 64 consecutive quads of which the
@@ -836,7 +696,7 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect(Grid g, Konst<T> k, int
 
 
 // ------------------------------------------------------------------------------------------------
-// K8J, overlapped-wave register tile: same arithmetic as k_jacobi_tile, but x-neighbours of the wave-edge quads come
+// K8J  JacobiPressureUpdater._update (fs/pressure_updater.py:62-66), overlapped-wave register tile: x-neighbours of the wave-edge quads come
 // from halo lanes (DPP) instead of per-row edge loads, and blocks are dealt to the XCDs in groups of tile rows.
 // ------------------------------------------------------------------------------------------------
 template <bool SRC, int RT, typename T>

@@ -15,6 +15,7 @@ numpy/gloo stand-in to check the slab logic without a GPU); `Device` binds it to
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -60,14 +61,16 @@ def create_device(resolution):
     dev = cls(resolution[0], resolution[1], _config["dtype"], gpu=_config["gpu"], rank=_config["rank"],
               nranks=_config["nranks"], halo=_config["halo"], bcast=_config["bcast"],
               allgather=_config["allgather"])
-    _devices.append(dev)
+    _devices[:] = [r for r in _devices if r() is not None]
+    _devices.append(weakref.ref(dev))
     return dev
 
 
 def current_device(resolution=None):
     """Most recently created device (optionally: with this (X, Y) resolution)."""
-    for dev in reversed(_devices):
-        if resolution is None or tuple(resolution) == (dev.nx, dev.ny):
+    for ref in reversed(_devices):
+        dev = ref()
+        if dev is not None and (resolution is None or tuple(resolution) == (dev.nx, dev.ny)):
             return dev
     raise RuntimeError(
         "no device context for this resolution yet: construct the BoundaryCondition first "
@@ -474,3 +477,9 @@ class Device(DeviceBase):
         if self._ctx is not None:
             ctx, self._ctx = self._ctx, None
             self._lib.fs_destroy(ctx)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-bench on the BASELINE grid (bc5 res 4096): per-kernel avg time / algorithmic GB/s via HIP events.
     python tools/kbench.py [--res 4096] [--bc 5] [--steps 20] [--sweeps 100]
-Env: FS_MARCH=0/1, FS_STRIP=<rows>."""
+Env: FS_MARCH=0/1, FS_JACOBI=22|24|21, FS_XCD_GROUP=<tile rows>."""
 import argparse, importlib, json, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -34,7 +34,7 @@ for _ in range(a.sweeps // 2):
     dev.jacobi_sweep_src(pb, pa, src); dev.jacobi_sweep_src(pa, pb, src)
 rep = dev.profile_report()
 tot = 0.0
-print(f"# FS_MARCH={os.environ.get('FS_MARCH','1')} FS_STRIP={os.environ.get('FS_STRIP','32')} res={res} bc={a.bc}")
+print(f"# FS_MARCH={os.environ.get('FS_MARCH','1')} res={res} bc={a.bc}")
 for name, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1] / max(kv[1][0], 1)):
     if n == 0: continue
     us = ms / n * 1e3
