@@ -1,0 +1,64 @@
+"""Error behaviour of the C-ABI through the Python shell: every misuse is a negative status + message (FsError), never a
+crash or a silent no-op.  (The reference raises plain Python exceptions only for unknown scheme / scene.)"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def dev(hip_lib):
+    import fs
+    from fs.boundary_condition import BoundaryCondition
+    fs.runtime.init(gpu=0, dtype="f32")
+    mask = np.zeros((32, 16), np.uint8); mask[:, :2] = 1; mask[:, -2:] = 1
+    bc = BoundaryCondition(np.zeros((32, 16, 2), np.float32), mask)
+    yield bc.device
+    bc.device.close()
+
+
+def test_wrong_channel_count_and_aliasing(dev):
+    from fs._lib import FsError
+    v, p, d = dev.alloc(2), dev.alloc(1), dev.alloc(3)
+    with pytest.raises(FsError, match="channel count"):
+        dev.jacobi_sweep(0.01, 0.1, v, p, v)                # pn must be 1-channel
+    with pytest.raises(FsError, match="alias"):
+        dev.cip_nonadv(0.01, 0.1, 100.0, v, v, p)           # fn == fc
+    with pytest.raises(FsError, match="distinct"):
+        dev.jacobi_sweep(0.01, 0.1, p, p, v)
+    with pytest.raises(FsError):
+        dev.mac_update(7, 0.01, 0.1, 100.0, dev.alloc(2), v, p)   # unknown scheme code
+    with pytest.raises(FsError, match="bc_dye"):
+        dev.dye_bc(d)                                        # no dye scene uploaded
+
+
+def test_row_range_and_foreign_field(dev, hip_lib):
+    import fs
+    from fs import _lib
+    from fs.boundary_condition import BoundaryCondition
+    v = dev.alloc(2)
+    assert hip_lib.fs_limit_field(dev._ctx, 10.0, v._h, 0, 17) < 0           # 17 > rows
+    assert b"row range" in hip_lib.fs_last_error()
+    other = BoundaryCondition(np.zeros((32, 16, 2), np.float32), np.ones((32, 16), np.uint8)).device
+    try:
+        assert hip_lib.fs_limit_field(dev._ctx, 10.0, other.alloc(2)._h, 0, 16) < 0
+        assert b"another context" in hip_lib.fs_last_error()
+    finally:
+        other.close()
+    with pytest.raises(ValueError, match="expected array of shape"):
+        v.from_numpy(np.zeros((16, 32, 2), np.float32))
+
+
+def test_kernel_before_mask_upload(hip_lib):
+    from fs import _lib
+    ctx = ctypes.c_void_p()
+    _lib.call("fs_create", ctypes.byref(ctx), 0, 32, 16, 0, 0, 16, 0)
+    f = ctypes.c_void_p()
+    _lib.call("fs_field_alloc", ctx, 2, ctypes.byref(f))
+    assert hip_lib.fs_limit_field(ctx, 10.0, f, 0, 16) == -3                 # FS_ERR_STATE
+    assert b"mask not uploaded" in hip_lib.fs_last_error()
+    assert hip_lib.fs_create(ctypes.byref(ctypes.c_void_p()), 0, 2, 2, 0, 0, 2, 0) == -1     # grid too small
+    assert hip_lib.fs_create(ctypes.byref(ctypes.c_void_p()), 0, 32, 16, 5, 0, 16, 0) == -1    # bad dtype
+    hip_lib.fs_destroy(ctx)
