@@ -714,6 +714,13 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, re);
+        if (ctx->use_march) {
+            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
+            return launch(ctx, "cip_nonadv_dye", [&] {
+                if (k.p2) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d);
+                else hipLaunchKernelGGL((k_cip_nonadv_dye_quad<false, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d);
+            });
+        }
         FS_LAUNCH_CELLS("cip_nonadv_dye", (k_cip_nonadv_dye<T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d)
     })
 }
@@ -745,7 +752,7 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
     })
 }
 
-#define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, false, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
 #define FS_K4N(CC, PP) hipLaunchKernelGGL((k_cip_advect<CC, PP, T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
@@ -778,6 +785,41 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
 
 #define FS_K34(PP, EE) hipLaunchKernelGGL((k_cip_grad_advect<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d)
+int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
+                              const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(fn, 3); FS_FIELD(fxn, 3); FS_FIELD(fyn, 3); FS_FIELD(fc, 3); FS_FIELD(fxc, 3); FS_FIELD(fyc, 3); FS_FIELD(v, 2);
+    FS_REQUIRE(fn != fc && fxn != fxc && fyn != fyc, "outputs must not alias inputs");
+    FS_REQUIRE(ctx->use_march, "needs X % 4 == 0 (use fs_cip_advect + fs_clamp_field)");
+    FS_ROWS();
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 3, XCD_ADVECT);
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(dt, dx, 1.0);
+        return launch(ctx, "cip_advect_c3_clamped", [&] {
+            if (k.p2) hipLaunchKernelGGL((k_cip_advect_quad<3, 1, false, true, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
+                                         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d);
+            else hipLaunchKernelGGL((k_cip_advect_quad<3, 1, false, false, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
+                                    (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d);
+        });
+    })
+}
+
+int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(dye, 3);
+    FS_ROWS();
+    if (!ctx->d_bc_dye) { set_error("bc_dye not uploaded"); return FS_ERR_STATE; }
+    if (ctx->ops_dye.ncomp == 0) return FS_OK;
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "clamp_inflow", [&] {
+            hipLaunchKernelGGL(k_clamp_inflow<T>, dim3((ctx->ops_dye.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T)low, (T)high, (T *)dye->d);
+        });
+    })
+}
+
 #define FS_K23(PP, EE) hipLaunchKernelGGL((k_cip_nonadv_fused<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
                 (T *)fn->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d)
 int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, fs_field *gx_out, fs_field *gy_out,

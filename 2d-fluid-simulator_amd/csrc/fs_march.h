@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx
 // (i - sign(u), j - sign(v)) becomes a per-cell select among the 3x3 gathered values.  blockIdx.z selects the
 // channel group (dye: 3 single-channel passes sharing the advecting velocity).
 // ------------------------------------------------------------------------------------------------
-template <int C, int NC, bool SELF, bool P2, typename T>
+template <int C, int NC, bool SELF, bool P2, bool CLAMP01, typename T>
 __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
                                                          const T *fc, const T *fxc, const T *fyc, const T *v)
 {
@@ -439,6 +439,12 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
             cip_point<P2>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
                       OF[c].a[q], OFX[c].a[q], OFY[c].a[q]);
         }
+    }
+    if (CLAMP01) {      // clamp_field(dye, 0, 1) (fs/solver.py:46-49) folded into the store of the advected value
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) OF[c].a[q] = tmin(tmax(OF[c].a[q], (T)0.0), (T)1.0);
     }
     if (lm.owner && fl) {
 #pragma unroll
@@ -942,6 +948,64 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_fused(Grid g, Konst<T> k, in
 {
     if (blockIdx.y == 0) cip_nonadv_fused_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc);
     else cip_nonadv_fused_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K12  DyeCipMacSolver._non_advection_phase_dye (fs/solver.py:378-383), quad form: dn = dc + (lap(dc)/re) dt on not-wall cells.
+// ------------------------------------------------------------------------------------------------
+template <bool P2, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_dye_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0, j = jb + by;
+    const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
+    if (!__any(nw != 0u)) return;
+    const bool need = lane_needed(nw);
+    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
+    Q4<T> D[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        D[c][0] = Q4<T>(load_quad_if<3>(need, dc, g, c, i0, jm));
+        D[c][1] = Q4<T>(load_quad_if<3>(need, dc, g, c, i0, j));
+        D[c][2] = Q4<T>(load_quad_if<3>(need, dc, g, c, i0, jp));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const T l = quad_left<T>(lm, D[c][1].quad()), r = quad_right<T>(lm, D[c][1].quad());
+        Q4<T> O;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T f0 = D[c][1].a[q];
+            const T fE = q == 3 ? r : D[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : D[c][1].a[q == 0 ? 0 : q - 1];
+            const T d2x = qdiv<P2>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq);
+            const T d2y = qdiv<P2>((D[c][2].a[q] - (T)2.0 * f0) + D[c][0].a[q], k.dx_sq, k.inv_dx_sq);
+            const T dif = (d2x + d2y) / k.re;
+            O.a[q] = f0 + dif * k.dt;
+        }
+        if (lm.owner && nw) store_quad_sel<T>(dn + idx<3, T>(g, c, i0, j), O.quad(), nw);
+    }
+}
+
+// clamp_field restricted to the inflow cells (op list of the dye boundary kernel): with the clamp folded into the advection
+// store these are the only other cells of the dye buffer whose value can lie outside [low, high] (the dye BC rewrites them
+// with the scene colour every step).
+template <typename T>
+__global__ __launch_bounds__(256) void k_clamp_inflow(Grid g, BcOps ops, int jb, int je, T lo, T hi, T *dye)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= ops.ncomp) return;
+    if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
+    for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {
+        const int t = ops.tgt[o];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t a = cell_off(g, t, 3, c);
+            dye[a] = tmin(tmax(dye[a], lo), hi);
+        }
+    }
 }
 
 }  // namespace fs

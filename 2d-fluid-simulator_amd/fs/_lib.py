@@ -60,6 +60,8 @@ _PROTOS = {
     "fs_poisson_residual": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _P(_c_dbl), _P(_c_dbl)],
     "fs_limit_field": [_c_vp, _c_dbl, _c_vp] + _ROWS,
     "fs_clamp_field": [_c_vp, _c_dbl, _c_dbl, _c_vp] + _ROWS,
+    "fs_cip_advect_dye_clamped": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
+    "fs_clamp_inflow": [_c_vp, _c_dbl, _c_dbl, _c_vp] + _ROWS,
     "fs_comm_unique_id": [_c_vp],
     "fs_comm_init": [_c_vp, _c_int, _c_int, _c_vp],
     "fs_comm_destroy": [_c_vp],

@@ -329,6 +329,14 @@ class DeviceBase:
     def clamp_field(self, low, high, f):                        # fs/solver.py:46-49
         self._run("clamp_field", (low, high, f._h), pointwise=True)
 
+    def cip_advect_dye_clamped(self, dt, dx, fn, fxn, fyn, fc, fxc, fyc, v):
+        """CIP advection of the dye with clamp_field(dye, 0, 1) folded into the store (fluid cells)."""
+        self._run("cip_advect_dye_clamped", (dt, dx, fn._h, fxn._h, fyn._h, fc._h, fxc._h, fyc._h, v._h),
+                  reads=[(fc, 1), (fxc, 1), (fyc, 1), (v, 1)], writes=[fn, fxn, fyn])
+
+    def clamp_inflow(self, low, high, dye):
+        self._run("clamp_inflow", (low, high, dye._h), pointwise=True)
+
     def poisson_residual(self, dt, dx, p, vc):
         """(sum of squared Jacobi residuals, cell count) over all not-wall cells of the GLOBAL grid."""
         if self.nranks > 1:

@@ -194,12 +194,20 @@ class DyeCipMacSolver(CipMacSolver):
         self.dyex = DoubleBuffer(res, 3, self._dev)
         self.dyey = DoubleBuffer(res, 3, self._dev)
         self._set_grad(self.dyex.current, self.dyey.current, self.dye.current)
+        # clamp_field(dye, 0, 1) folded into the advection store + a clamp of the inflow cells: after a step only fluid cells
+        # (advected) and inflow cells (rewritten by the dye BC) can leave [0, 1]; walls / outflow cells of this buffer are never
+        # written.  Holds for device-initialised buffers; user-uploaded dye data falls back to the full-grid clamp.
+        self._fused_clamp = self.resolution[0] % 4 == 0 and os.environ.get("FS_MARCH", "1") != "0"
 
     def update(self):
         self._flow_step()
         self._bc.set_dye_boundary_condition(self.dye.current)
-        self._update_dye(self.dye, self.dyex, self.dyey, self.v)
-        clamp_field(self.dye.current, 0.0, 1.0)
+        fold = self._fused_clamp and not (self.dye.current.user_data or self.dye.next.user_data)
+        self._update_dye(self.dye, self.dyex, self.dyey, self.v, clamp=fold)
+        if fold:
+            self._dev.clamp_inflow(0.0, 1.0, self.dye.current)
+        else:
+            clamp_field(self.dye.current, 0.0, 1.0)
 
     def get_fields(self):
         return self.v.current, self.p.current, self.dye.current
@@ -207,11 +215,14 @@ class DyeCipMacSolver(CipMacSolver):
     def _non_advection_phase_dye(self, dn, dc):
         self._dev.cip_nonadv_dye(self.dt, self.dx, self.re, dn, dc)
 
-    def _update_dye(self, dye, dyex, dyey, v):
+    def _update_dye(self, dye, dyex, dyey, v, clamp=False):
         self._non_advection_phase_dye(dye.next, dye.current)
         self._non_advection_phase_grad(dyex.next, dyey.next, dyex.current, dyey.current, dye.current, dye.next)
         for buf in (dye, dyex, dyey):
             buf.swap()
-        self._advection_phase(dye.next, dyex.next, dyey.next, dye.current, dyex.current, dyey.current, v.current)
+        if clamp:
+            self._dev.cip_advect_dye_clamped(self.dt, self.dx, dye.next, dyex.next, dyey.next, dye.current, dyex.current, dyey.current, v.current)
+        else:
+            self._advection_phase(dye.next, dyex.next, dyey.next, dye.current, dyex.current, dyey.current, v.current)
         for buf in (dye, dyex, dyey):
             buf.swap()

@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--scheme", default="cip")
     ap.add_argument("--vc", type=float, default=5.0)
     ap.add_argument("--re", type=float, default=1.0e6)
+    ap.add_argument("--dye", action="store_true", help="DyeFluidSimulator (what the reference's main.py runs by default)")
     ap.add_argument("--jacobi", type=int, default=0, help="use JacobiPressureUpdater with this many sweeps/step (BASELINE configs[1])")
     ap.add_argument("--sweeps", type=int, default=200, help="isolated Jacobi sweeps for the roofline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
@@ -73,6 +74,10 @@ def algorithmic_bytes(mask, esize=4):
         "mac_update_upwind": n + fl * (2 * e + e + 2 * e),
         "mac_update_kk": n + fl * (2 * e + e + 2 * e),
         "limit_field": n * 2 * e,                                        # read v (writes only where |v| > 10)
+        "cip_nonadv_dye": n + nw * (3 * e + 3 * e),
+        "cip_nonadv_grad_c3": n + nw * (6 * e + 6 * e + 6 * e),
+        "cip_advect_c3": n + fl * (9 * e + 2 * e + 9 * e),
+        "clamp_field": n * 6 * e,
         "poisson_source": n * 4 * e,
     }, {"cells": n, "fluid": fl, "not_wall": nw}
 
@@ -133,7 +138,7 @@ def main():
     dt, dx, re = 0.05 / res, 1.0 / res, args.re
     vc = args.vc if args.vc else None
     fs.runtime.init(gpu=local_rank, dtype="f32", rank=rank, nranks=world, bcast=bcast)
-    sim = fs.FluidSimulator.create(args.bc, res, dt, dx, re, vc, args.scheme,
+    sim = (fs.DyeFluidSimulator if args.dye else fs.FluidSimulator).create(args.bc, res, dt, dx, re, vc, args.scheme,
                                    pressure_updater=("jacobi", args.jacobi) if args.jacobi else None)
     dev = sim._solver._bc.device
     mask = sim._solver._bc.mask
@@ -170,7 +175,7 @@ def main():
     # HBM bytes per launch from rocprofv3 PMC passes of this same workload (tools/profile.sh -> profiles/*.json), if present
     pmc_traffic = {}
     pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_file) and (res, args.bc, args.scheme) == (4096, 5, "cip") and world == 1:
+    if os.path.exists(pmc_file) and (res, args.bc, args.scheme, args.dye) == (4096, 5, "cip", False) and world == 1:
         pmc_traffic = json.load(open(pmc_file)).get("bytes_per_launch", {})
     frac_rows = dev.nyl / dev.ny
     kernels = {}
@@ -217,8 +222,9 @@ def main():
         jac["reads_v_like_reference"] = leg("jacobi_sweep", "jacobi_sweep (k_jacobi_ov: p + v, S=8)")
 
     out = {
-        "metric": "simulation steps/sec (FluidSimulator.step, bc5 res 4096 CIP+VC)" if (res, args.bc) == (4096, 5)
-                  else f"simulation steps/sec (bc{args.bc} res {res} {args.scheme}{' jacobi' + str(args.jacobi) if args.jacobi else ''})",
+        "metric": "simulation steps/sec (FluidSimulator.step, bc5 res 4096 CIP+VC)"
+                  if (res, args.bc, args.scheme, args.jacobi, args.dye) == (4096, 5, "cip", 0, False)
+                  else f"simulation steps/sec (bc{args.bc} res {res} {args.scheme}{' jacobi' + str(args.jacobi) if args.jacobi else ''}{' +dye' if args.dye else ''})",
         "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 / steps_per_s, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

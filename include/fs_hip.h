@@ -170,6 +170,14 @@ int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, co
 int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int row_end);
 int fs_clamp_field(fs_ctx *ctx, double low, double high, fs_field *f, int row_begin, int row_end);
 
+/* Dye transport with the final clamp_field(dye, 0, 1) folded in (build-side optimisation, same bits): CIP advection of the
+ * 3-channel dye that stores clamp(value, 0, 1) on fluid cells, and the clamp of the inflow cells (the only other cells the
+ * step leaves outside [0, 1]).  Together they replace fs_cip_advect + fs_clamp_field over the whole grid.                    */
+int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn,
+                              const fs_field *fc, const fs_field *fxc, const fs_field *fyc, const fs_field *v,
+                              int row_begin, int row_end);
+int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row_begin, int row_end);
+
 /* ---- multi-GPU: y-slab halo exchange over RCCL (new; the reference is single-device) ---------- */
 #define FS_UNIQUE_ID_BYTES 128
 int fs_comm_unique_id(void *out_128_bytes);

@@ -19,7 +19,7 @@ def make_oracle(g, cfg=None):
                             dtype=np.float64 if cfg["fp64"] else np.float32)
 
 
-def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=True, fused_transport=None, fused_nonadv=None):
+def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=True, fused_transport=None, fused_nonadv=None, fused_clamp=None):
     """Compose the product classes by hand from the scene arrays stored in the fixture (constructor-level API)."""
     import fs
     from fs.boundary_condition import BoundaryCondition, DyeBoundaryCondition
@@ -35,6 +35,8 @@ def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=T
         solver = (fs.DyeCipMacSolver if cfg["dye"] else fs.CipMacSolver)(bc, pu, dt, dx, re, vc, fused_transport=fused_transport)
         if fused_nonadv is not None:
             solver._fused_nonadv = bool(fused_nonadv) and solver.resolution[0] % 4 == 0
+        if fused_clamp is not None and cfg["dye"]:
+            solver._fused_clamp = bool(fused_clamp) and solver.resolution[0] % 4 == 0
     else:
         adv = fs.advect_upwind if cfg["scheme"] == "upwind" else fs.advect_kk_scheme
         solver = (fs.DyeMacSolver if cfg["dye"] else fs.MacSolver)(bc, pu, adv, dt, dx, re, vc)

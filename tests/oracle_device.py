@@ -147,6 +147,15 @@ class OracleSlabDevice(DeviceBase):
             par = self.g_lo & 1
             O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, 1 ^ par, b.mask, pn, pc, vc)
             O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, 0 ^ par, b.mask, pn, pn, vc); written = [pn]
+        elif name == "cip_advect_dye_clamped":
+            dt, dx, fn, fxn, fyn, fc, fxc, fyc, v = A
+            O._call("oracle_cip_advect", dt_, X, Y, dt, dx, 3, b.mask, fn, fxn, fyn, fc, fxc, fyc, v)
+            fl = b.mask == 0
+            fn[fl] = np.fmin(np.fmax(fn[fl], dt_.type(0)), dt_.type(1)); written = [fn, fxn, fyn]
+        elif name == "clamp_inflow":
+            lo_, hi_, d = A
+            m2 = b.mask == 2
+            d[m2] = np.fmin(np.fmax(d[m2], dt_.type(lo_)), dt_.type(hi_))
         elif name == "limit_field":
             O.limit_field(A[1], A[0])
         elif name == "clamp_field":

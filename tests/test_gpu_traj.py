@@ -37,7 +37,7 @@ def test_trajectory_bitwise(fname, mode, hip_lib):
     elif mode == "fused-nonadv":
         sim = make_product(g, cfg, vc_kwargs={"store_fields": True}, fused_nonadv=True)
     else:
-        sim = make_product(g, cfg, vc_kwargs={"fused": False}, rb_fused=False, fused_transport=False, fused_nonadv=False, precompute_source=False)
+        sim = make_product(g, cfg, vc_kwargs={"fused": False}, rb_fused=False, fused_transport=False, fused_nonadv=False, fused_clamp=False, precompute_source=False)
     try:
         for step in range(1, max(cfg["snaps"]) + 1):
             sim.step()
