@@ -754,6 +754,8 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
 
 #define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, false, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
+#define FS_K4D(PP) hipLaunchKernelGGL((k_cip_advect_dye<PP, false, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
 #define FS_K4N(CC, PP) hipLaunchKernelGGL((k_cip_advect<CC, PP, T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
 int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
@@ -768,13 +770,13 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0);
         const bool self = (v == fc);
-        const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, (C == 2 && self) ? 1 : C, XCD_ADVECT);
+        const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, (C == 2 && !self) ? 2 : 1, XCD_ADVECT);   // C == 3: one pass over the channels
         const dim3 qgrid = og.grid;
         return launch(ctx, C == 2 ? "cip_advect" : "cip_advect_c3", [&] {
             if (ctx->use_march) {
                 if (C == 2 && self) { if (k.p2) FS_K4Q(2, 2, true, true); else FS_K4Q(2, 2, true, false); }
                 else if (C == 2) { if (k.p2) FS_K4Q(2, 1, false, true); else FS_K4Q(2, 1, false, false); }
-                else { if (k.p2) FS_K4Q(3, 1, false, true); else FS_K4Q(3, 1, false, false); }
+                else { if (k.p2) FS_K4D(true); else FS_K4D(false); }
             } else {
                 if (C == 2) { if (k.p2) FS_K4N(2, true); else FS_K4N(2, false); }
                 else { if (k.p2) FS_K4N(3, true); else FS_K4N(3, false); }
@@ -793,13 +795,13 @@ int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, f
     FS_REQUIRE(fn != fc && fxn != fxc && fyn != fyc, "outputs must not alias inputs");
     FS_REQUIRE(ctx->use_march, "needs X % 4 == 0 (use fs_cip_advect + fs_clamp_field)");
     FS_ROWS();
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 3, XCD_ADVECT);
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_ADVECT);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0);
         return launch(ctx, "cip_advect_c3_clamped", [&] {
-            if (k.p2) hipLaunchKernelGGL((k_cip_advect_quad<3, 1, false, true, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
+            if (k.p2) hipLaunchKernelGGL((k_cip_advect_dye<true, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
                                          (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d);
-            else hipLaunchKernelGGL((k_cip_advect_quad<3, 1, false, false, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
+            else hipLaunchKernelGGL((k_cip_advect_dye<false, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
                                     (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d);
         });
     })

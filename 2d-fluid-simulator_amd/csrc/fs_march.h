@@ -1008,4 +1008,75 @@ __global__ __launch_bounds__(256) void k_clamp_inflow(Grid g, BcOps ops, int jb,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K4 for the 3-channel dye (fs/solver.py:385-401 -> _advection_phase): one pass over the three channels.  The advecting
+// velocity (three rows of v.x, v.y), its central differences and the upwind selectors are loaded / formed once per cell and
+// kept in registers; the channels are then streamed one after the other (nine 16-byte loads each), re-using the same
+// registers.  Replaces three single-channel launches slices that each re-read the velocity.
+// ------------------------------------------------------------------------------------------------
+template <bool P2, bool CLAMP01, typename T>
+__global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+                                                        const T *fc, const T *fxc, const T *fyc, const T *v)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
+    const LaneMap lm = lane_map(g, bx);
+    const int i0 = lm.i0, j = jb + by;
+    const unsigned fl = sel_fluid(mask_quad(g, i0, j));
+    if (!__any(fl != 0u)) return;
+    const bool need = lane_needed(fl);
+    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
+
+    T vx[4], vy[4], dxx[4], dxy[4], dyx[4], dyy[4];
+    {
+        const Q4<T> X0(load_quad_if<2>(need, v, g, 0, i0, jm)), X1(load_quad_if<2>(need, v, g, 0, i0, j)), X2(load_quad_if<2>(need, v, g, 0, i0, jp));
+        const Q4<T> Y0(load_quad_if<2>(need, v, g, 1, i0, jm)), Y1(load_quad_if<2>(need, v, g, 1, i0, j)), Y2(load_quad_if<2>(need, v, g, 1, i0, jp));
+        const T xl = quad_left<T>(lm, X1.quad()), xr = quad_right<T>(lm, X1.quad());
+        const T yl = quad_left<T>(lm, Y1.quad()), yr = quad_right<T>(lm, Y1.quad());
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vx[q] = X1.a[q]; vy[q] = Y1.a[q];
+            const T xE = q == 3 ? xr : X1.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : X1.a[q == 0 ? 0 : q - 1];
+            const T yE = q == 3 ? yr : Y1.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : Y1.a[q == 0 ? 0 : q - 1];
+            dxx[q] = qdiv<P2>((T)0.5 * (xE - xW), k.dx, k.inv_dx); dxy[q] = qdiv<P2>((T)0.5 * (yE - yW), k.dx, k.inv_dx);
+            dyx[q] = qdiv<P2>((T)0.5 * (X2.a[q] - X0.a[q]), k.dx, k.inv_dx); dyy[q] = qdiv<P2>((T)0.5 * (Y2.a[q] - Y0.a[q]), k.dx, k.inv_dx);
+        }
+    }
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        Q4<T> F[3], FX[3], FY[3];
+        F[0] = Q4<T>(load_quad_if<3>(need, fc, g, c, i0, jm)); F[1] = Q4<T>(load_quad_if<3>(need, fc, g, c, i0, j)); F[2] = Q4<T>(load_quad_if<3>(need, fc, g, c, i0, jp));
+        FX[0] = Q4<T>(load_quad_if<3>(need, fxc, g, c, i0, jm)); FX[1] = Q4<T>(load_quad_if<3>(need, fxc, g, c, i0, j)); FX[2] = Q4<T>(load_quad_if<3>(need, fxc, g, c, i0, jp));
+        FY[0] = Q4<T>(load_quad_if<3>(need, fyc, g, c, i0, jm)); FY[1] = Q4<T>(load_quad_if<3>(need, fyc, g, c, i0, j)); FY[2] = Q4<T>(load_quad_if<3>(need, fyc, g, c, i0, jp));
+        T fl_[3], fr_[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { fl_[r] = quad_left<T>(lm, F[r].quad()); fr_[r] = quad_right<T>(lm, F[r].quad()); }
+        const T fxl = quad_left<T>(lm, FX[1].quad()), fxr = quad_right<T>(lm, FX[1].quad());
+        const T fyl = quad_left<T>(lm, FY[1].quad()), fyr = quad_right<T>(lm, FY[1].quad());
+        Q4<T> OF, OFX, OFY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool nx = vx[q] < (T)0.0, ny = vy[q] < (T)0.0;
+            const T fE1 = q == 3 ? fr_[1] : F[1].a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl_[1] : F[1].a[q == 0 ? 0 : q - 1];
+            const T fE0 = q == 3 ? fr_[0] : F[0].a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl_[0] : F[0].a[q == 0 ? 0 : q - 1];
+            const T fE2 = q == 3 ? fr_[2] : F[2].a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl_[2] : F[2].a[q == 0 ? 0 : q - 1];
+            const T fxE = q == 3 ? fxr : FX[1].a[q == 3 ? 3 : q + 1], fxW = q == 0 ? fxl : FX[1].a[q == 0 ? 0 : q - 1];
+            const T fyE = q == 3 ? fyr : FY[1].a[q == 3 ? 3 : q + 1], fyW = q == 0 ? fyl : FY[1].a[q == 0 ? 0 : q - 1];
+            const T f00 = F[1].a[q], f0m = ny ? F[2].a[q] : F[0].a[q], fm0 = nx ? fE1 : fW1;
+            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
+            const T fx00 = FX[1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? FX[2].a[q] : FX[0].a[q];
+            const T fy00 = FY[1].a[q], fy0m = ny ? FY[2].a[q] : FY[0].a[q], fym0 = nx ? fyE : fyW;
+            cip_point<P2>(k, vx[q], vy[q], dxx[q], dxy[q], dyx[q], dyy[q], f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
+                          OF.a[q], OFX.a[q], OFY.a[q]);
+            if (CLAMP01) OF.a[q] = tmin(tmax(OF.a[q], (T)0.0), (T)1.0);     // clamp_field(dye, 0, 1), fs/solver.py:46-49
+        }
+        if (lm.owner && fl) {
+            store_quad_sel<T>(fn + idx<3, T>(g, c, i0, j), OF.quad(), fl);
+            store_quad_sel<T>(fxn + idx<3, T>(g, c, i0, j), OFX.quad(), fl);
+            store_quad_sel<T>(fyn + idx<3, T>(g, c, i0, j), OFY.quad(), fl);
+        }
+    }
+}
+
 }  // namespace fs
