@@ -8,7 +8,7 @@
 // no LDS, no barrier); a wave covers 64 quads of which the inner 62 store ("overlapped waves", see lane_map).
 //
 // Work skipping: the mask quad (one u32 per lane and row) tells a wave whether any of its cells is active; tiles that are
-// all wall neither load nor compute, wall lanes issue no loads (scene 5 is one third wall).
+// all wall neither load nor compute (scene 5 is one third wall).
 //
 // Blocks are dealt to the 8 XCDs in groups of tile rows (band_coords) so that halo rows are re-read from the local L2.
 //
@@ -191,14 +191,13 @@ __global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx,
         if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
     }
     if (!__any(any)) return;
-    const bool need = lane_needed(any ? 1u : 0u);
 
     V VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1
 #pragma unroll
     for (int r = 0; r < RT + 4; ++r) {
         const int j = clampy(g, j0 - 2 + r);
-        VX[r] = load_quad_if<2>(need, vc, g, 0, i0, j);
-        VY[r] = load_quad_if<2>(need, vc, g, 1, i0, j);
+        VX[r] = load_quad<2>(vc, g, 0, i0, j);
+        VY[r] = load_quad<2>(vc, g, 1, i0, j);
     }
     // vorticity of rows j0-1 .. j0+RT  (index r <-> v slot r+1)
     V W[RT + 2];
@@ -323,19 +322,18 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx
         if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
     }
     if (!__any(any)) return;
-    const bool need = lane_needed(any ? 1u : 0u);
 
     Q4<T> PC[RT + 4], VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1 (clamped)
 #pragma unroll
     for (int r = 0; r < RT + 4; ++r) {
         const int j = clampy(g, j0 - 2 + r);
-        PC[r] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, j));
-        VX[r] = Q4<T>(load_quad_if<2>(need, vc, g, 0, i0, j));
-        VY[r] = Q4<T>(load_quad_if<2>(need, vc, g, 1, i0, j));
+        PC[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, j));
+        VX[r] = Q4<T>(load_quad<2>(vc, g, 0, i0, j));
+        VY[r] = Q4<T>(load_quad<2>(vc, g, 1, i0, j));
     }
     Q4<T> PO[RT + 2];                            // p.next after the odd pass, rows j0-1 .. j0+RT
 #pragma unroll
-    for (int r = 0; r < RT + 2; ++r) PO[r] = Q4<T>(load_quad_if<1>(need, pn, g, 0, i0, clampy(g, j0 - 1 + r)));
+    for (int r = 0; r < RT + 2; ++r) PO[r] = Q4<T>(load_quad<1>(pn, g, 0, i0, clampy(g, j0 - 1 + r)));
 
     // odd pass on rows j0-1 .. j0+RT (slot r <-> field slot r+1)
 #pragma unroll
@@ -383,23 +381,22 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
     const int c0 = blockIdx.y * NC;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
     if (!__any(fl != 0u)) return;
-    const bool need = lane_needed(fl);
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
 
     Q4<T> F[NC][3], FX[NC][3], FY[NC][3];      // rows j-1, j, j+1
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        F[c][0] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, jm)); F[c][1] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, j)); F[c][2] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, jp));
-        FX[c][0] = Q4<T>(load_quad_if<C>(need, fxc, g, c0 + c, i0, jm)); FX[c][1] = Q4<T>(load_quad_if<C>(need, fxc, g, c0 + c, i0, j)); FX[c][2] = Q4<T>(load_quad_if<C>(need, fxc, g, c0 + c, i0, jp));
-        FY[c][0] = Q4<T>(load_quad_if<C>(need, fyc, g, c0 + c, i0, jm)); FY[c][1] = Q4<T>(load_quad_if<C>(need, fyc, g, c0 + c, i0, j)); FY[c][2] = Q4<T>(load_quad_if<C>(need, fyc, g, c0 + c, i0, jp));
+        F[c][0] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jm)); F[c][1] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, j)); F[c][2] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jp));
+        FX[c][0] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, jm)); FX[c][1] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, j)); FX[c][2] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, jp));
+        FY[c][0] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, jm)); FY[c][1] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, j)); FY[c][2] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, jp));
     }
     Q4<T> VX[3], VY[3];
     if (SELF) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) { VX[r] = F[0][r]; VY[r] = F[1][r]; }
     } else {
-        VX[0] = Q4<T>(load_quad_if<2>(need, v, g, 0, i0, jm)); VX[1] = Q4<T>(load_quad_if<2>(need, v, g, 0, i0, j)); VX[2] = Q4<T>(load_quad_if<2>(need, v, g, 0, i0, jp));
-        VY[0] = Q4<T>(load_quad_if<2>(need, v, g, 1, i0, jm)); VY[1] = Q4<T>(load_quad_if<2>(need, v, g, 1, i0, j)); VY[2] = Q4<T>(load_quad_if<2>(need, v, g, 1, i0, jp));
+        VX[0] = Q4<T>(load_quad<2>(v, g, 0, i0, jm)); VX[1] = Q4<T>(load_quad<2>(v, g, 0, i0, j)); VX[2] = Q4<T>(load_quad<2>(v, g, 0, i0, jp));
+        VY[0] = Q4<T>(load_quad<2>(v, g, 1, i0, jm)); VY[1] = Q4<T>(load_quad<2>(v, g, 1, i0, j)); VY[2] = Q4<T>(load_quad<2>(v, g, 1, i0, jp));
     }
     // x-neighbours (left of cell 0 / right of cell 3)
     const T vxl = quad_left<T>(lm, VX[1].quad()), vxr = quad_right<T>(lm, VX[1].quad());
@@ -470,12 +467,11 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return;
-    const bool need = lane_needed(nw);
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> F[2][3], P[3];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { F[c][0] = Q4<T>(load_quad_if<2>(need, fc, g, c, i0, jm)); F[c][1] = Q4<T>(load_quad_if<2>(need, fc, g, c, i0, j)); F[c][2] = Q4<T>(load_quad_if<2>(need, fc, g, c, i0, jp)); }
-    P[0] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, jm)); P[1] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, j)); P[2] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, jp));
+    for (int c = 0; c < 2; ++c) { F[c][0] = Q4<T>(load_quad<2>(fc, g, c, i0, jm)); F[c][1] = Q4<T>(load_quad<2>(fc, g, c, i0, j)); F[c][2] = Q4<T>(load_quad<2>(fc, g, c, i0, jp)); }
+    P[0] = Q4<T>(load_quad<1>(pc, g, 0, i0, jm)); P[1] = Q4<T>(load_quad<1>(pc, g, 0, i0, j)); P[2] = Q4<T>(load_quad<1>(pc, g, 0, i0, jp));
     const T pl = quad_left<T>(lm, P[1].quad()), pr = quad_right<T>(lm, P[1].quad());
     Q4<T> O[2];
 #pragma unroll
@@ -519,15 +515,14 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k
     const int i0 = lm.i0, j = jb + by, c0 = blockIdx.y * NC;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return;
-    const bool need = lane_needed(nw);
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> N[NC][3], Fc[NC][3], GX[NC], GY[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        N[c][0] = Q4<T>(load_quad_if<C>(need, fn, g, c0 + c, i0, jm)); N[c][1] = Q4<T>(load_quad_if<C>(need, fn, g, c0 + c, i0, j)); N[c][2] = Q4<T>(load_quad_if<C>(need, fn, g, c0 + c, i0, jp));
-        Fc[c][0] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, jm)); Fc[c][1] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, j)); Fc[c][2] = Q4<T>(load_quad_if<C>(need, fc, g, c0 + c, i0, jp));
-        GX[c] = Q4<T>(load_quad_if<C>(need, fxc, g, c0 + c, i0, j));
-        GY[c] = Q4<T>(load_quad_if<C>(need, fyc, g, c0 + c, i0, j));
+        N[c][0] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, jm)); N[c][1] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, j)); N[c][2] = Q4<T>(load_quad<C>(fn, g, c0 + c, i0, jp));
+        Fc[c][0] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jm)); Fc[c][1] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, j)); Fc[c][2] = Q4<T>(load_quad<C>(fc, g, c0 + c, i0, jp));
+        GX[c] = Q4<T>(load_quad<C>(fxc, g, c0 + c, i0, j));
+        GY[c] = Q4<T>(load_quad<C>(fyc, g, c0 + c, i0, j));
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -722,21 +717,20 @@ __global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, 
         any |= sel[r];
     }
     if (!__any(any != 0u)) return;
-    const bool need = lane_needed(any);
 
     Q4<T> P[RT + 2], VX[RT + 2], VY[RT + 2], S2[RT], S3[RT];
 #pragma unroll
     for (int r = 0; r < RT + 2; ++r) {
         const int j = clampy(g, j0 - 1 + r);
-        P[r] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, j));
-        if (!SRC) { VX[r] = Q4<T>(load_quad_if<2>(need, vs, g, 0, i0, j)); VY[r] = Q4<T>(load_quad_if<2>(need, vs, g, 1, i0, j)); }
+        P[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, j));
+        if (!SRC) { VX[r] = Q4<T>(load_quad<2>(vs, g, 0, i0, j)); VY[r] = Q4<T>(load_quad<2>(vs, g, 1, i0, j)); }
     }
     if (SRC) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int j = clampy(g, j0 + r);
-            S2[r] = Q4<T>(load_quad_if<2>(sel[r] != 0u, vs, g, 0, i0, j));
-            S3[r] = Q4<T>(load_quad_if<2>(sel[r] != 0u, vs, g, 1, i0, j));
+            S2[r] = Q4<T>(load_quad<2>(vs, g, 0, i0, j));      // (per-lane predication of loads measured slower: each becomes its own
+            S3[r] = Q4<T>(load_quad<2>(vs, g, 1, i0, j));      //  exec-masked basic block and the loads no longer issue back to back)
         }
     }
 #pragma unroll
@@ -784,14 +778,13 @@ __global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int
     const int i0 = lm.i0, j = jb + by;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
     if (!__any(fl != 0u)) return;
-    const bool need = lane_needed(fl);
     Q4<T> V[2][NR], P[3];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < NR; ++r) V[c][r] = Q4<T>(load_quad_if<2>(need, vc, g, c, i0, clampy(g, j - R + r)));
+        for (int r = 0; r < NR; ++r) V[c][r] = Q4<T>(load_quad<2>(vc, g, c, i0, clampy(g, j - R + r)));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) P[r] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, clampy(g, j - 1 + r)));
+    for (int r = 0; r < 3; ++r) P[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, clampy(g, j - 1 + r)));
     const T pl = quad_left<T>(lm, P[1].quad()), pr = quad_right<T>(lm, P[1].quad());
     Q4<T> O[2];
 #pragma unroll
@@ -878,8 +871,8 @@ __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst
     Q4<T> F[5], P[5], GX, GY, FNold[3];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-        F[r] = Q4<T>(load_quad_if<2>(need, fc, g, c, i0, rows5[r]));
-        if (c == 1 || (r >= 1 && r <= 3)) P[r] = Q4<T>(load_quad_if<1>(need, pc, g, 0, i0, rows5[r]));
+        F[r] = Q4<T>(load_quad<2>(fc, g, c, i0, rows5[r]));
+        if (c == 1 || (r >= 1 && r <= 3)) P[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, rows5[r]));
     }
     GX = Q4<T>(load_quad_if<2>(nw[1] != 0u, gxc, g, c, i0, j));
     GY = Q4<T>(load_quad_if<2>(nw[1] != 0u, gyc, g, c, i0, j));
@@ -963,14 +956,13 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_dye_quad(Grid g, Konst<T> k,
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return;
-    const bool need = lane_needed(nw);
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> D[3][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        D[c][0] = Q4<T>(load_quad_if<3>(need, dc, g, c, i0, jm));
-        D[c][1] = Q4<T>(load_quad_if<3>(need, dc, g, c, i0, j));
-        D[c][2] = Q4<T>(load_quad_if<3>(need, dc, g, c, i0, jp));
+        D[c][0] = Q4<T>(load_quad<3>(dc, g, c, i0, jm));
+        D[c][1] = Q4<T>(load_quad<3>(dc, g, c, i0, j));
+        D[c][2] = Q4<T>(load_quad<3>(dc, g, c, i0, jp));
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -1025,13 +1017,12 @@ __global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int 
     const int i0 = lm.i0, j = jb + by;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
     if (!__any(fl != 0u)) return;
-    const bool need = lane_needed(fl);
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
 
     T vx[4], vy[4], dxx[4], dxy[4], dyx[4], dyy[4];
     {
-        const Q4<T> X0(load_quad_if<2>(need, v, g, 0, i0, jm)), X1(load_quad_if<2>(need, v, g, 0, i0, j)), X2(load_quad_if<2>(need, v, g, 0, i0, jp));
-        const Q4<T> Y0(load_quad_if<2>(need, v, g, 1, i0, jm)), Y1(load_quad_if<2>(need, v, g, 1, i0, j)), Y2(load_quad_if<2>(need, v, g, 1, i0, jp));
+        const Q4<T> X0(load_quad<2>(v, g, 0, i0, jm)), X1(load_quad<2>(v, g, 0, i0, j)), X2(load_quad<2>(v, g, 0, i0, jp));
+        const Q4<T> Y0(load_quad<2>(v, g, 1, i0, jm)), Y1(load_quad<2>(v, g, 1, i0, j)), Y2(load_quad<2>(v, g, 1, i0, jp));
         const T xl = quad_left<T>(lm, X1.quad()), xr = quad_right<T>(lm, X1.quad());
         const T yl = quad_left<T>(lm, Y1.quad()), yr = quad_right<T>(lm, Y1.quad());
 #pragma unroll
@@ -1046,9 +1037,9 @@ __global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int 
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         Q4<T> F[3], FX[3], FY[3];
-        F[0] = Q4<T>(load_quad_if<3>(need, fc, g, c, i0, jm)); F[1] = Q4<T>(load_quad_if<3>(need, fc, g, c, i0, j)); F[2] = Q4<T>(load_quad_if<3>(need, fc, g, c, i0, jp));
-        FX[0] = Q4<T>(load_quad_if<3>(need, fxc, g, c, i0, jm)); FX[1] = Q4<T>(load_quad_if<3>(need, fxc, g, c, i0, j)); FX[2] = Q4<T>(load_quad_if<3>(need, fxc, g, c, i0, jp));
-        FY[0] = Q4<T>(load_quad_if<3>(need, fyc, g, c, i0, jm)); FY[1] = Q4<T>(load_quad_if<3>(need, fyc, g, c, i0, j)); FY[2] = Q4<T>(load_quad_if<3>(need, fyc, g, c, i0, jp));
+        F[0] = Q4<T>(load_quad<3>(fc, g, c, i0, jm)); F[1] = Q4<T>(load_quad<3>(fc, g, c, i0, j)); F[2] = Q4<T>(load_quad<3>(fc, g, c, i0, jp));
+        FX[0] = Q4<T>(load_quad<3>(fxc, g, c, i0, jm)); FX[1] = Q4<T>(load_quad<3>(fxc, g, c, i0, j)); FX[2] = Q4<T>(load_quad<3>(fxc, g, c, i0, jp));
+        FY[0] = Q4<T>(load_quad<3>(fyc, g, c, i0, jm)); FY[1] = Q4<T>(load_quad<3>(fyc, g, c, i0, j)); FY[2] = Q4<T>(load_quad<3>(fyc, g, c, i0, jp));
         T fl_[3], fr_[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { fl_[r] = quad_left<T>(lm, F[r].quad()); fr_[r] = quad_right<T>(lm, F[r].quad()); }
