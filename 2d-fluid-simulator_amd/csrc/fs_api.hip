@@ -92,7 +92,14 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
 template <bool SRC, typename T>
 static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
 {
-    const int v = ctx->jacobi_variant;               // overlapped-wave tiles of 2 (default), 4 or 1 rows
+    const int v = ctx->jacobi_variant;               // overlapped-wave tiles of 2 (default), 4 or 1 rows; 30 = LDS halo tile
+    if (v == 30) {
+        constexpr int TY = 16;
+        const dim3 grid((ctx->X + 255) / 256, (je - jb + TY - 1) / TY, 1);
+        return launch(ctx, name, [&] {
+            hipLaunchKernelGGL((k_jacobi_lds<SRC, TY, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
+        });
+    }
     const int rt = v == 24 ? 4 : (v == 21 ? 1 : 2);
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
     return launch(ctx, name, [&] {

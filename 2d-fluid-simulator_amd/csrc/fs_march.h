@@ -1070,4 +1070,79 @@ __global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K8J with an LDS halo tile - the textbook GPU stencil form, kept as a measured ALTERNATIVE (env FS_JACOBI=30), not the
+// default: a 256-thread workgroup stages a (256+2) x (TY+2) tile of p (and of v.x, v.y when it reads v) in LDS with 16-byte
+// global loads, barriers, and every lane then relaxes a quad x TY/4 rows from LDS (ds_read_b128 for the rows above / below,
+// two ds_read_b32 for the side cells).  Same arithmetic, same bits.  On MI355X the LDS round trip + barrier cost more than
+// the DPP/register form (see DESIGN.md for the numbers); the 5-point stencil simply has too little reuse to pay for LDS.
+// ------------------------------------------------------------------------------------------------
+template <bool SRC, int TY, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_lds(Grid g, Konst<T> k, int jb, int je, T *pn, const T *pc, const T *vs)
+{
+    using V = typename Quad<T>::type;
+    constexpr int NP = SRC ? 1 : 3;                 // planes staged: p [, v.x, v.y]
+    constexpr int W = 256 + 8;                      // tile row: 4 pad + 256 cells + 4 pad (keeps 16-byte alignment; halo cells at [3], [260])
+    __shared__ __attribute__((aligned(16))) T tile[NP][TY + 2][W];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * 256;                // first cell of the tile
+    const int j0 = jb + blockIdx.y * TY;
+    const int i0 = x0 + lane * 4;                   // this lane's quad (every wave covers the full 256-cell width)
+    const bool inx = i0 < g.X;
+
+    // ---- stage rows j0-1 .. j0+TY (clamped) : wave w takes rows w, w+4, ... ----
+    for (int r = wave; r < TY + 2; r += 4) {
+        const int jr = clampy(g, j0 - 1 + r);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            const T *src = pl == 0 ? pc : vs;
+            const int C = pl == 0 ? 1 : 2, c = pl == 0 ? 0 : pl - 1;
+            const size_t row = ((size_t)jr * C + c) * g.P;
+            if (inx) *reinterpret_cast<V *>(&tile[pl][r][4 + lane * 4]) = *reinterpret_cast<const V *>(src + row + i0);
+            if (lane == 0) tile[pl][r][3] = src[row + (x0 > 0 ? x0 - 1 : 0)];                                   // left halo cell (clamped)
+            if (lane == 63) { const int xr = x0 + 256 < g.X ? x0 + 256 : g.X - 1; tile[pl][r][260] = src[row + xr]; }   // right halo cell
+        }
+    }
+    __syncthreads();
+    if (!inx) return;
+    // right edge of the domain inside this tile: the clamped right neighbour of cell X-1 is cell X-1 itself
+    // ---- relax: wave w handles tile rows w*(TY/4) .. ----
+#pragma unroll
+    for (int rr = 0; rr < TY / 4; ++rr) {
+        const int r = wave * (TY / 4) + rr;         // tile row index 0..TY-1  <->  LDS row r+1
+        const int j = j0 + r;
+        if (j >= je) break;
+        const unsigned sel = sel_not_wall(mask_quad(g, i0, j));
+        if (sel == 0u) continue;
+        const int o = 4 + lane * 4;
+        const V c = *reinterpret_cast<const V *>(&tile[0][r + 1][o]);
+        const V n = *reinterpret_cast<const V *>(&tile[0][r + 2][o]);
+        const V m = *reinterpret_cast<const V *>(&tile[0][r][o]);
+        T pl_ = tile[0][r + 1][o - 1], pr_ = tile[0][r + 1][o + 4];
+        if (i0 + 4 >= g.X) pr_ = c.w;
+        V s2, s3;
+        if (SRC) {
+            s2 = load_quad<2>(vs, g, 0, i0, j);
+            s3 = load_quad<2>(vs, g, 1, i0, j);
+        } else {
+            const V xc = *reinterpret_cast<const V *>(&tile[1][r + 1][o]), yc = *reinterpret_cast<const V *>(&tile[2][r + 1][o]);
+            const V xn = *reinterpret_cast<const V *>(&tile[1][r + 2][o]), xm = *reinterpret_cast<const V *>(&tile[1][r][o]);
+            const V yn = *reinterpret_cast<const V *>(&tile[2][r + 2][o]), ym = *reinterpret_cast<const V *>(&tile[2][r][o]);
+            T xl = tile[1][r + 1][o - 1], xr = tile[1][r + 1][o + 4], yl = tile[2][r + 1][o - 1], yr = tile[2][r + 1][o + 4];
+            if (i0 + 4 >= g.X) { xr = xc.w; yr = yc.w; }
+            source_from(k, xc.y, xl, yc.y, yl, xn.x, xm.x, yn.x, ym.x, s2.x, s3.x);
+            source_from(k, xc.z, xc.x, yc.z, yc.x, xn.y, xm.y, yn.y, ym.y, s2.y, s3.y);
+            source_from(k, xc.w, xc.y, yc.w, yc.y, xn.z, xm.z, yn.z, ym.z, s2.z, s3.z);
+            source_from(k, xr, xc.z, yr, yc.z, xn.w, xm.w, yn.w, ym.w, s2.w, s3.w);
+        }
+        V out;
+        out.x = predict_from(c.y, pl_, n.x, m.x, s2.x, s3.x);
+        out.y = predict_from(c.z, c.x, n.y, m.y, s2.y, s3.y);
+        out.z = predict_from(c.w, c.y, n.z, m.z, s2.z, s3.z);
+        out.w = predict_from(pr_, c.z, n.w, m.w, s2.w, s3.w);
+        store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), out, sel);
+    }
+}
+
 }  // namespace fs
