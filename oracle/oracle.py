@@ -31,6 +31,14 @@ def build(force=False):
     return so
 
 
+def set_threads(n):
+    """OpenMP team size of the oracle's race-free kernels (tests keep it small for tiny grids, large for BASELINE sizes)."""
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
 def lib():
     global _LIB
     if _LIB is None:

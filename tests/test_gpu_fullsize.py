@@ -109,6 +109,30 @@ def test_against_oracle_at_moderate_size(bc, res, scheme, vc, re, dt, steps, hip
         sim._solver._bc.device.close()
 
 
+def test_against_oracle_at_baseline_size(hip_lib):
+    """BASELINE configs[2] itself (bc5, res 4096, CIP + VC): two steps on the GPU against two steps of the CPU oracle, bit for bit."""
+    import os
+    from fs.boundary_condition import create_scene_arrays
+    from oracle import oracle as O
+    res = 4096
+    dt, dx = 0.05 / res, 1.0 / res
+    sim = _build(5, res, "cip", 5.0, 1e6, None, True)
+    O.set_threads(min(64, len(os.sched_getaffinity(0))))
+    try:
+        const, mask, _ = create_scene_arrays(5, res)
+        ref = O.make_simulator(const, mask, None, scheme="cip", dt=dt, dx=dx, re=1e6, vor_eps=5.0)
+        for _ in range(2):
+            sim.step()
+            ref.update()
+        out = sim.field_to_numpy()
+        for k, e in ref.fields().items():
+            assert np.array_equal(out[k], e), f"{k}: rel-L2 {rel_l2(out[k], e):.3e}"
+        assert float(np.abs(out["p"]).max()) > 0
+    finally:
+        O.set_threads(8)
+        sim._solver._bc.device.close()
+
+
 def test_f64_vs_f32_tolerance_sweep(hip_lib, capsys):
     """BASELINE configs[4] asks for an fp64-vs-fp32 sweep (bc3, KK, Re 1e8, VC 10).  f64 is the build's own truth
     (the reference is f32 only)."""
