@@ -89,13 +89,12 @@ CASES = [
     ("traj_cfg5_bc3_res96_kk_vc10_re1e8.npz", 3, 8), ("traj_bc2_cip_jacobi50_vc0.npz", 2, 4),
     ("traj_dye_bc2_cip_vc5.npz", 2, 8), ("traj_bc1_upwind_vc0.npz", 4, 2), ("traj_bc6_res64_cip_vc5_dye.npz", 2, 8),
     ("traj_f64_bc1_cip_vc0.npz", 2, 4),
+    # the 8-rank shape of the driver's scaling run: 4 owned rows per slab (halo 4), 12 owned rows (halo 8)
+    ("traj_bc5_cip_vc5.npz", 8, 4), ("traj_cfg5_bc3_res96_kk_vc10_re1e8.npz", 8, 8),
 ]
 
 
-@pytest.mark.parametrize("fname,world,halo", CASES)
-def test_slabs_on_one_gpu_are_bit_identical(fname, world, halo, hip_lib):
-    g = np.load(os.path.join(GOLDEN, fname))
-    cfg = traj_config(g)
+def _run_slabs(g, cfg, world, halo):
     shared = {"barrier": threading.Barrier(world), "box": [None] * world}
     Dev = _make_device_cls(world, shared)
     results, errors = [None] * world, []
@@ -108,6 +107,14 @@ def test_slabs_on_one_gpu_are_bit_identical(fname, world, halo, hip_lib):
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("fname,world,halo", CASES)
+def test_slabs_on_one_gpu_are_bit_identical(fname, world, halo, hip_lib):
+    g = np.load(os.path.join(GOLDEN, fname))
+    cfg = traj_config(g)
+    results = _run_slabs(g, cfg, world, halo)
     names = ["v", "p", "dye"]
     for step in cfg["snaps"]:
         for k in range(len(results[0][0][step])):
@@ -115,3 +122,32 @@ def test_slabs_on_one_gpu_are_bit_identical(fname, world, halo, hip_lib):
             assert np.array_equal(full, g[f"step{step}.{names[k]}"]), f"{fname} step {step} {names[k]}"
     if halo >= 8 and cfg["updater"][0] == "rbsor" and not cfg["dye"]:
         assert results[0][1] <= 6.0
+
+
+@pytest.mark.parametrize("bc,res,scheme,vc,updater,world,halo", [
+    (5, 1024, "cip", 5.0, ("rbsor", 1.3, 2), 8, 8),      # configs[2]'s physics, the 8-slab cut of the scaling run
+    (5, 4096, "cip", 5.0, ("rbsor", 1.3, 2), 8, 8),      # configs[2] itself, as the driver's --gpus 8 run cuts it
+    (2, 1024, "cip", None, ("jacobi", 12), 8, 8),        # configs[3]'s scene (bc2 CIP) with Jacobi
+    (3, 1000, "kk", 10.0, ("rbsor", 1.3, 2), 4, 16),     # configs[4]: 4 slabs, 250 rows each (not a multiple of 4)
+])
+def test_slabs_at_size_equal_single_domain(bc, res, scheme, vc, updater, world, halo, hip_lib):
+    """Grids wide enough for many waves per row and many tile rows per slab (the XCD band mapping, the overlapped-wave
+    column mapping and the red-black parity offset all engage): N slabs == one domain, bit for bit."""
+    import fs
+    from fs.boundary_condition import create_scene_arrays
+    const, mask, _ = create_scene_arrays(bc, res)
+    g = {"bc_const": const, "bc_mask": mask}
+    steps = 4
+    cfg = dict(bc=bc, res=res, dt=0.05 / res, dx=1.0 / res, re=1e6, vor_eps=vc, scheme=scheme, updater=updater,
+               dye=False, fp64=False, snaps=[steps])
+    results = _run_slabs(g, cfg, world, halo)
+    fs.runtime.init(gpu=0, dtype="f32")
+    one = fs.FluidSimulator.create(bc, res, cfg["dt"], cfg["dx"], cfg["re"], vc, scheme, pressure_updater=updater)
+    for _ in range(steps):
+        one.step()
+    ref = one.field_to_numpy()
+    for k, name in enumerate(("v", "p")):
+        full = np.concatenate([results[r][0][steps][k] for r in range(world)], axis=1)
+        assert np.array_equal(full, ref[name]), name
+    assert float(np.abs(ref["p"]).max()) > 0
+    one._solver._bc.device.close()
