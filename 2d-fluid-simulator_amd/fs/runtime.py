@@ -160,6 +160,7 @@ class DeviceBase:
         self.bc_radius_v, self.bc_radius_p = 2, 1
         self.n_exchanges = 0          # grouped send/recv launches issued
         self.n_exchanged_fields = 0   # fields refreshed by them
+        self.n_exchanged_bytes = 0    # payload sent to ONE neighbour by them (an interior rank sends twice that)
 
     # ---- ghost-row bookkeeping --------------------------------------------------------------------
     def exchange(self, field, depth=None):
@@ -176,6 +177,7 @@ class DeviceBase:
             f.valid = depth
         self.n_exchanges += 1
         self.n_exchanged_fields += len(fields)
+        self.n_exchanged_bytes += depth * self.nx * self.dtype.itemsize * sum(f.nchan for f in fields)
 
     def _p_exchange_many(self, handles, depth):     # backends without a grouped primitive: one by one
         for h, nchan in handles:

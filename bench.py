@@ -148,6 +148,9 @@ def main():
     for _ in range(args.warmup):
         sim.step()
     graph = None
+    aligned = args.steps % 2 == 0 and args.warmup % 2 == 0
+    if aligned and not use_graph:
+        sim.step(), sim.step()         # the graph mode runs its captured pair once: keep every mode on the same trajectory
     if use_graph:
         # two consecutive steps return every DoubleBuffer to its starting parity, so the captured pair replays
         graph = dev.capture(lambda: (sim.step(), sim.step()))
@@ -171,6 +174,15 @@ def main():
         sim.step()
     rep = dev.profile_report()
     dev.profile(False)
+    # order-independent exact checksum of the final state (sum of the f32 bit patterns mod 2^64 over the whole grid):
+    # equal numbers from the --gpus 1/2/4/8 runs of the same command line mean the slab runs are bit-identical.
+    total_steps = args.warmup + (2 if aligned else 0) + args.steps + prof_steps
+    checksum = {"after_steps": total_steps}
+    for name, f in zip(("v", "p", "dye"), sim._solver.get_fields()):
+        local = int(np.ascontiguousarray(f.to_numpy(local=True)).view(np.uint32).astype(np.uint64).sum(dtype=np.uint64))
+        parts = [dev.allgather_scalars(float((local >> sh) & 0x1FFFFF)) for sh in (0, 21, 42, 63)]
+        tot = sum(int(parts[k][r]) << sh for k, sh in enumerate((0, 21, 42, 63)) for r in range(world))
+        checksum[name] = f"{tot & 0xFFFFFFFFFFFFFFFF:016x}"
     abytes, counts = algorithmic_bytes(mask)
     # HBM bytes per launch from rocprofv3 PMC passes of this same workload (tools/profile.sh -> profiles/*.json), if present
     pmc_traffic = {}
@@ -236,9 +248,12 @@ def main():
                                + ("; BASELINE.json configs[2]" if (res, args.bc, args.scheme, args.jacobi) == (4096, 5, "cip", 0) else ""),
                    "cells": counts["cells"], "fluid_cells": counts["fluid"], "parallelism": f"y-slab x{world}",
                    "launch": "hipGraph replay of 2-step pairs" if graph is not None else "eager (python per step)"},
+        "state_checksum": checksum,
         "halo_exchanges_per_step": None if world == 1 else {
             "grouped_launches": round(dev.n_exchanges / max(args.warmup + args.steps + prof_steps, 1), 2),
-            "fields": round(dev.n_exchanged_fields / max(args.warmup + args.steps + prof_steps, 1), 2)},
+            "fields": round(dev.n_exchanged_fields / max(args.warmup + args.steps + prof_steps, 1), 2),
+            "KB_per_neighbour": round(dev.n_exchanged_bytes / max(args.warmup + args.steps + prof_steps, 1) / 1024, 1),
+            "halo_rows": dev.halo},
     }
     if dominant:
         kd = kernels[dominant]
