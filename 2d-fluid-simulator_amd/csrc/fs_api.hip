@@ -1068,7 +1068,14 @@ int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int ro
     FS_REQUIRE(ctx, "ctx is null");
     FS_FIELD(v, 2);
     FS_ROWS();
-    FS_DISPATCH(ctx, { FS_LAUNCH_CELLS("limit_field", (k_limit<T>), ctx->grid(), row_begin, (T)limit, (T *)v->d) })
+    FS_DISPATCH(ctx, {
+        if (ctx->use_march)
+            return launch(ctx, "limit_field", [&] {
+                hipLaunchKernelGGL((k_limit_quad<T>), dim3((ctx->X / 4 + 255) / 256, row_end - row_begin), dim3(256), 0, ctx->stream,
+                                   ctx->grid(), row_begin, (T)limit, (T *)v->d);
+            });
+        FS_LAUNCH_CELLS("limit_field", (k_limit<T>), ctx->grid(), row_begin, (T)limit, (T *)v->d)
+    })
 }
 
 int fs_clamp_field(fs_ctx *ctx, double low, double high, fs_field *f, int row_begin, int row_end)

@@ -945,6 +945,29 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_fused(Grid g, Konst<T> k, in
 
 
 // ------------------------------------------------------------------------------------------------
+// limit_field (fs/solver.py:38-43), quad form: one 16-byte load per channel and lane, one row per blockIdx.y, nothing else in
+// flight - the shape that streams fastest on this chip (tools/membw.hip: 6.5 TB/s read-only).  Cells are rewritten only
+// where the norm exceeds the limit (never in a healthy run), so the pass is read-only in practice.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, T lim, T *v)
+{
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) << 2, j = jb + blockIdx.y;
+    if (i0 >= g.X) return;
+    T *px = v + idx<2, T>(g, 0, i0, j), *py = v + idx<2, T>(g, 1, i0, j);
+    const Q4<T> X(*reinterpret_cast<const typename Quad<T>::type *>(px)), Y(*reinterpret_cast<const typename Quad<T>::type *>(py));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const T x = X.a[q], y = Y.a[q];
+        const T nrm = tsqrt(x * x + y * y);
+        if (nrm > lim) {
+            px[q] = lim * (x / nrm);
+            py[q] = lim * (y / nrm);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K12  DyeCipMacSolver._non_advection_phase_dye (fs/solver.py:378-383), quad form: dn = dc + (lap(dc)/re) dt on not-wall cells.
 // ------------------------------------------------------------------------------------------------
 template <bool P2, typename T>
