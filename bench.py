@@ -183,6 +183,11 @@ def main():
         parts = [dev.allgather_scalars(float((local >> sh) & 0x1FFFFF)) for sh in (0, 21, 42, 63)]
         tot = sum(int(parts[k][r]) << sh for k, sh in enumerate((0, 21, 42, 63)) for r in range(world))
         checksum[name] = f"{tot & 0xFFFFFFFFFFFFFFFF:016x}"
+    # Poisson residual of the final state (new diagnostic, not in the reference): wave-level reduction per slab + one
+    # ncclAllReduce of 2 doubles over the node; rms over the not-wall cells of the global grid
+    v_f, p_f = sim._solver.get_fields()[:2]
+    r_sum, r_cnt = dev.poisson_residual(dt, dx, p_f, v_f)
+    residual = {"rms": float(np.sqrt(r_sum / max(r_cnt, 1.0))), "cells": int(r_cnt)}
     abytes, counts = algorithmic_bytes(mask)
     # HBM bytes per launch from rocprofv3 PMC passes of this same workload (tools/profile.sh -> profiles/*.json), if present
     pmc_traffic = {}
@@ -249,6 +254,7 @@ def main():
                    "cells": counts["cells"], "fluid_cells": counts["fluid"], "parallelism": f"y-slab x{world}",
                    "launch": "hipGraph replay of 2-step pairs" if graph is not None else "eager (python per step)"},
         "state_checksum": checksum,
+        "poisson_residual": residual,
         "halo_exchanges_per_step": None if world == 1 else {
             "grouped_launches": round(dev.n_exchanges / max(args.warmup + args.steps + prof_steps, 1), 2),
             "fields": round(dev.n_exchanged_fields / max(args.warmup + args.steps + prof_steps, 1), 2),
