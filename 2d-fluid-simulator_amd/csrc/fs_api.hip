@@ -391,6 +391,7 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_bc_dye) hipFree(ctx->d_bc_dye);
     if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->d_acc) hipFree(ctx->d_acc);
+    if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return FS_OK;
@@ -1044,13 +1045,20 @@ int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, co
     FS_REQUIRE(!ctx->capturing, "residual during graph capture");
     if (!ctx->mask_set) { set_error("mask not uploaded"); return FS_ERR_STATE; }
     const int row_begin = ctx->halo, row_end = ctx->halo + ctx->nyl;
-    FS_HIP(hipMemsetAsync(ctx->d_acc, 0, 2 * sizeof(double), ctx->stream));
+    const dim3 grid((ctx->X + 255) / 256, (row_end - row_begin + RES_ROWS - 1) / RES_ROWS);
+    const size_t nblocks = (size_t)grid.x * grid.y;
+    if (nblocks > ctx->partial_cap) {
+        if (ctx->d_partial) { FS_HIP(hipStreamSynchronize(ctx->stream)); FS_HIP(hipFree(ctx->d_partial)); ctx->d_partial = nullptr; ctx->partial_cap = 0; }
+        FS_HIP(hipMalloc(&ctx->d_partial, nblocks * 2 * sizeof(double)));
+        ctx->partial_cap = nblocks;
+    }
     int rc;
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0);
         rc = launch(ctx, "poisson_residual", [&] {
-            hipLaunchKernelGGL((k_residual<T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
-                               row_begin, (const T *)p->d, (const T *)vc->d, ctx->d_acc);
+            hipLaunchKernelGGL((k_residual<T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end,
+                               (const T *)p->d, (const T *)vc->d, ctx->d_partial);
+            hipLaunchKernelGGL((k_residual_final<double>), dim3(1), dim3(1024), 0, ctx->stream, (const double *)ctx->d_partial, (int)nblocks, ctx->d_acc);
         });
     })
     if (rc) return rc;

@@ -63,6 +63,8 @@ struct fs_ctx {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     double *d_acc = nullptr;  // 2 doubles (residual)
+    double *d_partial = nullptr;   // per-block partial (sum, count) pairs of the residual reduction
+    size_t partial_cap = 0;        // pairs
     // graphs
     bool capturing = false;
     std::vector<hipGraphExec_t> graphs;
