@@ -92,7 +92,9 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
 template <bool SRC, typename T>
 static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
 {
-    const int v = ctx->jacobi_variant;               // overlapped-wave tiles of 2 (default), 4 or 1 rows; 30 = LDS halo tile
+    // overlapped-wave register tiles of 1, 2 or 4 rows (FS_JACOBI=21/22/24), 30 = LDS halo tile.  Default (0): the source-pair
+    // form streams best with 1-row tiles at 8 waves/SIMD (76 vs 79 us), the v-reading form with 2-row tiles (89 vs 95 us)
+    const int v = ctx->jacobi_variant ? ctx->jacobi_variant : (SRC ? 21 : 22);
     if (v == 30) {
         constexpr int TY = 16;
         const dim3 grid((ctx->X + 255) / 256, (je - jb + TY - 1) / TY, 1);
