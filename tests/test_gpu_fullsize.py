@@ -51,6 +51,9 @@ CONFIGS = [
     pytest.param(dict(bc=2, res=1600, scheme="cip", vc=5.0, re=1e6, updater=("jacobi", 50)), 4, id="cfg2-bc2-res1600-cip-jacobi50"),
     # dye transport at size (next-row component)
     pytest.param(dict(bc=5, res=2048, scheme="cip", vc=5.0, re=1e6, updater=None, dye=True), 4, id="dye-bc5-res2048-cip"),
+    # the f64 instantiations of the fast paths (double4 quads, shuffle instead of DPP)
+    pytest.param(dict(bc=3, res=1024, scheme="kk", vc=10.0, re=1e8, updater=None, dtype="f64"), 4, id="f64-bc3-res1024-kk-vc10"),
+    pytest.param(dict(bc=5, res=1000, scheme="cip", vc=5.0, re=1e6, updater=("jacobi", 10), dtype="f64", dye=True), 3, id="f64-dye-bc5-res1000-cip-jacobi10"),
 ]
 
 
