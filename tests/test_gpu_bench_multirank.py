@@ -1,0 +1,67 @@
+"""bench.py end to end as 2 and 3 ranks on ONE GPU (ghost rows and scalar collectives over local sockets instead of RCCL,
+tests/bench_socket_worker.py): the N > 1 control flow of the benchmark runs here before it runs on the driver's multi-GPU
+node, and its `state_checksum` must equal the single-rank run's - the same comparison the --gpus 1/2/4/8 lines allow."""
+import json
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--res", "256", "--steps", "10", "--warmup", "4", "--sweeps", "20", "--no-cpu"]
+
+
+def _single():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + ARGS, capture_output=True, text=True, timeout=600,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def _multi(world, extra_env=None):
+    port = random.randint(20000, 50000)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", FS_FAKE_PORT=str(port),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + 100), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "bench_socket_worker.py"), "--gpus", str(world)] + ARGS,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: {se[-2000:]}"
+    for r in range(1, world):
+        assert outs[r][0].strip() == "", f"rank {r} printed to stdout"
+    lines = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert len(lines) == 1, outs[0][0]
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def single(hip_lib):
+    return _single()
+
+
+@pytest.mark.parametrize("world,halo", [(2, None), (3, "4"), (4, "16")])
+def test_bench_as_n_ranks_matches_single_rank(world, halo, single):
+    d = _multi(world, {"FS_HALO": halo} if halo else None)
+    assert d["n_gpus"] == world and d["steps"] == 10 and d["warmup"] == 4 and d["scaling"] == "strong"
+    assert d["config"]["parallelism"] == f"y-slab x{world}"
+    assert d["state_checksum"] == single["state_checksum"]
+    assert d["poisson_residual"]["cells"] == single["poisson_residual"]["cells"]
+    assert abs(d["poisson_residual"]["rms"] - single["poisson_residual"]["rms"]) <= 1e-12 * max(1.0, single["poisson_residual"]["rms"])
+    assert d["halo_exchanges_per_step"]["grouped_launches"] > 0
+    assert d["roofline"]["frac"] > 0 and d["poisson_jacobi_sweep"]["frac"] > 0
+    assert "cpu_baseline" not in d and single["value"] > 0
