@@ -121,17 +121,12 @@ int fs_comm_destroy(fs_ctx *ctx)
 }
 
 // Refresh `depth` ghost rows on each side of the owned rows [halo, halo + nyl).
-//   to the lower neighbour (rank - 1): my first `depth` owned rows  -> their upper ghost rows
-//   to the upper neighbour (rank + 1): my last  `depth` owned rows  -> their lower ghost rows
-int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
+//   to the lower neighbour: my first `depth` owned rows  -> their upper ghost rows
+//   to the upper neighbour: my last  `depth` owned rows  -> their lower ghost rows
+// `lower` / `upper` are the peer ranks (-1 = domain edge, no neighbour).
+static int exchange(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth, int lower, int upper)
 {
-    FS_REQUIRE(ctx && fields && nfields >= 0, "null argument");
-    FS_REQUIRE(depth >= 0 && depth <= ctx->halo && depth <= ctx->nyl, "halo depth exceeds the slab's ghost rows or owned rows");
-    for (int n = 0; n < nfields; ++n) FS_REQUIRE(fields[n] && fields[n]->ctx == ctx, "null / foreign field");
-    if (depth == 0 || nfields == 0) return FS_OK;
     Comm *cm = ctx->comm;
-    if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
-    if (cm->nranks == 1) return FS_OK;
     const ncclDataType_t dt = ctx->dtype == 0 ? ncclFloat32 : ncclFloat64;
     const int H = ctx->halo, n = ctx->nyl;
     FS_NCCL(g_rccl.GroupStart());
@@ -141,17 +136,47 @@ int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, in
         const size_t count = (size_t)depth * row_elems;
         char *base = (char *)f->d;
         auto rowp = [&](int r) { return base + (size_t)r * row_elems * ctx->esize; };
-        if (cm->rank > 0) {
-            FS_NCCL(g_rccl.Send(rowp(H), count, dt, cm->rank - 1, cm->comm, ctx->stream));
-            FS_NCCL(g_rccl.Recv(rowp(H - depth), count, dt, cm->rank - 1, cm->comm, ctx->stream));
+        if (lower >= 0) {
+            FS_NCCL(g_rccl.Send(rowp(H), count, dt, lower, cm->comm, ctx->stream));
+            FS_NCCL(g_rccl.Recv(rowp(H - depth), count, dt, lower, cm->comm, ctx->stream));
         }
-        if (cm->rank < cm->nranks - 1) {
-            FS_NCCL(g_rccl.Send(rowp(H + n - depth), count, dt, cm->rank + 1, cm->comm, ctx->stream));
-            FS_NCCL(g_rccl.Recv(rowp(H + n), count, dt, cm->rank + 1, cm->comm, ctx->stream));
+        if (upper >= 0) {
+            FS_NCCL(g_rccl.Send(rowp(H + n - depth), count, dt, upper, cm->comm, ctx->stream));
+            FS_NCCL(g_rccl.Recv(rowp(H + n), count, dt, upper, cm->comm, ctx->stream));
         }
     }
     FS_NCCL(g_rccl.GroupEnd());
     return FS_OK;
+}
+
+static int check_exchange_args(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
+{
+    FS_REQUIRE(ctx && fields && nfields >= 0, "null argument");
+    FS_REQUIRE(depth >= 0 && depth <= ctx->halo && depth <= ctx->nyl, "halo depth exceeds the slab's ghost rows or owned rows");
+    for (int n = 0; n < nfields; ++n) FS_REQUIRE(fields[n] && fields[n]->ctx == ctx, "null / foreign field");
+    return FS_OK;
+}
+
+int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
+{
+    int rc = check_exchange_args(ctx, fields, nfields, depth); if (rc) return rc;
+    if (depth == 0 || nfields == 0) return FS_OK;
+    Comm *cm = ctx->comm;
+    if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
+    if (cm->nranks == 1) return FS_OK;
+    return exchange(ctx, fields, nfields, depth, cm->rank > 0 ? cm->rank - 1 : -1, cm->rank < cm->nranks - 1 ? cm->rank + 1 : -1);
+}
+
+// Loop-back self-test of the same code on a 1-rank communicator: the rank is its own lower AND upper neighbour.  RCCL matches
+// the sends and receives of one peer in issue order, so afterwards   lower ghost rows == first owned rows   and
+// upper ghost rows == last owned rows.  Lets a single-GPU box check row offsets, counts, dtype and stream order of the RCCL leg.
+int fs_halo_exchange_self(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
+{
+    int rc = check_exchange_args(ctx, fields, nfields, depth); if (rc) return rc;
+    Comm *cm = ctx->comm;
+    if (!cm || cm->nranks != 1) { set_error("fs_halo_exchange_self needs a 1-rank communicator"); return FS_ERR_COMM; }
+    if (depth == 0 || nfields == 0) return FS_OK;
+    return exchange(ctx, fields, nfields, depth, 0, 0);
 }
 
 int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth) { return fs_halo_exchange_multi(ctx, &f, 1, depth); }

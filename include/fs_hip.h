@@ -187,6 +187,9 @@ int fs_comm_destroy(fs_ctx *ctx);
 int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth);
 /* Same for several fields in ONE grouped RCCL call (one fused send/recv launch instead of n).     */
 int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth);
+/* Loop-back self-test on a 1-rank communicator: the rank is its own lower and upper neighbour, so afterwards
+ * lower ghost rows == first owned rows and upper ghost rows == last owned rows (single-GPU check of the RCCL leg). */
+int fs_halo_exchange_self(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth);
 int fs_allreduce_sum(fs_ctx *ctx, double *values, int n);
 
 /* ---- launch-overhead removal: capture the launches issued between begin/end into a hipGraph ---- */
