@@ -368,6 +368,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
+    if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
     if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);
     if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
