@@ -5,7 +5,14 @@
 // ncclSend/ncclRecv pair per neighbour.  A y-halo of `depth` rows is ONE contiguous block of
 // depth*C*P elements in the [row][channel][x] device layout, so no packing kernels are needed.
 // Each rank talks to at most two peers (its slab neighbours), i.e. point-to-point traffic on dedicated
-// xGMI links; messages are 64 KiB - a few MiB, so the exchange is latency- rather than link-bound.
+// xGMI links; messages are 64 KiB - a few MiB.
+//
+// Streams: every RCCL call of a context is issued on ONE dedicated communication stream (the communicator never sees
+// two streams).  fs_halo_exchange_begin() makes that stream wait for everything already queued on the compute stream
+// (event), queues pack -> grouped send/recv -> unpack there and records a completion event; fs_halo_exchange_wait() makes
+// the compute stream wait for it.  Between the two calls the caller may launch kernels that neither read ghost rows nor
+// write the `depth` outermost owned rows of the exchanged fields (the interior rows of the kernel that needed the
+// exchange): they overlap with the transfer.  A blocking exchange is begin + wait.
 //
 // librccl is dlopen()ed on first use so that single-GPU users never pay for loading it.
 #include <dlfcn.h>
@@ -62,6 +69,12 @@ struct Comm {
     double *d_red = nullptr;
     char *stage = nullptr;       // 4 equal parts: send-to-lower, send-to-upper, recv-from-lower, recv-from-upper
     size_t stage_part = 0;       // bytes per part
+    hipStream_t stream = nullptr;            // the communication stream
+    hipEvent_t ev_compute = nullptr, ev_comm = nullptr;
+    bool in_flight = false;      // begin() issued, wait() pending
+    bool armed = false;          // ... and ev_comm was recorded for it
+    bool marked = false;         // fs_halo_exchange_mark() already recorded ev_compute for the next begin()
+    bool loopback = false;       // 1-rank communicator: the rank is its own lower and upper neighbour (self-test)
 };
 
 // Ghost-row blocks of several fields <-> one contiguous staging buffer per direction.  A grouped RCCL call costs ~2 us per
@@ -130,7 +143,16 @@ int fs_comm_init(fs_ctx *ctx, int rank, int nranks, const void *unique_id_128_by
     ncclResult_t r = g_rccl.CommInitRank(&cm->comm, nranks, id, rank);
     if (r != ncclSuccess) { delete cm; return nccl_fail(r, "ncclCommInitRank"); }
     hipError_t e = hipMalloc(&cm->d_red, 16 * sizeof(double));
-    if (e != hipSuccess) { g_rccl.CommDestroy(cm->comm); delete cm; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_compute, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_comm, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (cm->d_red) hipFree(cm->d_red);
+        if (cm->stream) hipStreamDestroy(cm->stream);
+        if (cm->ev_compute) hipEventDestroy(cm->ev_compute);
+        g_rccl.CommDestroy(cm->comm); delete cm;
+        return hip_fail(e, "hipMalloc / stream / event (comm)", __FILE__, __LINE__);
+    }
     ctx->comm = cm;
     return FS_OK;
 }
@@ -139,8 +161,12 @@ int fs_comm_destroy(fs_ctx *ctx)
 {
     if (!ctx || !ctx->comm) return FS_OK;
     hipStreamSynchronize(ctx->stream);
+    if (ctx->comm->stream) hipStreamSynchronize(ctx->comm->stream);
     if (ctx->comm->d_red) hipFree(ctx->comm->d_red);
     if (ctx->comm->stage) hipFree(ctx->comm->stage);
+    if (ctx->comm->ev_compute) hipEventDestroy(ctx->comm->ev_compute);
+    if (ctx->comm->ev_comm) hipEventDestroy(ctx->comm->ev_comm);
+    if (ctx->comm->stream) hipStreamDestroy(ctx->comm->stream);
     if (ctx->comm->comm) g_rccl.CommDestroy(ctx->comm->comm);
     delete ctx->comm;
     ctx->comm = nullptr;
@@ -160,12 +186,12 @@ static int exchange_direct(fs_ctx *ctx, fs_field *const *fields, int nfields, in
         char *base = (char *)f->d;
         auto rowp = [&](int r) { return base + (size_t)r * row_elems * ctx->esize; };
         if (lower >= 0) {
-            FS_NCCL(g_rccl.Send(rowp(H), count, dt, lower, cm->comm, ctx->stream));
-            FS_NCCL(g_rccl.Recv(rowp(H - depth), count, dt, lower, cm->comm, ctx->stream));
+            FS_NCCL(g_rccl.Send(rowp(H), count, dt, lower, cm->comm, cm->stream));
+            FS_NCCL(g_rccl.Recv(rowp(H - depth), count, dt, lower, cm->comm, cm->stream));
         }
         if (upper >= 0) {
-            FS_NCCL(g_rccl.Send(rowp(H + n - depth), count, dt, upper, cm->comm, ctx->stream));
-            FS_NCCL(g_rccl.Recv(rowp(H + n), count, dt, upper, cm->comm, ctx->stream));
+            FS_NCCL(g_rccl.Send(rowp(H + n - depth), count, dt, upper, cm->comm, cm->stream));
+            FS_NCCL(g_rccl.Recv(rowp(H + n), count, dt, upper, cm->comm, cm->stream));
         }
     }
     FS_NCCL(g_rccl.GroupEnd());
@@ -192,7 +218,7 @@ static int exchange_packed(fs_ctx *ctx, fs_field *const *fields, int nfields, in
         ghost.hi[k] = upper >= 0 ? base + (size_t)(H + n) * row_bytes : nullptr;
     }
     if (total > cm->stage_part) {
-        FS_HIP(hipStreamSynchronize(ctx->stream));
+        FS_HIP(hipStreamSynchronize(cm->stream));
         if (cm->stage) { FS_HIP(hipFree(cm->stage)); cm->stage = nullptr; cm->stage_part = 0; }
         const size_t part = (total + 4095) / 4096 * 4096 * 2;     // headroom: more / deeper fields may follow
         FS_HIP(hipMalloc(&cm->stage, 4 * part));
@@ -200,18 +226,18 @@ static int exchange_packed(fs_ctx *ctx, fs_field *const *fields, int nfields, in
     }
     char *send_lo = cm->stage, *send_hi = cm->stage + cm->stage_part, *recv_lo = cm->stage + 2 * cm->stage_part, *recv_hi = cm->stage + 3 * cm->stage_part;
     const dim3 grid(64, 2 * nfields);
-    hipLaunchKernelGGL(k_halo_pack<true>, grid, dim3(256), 0, ctx->stream, own, send_lo, send_hi);
+    hipLaunchKernelGGL(k_halo_pack<true>, grid, dim3(256), 0, cm->stream, own, send_lo, send_hi);
     FS_NCCL(g_rccl.GroupStart());
     if (lower >= 0) {
-        FS_NCCL(g_rccl.Send(send_lo, total, ncclUint8, lower, cm->comm, ctx->stream));
-        FS_NCCL(g_rccl.Recv(recv_lo, total, ncclUint8, lower, cm->comm, ctx->stream));
+        FS_NCCL(g_rccl.Send(send_lo, total, ncclUint8, lower, cm->comm, cm->stream));
+        FS_NCCL(g_rccl.Recv(recv_lo, total, ncclUint8, lower, cm->comm, cm->stream));
     }
     if (upper >= 0) {
-        FS_NCCL(g_rccl.Send(send_hi, total, ncclUint8, upper, cm->comm, ctx->stream));
-        FS_NCCL(g_rccl.Recv(recv_hi, total, ncclUint8, upper, cm->comm, ctx->stream));
+        FS_NCCL(g_rccl.Send(send_hi, total, ncclUint8, upper, cm->comm, cm->stream));
+        FS_NCCL(g_rccl.Recv(recv_hi, total, ncclUint8, upper, cm->comm, cm->stream));
     }
     FS_NCCL(g_rccl.GroupEnd());
-    hipLaunchKernelGGL(k_halo_pack<false>, grid, dim3(256), 0, ctx->stream, ghost, recv_lo, recv_hi);
+    hipLaunchKernelGGL(k_halo_pack<false>, grid, dim3(256), 0, cm->stream, ghost, recv_lo, recv_hi);
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -235,14 +261,58 @@ static int check_exchange_args(fs_ctx *ctx, fs_field *const *fields, int nfields
     return FS_OK;
 }
 
-int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
+static int begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth, bool self)
 {
     int rc = check_exchange_args(ctx, fields, nfields, depth); if (rc) return rc;
-    if (depth == 0 || nfields == 0) return FS_OK;
     Comm *cm = ctx->comm;
     if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
-    if (cm->nranks == 1) return FS_OK;
-    return exchange(ctx, fields, nfields, depth, cm->rank > 0 ? cm->rank - 1 : -1, cm->rank < cm->nranks - 1 ? cm->rank + 1 : -1);
+    FS_REQUIRE(!cm->in_flight, "fs_halo_exchange_begin while another exchange is in flight (call fs_halo_exchange_wait first)");
+    FS_REQUIRE(!ctx->capturing, "halo exchange during graph capture");
+    if (self && cm->nranks != 1) { set_error("loop-back exchange needs a 1-rank communicator"); return FS_ERR_COMM; }
+    int lower = cm->rank > 0 ? cm->rank - 1 : -1, upper = cm->rank < cm->nranks - 1 ? cm->rank + 1 : -1;
+    if (self || (cm->loopback && cm->nranks == 1)) lower = upper = 0;
+    if (depth == 0 || nfields == 0 || (lower < 0 && upper < 0)) { cm->in_flight = true; cm->armed = false; cm->marked = false; return FS_OK; }
+    if (!cm->marked) FS_HIP(hipEventRecord(cm->ev_compute, ctx->stream));   // everything queued so far produces the rows we send
+    cm->marked = false;
+    FS_HIP(hipStreamWaitEvent(cm->stream, cm->ev_compute, 0));
+    rc = exchange(ctx, fields, nfields, depth, lower, upper);
+    if (rc) return rc;
+    FS_HIP(hipEventRecord(cm->ev_comm, cm->stream));
+    cm->in_flight = true;
+    cm->armed = true;
+    return FS_OK;
+}
+
+int fs_halo_exchange_begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth) { return begin(ctx, fields, nfields, depth, false); }
+
+// Optional, before begin(): fix the point of the compute stream the exchange depends on NOW, so that kernels launched between
+// mark() and begin() (the interior rows) are already running while the host is still issuing the exchange.
+int fs_halo_exchange_mark(fs_ctx *ctx)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    Comm *cm = ctx->comm;
+    if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
+    FS_REQUIRE(!cm->in_flight, "fs_halo_exchange_mark while an exchange is in flight");
+    FS_HIP(hipEventRecord(cm->ev_compute, ctx->stream));
+    cm->marked = true;
+    return FS_OK;
+}
+
+int fs_halo_exchange_wait(fs_ctx *ctx)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    Comm *cm = ctx->comm;
+    if (!cm || !cm->in_flight) return FS_OK;
+    cm->in_flight = false;
+    if (cm->armed) FS_HIP(hipStreamWaitEvent(ctx->stream, cm->ev_comm, 0));   // later compute-stream work sees the filled ghost rows
+    cm->armed = false;
+    return FS_OK;
+}
+
+int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
+{
+    int rc = begin(ctx, fields, nfields, depth, false);
+    return rc ? rc : fs_halo_exchange_wait(ctx);
 }
 
 // Loop-back self-test of the same code on a 1-rank communicator: the rank is its own lower AND upper neighbour.  RCCL matches
@@ -250,11 +320,19 @@ int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, in
 // upper ghost rows == last owned rows.  Lets a single-GPU box check row offsets, counts, dtype and stream order of the RCCL leg.
 int fs_halo_exchange_self(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
 {
-    int rc = check_exchange_args(ctx, fields, nfields, depth); if (rc) return rc;
-    Comm *cm = ctx->comm;
-    if (!cm || cm->nranks != 1) { set_error("fs_halo_exchange_self needs a 1-rank communicator"); return FS_ERR_COMM; }
-    if (depth == 0 || nfields == 0) return FS_OK;
-    return exchange(ctx, fields, nfields, depth, 0, 0);
+    int rc = begin(ctx, fields, nfields, depth, true);
+    return rc ? rc : fs_halo_exchange_wait(ctx);
+}
+
+// 1-rank communicators only: from now on every exchange (begin / multi) treats the rank as its own neighbour on both sides, so a
+// whole slab simulation can run through the real RCCL path on one GPU (results are those of a domain whose ghost rows mirror its
+// own edge rows - meaningless physically, but deterministic: blocking and overlapped exchanges must give the same bits).
+int fs_comm_loopback(fs_ctx *ctx, int on)
+{
+    FS_REQUIRE(ctx && ctx->comm, "no communicator");
+    FS_REQUIRE(ctx->comm->nranks == 1, "loop-back needs a 1-rank communicator");
+    ctx->comm->loopback = on != 0;
+    return FS_OK;
 }
 
 int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth) { return fs_halo_exchange_multi(ctx, &f, 1, depth); }
@@ -264,10 +342,12 @@ int fs_allreduce_sum(fs_ctx *ctx, double *values, int n)
     FS_REQUIRE(ctx && values && n >= 0 && n <= 16, "bad argument (n <= 16)");
     Comm *cm = ctx->comm;
     if (!cm || cm->nranks == 1 || n == 0) return FS_OK;
-    FS_HIP(hipMemcpyAsync(cm->d_red, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    FS_NCCL(g_rccl.AllReduce(cm->d_red, cm->d_red, n, ncclFloat64, ncclSum, cm->comm, ctx->stream));
-    FS_HIP(hipMemcpyAsync(values, cm->d_red, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(hipStreamSynchronize(ctx->stream));
+    FS_REQUIRE(!cm->in_flight, "fs_allreduce_sum while a halo exchange is in flight");
+    FS_HIP(hipStreamSynchronize(ctx->stream));                      // host-side collective: the compute stream drains first
+    FS_HIP(hipMemcpyAsync(cm->d_red, values, n * sizeof(double), hipMemcpyHostToDevice, cm->stream));
+    FS_NCCL(g_rccl.AllReduce(cm->d_red, cm->d_red, n, ncclFloat64, ncclSum, cm->comm, cm->stream));
+    FS_HIP(hipMemcpyAsync(values, cm->d_red, n * sizeof(double), hipMemcpyDeviceToHost, cm->stream));
+    FS_HIP(hipStreamSynchronize(cm->stream));
     return FS_OK;
 }
 

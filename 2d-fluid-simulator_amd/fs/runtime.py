@@ -137,8 +137,11 @@ class DeviceBase:
     """Slab geometry + ghost-row bookkeeping + one method per reference kernel (backend-agnostic)."""
 
     MIN_HALO = 2       # deepest stencil on the path: Kawamura-Kuwahara / velocity-BC mirror (fs/advection.py:39-55)
-    DEFAULT_HALO = 8   # slabs: ghost rows per side.  Deeper = fewer, larger exchanges (6 / 3 / 1.9 / 1.0 grouped
-                       # send/recv launches per CIP+VC step at depth 2 / 4 / 8 / 16) for (depth/rows) redundant compute
+    DEFAULT_HALO = 16  # slabs: ghost rows per side.  Deeper = fewer, larger exchanges (6 / 3 / 2 / 1 grouped send/recv
+                       # launches per CIP+VC step at depth 2 / 4 / 8 / 16) for (depth/rows) redundant compute.  One grouped
+                       # exchange costs ~45 us of GPU-side latency (pack, RCCL kernel, unpack, stream hand-offs) whatever
+                       # its size, a 512-row slab step 130 us: the fewest exchanges win (tools/overlap_bench.py).
+                       # Slabs thinner than 128 rows default to 8.
 
     def __init__(self, nx, ny, dtype, gpu=0, rank=0, nranks=1, halo=None, bcast=None, allgather=None):
         self.nx, self.ny = int(nx), int(ny)
@@ -147,7 +150,7 @@ class DeviceBase:
         self.bcast, self.allgather = bcast, allgather
         self.y0, self.nyl = slab_rows(self.ny, rank, nranks)
         if halo is None:
-            halo = 0 if nranks == 1 else int(os.environ.get("FS_HALO", min(self.DEFAULT_HALO, self.nyl)))
+            halo = 0 if nranks == 1 else int(os.environ.get("FS_HALO", self.DEFAULT_HALO if self.nyl >= 128 else min(8, self.nyl)))
         self.halo = int(halo)
         if nranks > 1 and self.halo < self.MIN_HALO:
             raise ValueError(f"slab decomposition needs halo >= {self.MIN_HALO}")
@@ -161,6 +164,8 @@ class DeviceBase:
         self.n_exchanges = 0          # grouped send/recv launches issued
         self.n_exchanged_fields = 0   # fields refreshed by them
         self.n_exchanged_bytes = 0    # payload sent to ONE neighbour by them (an interior rank sends twice that)
+        self.n_overlapped = 0         # exchanges that ran behind the interior rows of the kernel that needed them
+        self.overlap = nranks > 1 and os.environ.get("FS_OVERLAP", "1") != "0"
 
     # ---- ghost-row bookkeeping --------------------------------------------------------------------
     def exchange(self, field, depth=None):
@@ -183,7 +188,34 @@ class DeviceBase:
         for h, nchan in handles:
             self._p_exchange(h, nchan, depth)
 
-    def _run(self, name, args, reads=(), writes=(), pointwise=False, full_writes=()):
+    def exchange_begin(self, fields, depth=None):
+        """Start refreshing the ghost rows of `fields`; until exchange_wait() only kernels that neither read ghost rows nor
+        write the `depth` outermost owned rows of these fields may be launched (see _run)."""
+        depth = self.halo if depth is None else depth
+        self._p_exchange_begin([(f._h, f.nchan) for f in fields], depth)
+        for f in fields:
+            f.valid = depth
+        self.n_exchanges += 1
+        self.n_overlapped += 1
+        self.n_exchanged_fields += len(fields)
+        self.n_exchanged_bytes += depth * self.nx * self.dtype.itemsize * sum(f.nchan for f in fields)
+
+    def exchange_wait(self):
+        self._p_exchange_wait()
+
+    def _p_exchange_begin(self, handles, depth):    # backends without an asynchronous primitive: blocking
+        self._p_exchange_many(handles, depth)
+
+    def _p_exchange_wait(self):
+        pass
+
+    def _after_kernel(self, name, written, lo, hi):   # test hook: `written` fields were computed on local rows [lo, hi)
+        pass
+
+    def _p_exchange_mark(self):
+        pass
+
+    def _run(self, name, args, reads=(), writes=(), pointwise=False, full_writes=(), split=True):
         """Launch one kernel on this slab.
 
         Single rank: rows [0, Y), nothing else happens.  Slabs: every field carries `valid` = how many ghost rows are
@@ -212,19 +244,36 @@ class DeviceBase:
             return out
 
         e_reads = min([f.valid - r for f, r in reads], default=H)
+        need = []
         if e_reads < 0:
-            self.exchange_many(unique([f for f, _ in reads if f.valid < H] + [f for f in writes if f.valid < H]))
-            e_reads = min([f.valid - r for f, r in reads], default=H)
+            need = unique([f for f, _ in reads if f.valid < H] + [f for f in writes if f.valid < H])
         elif e_reads >= 2:
-            low = unique([f for f in writes if f.valid < e_reads])
-            if low:                     # lift the outputs so that the extension is not wasted
-                self.exchange_many(low)
+            need = unique([f for f in writes if f.valid < e_reads])     # lift the outputs so that the extension is not wasted
+        pending = False
+        if need:
+            if self.overlap and split and self.nyl >= 2 * H + 8:
+                # The exchange (depth H) runs on the communication stream.  Rows [2H, nyl) of this slab depend on owned rows only
+                # and their outputs are not among the rows being sent: launch them FIRST (the GPU is busy while the host issues
+                # the exchange), the two edge strips after the exchange has landed.
+                self._p_exchange_mark()
+                self._p_kernel(name, *args, 2 * H, self.nyl)
+                self.exchange_begin(need)
+                pending = True
+            else:
+                self.exchange_many(need)
+            e_reads = min([f.valid - r for f, r in reads], default=H)
         e = max(0, min([e_reads] + [f.valid for f in writes]))
         lo = max(H - e, self.g_lo - off)
         hi = min(H + self.nyl + e, self.g_hi - off)
-        self._p_kernel(name, *args, lo, hi)
+        if pending:
+            self.exchange_wait()
+            self._p_kernel(name, *args, lo, 2 * H)
+            self._p_kernel(name, *args, self.nyl, hi)
+        else:
+            self._p_kernel(name, *args, lo, hi)
         for f in list(writes) + list(full_writes):      # full_writes: every cell of the computed rows is overwritten
             f.valid = e
+        self._after_kernel(name, list(writes) + list(full_writes), lo, hi)
 
     def alloc(self, nchan):
         return Field(self, nchan)
@@ -249,13 +298,13 @@ class DeviceBase:
 
     # ---- one wrapper per reference kernel: (C-ABI name, scalars + fields, reads with radius, writes) ----
     def velocity_bc(self, v):                                   # fs/boundary_condition.py:16-39
-        self._run("velocity_bc", (v._h,), reads=[(v, self.bc_radius_v)], writes=[v])
+        self._run("velocity_bc", (v._h,), reads=[(v, self.bc_radius_v)], writes=[v], split=False)   # op list with serial hazards
 
     def pressure_bc(self, p):                                   # fs/boundary_condition.py:41-65
-        self._run("pressure_bc", (p._h,), reads=[(p, self.bc_radius_p)], writes=[p])
+        self._run("pressure_bc", (p._h,), reads=[(p, self.bc_radius_p)], writes=[p], split=False)
 
     def dye_bc(self, dye):                                      # fs/boundary_condition.py:94-99
-        self._run("dye_bc", (dye._h,), reads=[], writes=[dye])
+        self._run("dye_bc", (dye._h,), reads=[], writes=[dye], split=False)
 
     def mac_update(self, scheme, dt, dx, re, vn, vc, pc):       # fs/solver.py:94-107
         r = 1 if scheme == 0 else 2
@@ -420,6 +469,16 @@ class Device(DeviceBase):
     def _p_exchange_many(self, handles, depth):
         arr = (ctypes.c_void_p * len(handles))(*[h for h, _ in handles])
         _lib.call("fs_halo_exchange_multi", self._ctx, arr, len(handles), depth)
+
+    def _p_exchange_begin(self, handles, depth):
+        arr = (ctypes.c_void_p * len(handles))(*[h for h, _ in handles])
+        _lib.call("fs_halo_exchange_begin", self._ctx, arr, len(handles), depth)
+
+    def _p_exchange_wait(self):
+        _lib.call("fs_halo_exchange_wait", self._ctx)
+
+    def _p_exchange_mark(self):
+        _lib.call("fs_halo_exchange_mark", self._ctx)
 
     def _p_residual(self, dt, dx, ph, vh):
         s, n = ctypes.c_double(), ctypes.c_double()

@@ -259,6 +259,7 @@ def main():
             "grouped_launches": round(dev.n_exchanges / max(args.warmup + args.steps + prof_steps, 1), 2),
             "fields": round(dev.n_exchanged_fields / max(args.warmup + args.steps + prof_steps, 1), 2),
             "KB_per_neighbour": round(dev.n_exchanged_bytes / max(args.warmup + args.steps + prof_steps, 1) / 1024, 1),
+            "overlapped_fraction": round(dev.n_overlapped / max(dev.n_exchanges, 1), 2),
             "halo_rows": dev.halo},
     }
     if dominant:

@@ -183,13 +183,25 @@ int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row
 int fs_comm_unique_id(void *out_128_bytes);
 int fs_comm_init(fs_ctx *ctx, int rank, int nranks, const void *unique_id_128_bytes);
 int fs_comm_destroy(fs_ctx *ctx);
-/* Fill `depth` ghost rows on each side from the slab neighbours (ncclSend/ncclRecv pairs).       */
+/* Fill `depth` ghost rows on each side from the slab neighbours (ncclSend/ncclRecv pairs).  All RCCL calls of a context
+ * run on its own communication stream; these two are begin + wait (see below).                                          */
 int fs_halo_exchange(fs_ctx *ctx, fs_field *f, int depth);
-/* Same for several fields in ONE grouped RCCL call (one fused send/recv launch instead of n).     */
+/* Same for several fields in ONE grouped RCCL call: their ghost-row blocks travel as one packed message per neighbour.   */
 int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth);
+/* Split form for overlap: begin() queues the exchange on the communication stream after everything already queued on the
+ * compute stream; until wait() the caller may launch kernels that neither read ghost rows nor write the `depth` outermost
+ * owned rows of these fields (the interior rows of the kernel that needed the exchange).  wait() orders the compute
+ * stream after the exchange.  One exchange in flight per context.                                                        */
+int fs_halo_exchange_begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth);
+int fs_halo_exchange_wait(fs_ctx *ctx);
+/* Optional, before begin(): the exchange will depend on the compute stream as of NOW - kernels launched between mark() and
+ * begin() (same restrictions as above) are already running while the host still issues the exchange.                     */
+int fs_halo_exchange_mark(fs_ctx *ctx);
 /* Loop-back self-test on a 1-rank communicator: the rank is its own lower and upper neighbour, so afterwards
- * lower ghost rows == first owned rows and upper ghost rows == last owned rows (single-GPU check of the RCCL leg). */
+ * lower ghost rows == first owned rows and upper ghost rows == last owned rows (single-GPU check of the RCCL leg).
+ * fs_comm_loopback(ctx, 1) makes every later exchange of a 1-rank communicator behave that way.                          */
 int fs_halo_exchange_self(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth);
+int fs_comm_loopback(fs_ctx *ctx, int on);
 int fs_allreduce_sum(fs_ctx *ctx, double *values, int n);
 
 /* ---- launch-overhead removal: capture the launches issued between begin/end into a hipGraph ---- */

@@ -5,9 +5,10 @@ oracle as the kernel provider and torch.distributed (gloo) as the ghost-row tran
 primitives - slab geometry, ghost-row validity tracking, which exchange happens when, the reference's solver
 orchestration - is the product's own Python code, exercised unchanged.
 
-After every kernel the ghost rows of the fields it wrote are POISONED with NaN: if the host logic ever lets a
-stencil read a stale ghost row, the NaN reaches the owned rows and the comparison with the single-domain
-result fails.
+A kernel launch changes only the local rows [lo, hi) it was asked for (the oracle computes all rows; the others are
+restored).  After every kernel (all its launches - an overlapped exchange splits it into three) the rows of the fields
+it wrote that lie OUTSIDE the computed range are POISONED with NaN: if the host logic ever lets a stencil read a stale
+ghost row, the NaN reaches the owned rows and the comparison with the single-domain result fails.
 """
 import numpy as np
 import torch
@@ -81,6 +82,7 @@ class OracleSlabDevice(DeviceBase):
         *args, lo, hi = args
         b, X, Y, dt_ = self.obc, self.nx, self.nloc, self.dtype
         A = [x.a if isinstance(x, _Arr) else x for x in args]
+        saved = [(x, x.copy()) for x in A if isinstance(x, np.ndarray)]
         written = []
         if name == "velocity_bc":
             b.set_velocity_boundary_condition(A[0]); written = [A[0]]
@@ -162,11 +164,17 @@ class OracleSlabDevice(DeviceBase):
             O.clamp_field(A[2], A[0], A[1])
         else:
             raise NotImplementedError(name)
-        if self.poison and written:
-            a_lo, a_hi = lo - self.r_off, hi - self.r_off
-            for w in written:
-                w[:, :a_lo] = np.nan
-                w[:, a_hi:] = np.nan
+        a_lo, a_hi = max(lo - self.r_off, 0), max(hi - self.r_off, 0)
+        for arr, old in saved:                       # rows outside [lo, hi) keep their previous content
+            arr[:, :a_lo] = old[:, :a_lo]
+            arr[:, a_hi:] = old[:, a_hi:]
+
+    def _after_kernel(self, name, written, lo, hi):
+        if self.poison:
+            a_lo, a_hi = max(lo - self.r_off, 0), max(hi - self.r_off, 0)
+            for f in written:
+                f._h.a[:, :a_lo] = np.nan
+                f._h.a[:, a_hi:] = np.nan
 
     def sync(self):
         pass

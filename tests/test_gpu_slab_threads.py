@@ -48,6 +48,15 @@ def _make_device_cls(world, shared):
                     self._p_upload(h, c, np.ascontiguousarray(shared["box"][self.rank + 1][k][0]), H + n, depth)
             shared["barrier"].wait()
 
+        def _p_exchange_begin(self, handles, depth):   # host copies are synchronous: the kernel split is still exercised
+            self._p_exchange_many(handles, depth)
+
+        def _p_exchange_wait(self):
+            pass
+
+        def _p_exchange_mark(self):
+            pass
+
     return ThreadSlabDevice
 
 

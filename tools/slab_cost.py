@@ -33,6 +33,15 @@ class LoneSlab(Device):
     def _p_exchange_many(self, handles, depth):
         pass
 
+    def _p_exchange_begin(self, handles, depth):
+        pass
+
+    def _p_exchange_wait(self):
+        pass
+
+    def _p_exchange_mark(self):
+        pass
+
 
 def main():
     res = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
