@@ -110,7 +110,7 @@ struct LaneMap {
 // XCD measured 15 % slower on scene 5 because the dispatcher does not rebalance.  Placement only affects speed.
 __device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by)
 {
-    const int nby = nby_packed & 0xffffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte
+    const int nby = nby_packed & 0x7fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked
     if (nbx < 0) {   // plain row-major decode (rows of one tile row spread over the XCDs)
         nbx = -nbx;
         by = blockIdx.x / nbx;
@@ -125,16 +125,28 @@ __device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, in
     by = (lg * 8 + xcd) * FS_XCD_GROUP + ly;
     return by < nby;
 }
+// Workgroup shape.  Side by side (default): the waves of a workgroup are consecutive wave columns of ONE tile row.  Stacked (bit 23 of
+// nby_packed): they are consecutive tile rows of ONE wave column, so the halo rows a tile shares with the tile below are re-read
+// by the same CU within microseconds (L1 / local L2 hits).  Returns this wave's column and tile row, false if it has no work.
+constexpr int FS_STACKED = 1 << 23;
+__device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y)
+{
+    int bx, by;
+    if (!band_coords(nbx, nby_packed, bx, by)) return false;
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
+    else { wave_x = bx * nw + w; tile_y = by; }
+    return wave_x * 62 < (g.X >> 2) && jb + tile_y * rt < je;
+}
 static inline int band_blocks(int nbx, int nby, int FS_XCD_GROUP)
 {
     const int groups = (nby + FS_XCD_GROUP - 1) / FS_XCD_GROUP;
     return 8 * ((groups + 7) / 8) * FS_XCD_GROUP * nbx;
 }
 
-__device__ __forceinline__ LaneMap lane_map(const Grid &g, int bx)
+__device__ __forceinline__ LaneMap lane_map_wave(const Grid &g, int wave)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = bx * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nq = g.X >> 2;
     int q = wave * 62 - 1 + lane;
     LaneMap m;
@@ -144,11 +156,6 @@ __device__ __forceinline__ LaneMap lane_map(const Grid &g, int bx)
     m.at_lo = q == 0;
     m.at_hi = q == nq - 1;
     return m;
-}
-__device__ __forceinline__ bool wave_in_range(const Grid &g, int bx)
-{
-    const int wave = bx * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    return wave * 62 < (g.X >> 2);
 }
 
 template <typename T>
@@ -177,8 +184,8 @@ __global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx,
 {
     using V = typename Quad<T>::type;
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j0 = jb + by * RT;
 
@@ -309,8 +316,8 @@ template <int RT, typename T>
 __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j0 = jb + by * RT;
 
@@ -374,8 +381,8 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
                                                          const T *fc, const T *fxc, const T *fyc, const T *v)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j = jb + by;
     const int c0 = blockIdx.y * NC;
@@ -462,8 +469,8 @@ template <bool P2, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return;
@@ -510,8 +517,8 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k
                                                               const T *fxc, const T *fyc, const T *fc, const T *fn)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by, c0 = blockIdx.y * NC;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return;
@@ -583,8 +590,8 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
                                                      const T *gxc, const T *gyc)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     constexpr int o = 1 - c;                        // c: this pass's component (compile time: runtime selection among the
                                                     // register arrays below would push them to scratch), o: the other one
@@ -704,8 +711,8 @@ template <bool SRC, int RT, typename T>
 __global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j0 = jb + by * RT;
 
@@ -773,8 +780,8 @@ __global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int
     constexpr int R = SCHEME == 0 ? 1 : 2;          // stencil radius
     constexpr int NR = 2 * R + 1;
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
     if (!__any(fl != 0u)) return;
@@ -859,8 +866,8 @@ __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst
                                                       T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const int rows5[5] = {clampy(g, j - 2), clampy(g, j - 1), j, clampy(g, j + 1), clampy(g, j + 2)};
     const uint32_t m4[3] = {mask_quad(g, i0, rows5[1]), mask_quad(g, i0, rows5[2]), mask_quad(g, i0, rows5[3])};
@@ -974,8 +981,8 @@ template <bool P2, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv_dye_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return;
@@ -1035,8 +1042,8 @@ __global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int 
                                                         const T *fc, const T *fxc, const T *fyc, const T *v)
 {
     int bx, by;
-    if (!band_coords(nbx, nby, bx, by) || !wave_in_range(g, bx)) return;
-    const LaneMap lm = lane_map(g, bx);
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
     if (!__any(fl != 0u)) return;

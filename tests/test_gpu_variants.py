@@ -3,6 +3,7 @@ one-cell-per-lane kernels (FS_MARCH=0), which the small-size tests pin against t
   FS_JACOBI   22 / 24 / 21 = overlapped-wave register tiles of 2 / 4 / 1 rows, 30 = LDS halo tile
   FS_XCD      bit mask of the kernels launched in XCD-grouped block order (0 = all row-major, 63 = all grouped, default);
   FS_XCD_GROUP = tile rows per XCD group (1..128, default 8)
+  FS_STACK    bit mask of the kernels whose workgroups are 4 stacked tile rows of one wave column instead of 4 wave columns of one row
 Grid 2*res x res with res = 520: several waves per row, a ragged last wave, row count not a multiple of any tile."""
 import numpy as np
 import pytest
@@ -16,7 +17,7 @@ def _run(monkeypatch, env, what):
     import fs
     from fs.boundary_condition import BoundaryCondition, create_scene_arrays
     from fs.runtime import Device
-    for k in ("FS_MARCH", "FS_JACOBI", "FS_XCD", "FS_XCD_GROUP"):
+    for k in ("FS_MARCH", "FS_JACOBI", "FS_XCD", "FS_XCD_GROUP", "FS_STACK"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -58,7 +59,8 @@ def test_jacobi_tile_variants(variant, hip_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"FS_XCD": "0"}, {"FS_XCD": "21"}, {"FS_XCD_GROUP": "1"}, {"FS_XCD_GROUP": "3"},
-                                 {"FS_XCD_GROUP": "16"}, {"FS_XCD_GROUP": "128"}],
+                                 {"FS_XCD_GROUP": "16"}, {"FS_XCD_GROUP": "128"}, {"FS_STACK": "63"}, {"FS_STACK": "63", "FS_XCD": "0"},
+                                 {"FS_STACK": "21", "FS_XCD_GROUP": "3"}],
                          ids=lambda e: "-".join(f"{k[3:]}{v}" for k, v in e.items()))
 def test_block_order_variants(env, hip_lib, monkeypatch):
     ref = _run(monkeypatch, {"FS_MARCH": "0"}, "step")
