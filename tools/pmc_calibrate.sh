@@ -5,6 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_cal
 mkdir -p $OUT
+[ -x tools/membw.bin ] || hipcc -O3 --offload-arch=gfx950 tools/membw.hip -o tools/membw.bin
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- ./tools/membw.bin > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- ./tools/membw.bin > $OUT/write.log 2>&1
 python3 - <<'PY' > $OUT/summary.txt
