@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "fs_host.h"
@@ -173,7 +174,9 @@ int fs_comm_destroy(fs_ctx *ctx)
     return FS_OK;
 }
 
-static int exchange_direct(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth, int lower, int upper)
+// valid[k] (or 0): ghost rows of field k that are still correct, counted from the slab edge outwards - only the rows beyond them,
+// i.e. depth offsets [valid[k], depth), travel.
+static int exchange_direct(fs_ctx *ctx, fs_field *const *fields, const int *valid, int nfields, int depth, int lower, int upper)
 {
     Comm *cm = ctx->comm;
     const ncclDataType_t dt = ctx->dtype == 0 ? ncclFloat32 : ncclFloat64;
@@ -181,24 +184,26 @@ static int exchange_direct(fs_ctx *ctx, fs_field *const *fields, int nfields, in
     FS_NCCL(g_rccl.GroupStart());
     for (int k = 0; k < nfields; ++k) {
         fs_field *f = fields[k];
+        const int v = valid ? valid[k] : 0;
+        if (v >= depth) continue;
         const size_t row_elems = (size_t)f->C * ctx->P;
-        const size_t count = (size_t)depth * row_elems;
+        const size_t count = (size_t)(depth - v) * row_elems;
         char *base = (char *)f->d;
         auto rowp = [&](int r) { return base + (size_t)r * row_elems * ctx->esize; };
         if (lower >= 0) {
-            FS_NCCL(g_rccl.Send(rowp(H), count, dt, lower, cm->comm, cm->stream));
+            FS_NCCL(g_rccl.Send(rowp(H + v), count, dt, lower, cm->comm, cm->stream));
             FS_NCCL(g_rccl.Recv(rowp(H - depth), count, dt, lower, cm->comm, cm->stream));
         }
         if (upper >= 0) {
             FS_NCCL(g_rccl.Send(rowp(H + n - depth), count, dt, upper, cm->comm, cm->stream));
-            FS_NCCL(g_rccl.Recv(rowp(H + n), count, dt, upper, cm->comm, cm->stream));
+            FS_NCCL(g_rccl.Recv(rowp(H + n + v), count, dt, upper, cm->comm, cm->stream));
         }
     }
     FS_NCCL(g_rccl.GroupEnd());
     return FS_OK;
 }
 
-static int exchange_packed(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth, int lower, int upper)
+static int exchange_packed(fs_ctx *ctx, fs_field *const *fields, const int *valid, int nfields, int depth, int lower, int upper)
 {
     Comm *cm = ctx->comm;
     const int H = ctx->halo, n = ctx->nyl;
@@ -209,14 +214,17 @@ static int exchange_packed(fs_ctx *ctx, fs_field *const *fields, int nfields, in
         fs_field *f = fields[k];
         const size_t row_bytes = (size_t)f->C * ctx->P * ctx->esize;
         char *base = (char *)f->d;
-        own.bytes[k] = ghost.bytes[k] = (size_t)depth * row_bytes;
+        const int v = valid ? std::min(valid[k], depth) : 0;
+        own.bytes[k] = ghost.bytes[k] = (size_t)(depth - v) * row_bytes;
         own.off[k] = ghost.off[k] = total;
         total += own.bytes[k];
-        own.lo[k] = lower >= 0 ? base + (size_t)H * row_bytes : nullptr;
-        own.hi[k] = upper >= 0 ? base + (size_t)(H + n - depth) * row_bytes : nullptr;
-        ghost.lo[k] = lower >= 0 ? base + (size_t)(H - depth) * row_bytes : nullptr;
-        ghost.hi[k] = upper >= 0 ? base + (size_t)(H + n) * row_bytes : nullptr;
+        const bool any = v < depth;
+        own.lo[k] = lower >= 0 && any ? base + (size_t)(H + v) * row_bytes : nullptr;             // my first owned rows, offsets [v, depth)
+        own.hi[k] = upper >= 0 && any ? base + (size_t)(H + n - depth) * row_bytes : nullptr;     // my last owned rows, offsets [v, depth) from the top
+        ghost.lo[k] = lower >= 0 && any ? base + (size_t)(H - depth) * row_bytes : nullptr;       // lower ghost rows at depth (v, depth]
+        ghost.hi[k] = upper >= 0 && any ? base + (size_t)(H + n + v) * row_bytes : nullptr;       // upper ghost rows at depth (v, depth]
     }
+    if (total == 0) return FS_OK;
     if (total > cm->stage_part) {
         FS_HIP(hipStreamSynchronize(cm->stream));
         if (cm->stage) { FS_HIP(hipFree(cm->stage)); cm->stage = nullptr; cm->stage_part = 0; }
@@ -247,23 +255,24 @@ static int exchange_packed(fs_ctx *ctx, fs_field *const *fields, int nfields, in
 //   to the upper neighbour: my last  `depth` owned rows  -> their lower ghost rows
 // `lower` / `upper` are the peer ranks (-1 = domain edge, no neighbour).  One field goes straight from / to its rows
 // (a ghost-row block is contiguous in the [row][channel][x] layout); several fields travel as one packed message.
-static int exchange(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth, int lower, int upper)
+static int exchange(fs_ctx *ctx, fs_field *const *fields, const int *valid, int nfields, int depth, int lower, int upper)
 {
-    if (nfields >= 2 && nfields <= MAX_PACK && ctx->pack_halo) return exchange_packed(ctx, fields, nfields, depth, lower, upper);
-    return exchange_direct(ctx, fields, nfields, depth, lower, upper);
+    if (nfields >= 2 && nfields <= MAX_PACK && ctx->pack_halo) return exchange_packed(ctx, fields, valid, nfields, depth, lower, upper);
+    return exchange_direct(ctx, fields, valid, nfields, depth, lower, upper);
 }
 
-static int check_exchange_args(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
+static int check_exchange_args(fs_ctx *ctx, fs_field *const *fields, const int *valid, int nfields, int depth)
 {
     FS_REQUIRE(ctx && fields && nfields >= 0, "null argument");
+    if (valid) for (int n = 0; n < nfields; ++n) FS_REQUIRE(valid[n] >= 0, "negative valid-row count");
     FS_REQUIRE(depth >= 0 && depth <= ctx->halo && depth <= ctx->nyl, "halo depth exceeds the slab's ghost rows or owned rows");
     for (int n = 0; n < nfields; ++n) FS_REQUIRE(fields[n] && fields[n]->ctx == ctx, "null / foreign field");
     return FS_OK;
 }
 
-static int begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth, bool self)
+static int begin(fs_ctx *ctx, fs_field *const *fields, const int *valid, int nfields, int depth, bool self)
 {
-    int rc = check_exchange_args(ctx, fields, nfields, depth); if (rc) return rc;
+    int rc = check_exchange_args(ctx, fields, valid, nfields, depth); if (rc) return rc;
     Comm *cm = ctx->comm;
     if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
     FS_REQUIRE(!cm->in_flight, "fs_halo_exchange_begin while another exchange is in flight (call fs_halo_exchange_wait first)");
@@ -275,7 +284,7 @@ static int begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth, b
     if (!cm->marked) FS_HIP(hipEventRecord(cm->ev_compute, ctx->stream));   // everything queued so far produces the rows we send
     cm->marked = false;
     FS_HIP(hipStreamWaitEvent(cm->stream, cm->ev_compute, 0));
-    rc = exchange(ctx, fields, nfields, depth, lower, upper);
+    rc = exchange(ctx, fields, valid, nfields, depth, lower, upper);
     if (rc) return rc;
     FS_HIP(hipEventRecord(cm->ev_comm, cm->stream));
     cm->in_flight = true;
@@ -283,7 +292,12 @@ static int begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth, b
     return FS_OK;
 }
 
-int fs_halo_exchange_begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth) { return begin(ctx, fields, nfields, depth, false); }
+int fs_halo_exchange_begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth) { return begin(ctx, fields, nullptr, nfields, depth, false); }
+
+// As begin(), but field k's ghost rows are already correct to depth valid_rows[k]: only the rows beyond travel
+// (the validity tracker of fs/runtime.py knows these numbers; they are the same on both sides of a slab boundary).
+int fs_halo_exchange_begin_partial(fs_ctx *ctx, fs_field *const *fields, const int *valid_rows, int nfields, int depth)
+{ return begin(ctx, fields, valid_rows, nfields, depth, false); }
 
 // Optional, before begin(): fix the point of the compute stream the exchange depends on NOW, so that kernels launched between
 // mark() and begin() (the interior rows) are already running while the host is still issuing the exchange.
@@ -311,7 +325,7 @@ int fs_halo_exchange_wait(fs_ctx *ctx)
 
 int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
 {
-    int rc = begin(ctx, fields, nfields, depth, false);
+    int rc = begin(ctx, fields, nullptr, nfields, depth, false);
     return rc ? rc : fs_halo_exchange_wait(ctx);
 }
 
@@ -320,7 +334,7 @@ int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, in
 // upper ghost rows == last owned rows.  Lets a single-GPU box check row offsets, counts, dtype and stream order of the RCCL leg.
 int fs_halo_exchange_self(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth)
 {
-    int rc = begin(ctx, fields, nfields, depth, true);
+    int rc = begin(ctx, fields, nullptr, nfields, depth, true);
     return rc ? rc : fs_halo_exchange_wait(ctx);
 }
 

@@ -69,6 +69,7 @@ _PROTOS = {
     "fs_halo_exchange_multi": [_c_vp, _P(_c_vp), _c_int, _c_int],
     "fs_halo_exchange_self": [_c_vp, _P(_c_vp), _c_int, _c_int],
     "fs_halo_exchange_begin": [_c_vp, _P(_c_vp), _c_int, _c_int],
+    "fs_halo_exchange_begin_partial": [_c_vp, _P(_c_vp), _P(_c_int), _c_int, _c_int],
     "fs_halo_exchange_wait": [_c_vp],
     "fs_halo_exchange_mark": [_c_vp],
     "fs_comm_loopback": [_c_vp, _c_int],

@@ -166,39 +166,42 @@ class DeviceBase:
         self.n_exchanged_bytes = 0    # payload sent to ONE neighbour by them (an interior rank sends twice that)
         self.n_overlapped = 0         # exchanges that ran behind the interior rows of the kernel that needed them
         self.overlap = nranks > 1 and os.environ.get("FS_OVERLAP", "1") != "0"
+        self.partial = os.environ.get("FS_PARTIAL_HALO", "1") != "0"     # send only the ghost rows beyond a field's validity
 
     # ---- ghost-row bookkeeping --------------------------------------------------------------------
     def exchange(self, field, depth=None):
         self.exchange_many([field], depth)
 
-    def exchange_many(self, fields, depth=None):
-        """Refresh the ghost rows of several fields with ONE grouped send/recv (one launch, one latency)."""
-        depth = self.halo if depth is None else depth
-        if len(fields) == 1:
-            self._p_exchange(fields[0]._h, fields[0].nchan, depth)
-        else:
-            self._p_exchange_many([(f._h, f.nchan) for f in fields], depth)
+    def _handles(self, fields, depth):
+        """(handle, channels, rows already valid) per field: only the ghost rows beyond a field's validity have to travel."""
+        return [(f._h, f.nchan, min(max(f.valid, 0), depth) if self.partial else 0) for f in fields]
+
+    def _account(self, fields, handles, depth):
         for f in fields:
             f.valid = depth
         self.n_exchanges += 1
         self.n_exchanged_fields += len(fields)
-        self.n_exchanged_bytes += depth * self.nx * self.dtype.itemsize * sum(f.nchan for f in fields)
+        self.n_exchanged_bytes += self.nx * self.dtype.itemsize * sum((depth - v) * c for _, c, v in handles)
 
-    def _p_exchange_many(self, handles, depth):     # backends without a grouped primitive: one by one
-        for h, nchan in handles:
+    def exchange_many(self, fields, depth=None):
+        """Refresh the ghost rows of several fields with ONE grouped send/recv (one launch, one latency)."""
+        depth = self.halo if depth is None else depth
+        handles = self._handles(fields, depth)
+        self._p_exchange_many(handles, depth)
+        self._account(fields, handles, depth)
+
+    def _p_exchange_many(self, handles, depth):     # backends without a grouped primitive: one by one, full depth
+        for h, nchan, _ in handles:
             self._p_exchange(h, nchan, depth)
 
     def exchange_begin(self, fields, depth=None):
         """Start refreshing the ghost rows of `fields`; until exchange_wait() only kernels that neither read ghost rows nor
         write the `depth` outermost owned rows of these fields may be launched (see _run)."""
         depth = self.halo if depth is None else depth
-        self._p_exchange_begin([(f._h, f.nchan) for f in fields], depth)
-        for f in fields:
-            f.valid = depth
-        self.n_exchanges += 1
+        handles = self._handles(fields, depth)
+        self._p_exchange_begin(handles, depth)
+        self._account(fields, handles, depth)
         self.n_overlapped += 1
-        self.n_exchanged_fields += len(fields)
-        self.n_exchanged_bytes += depth * self.nx * self.dtype.itemsize * sum(f.nchan for f in fields)
 
     def exchange_wait(self):
         self._p_exchange_wait()
@@ -467,12 +470,13 @@ class Device(DeviceBase):
         _lib.call("fs_halo_exchange", self._ctx, h, depth)
 
     def _p_exchange_many(self, handles, depth):
-        arr = (ctypes.c_void_p * len(handles))(*[h for h, _ in handles])
-        _lib.call("fs_halo_exchange_multi", self._ctx, arr, len(handles), depth)
+        self._p_exchange_begin(handles, depth)
+        self._p_exchange_wait()
 
     def _p_exchange_begin(self, handles, depth):
-        arr = (ctypes.c_void_p * len(handles))(*[h for h, _ in handles])
-        _lib.call("fs_halo_exchange_begin", self._ctx, arr, len(handles), depth)
+        arr = (ctypes.c_void_p * len(handles))(*[h for h, _, _ in handles])
+        val = (ctypes.c_int * len(handles))(*[v for _, _, v in handles])
+        _lib.call("fs_halo_exchange_begin_partial", self._ctx, arr, val, len(handles), depth)
 
     def _p_exchange_wait(self):
         _lib.call("fs_halo_exchange_wait", self._ctx)

@@ -193,6 +193,9 @@ int fs_halo_exchange_multi(fs_ctx *ctx, fs_field *const *fields, int nfields, in
  * owned rows of these fields (the interior rows of the kernel that needed the exchange).  wait() orders the compute
  * stream after the exchange.  One exchange in flight per context.                                                        */
 int fs_halo_exchange_begin(fs_ctx *ctx, fs_field *const *fields, int nfields, int depth);
+/* As begin(), but field k's ghost rows are known to be correct to depth valid_rows[k] already: only depth offsets
+ * [valid_rows[k], depth) travel (same numbers on both sides of a slab boundary; the host tracker has them).          */
+int fs_halo_exchange_begin_partial(fs_ctx *ctx, fs_field *const *fields, const int *valid_rows, int nfields, int depth);
 int fs_halo_exchange_wait(fs_ctx *ctx);
 /* Optional, before begin(): the exchange will depend on the compute stream as of NOW - kernels launched between mark() and
  * begin() (same restrictions as above) are already running while the host still issues the exchange.                     */

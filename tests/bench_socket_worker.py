@@ -70,22 +70,24 @@ class SocketSlabDevice(runtime.Device):
         self._graphs = []
 
     def _p_exchange(self, h, nchan, depth):
-        self._p_exchange_many([(h, nchan)], depth)
+        self._p_exchange_many([(h, nchan, 0)], depth)
 
     def _p_exchange_many(self, handles, depth):
+        # depth offsets [v, depth) of every field travel (v = rows the tracker still trusts), as in fs_halo_exchange_begin_partial
         H, n, r = self.halo, self.nyl, self.rank
-        lo = [self._p_download(h, c, H, depth) for h, c in handles]
-        hi = [self._p_download(h, c, H + n - depth, depth) for h, c in handles]
+        live = [(h, c, v) for h, c, v in handles if v < depth]
+        lo = [self._p_download(h, c, H + v, depth - v) for h, c, v in live]
+        hi = [self._p_download(h, c, H + n - depth, depth - v) for h, c, v in live]
         # pairs (even, even+1) first, then (odd, odd+1): every rank is in at most one pair per phase
         for phase in (0, 1):
             if r % 2 == phase and r + 1 < self.nranks:
                 got = _swap(r + 1, hi, True)
-                for (h, c), a in zip(handles, got):
-                    self._p_upload(h, c, np.ascontiguousarray(a), H + n, depth)
+                for (h, c, v), a in zip(live, got):
+                    self._p_upload(h, c, np.ascontiguousarray(a), H + n + v, depth - v)
             elif r % 2 != phase and r - 1 >= 0:
                 got = _swap(r - 1, lo, False)
-                for (h, c), a in zip(handles, got):
-                    self._p_upload(h, c, np.ascontiguousarray(a), H - depth, depth)
+                for (h, c, v), a in zip(live, got):
+                    self._p_upload(h, c, np.ascontiguousarray(a), H - depth, depth - v)
 
     def _p_exchange_begin(self, handles, depth):     # no asynchronous transport here: the split of the kernel is still exercised
         self._p_exchange_many(handles, depth)

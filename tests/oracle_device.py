@@ -55,7 +55,11 @@ class OracleSlabDevice(DeviceBase):
         self.obc = O.OracleBC(bc_const[:, sl], bc_mask[:, sl], None if bc_dye is None else bc_dye[:, sl], self.dtype)
         return 2, 1
 
-    def _p_exchange(self, h, nchan, depth):
+    def _p_exchange(self, h, nchan, depth, v=0):
+        """Ghost rows at depth offsets [v, depth) on each side (v = rows the tracker still trusts: they are NOT refreshed, so
+        a wrong validity count leaves poisoned rows in place)."""
+        if v >= depth:
+            return
         a = h.a
         lo = self.halo - self.r_off                # array row of the first owned row
         hi = lo + self.nyl
@@ -65,17 +69,21 @@ class OracleSlabDevice(DeviceBase):
             return torch.from_numpy(np.ascontiguousarray(a[:, s]))
 
         if self.rank > 0:
-            ops.append(dist.P2POp(dist.isend, rows(slice(lo, lo + depth)), self.rank - 1))
-            t = rows(slice(lo - depth, lo)); recvs.append((slice(lo - depth, lo), t))
+            ops.append(dist.P2POp(dist.isend, rows(slice(lo + v, lo + depth)), self.rank - 1))
+            t = rows(slice(lo - depth, lo - v)); recvs.append((slice(lo - depth, lo - v), t))
             ops.append(dist.P2POp(dist.irecv, t, self.rank - 1))
         if self.rank < self.nranks - 1:
-            ops.append(dist.P2POp(dist.isend, rows(slice(hi - depth, hi)), self.rank + 1))
-            t = rows(slice(hi, hi + depth)); recvs.append((slice(hi, hi + depth), t))
+            ops.append(dist.P2POp(dist.isend, rows(slice(hi - depth, hi - v)), self.rank + 1))
+            t = rows(slice(hi + v, hi + depth)); recvs.append((slice(hi + v, hi + depth), t))
             ops.append(dist.P2POp(dist.irecv, t, self.rank + 1))
         for r in dist.batch_isend_irecv(ops):
             r.wait()
         for s, t in recvs:
             a[:, s] = t.numpy()
+
+    def _p_exchange_many(self, handles, depth):
+        for h, nchan, v in handles:
+            self._p_exchange(h, nchan, depth, v)
 
     # ---- kernels: same argument order as the C-ABI (include/fs_hip.h) --------------------------------
     def _p_kernel(self, name, *args):

@@ -34,18 +34,22 @@ def _make_device_cls(world, shared):
             self._ctx = ctx
 
         def _p_exchange(self, h, nchan, depth):
-            self._p_exchange_many([(h, nchan)], depth)
+            self._p_exchange_many([(h, nchan, 0)], depth)
 
         def _p_exchange_many(self, handles, depth):
+            # depth offsets [v, depth) of every field travel (v = rows the tracker still trusts), as in fs_halo_exchange_begin_partial
             H, n = self.halo, self.nyl
-            mine = [(self._p_download(h, c, H, depth), self._p_download(h, c, H + n - depth, depth)) for h, c in handles]
+            mine = [(self._p_download(h, c, H + v, depth - v), self._p_download(h, c, H + n - depth, depth - v)) if v < depth else None
+                    for h, c, v in handles]
             shared["box"][self.rank] = mine
             shared["barrier"].wait()
-            for k, (h, c) in enumerate(handles):
+            for k, (h, c, v) in enumerate(handles):
+                if v >= depth:
+                    continue
                 if self.rank > 0:
-                    self._p_upload(h, c, np.ascontiguousarray(shared["box"][self.rank - 1][k][1]), H - depth, depth)
+                    self._p_upload(h, c, np.ascontiguousarray(shared["box"][self.rank - 1][k][1]), H - depth, depth - v)
                 if self.rank < world - 1:
-                    self._p_upload(h, c, np.ascontiguousarray(shared["box"][self.rank + 1][k][0]), H + n, depth)
+                    self._p_upload(h, c, np.ascontiguousarray(shared["box"][self.rank + 1][k][0]), H + n + v, depth - v)
             shared["barrier"].wait()
 
         def _p_exchange_begin(self, handles, depth):   # host copies are synchronous: the kernel split is still exercised
