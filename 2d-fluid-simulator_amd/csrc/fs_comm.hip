@@ -144,7 +144,11 @@ int fs_comm_init(fs_ctx *ctx, int rank, int nranks, const void *unique_id_128_by
     ncclResult_t r = g_rccl.CommInitRank(&cm->comm, nranks, id, rank);
     if (r != ncclSuccess) { delete cm; return nccl_fail(r, "ncclCommInitRank"); }
     hipError_t e = hipMalloc(&cm->d_red, 16 * sizeof(double));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {      // highest priority: the short pack / RCCL / unpack kernels must not queue behind the interior rows they overlap with
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&cm->stream, hipStreamNonBlocking, greatest);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_compute, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_comm, hipEventDisableTiming);
     if (e != hipSuccess) {
