@@ -112,6 +112,34 @@ def test_against_oracle_at_moderate_size(bc, res, scheme, vc, re, dt, steps, hip
         sim._solver._bc.device.close()
 
 
+@pytest.mark.parametrize("bc,res,scheme,vc,dye,steps", [
+    (5, 256, "cip", 5.0, False, 600),      # the flow is fully developed by then: every sign / NaN branch of CIP and VC is taken
+    (2, 200, "cip", 5.0, True, 300),       # the reference's default mode (dye on), dx not a power of two
+    (3, 192, "kk", 10.0, False, 400),
+    (5, 512, "cip", 5.0, False, 1500),
+])
+def test_long_run_stays_bit_identical(bc, res, scheme, vc, dye, steps, hip_lib):
+    """Hundreds of steps: with vorticity confinement a one-ulp difference anywhere grows to O(1e-3) within a few steps
+    (hazard H4), so equality at the end of a long run is a much stronger statement than at step 20."""
+    from fs.boundary_condition import create_scene_arrays
+    from oracle import oracle as O
+    dt, dx = 0.05 / res, 1.0 / res
+    sim = _build(bc, res, scheme, vc, 1e6, None, True, dye=dye)
+    try:
+        const, mask, bdye = create_scene_arrays(bc, res)
+        ref = O.make_simulator(const, mask, bdye if dye else None, scheme=scheme, dt=dt, dx=dx, re=1e6, vor_eps=vc)
+        for step in range(1, steps + 1):
+            sim.step()
+            ref.update()
+            if step % 100 == 0 or step == steps:
+                out = sim.field_to_numpy()
+                for k, e in ref.fields().items():
+                    assert np.array_equal(out[k], e, equal_nan=True), f"step {step} {k}: rel-L2 {rel_l2(out[k], e):.3e}"
+        assert np.isfinite(out["v"]).all() and float(np.abs(out["v"]).max()) > 0.5
+    finally:
+        sim._solver._bc.device.close()
+
+
 def test_against_oracle_at_baseline_size(hip_lib):
     """BASELINE configs[2] itself (bc5, res 4096, CIP + VC): two steps on the GPU against two steps of the CPU oracle, bit for bit."""
     import os
