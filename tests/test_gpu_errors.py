@@ -62,3 +62,43 @@ def test_kernel_before_mask_upload(hip_lib):
     assert hip_lib.fs_create(ctypes.byref(ctypes.c_void_p()), 0, 2, 2, 0, 0, 2, 0) == -1     # grid too small
     assert hip_lib.fs_create(ctypes.byref(ctypes.c_void_p()), 0, 32, 16, 5, 0, 16, 0) == -1    # bad dtype
     hip_lib.fs_destroy(ctx)
+
+
+def test_exchange_misuse(dev, hip_lib):
+    """Ghost-row exchange entry points without a communicator, and the begin / wait protocol on a 1-rank communicator."""
+    import os
+    from fs import _lib
+    from fs._lib import FsError
+    v = dev.alloc(2)
+    arr = (ctypes.c_void_p * 1)(v._h)
+    for name, args in (("fs_halo_exchange_multi", (arr, 1, 0)), ("fs_halo_exchange_begin", (arr, 1, 0)),
+                       ("fs_halo_exchange_self", (arr, 1, 0))):
+        with pytest.raises(FsError, match="fs_comm_init"):
+            _lib.call(name, dev._ctx, *args)
+    with pytest.raises(FsError, match="fs_comm_init"):
+        _lib.call("fs_halo_exchange_mark", dev._ctx)
+    _lib.call("fs_halo_exchange_wait", dev._ctx)                      # nothing in flight: a no-op, not an error
+    with pytest.raises(FsError, match="communicator"):
+        _lib.call("fs_comm_loopback", dev._ctx, 1)
+    # 1-rank communicator: protocol errors
+    uid = ctypes.create_string_buffer(128)
+    _lib.call("fs_comm_unique_id", uid)
+    saved = os.dup(1); os.dup2(2, 1)
+    try:
+        _lib.call("fs_comm_init", dev._ctx, 0, 1, ctypes.c_char_p(uid.raw))
+    finally:
+        ctypes.CDLL(None).fflush(None); os.dup2(saved, 1); os.close(saved)
+    with pytest.raises(FsError, match="already initialised"):
+        _lib.call("fs_comm_init", dev._ctx, 0, 1, ctypes.c_char_p(uid.raw))
+    with pytest.raises(FsError, match="depth"):
+        _lib.call("fs_halo_exchange_begin", dev._ctx, arr, 1, 1)      # this context has no ghost rows (halo 0)
+    _lib.call("fs_halo_exchange_begin", dev._ctx, arr, 1, 0)
+    with pytest.raises(FsError, match="in flight"):
+        _lib.call("fs_halo_exchange_begin", dev._ctx, arr, 1, 0)
+    with pytest.raises(FsError, match="in flight"):
+        _lib.call("fs_halo_exchange_mark", dev._ctx)
+    _lib.call("fs_halo_exchange_wait", dev._ctx)
+    neg = (ctypes.c_int * 1)(-1)
+    with pytest.raises(FsError, match="negative"):
+        _lib.call("fs_halo_exchange_begin_partial", dev._ctx, arr, neg, 1, 0)
+    _lib.load().fs_comm_destroy(dev._ctx)
