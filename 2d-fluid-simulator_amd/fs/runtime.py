@@ -226,7 +226,9 @@ class DeviceBase:
         e = min(f.valid - r) ghost rows as well (communication-avoiding: with a deep halo several kernels run between
         two exchanges); the cells a masked kernel does NOT write keep their old content, so the outputs' previous
         validity caps e too.  When an input lacks its radius, every field of this kernel that is below full depth is
-        refreshed in ONE grouped send/recv.
+        refreshed in ONE grouped send/recv (only the rows beyond each field's validity travel).  For `split` kernels (all
+        but the op-list boundary kernels) that exchange runs behind the kernel's own interior rows: mark -> rows [2H, nyl)
+        -> begin -> wait -> the two edge strips.
         """
         multi = self.nranks > 1
         off = self.y0 - self.halo
