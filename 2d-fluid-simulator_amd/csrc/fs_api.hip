@@ -266,9 +266,11 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
     h_begin.push_back((int)h_kind.size());
     out.ncomp = (int)h_rlo.size();
     out.nops = (int)h_kind.size();
+    // Stream-ordered like every other memory operation of a context: its stream is non-blocking, so work on the null stream
+    // (hipMemcpy / hipMemset) is NOT ordered against the kernels that follow.  The host vectors outlive the copies (sync below).
     auto up = [&](int *&d, const std::vector<int> &h) -> int {
         FS_HIP(hipMalloc(&d, std::max<size_t>(h.size(), 1) * sizeof(int)));
-        if (!h.empty()) FS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (!h.empty()) FS_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         return FS_OK;
     };
     int rc;
@@ -279,6 +281,7 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
     if ((rc = up(out.tgt, h_tgt))) return rc;
     if ((rc = up(out.s1, h_s1))) return rc;
     if ((rc = up(out.s2, h_s2))) return rc;
+    FS_HIP(hipStreamSynchronize(c->stream));
     return FS_OK;
 }
 
@@ -368,7 +371,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     e = hipMalloc(&c->d_mask, (size_t)c->rows * c->Pm);
-    if (e == hipSuccess) e = hipMemset(c->d_mask, 1, (size_t)c->rows * c->Pm);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_mask, 1, (size_t)c->rows * c->Pm, c->stream);   // never the null stream: see upload_ops
     if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;

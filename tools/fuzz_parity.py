@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Differential fuzzing: random grids / masks / parameters, HIP library vs CPU oracle, bit for bit.
+    python tools/fuzz_parity.py [--cases 200] [--seed 0] [--max-cells 120000]
+Prints one line per failing case (with the seed to reproduce) and a summary; exit code 1 on any mismatch."""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+importlib.import_module("2d-fluid-simulator_amd")
+import fs  # noqa: E402
+from fs.boundary_condition import BoundaryCondition, DyeBoundaryCondition  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def random_scene(rng, X, Y):
+    style = rng.integers(0, 4)
+    mask = np.zeros((X, Y), np.uint8)
+    if style == 0:                                   # salt-and-pepper walls
+        mask[rng.random((X, Y)) < rng.uniform(0.0, 0.4)] = 1
+    elif style == 1:                                 # boxes
+        for _ in range(rng.integers(1, 12)):
+            i, j = rng.integers(0, X), rng.integers(0, Y)
+            mask[i:i + rng.integers(1, max(2, X // 3)), j:j + rng.integers(1, max(2, Y // 3))] = 1
+    elif style == 2:                                 # channel: wall rings like the reference scenes, inflow left, outflow right
+        mask[:, :2] = 1; mask[:, -2:] = 1
+        mask[:2, 2:-2] = 2; mask[-2:, 2:-2] = 3
+        for _ in range(rng.integers(0, 6)):
+            i, j = rng.integers(2, max(3, X - 2)), rng.integers(2, max(3, Y - 2))
+            mask[i:i + rng.integers(1, max(2, X // 4)), j:j + rng.integers(1, max(2, Y // 4))] = 1
+    else:                                            # thin diagonal walls (chained BC hazards)
+        for k in range(rng.integers(1, 5)):
+            o = rng.integers(0, X)
+            idx = (np.arange(Y) + o) % X
+            mask[idx, np.arange(Y)] = 1
+    io = rng.random((X, Y))
+    p_io = rng.uniform(0, 0.05)
+    mask[(io < p_io) & (mask == 0)] = 2
+    mask[(io > 1 - p_io) & (mask == 0)] = 3
+    const = np.zeros((X, Y, 2), np.float32)
+    n2 = int((mask == 2).sum())
+    const[mask == 2] = rng.uniform(-2, 2, (n2, 2)).astype(np.float32)
+    dye = rng.uniform(0, 1, (X, Y, 3)).astype(np.float32)
+    return const, mask, dye
+
+
+def one_case(seed, max_cells, debug=False):
+    rng = np.random.default_rng(seed)
+    X = int(rng.choice([rng.integers(4, 40), rng.integers(40, 300), rng.integers(300, 1300), 4 * rng.integers(1, 320)]))
+    Y = int(rng.integers(4, max(5, min(300, max_cells // X))))
+    const, mask, dye = random_scene(rng, X, Y)
+    f64 = rng.random() < 0.25
+    dtype = np.float64 if f64 else np.float32
+    scheme = str(rng.choice(["cip", "cip", "kk", "upwind"]))
+    with_dye = rng.random() < 0.35
+    vc = None if rng.random() < 0.3 else float(rng.choice([0.5, 5.0, 10.0, 50.0]))
+    updater = ("rbsor", float(rng.choice([1.0, 1.3, 1.9])), int(rng.integers(1, 4))) if rng.random() < 0.6 else ("jacobi", int(rng.choice([1, 3, 6, 12])))
+    res = float(rng.choice([2 ** rng.integers(3, 11), rng.integers(10, 1500)]))
+    dx = 1.0 / res
+    dt = float(rng.choice([0.05 / res, 0.2 / res, 1e-4]))
+    re = float(rng.choice([1.0, 100.0, 1e6, 1e8]))
+    os.environ["FS_FUSE_TRANSPORT"] = "1" if rng.random() < 0.2 else "0"
+    os.environ["FS_FUSE_NONADV"] = "1" if rng.random() < 0.2 else "0"
+    desc = (f"seed {seed}: {X}x{Y} {np.dtype(dtype).name} {scheme} vc={vc} {updater} dye={with_dye} res={res:g} dt={dt:g} re={re:g} "
+            f"fuse={os.environ['FS_FUSE_TRANSPORT']}{os.environ['FS_FUSE_NONADV']}")
+    fs.runtime.init(gpu=0, dtype="f64" if f64 else "f32")
+    bc = (DyeBoundaryCondition(const.astype(dtype), dye.astype(dtype), mask) if with_dye else BoundaryCondition(const.astype(dtype), mask))
+    try:
+        vcobj = fs.VorticityConfinement(bc, dt, dx, vc) if vc is not None else None
+        pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, updater[1], updater[2]) if updater[0] == "rbsor" else fs.JacobiPressureUpdater(bc, dt, dx, updater[1]))
+        if scheme == "cip":
+            solver = (fs.DyeCipMacSolver if with_dye else fs.CipMacSolver)(bc, pu, dt, dx, re, vcobj)
+        else:
+            adv = fs.advect_upwind if scheme == "upwind" else fs.advect_kk_scheme
+            solver = (fs.DyeMacSolver if with_dye else fs.MacSolver)(bc, pu, adv, dt, dx, re, vcobj)
+        ref = O.make_simulator(const.astype(dtype), mask, dye.astype(dtype) if with_dye else None, scheme=scheme, dt=dt, dx=dx, re=re,
+                               vor_eps=vc, updater=updater, dtype=dtype)
+        amp = float(rng.choice([1e-3, 1.0, 20.0]))          # 20: the velocity limiter engages
+        desc += f" amp={amp:g} march={os.environ.get('FS_MARCH', '1')}"
+        v0 = (rng.uniform(-1, 1, (X, Y, 2)) * amp).astype(dtype)
+        p0 = rng.uniform(-1, 1, (X, Y)).astype(dtype)
+        solver.v.current.from_numpy(v0); ref.v.current[...] = v0
+        solver.p.current.from_numpy(p0); ref.p.current[...] = p0
+        for step in range(3):
+            solver.update()
+            ref.update()
+            for a, e, name in zip([f.to_numpy() for f in solver.get_fields()], list(ref.fields().values()), ("v", "p", "dye")):
+                if not np.array_equal(a, e, equal_nan=True):
+                    bad = np.argwhere(~((a == e) | (np.isnan(a) & np.isnan(e))))
+                    msg = f"MISMATCH {desc} step {step + 1} field {name}: {len(bad)} cells, first {bad[0].tolist()}"
+                    if debug:
+                        msg += (f"\n   i range {bad[:, 0].min()}..{bad[:, 0].max()}  j range {bad[:, 1].min()}..{bad[:, 1].max()}"
+                                f"  nan(gpu) {int(np.isnan(a).sum())} nan(ref) {int(np.isnan(e).sum())}  max|d| {np.nanmax(np.abs(a - e)):.3e}"
+                                f"  mask classes at bad cells {np.bincount(mask[bad[:, 0], bad[:, 1]], minlength=4).tolist()}")
+                    return msg
+        return None
+    finally:
+        bc.device.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-cells", type=int, default=120000)
+    ap.add_argument("--only", type=int, nargs="*", help="run just these seeds, with diagnostics, fast paths on and off")
+    a = ap.parse_args()
+    if a.only:
+        for sd in a.only:
+            for march in ("1", "0"):
+                os.environ["FS_MARCH"] = march
+                print(one_case(sd, a.max_cells, debug=True) or f"ok seed {sd} march={march}", flush=True)
+        return
+    O.set_threads(8)
+    t0, bad, nmis = time.time(), 0, 0
+    hip = None
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        pass
+    for k in range(a.cases):
+        if hip is not None and k % 1000 == 0:
+            fr, tot = ctypes.c_size_t(), ctypes.c_size_t()
+            hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot))
+            import resource
+            print(f"[case {k}] GPU memory free {fr.value / 2**30:.2f} of {tot.value / 2**30:.2f} GiB, host RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20:.2f} GiB, "
+                  f"open fds {len(os.listdir('/proc/self/fd'))}", flush=True)
+        try:
+            r = one_case(a.seed + k, a.max_cells)
+        except Exception as exc:     # noqa: BLE001 - report and continue
+            r = f"ERROR seed {a.seed + k}: {type(exc).__name__}: {exc}"
+        if r:
+            bad += 1
+            print(f"[case {k}] " + r, flush=True)
+            nmis += r.startswith("MISMATCH")
+            if nmis <= 5 and r.startswith("MISMATCH"):      # does it reproduce right away?  with the fast paths off?
+                again = one_case(a.seed + k, a.max_cells, debug=True)
+                print("    again      :", (again or "ok").replace("\n", " | "), flush=True)
+                os.environ["FS_MARCH"] = "0"
+                lit = one_case(a.seed + k, a.max_cells, debug=True)
+                os.environ.pop("FS_MARCH")
+                print("    FS_MARCH=0 :", (lit or "ok").replace("\n", " | "), flush=True)
+    print(f"{a.cases} cases from seed {a.seed}: {bad} failing, {time.time() - t0:.0f} s", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
