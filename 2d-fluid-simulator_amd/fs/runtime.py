@@ -218,6 +218,12 @@ class DeviceBase:
     def _p_exchange_mark(self):
         pass
 
+    def _p_max_over_ranks(self, values):
+        """Element-wise maximum of a short list of non-negative numbers over all ranks (collective)."""
+        if self.nranks == 1:
+            return list(values)
+        raise NotImplementedError("this backend needs _p_max_over_ranks for slab runs")
+
     def _run(self, name, args, reads=(), writes=(), pointwise=False, full_writes=(), split=True):
         """Launch one kernel on this slab.
 
@@ -295,7 +301,10 @@ class DeviceBase:
             if bc_dye.shape != shape + (3,):
                 raise ValueError("bc_dye must be (X, Y, 3)")
         rv, rp = self._p_upload_scene(bc_mask, bc_const, bc_dye)
-        self.bc_radius_v, self.bc_radius_p = max(2, rv), max(1, rp)
+        # every slab analysed its own rows of the mask: the reach of chained thin walls differs from slab to slab, but the
+        # ranks must run the SAME validity bookkeeping (same exchanges, same message sizes) -> one global pair of radii
+        rv, rp = self._p_max_over_ranks([rv, rp])
+        self.bc_radius_v, self.bc_radius_p = max(2, int(rv)), max(1, int(rp))
         if self.nranks > 1 and max(self.bc_radius_v, self.bc_radius_p) > self.halo:
             raise RuntimeError(
                 f"the boundary kernels reach {max(self.bc_radius_v, self.bc_radius_p)} rows on this mask (chained thin "
@@ -485,6 +494,11 @@ class Device(DeviceBase):
 
     def _p_exchange_mark(self):
         _lib.call("fs_halo_exchange_mark", self._ctx)
+
+    def _p_max_over_ranks(self, values):
+        if self.nranks == 1:
+            return list(values)
+        return [max(self.allgather_scalars(v)) for v in values]
 
     def _p_residual(self, dt, dx, ph, vh):
         s, n = ctypes.c_double(), ctypes.c_double()

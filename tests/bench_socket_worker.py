@@ -98,6 +98,18 @@ class SocketSlabDevice(runtime.Device):
     def _p_exchange_mark(self):
         pass
 
+    def _p_max_over_ranks(self, values):
+        vals = np.asarray(values, dtype=np.float64)
+        if self.rank == 0:
+            for j in range(1, self.nranks):
+                vals = np.maximum(vals, CONNS[j].recv())
+            for j in range(1, self.nranks):
+                CONNS[j].send(vals)
+        else:
+            CONNS[0].send(vals)
+            vals = CONNS[0].recv()
+        return vals.tolist()
+
     def _p_allreduce(self, values):
         self.sync()
         vals = np.asarray(values, dtype=np.float64)

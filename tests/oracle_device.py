@@ -85,6 +85,13 @@ class OracleSlabDevice(DeviceBase):
         for h, nchan, v in handles:
             self._p_exchange(h, nchan, depth, v)
 
+    def _p_max_over_ranks(self, values):
+        if self.nranks == 1:
+            return list(values)
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
     # ---- kernels: same argument order as the C-ABI (include/fs_hip.h) --------------------------------
     def _p_kernel(self, name, *args):
         *args, lo, hi = args

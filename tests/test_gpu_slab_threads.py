@@ -61,6 +61,13 @@ def _make_device_cls(world, shared):
         def _p_exchange_mark(self):
             pass
 
+        def _p_max_over_ranks(self, values):
+            shared["radii"][self.rank] = list(values)
+            shared["barrier"].wait()
+            out = [max(col) for col in zip(*shared["radii"])]
+            shared["barrier"].wait()
+            return out
+
     return ThreadSlabDevice
 
 
@@ -108,7 +115,7 @@ CASES = [
 
 
 def _run_slabs(g, cfg, world, halo):
-    shared = {"barrier": threading.Barrier(world), "box": [None] * world}
+    shared = {"barrier": threading.Barrier(world), "box": [None] * world, "radii": [None] * world}
     Dev = _make_device_cls(world, shared)
     results, errors = [None] * world, []
     threads = []

@@ -35,6 +35,9 @@ class LoopbackSlab(Device):
         ctypes.CDLL(None).fflush(None); os.dup2(saved, 1); os.close(saved)
         _lib.call("fs_comm_loopback", ctx, 1)
 
+    def _p_max_over_ranks(self, values):
+        return list(values)
+
     def _p_exchange_many(self, handles, depth):
         if self.mode != "none":
             super()._p_exchange_many(handles, depth)
