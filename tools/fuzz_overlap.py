@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Race hunting on the real RCCL path (one GPU, loop-back communicator): random slab shapes / masks / schemes, blocking exchanges
+vs exchanges hidden behind the interior rows (communication stream + events, packed and partial-depth messages) - bit for bit.
+    python tools/fuzz_overlap.py [--cases 60] [--seed 0]"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+importlib.import_module("2d-fluid-simulator_amd")
+import fs  # noqa: E402
+from fs.boundary_condition import BoundaryCondition  # noqa: E402
+import fuzz_parity  # noqa: E402
+import test_gpu_rccl_overlap as T  # noqa: E402
+
+
+def run(const, mask, halo, overlap, scheme, updater, vc, res, steps):
+    dev = T._device_cls()(mask.shape[0], mask.shape[1], halo, overlap)
+    dt, dx = 0.05 / res, 1.0 / res
+    bc = BoundaryCondition(const, mask, device=dev)
+    vcobj = fs.VorticityConfinement(bc, dt, dx, vc) if vc else None
+    pu = fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2) if updater == "rbsor" else fs.JacobiPressureUpdater(bc, dt, dx, 9)
+    if scheme == "cip":
+        solver = fs.CipMacSolver(bc, pu, dt, dx, 1e6, vcobj)
+    else:
+        solver = fs.MacSolver(bc, pu, fs.advect_kk_scheme if scheme == "kk" else fs.advect_upwind, dt, dx, 1e6, vcobj)
+    rng = np.random.default_rng(1)
+    solver.v.current.from_numpy(rng.uniform(-1, 1, mask.shape + (2,)).astype(np.float32))
+    for _ in range(steps):
+        solver.update()
+    out = {n: getattr(solver, n).current.local_window() for n in ("v", "p", "vx", "vy") if hasattr(solver, n)}
+    st = (dev.n_exchanges, dev.n_overlapped)
+    dev.close()
+    return out, st
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    halo = int(rng.choice([2, 4, 8, 16]))
+    nyl = 2 * halo + 8 + int(rng.integers(0, 200))
+    Y = 3 * nyl                                            # the tracker believes in three slabs, this is the middle one
+    X = int(rng.choice([4 * rng.integers(2, 600), rng.integers(9, 900)]))
+    const, mask, _ = fuzz_parity.random_scene(rng, X, Y)
+    scheme = str(rng.choice(["cip", "cip", "kk", "upwind"]))
+    updater = str(rng.choice(["rbsor", "jacobi"]))
+    vc = float(rng.choice([0.0, 5.0]))
+    res = float(rng.choice([64, 256, 300]))
+    steps = int(rng.integers(2, 8))
+    os.environ["FS_PACK_HALO"] = "1" if rng.random() < 0.8 else "0"
+    os.environ["FS_PARTIAL_HALO"] = "1" if rng.random() < 0.8 else "0"
+    desc = f"seed {seed}: {X}x{Y} (slab {nyl} rows) halo={halo} {scheme} {updater} vc={vc} steps={steps} pack={os.environ['FS_PACK_HALO']} partial={os.environ['FS_PARTIAL_HALO']}"
+    try:
+        a, (na, oa) = run(const, mask, halo, False, scheme, updater, vc, res, steps)
+        b, (nb, ob) = run(const, mask, halo, True, scheme, updater, vc, res, steps)
+    except RuntimeError as exc:
+        if "ghost rows" in str(exc):
+            return None
+        raise
+    if na != nb or oa != 0 or (na > 0 and ob == 0):
+        return f"BOOKKEEPING {desc}: exchanges {na}/{nb}, overlapped {oa}/{ob}"
+    for k in a:
+        if not np.array_equal(a[k], b[k], equal_nan=True):
+            return f"MISMATCH {desc} field {k}"
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    t0, bad = time.time(), 0
+    for k in range(a.cases):
+        try:
+            r = one_case(a.seed + k)
+        except Exception as exc:     # noqa: BLE001
+            r = f"ERROR seed {a.seed + k}: {type(exc).__name__}: {str(exc)[:300]}"
+        if r:
+            bad += 1
+            print(r, flush=True)
+    print(f"{a.cases} overlap cases from seed {a.seed}: {bad} failing, {time.time() - t0:.0f} s", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -52,7 +52,9 @@ def random_scene(rng, X, Y):
 
 def one_case(seed, max_cells, debug=False):
     rng = np.random.default_rng(seed)
-    X = int(rng.choice([rng.integers(4, 40), rng.integers(40, 300), rng.integers(300, 1300), 4 * rng.integers(1, 320)]))
+    X = int(rng.choice([rng.integers(4, 40), rng.integers(40, 300), rng.integers(300, 1300), 4 * rng.integers(1, 320),
+                        4 * rng.integers(320, 2400), rng.integers(1300, 9000)] if max_cells >= 100000 else
+                       [rng.integers(4, 40), rng.integers(40, 300), rng.integers(300, 1300), 4 * rng.integers(1, 320)]))
     Y = int(rng.integers(4, max(5, min(300, max_cells // X))))
     const, mask, dye = random_scene(rng, X, Y)
     f64 = rng.random() < 0.25
@@ -87,6 +89,17 @@ def one_case(seed, max_cells, debug=False):
         p0 = rng.uniform(-1, 1, (X, Y)).astype(dtype)
         solver.v.current.from_numpy(v0); ref.v.current[...] = v0
         solver.p.current.from_numpy(p0); ref.p.current[...] = p0
+        if os.environ["FS_FUSE_TRANSPORT"] == "0" and os.environ["FS_FUSE_NONADV"] == "0" and rng.random() < 0.15:
+            # hipGraph mode (what bench.py times): a captured pair of steps replayed twice = 4 steps, compared at the end
+            dev = bc.device
+            gid = dev.capture(lambda: (solver.update(), solver.update()))
+            dev.replay(gid, 2)
+            for _ in range(4):
+                ref.update()
+            for a, e, name in zip([f.to_numpy() for f in solver.get_fields()], list(ref.fields().values()), ("v", "p", "dye")):
+                if not np.array_equal(a, e, equal_nan=True):
+                    return f"MISMATCH {desc} hipGraph replay, field {name}"
+            return None
         for step in range(3):
             solver.update()
             ref.update()
