@@ -179,7 +179,7 @@ static void free_ops(BcOpsDev &o)
 }
 
 // Group the serial-order op list into hazard components and upload it in local cell offsets.
-static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, int &reach)
+static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, int &reach, int min_radius)
 {
     free_ops(out);
     const int n = (int)ops.size();
@@ -246,20 +246,48 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
                 dep[op.t] = {tr, tr};   // constant assignment (inflow value, p = 0)
             }
         }
-        const bool inside = clo >= 0 && chi < c->rows;
-        if (inside) {
+        // A slab can evaluate an assignment when its target and its sources lie in its local rows and no source is a cell that an
+        // earlier, non-evaluable assignment of the chain should have rewritten.  A hazard component that leaves the local rows (thin
+        // walls: the mirror of a one-cell wall overwrites a FLUID cell that a later mirror reads) is therefore pruned to its evaluable
+        // prefix relations instead of being dropped as a whole - dropping it left ghost rows un-updated that the validity tracker
+        // (fs/runtime.py) counts as correct to depth halo - radius.  Cells that end up with an unknowable value ("bad") must lie
+        // deeper than that, otherwise this decomposition is refused.
+        (void)clo; (void)chi;
+        std::unordered_map<long long, bool> bad;
+        std::vector<int> kept;
+        for (int q = pos; q < end; ++q) {
+            const HostOp &op = ops[order[q]];
+            const int tr = local_row(op.t);
+            bool ok = tr >= 0 && tr < c->rows;
+            const long long srcs[2] = {op.s1, op.s2};
+            for (long long s : srcs) if (s >= 0) {
+                const int sr = local_row(s);
+                auto b = bad.find(s);
+                if (sr < 0 || sr >= c->rows || (b != bad.end() && b->second)) ok = false;
+            }
+            if (ok) { kept.push_back(order[q]); bad[op.t] = false; }
+            else bad[op.t] = true;
+        }
+        for (const auto &b : bad) {
+            if (!b.second) continue;
+            const int r = local_row(b.first);
+            if (r < 0 || r >= c->rows) continue;
+            const int depth = r < c->halo ? c->halo - r : (r >= c->halo + c->nyl ? r - (c->halo + c->nyl) + 1 : 0);
+            if (depth <= c->halo - min_radius) c->bc_incomplete = true;   // an owned row, or a ghost row the tracker may rely on
+        }
+        if (!kept.empty()) {
+            int klo = INT32_MAX, khi = INT32_MIN;
+            for (int o : kept) { const int tr = local_row(ops[o].t); klo = std::min(klo, tr); khi = std::max(khi, tr); }
             h_begin.push_back((int)h_kind.size());
-            h_rlo.push_back(tlo);
-            h_rhi.push_back(thi);
-            for (int q = pos; q < end; ++q) {
-                const HostOp &op = ops[order[q]];
+            h_rlo.push_back(klo);
+            h_rhi.push_back(khi);
+            for (int o : kept) {
+                const HostOp &op = ops[o];
                 h_kind.push_back(op.kind);
                 h_tgt.push_back(local_off(op.t));
                 h_s1.push_back(op.s1 >= 0 ? local_off(op.s1) : -1);
                 h_s2.push_back(op.s2 >= 0 ? local_off(op.s2) : -1);
             }
-        } else if (thi >= c->halo && tlo < c->halo + c->nyl) {
-            c->bc_incomplete = true;  // a hazard chain reaches past this slab's ghost rows
         }
         pos = end;
     }
@@ -332,9 +360,10 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
     c->bc_incomplete = false;
     c->bc_radius_vel = c->bc_radius_prs = 0;
     int rc, dummy = 0;
-    if ((rc = upload_ops(c, vel, c->ops_vel, c->bc_radius_vel))) return rc;
-    if ((rc = upload_ops(c, prs, c->ops_prs, c->bc_radius_prs))) return rc;
-    if ((rc = upload_ops(c, dye, c->ops_dye, dummy))) return rc;
+    // min_radius: the least radius the host tracker charges for the kernel (fs/runtime.py: max(2, .) / max(1, .) / 0)
+    if ((rc = upload_ops(c, vel, c->ops_vel, c->bc_radius_vel, 2))) return rc;
+    if ((rc = upload_ops(c, prs, c->ops_prs, c->bc_radius_prs, 1))) return rc;
+    if ((rc = upload_ops(c, dye, c->ops_dye, dummy, 0))) return rc;
     return FS_OK;
 }
 
@@ -504,6 +533,9 @@ int fs_bc_radius(const fs_ctx *ctx, int *velocity_rows, int *pressure_rows)
     FS_REQUIRE(ctx && velocity_rows && pressure_rows, "null argument");
     *velocity_rows = ctx->bc_radius_vel;
     *pressure_rows = ctx->bc_radius_prs;
+    // a hazard chain that leaves this slab's ghost rows cannot be evaluated here at all: report "deeper than the halo", so that the
+    // callers' collective maximum makes EVERY rank refuse the decomposition (not just this one, with the others waiting in RCCL)
+    if (ctx->bc_incomplete) *velocity_rows = std::max(*velocity_rows, ctx->halo + 1);
     return FS_OK;
 }
 

@@ -39,6 +39,11 @@ def one_case(seed):
     os.environ["FS_OVERLAP"] = "1" if rng.random() < 0.7 else "0"
     os.environ["FS_PARTIAL_HALO"] = "1" if rng.random() < 0.8 else "0"
     steps = int(rng.integers(2, 7))
+    for k in ("FS_FUSE_TRANSPORT", "FS_OVERLAP", "FS_PARTIAL_HALO"):          # FORCE_<knob>=0/1 overrides the drawn value (diagnosis)
+        if os.environ.get("FORCE_" + k):
+            os.environ[k] = os.environ["FORCE_" + k]
+    if os.environ.get("FORCE_HALO"):
+        halo = int(os.environ["FORCE_HALO"])
     cfg = dict(bc=0, res=res, dt=0.05 / res, dx=1.0 / res, re=float(rng.choice([100.0, 1e6])), vor_eps=vc, scheme=scheme, updater=updater,
                dye=with_dye, fp64=f64, snaps=[steps])
     desc = (f"seed {seed}: {X}x{Y} world={world} halo={halo} {np.dtype(dtype).name} {scheme} vc={vc} {updater} dye={with_dye} steps={steps} "
@@ -67,8 +72,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", type=int, nargs="*")
     a = ap.parse_args()
     O.set_threads(8)
+    if a.only:
+        for sd in a.only:
+            print(one_case(sd) or f"ok seed {sd}", flush=True)
+        return
     t0, bad = time.time(), 0
     for k in range(a.cases):
         try:
