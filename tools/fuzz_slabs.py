@@ -24,7 +24,7 @@ def one_case(seed):
     rng = np.random.default_rng(seed)
     world = int(rng.integers(2, 6))
     halo = int(rng.choice([2, 3, 4, 6, 8, 16]))
-    nyl_min = max(halo, 4) + int(rng.integers(0, 40))
+    nyl_min = max(halo, 4) + int(rng.integers(0, 40 if rng.random() < 0.7 else 160))
     Y = world * nyl_min + int(rng.integers(0, world))
     X = int(rng.choice([rng.integers(4, 80), 4 * rng.integers(1, 150), rng.integers(80, 700)]))
     const, mask, dye = fuzz_parity.random_scene(rng, X, Y)
