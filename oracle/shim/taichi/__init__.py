@@ -20,7 +20,9 @@ executed here under this module, which gives the DSL a deterministic serial mean
 Only the API subset the reference uses is provided.
 """
 import builtins
+import ast
 import inspect
+import textwrap
 import itertools
 
 import numpy as np
@@ -201,12 +203,61 @@ def _cast_args(fn):
     return wrapper
 
 
+def _ipow(a, n):
+    """Taichi lowers `x ** <integer literal>` to multiplications (demote_operations: exponentiation by squaring), so a run-time
+    f32 value squared is x * x rounded once - NOT libm's powf(x, 2), which numpy uses for scalar ** and which is not correctly
+    rounded (a 1-ulp difference roughly once per 10^5 values; found by tests/golden/fuzz_oracle_vs_reference.py).  Python floats are
+    compile-time constants that Taichi folds in double precision: they keep Python's own power."""
+    if isinstance(a, (float, int)) and not isinstance(a, np.generic):
+        return a ** n
+    result, base = None, a
+    while n:
+        if n & 1:
+            result = base if result is None else result * base
+        n >>= 1
+        if n:
+            base = base * base
+    return result
+
+
+class _DemoteIntPow(ast.NodeTransformer):
+    def visit_BinOp(self, node):
+        self.generic_visit(node)
+        if (isinstance(node.op, ast.Pow) and isinstance(node.right, ast.Constant) and type(node.right.value) is int
+                and 1 <= node.right.value <= 16):
+            return ast.copy_location(ast.Call(func=ast.Name(id="__ti_ipow", ctx=ast.Load()), args=[node.left, node.right], keywords=[]), node)
+        return node
+
+
+def _demote_int_pow(fn):
+    """Recompile fn with every `expr ** <int literal>` replaced by __ti_ipow(expr, n)."""
+    if fn.__closure__:
+        return fn
+    try:
+        tree = ast.parse(textwrap.dedent(inspect.getsource(fn)))
+    except (OSError, TypeError, SyntaxError):
+        return fn
+    fdef = tree.body[0]
+    if not isinstance(fdef, ast.FunctionDef) or "**" not in ast.unparse(fdef):
+        return fn
+    fdef.decorator_list = []
+    tree = ast.fix_missing_locations(_DemoteIntPow().visit(tree))
+    ns = {}
+    glb = fn.__globals__
+    glb.setdefault("__ti_ipow", _ipow)
+    exec(compile(tree, inspect.getsourcefile(fn) or "<shim>", "exec"), glb, ns)
+    new = ns[fdef.name]
+    new.__defaults__, new.__kwdefaults__ = fn.__defaults__, fn.__kwdefaults__
+    new.__qualname__, new.__module__, new.__doc__ = fn.__qualname__, fn.__module__, fn.__doc__
+    return new
+
+
 def func(fn):
-    return _cast_args(fn)
+    return _cast_args(_demote_int_pow(fn))
 
 
 def kernel(fn):
-    return _cast_args(fn)
+    return _cast_args(_demote_int_pow(fn))
 
 
 def data_oriented(cls):

@@ -14,9 +14,13 @@ def traj_config(g):
 def make_oracle(g, cfg=None):
     from oracle import oracle as O
     cfg = cfg or traj_config(g)
-    return O.make_simulator(g["bc_const"], g["bc_mask"], g["bc_dye"] if cfg["dye"] else None, scheme=cfg["scheme"],
-                            dt=cfg["dt"], dx=cfg["dx"], re=cfg["re"], vor_eps=cfg["vor_eps"], updater=cfg["updater"],
-                            dtype=np.float64 if cfg["fp64"] else np.float32)
+    sim = O.make_simulator(g["bc_const"], g["bc_mask"], g["bc_dye"] if cfg["dye"] else None, scheme=cfg["scheme"],
+                           dt=cfg["dt"], dx=cfg["dx"], re=cfg["re"], vor_eps=cfg["vor_eps"], updater=cfg["updater"],
+                           dtype=np.float64 if cfg["fp64"] else np.float32)
+    if "init.v" in g:        # fuzz trajectories (tests/golden/fuzz_oracle_vs_reference.py) start from a random state
+        sim.v.current[...] = g["init.v"]
+        sim.p.current[...] = g["init.p"]
+    return sim
 
 
 def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=True, fused_transport=None, fused_nonadv=None, fused_clamp=None):
@@ -40,6 +44,9 @@ def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=T
     else:
         adv = fs.advect_upwind if cfg["scheme"] == "upwind" else fs.advect_kk_scheme
         solver = (fs.DyeMacSolver if cfg["dye"] else fs.MacSolver)(bc, pu, adv, dt, dx, re, vc)
+    if "init.v" in g:
+        solver.v.current.from_numpy(g["init.v"])
+        solver.p.current.from_numpy(g["init.p"])
     return (fs.DyeFluidSimulator if cfg["dye"] else fs.FluidSimulator)(solver)
 
 
