@@ -29,9 +29,19 @@ static hipEvent_t prof_event(fs_ctx *c)
     return e;
 }
 
+// Every kernel launch of the library goes through here.  The callable captures its arguments BY VALUE: while a tape is being
+// recorded (fs_tape_begin) a copy is kept and re-issued by fs_tape_replay without going back through the caller.
 template <typename F>
 static int launch(fs_ctx *c, const char *name, F &&f)
 {
+    if (c->tape_rec) {
+        c->tape_rec->ops.emplace_back([f]() -> int {
+            f();
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? FS_OK : hip_fail(e, "tape replay", __FILE__, __LINE__);
+        });
+        if (!c->tape_execute) return FS_OK;
+    }
     const bool prof = c->prof_on && !c->capturing;
     ProfRec rec{};
     if (prof) {
@@ -103,13 +113,13 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
     if (v == 30) {
         constexpr int TY = 16;
         const dim3 grid((ctx->X + 255) / 256, (je - jb + TY - 1) / TY, 1);
-        return launch(ctx, name, [&] {
+        return launch(ctx, name, [=] {
             hipLaunchKernelGGL((k_jacobi_lds<SRC, TY, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
         });
     }
     const int rt = v == 24 ? 4 : (v == 21 ? 1 : 2);
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
-    return launch(ctx, name, [&] {
+    return launch(ctx, name, [=] {
         if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
         else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
         else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
@@ -423,6 +433,8 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     fs_comm_destroy(ctx);
     for (auto g : ctx->graphs) if (g) hipGraphExecDestroy(g);
+    for (auto t : ctx->tapes) delete t;
+    delete ctx->tape_rec;
     for (auto &r : ctx->prof_recs) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
     for (auto e : ctx->prof_pool) hipEventDestroy(e);
     free_ops(ctx->ops_vel); free_ops(ctx->ops_prs); free_ops(ctx->ops_dye);
@@ -575,7 +587,7 @@ int fs_field_fill(fs_field *f, double value)
     fs_ctx *ctx = f->ctx;
     const size_t n = f->bytes / ctx->esize;
     FS_DISPATCH(ctx, {
-        return launch(ctx, "fill", [&] { hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value); });
+        return launch(ctx, "fill", [=] { hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value); });
     })
 }
 
@@ -642,7 +654,7 @@ int fs_velocity_bc(fs_ctx *ctx, fs_field *v, int row_begin, int row_end)
     int rc = bc_guard(ctx); if (rc) return rc;
     if (ctx->ops_vel.ncomp == 0) return FS_OK;
     FS_DISPATCH(ctx, {
-        return launch(ctx, "velocity_bc", [&] {
+        return launch(ctx, "velocity_bc", [=] {
             hipLaunchKernelGGL(k_velocity_bc<T>, dim3((ctx->ops_vel.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, (T *)v->d, (const T *)ctx->d_bc_const);
         });
@@ -657,7 +669,7 @@ int fs_pressure_bc(fs_ctx *ctx, fs_field *p, int row_begin, int row_end)
     int rc = bc_guard(ctx); if (rc) return rc;
     if (ctx->ops_prs.ncomp == 0) return FS_OK;
     FS_DISPATCH(ctx, {
-        return launch(ctx, "pressure_bc", [&] {
+        return launch(ctx, "pressure_bc", [=] {
             hipLaunchKernelGGL(k_pressure_bc<T>, dim3((ctx->ops_prs.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_prs.view(), row_begin, row_end, (T *)p->d);
         });
@@ -672,7 +684,7 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
     if (!ctx->d_bc_dye) { set_error("bc_dye not uploaded"); return FS_ERR_STATE; }
     if (ctx->ops_dye.ncomp == 0) return FS_OK;
     FS_DISPATCH(ctx, {
-        return launch(ctx, "dye_bc", [&] {
+        return launch(ctx, "dye_bc", [=] {
             hipLaunchKernelGGL(k_dye_bc<T>, dim3((ctx->ops_dye.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T *)dye->d, (const T *)ctx->d_bc_dye);
         });
@@ -681,7 +693,7 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
 
 // ---- transport -----------------------------------------------------------------------------------------
 #define FS_LAUNCH_CELLS(name, kern, ...)                                                                   \
-    return launch(ctx, name, [&] {                                                                         \
+    return launch(ctx, name, [=] {                                                                         \
         hipLaunchKernelGGL(kern, cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, __VA_ARGS__); \
     });
 
@@ -699,7 +711,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
         auto k = make_konst<T>(dt, dx, re);
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
-            return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [&] {
+            return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
                 if (scheme == FS_UPWIND) { if (k.p2) FS_K2M(0, true); else FS_K2M(0, false); }
                 else { if (k.p2) FS_K2M(1, true); else FS_K2M(1, false); }
             });
@@ -749,7 +761,7 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
         auto k = make_konst<T>(dt, dx, re);
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
-            return launch(ctx, "cip_nonadv", [&] {
+            return launch(ctx, "cip_nonadv", [=] {
                 if (k.p2) hipLaunchKernelGGL((k_cip_nonadv_quad<true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d);
                 else hipLaunchKernelGGL((k_cip_nonadv_quad<false, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d);
             });
@@ -769,7 +781,7 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
         auto k = make_konst<T>(dt, dx, re);
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
-            return launch(ctx, "cip_nonadv_dye", [&] {
+            return launch(ctx, "cip_nonadv_dye", [=] {
                 if (k.p2) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d);
                 else hipLaunchKernelGGL((k_cip_nonadv_dye_quad<false, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d);
             });
@@ -793,7 +805,7 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
         auto k = make_konst<T>(1.0, dx, 1.0);
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, C == 2 ? 1 : 3, XCD_GRAD);
-            return launch(ctx, C == 2 ? "cip_nonadv_grad" : "cip_nonadv_grad_c3", [&] {
+            return launch(ctx, C == 2 ? "cip_nonadv_grad" : "cip_nonadv_grad_c3", [=] {
                 if (C == 2) { if (k.p2) FS_K3Q(2, 2, true); else FS_K3Q(2, 2, false); }
                 else { if (k.p2) FS_K3Q(3, 1, true); else FS_K3Q(3, 1, false); }
             });
@@ -825,7 +837,7 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
         const bool self = (v == fc);
         const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, (C == 2 && !self) ? 2 : 1, XCD_ADVECT);   // C == 3: one pass over the channels
         const dim3 qgrid = og.grid;
-        return launch(ctx, C == 2 ? "cip_advect" : "cip_advect_c3", [&] {
+        return launch(ctx, C == 2 ? "cip_advect" : "cip_advect_c3", [=] {
             if (ctx->use_march) {
                 if (C == 2 && self) { if (k.p2) FS_K4Q(2, 2, true, true); else FS_K4Q(2, 2, true, false); }
                 else if (C == 2) { if (k.p2) FS_K4Q(2, 1, false, true); else FS_K4Q(2, 1, false, false); }
@@ -851,7 +863,7 @@ int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, f
     const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_ADVECT);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0);
-        return launch(ctx, "cip_advect_c3_clamped", [&] {
+        return launch(ctx, "cip_advect_c3_clamped", [=] {
             if (k.p2) hipLaunchKernelGGL((k_cip_advect_dye<true, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
                                          (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d);
             else hipLaunchKernelGGL((k_cip_advect_dye<false, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
@@ -868,7 +880,7 @@ int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row
     if (!ctx->d_bc_dye) { set_error("bc_dye not uploaded"); return FS_ERR_STATE; }
     if (ctx->ops_dye.ncomp == 0) return FS_OK;
     FS_DISPATCH(ctx, {
-        return launch(ctx, "clamp_inflow", [&] {
+        return launch(ctx, "clamp_inflow", [=] {
             hipLaunchKernelGGL(k_clamp_inflow<T>, dim3((ctx->ops_dye.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T)low, (T)high, (T *)dye->d);
         });
@@ -892,7 +904,7 @@ int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *
         auto run = [&](int jb, int je, bool edge) -> int {
             if (jb >= je) return FS_OK;
             const OvGrid og = ov_grid(ctx, jb, je, 1, 2, XCD_NONADV);
-            return launch(ctx, edge ? "cip_nonadv_fused_edge" : "cip_nonadv_fused", [&] {
+            return launch(ctx, edge ? "cip_nonadv_fused_edge" : "cip_nonadv_fused", [=] {
                 if (k.p2) { if (edge) FS_K23(true, true); else FS_K23(true, false); }
                 else { if (edge) FS_K23(false, true); else FS_K23(false, false); }
             });
@@ -920,7 +932,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
         auto run = [&](int jb, int je, bool edge) -> int {
             if (jb >= je) return FS_OK;
             const OvGrid og = ov_grid(ctx, jb, je, 1, 2, XCD_ADVECT);
-            return launch(ctx, edge ? "cip_grad_advect_edge" : "cip_grad_advect", [&] {
+            return launch(ctx, edge ? "cip_grad_advect_edge" : "cip_grad_advect", [=] {
                 if (k.p2) { if (edge) FS_K34(true, true); else FS_K34(true, false); }
                 else { if (edge) FS_K34(false, true); else FS_K34(false, false); }
             });
@@ -978,7 +990,7 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
         auto k = make_konst<T>(dt, dx, 1.0, weight);
         const bool p2 = k.p2 != 0;
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
-        return launch(ctx, "vort_confine", [&] {
+        return launch(ctx, "vort_confine", [=] {
             if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
             else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
             else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
@@ -1025,7 +1037,7 @@ int fs_rbsor_halfsweep(fs_ctx *ctx, double dt, double dx, double omega, int pari
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0, 0.0, omega);
-        return launch(ctx, parity ? "rbsor_odd" : "rbsor_even", [&] {
+        return launch(ctx, parity ? "rbsor_odd" : "rbsor_even", [=] {
             hipLaunchKernelGGL((k_rbsor<false, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
                                row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
         });
@@ -1048,7 +1060,7 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
     const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 1, XCD_RBSOR);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0, 0.0, omega);
-        return launch(ctx, "rbsor_iteration", [&] {
+        return launch(ctx, "rbsor_iteration", [=] {
             hipLaunchKernelGGL((k_rbsor_fused<RT, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
                                (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
         });
@@ -1064,7 +1076,7 @@ int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, 
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(1.0, 1.0, 1.0, 0.0, omega);
-        return launch(ctx, parity ? "rbsor_odd_src" : "rbsor_even_src", [&] {
+        return launch(ctx, parity ? "rbsor_odd_src" : "rbsor_even_src", [=] {
             hipLaunchKernelGGL((k_rbsor<true, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
                                row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
         });
@@ -1087,7 +1099,7 @@ int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, co
 {
     FS_REQUIRE(ctx && sum_sq && count, "null argument");
     FS_FIELD(p, 1); FS_FIELD(vc, 2);
-    FS_REQUIRE(!ctx->capturing, "residual during graph capture");
+    FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "residual during graph capture / tape recording");
     if (!ctx->mask_set) { set_error("mask not uploaded"); return FS_ERR_STATE; }
     const int row_begin = ctx->halo, row_end = ctx->halo + ctx->nyl;
     const dim3 grid((ctx->X + 255) / 256, (row_end - row_begin + RES_ROWS - 1) / RES_ROWS);
@@ -1100,7 +1112,7 @@ int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, co
     int rc;
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(dt, dx, 1.0);
-        rc = launch(ctx, "poisson_residual", [&] {
+        rc = launch(ctx, "poisson_residual", [=] {
             hipLaunchKernelGGL((k_residual<T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end,
                                (const T *)p->d, (const T *)vc->d, ctx->d_partial);
             hipLaunchKernelGGL((k_residual_final<double>), dim3(1), dim3(1024), 0, ctx->stream, (const double *)ctx->d_partial, (int)nblocks, ctx->d_acc);
@@ -1123,7 +1135,7 @@ int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int ro
     FS_ROWS();
     FS_DISPATCH(ctx, {
         if (ctx->use_march)
-            return launch(ctx, "limit_field", [&] {
+            return launch(ctx, "limit_field", [=] {
                 hipLaunchKernelGGL((k_limit_quad<T>), dim3((ctx->X / 4 + 255) / 256, row_end - row_begin), dim3(256), 0, ctx->stream,
                                    ctx->grid(), row_begin, (T)limit, (T *)v->d);
             });
@@ -1142,6 +1154,56 @@ int fs_clamp_field(fs_ctx *ctx, double low, double high, fs_field *f, int row_be
         else if (C == 2) { FS_LAUNCH_CELLS("clamp_field_c2", (k_clamp<2, T>), ctx->grid(), row_begin, (T)low, (T)high, (T *)f->d) }
         else { FS_LAUNCH_CELLS("clamp_field", (k_clamp<3, T>), ctx->grid(), row_begin, (T)low, (T)high, (T *)f->d) }
     })
+}
+
+// ---- visualisation (GUI side of the reference; device kernels so that a frame costs one pass + one download) ------------
+static int visualize(fs_ctx *ctx, int mode, double dx, fs_field *rgb, const fs_field *a, const fs_field *b, int row_begin, int row_end)
+{
+    static const char *names[4] = {"vis_norm", "vis_pressure", "vis_vorticity", "vis_dye"};
+    FS_DISPATCH(ctx, {
+        auto k = make_konst<T>(1.0, dx, 1.0);
+        const T *pa = (const T *)a->d, *pb = b ? (const T *)b->d : nullptr;
+        return launch(ctx, names[mode], [=] {
+            const dim3 grid = cells_grid(ctx, row_begin, row_end);
+            if (mode == 0) hipLaunchKernelGGL((k_visualize<0, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
+            else if (mode == 1) hipLaunchKernelGGL((k_visualize<1, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
+            else if (mode == 2) hipLaunchKernelGGL((k_visualize<2, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
+            else hipLaunchKernelGGL((k_visualize<3, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
+        });
+    })
+}
+
+int fs_vis_norm(fs_ctx *ctx, fs_field *rgb, const fs_field *v, const fs_field *p, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(rgb, 3); FS_FIELD(v, 2); FS_FIELD(p, 1);
+    FS_ROWS();
+    return visualize(ctx, 0, 1.0, rgb, v, p, row_begin, row_end);
+}
+
+int fs_vis_pressure(fs_ctx *ctx, fs_field *rgb, const fs_field *p, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(rgb, 3); FS_FIELD(p, 1);
+    FS_ROWS();
+    return visualize(ctx, 1, 1.0, rgb, p, nullptr, row_begin, row_end);
+}
+
+int fs_vis_vorticity(fs_ctx *ctx, double dx, fs_field *rgb, const fs_field *v, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(rgb, 3); FS_FIELD(v, 2);
+    FS_ROWS();
+    return visualize(ctx, 2, dx, rgb, v, nullptr, row_begin, row_end);
+}
+
+int fs_vis_dye(fs_ctx *ctx, fs_field *rgb, const fs_field *dye, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(rgb, 3); FS_FIELD(dye, 3);
+    FS_REQUIRE(rgb != dye, "rgb must not alias dye");
+    FS_ROWS();
+    return visualize(ctx, 3, 1.0, rgb, dye, nullptr, row_begin, row_end);
 }
 
 // ---- hipGraph capture ---------------------------------------------------------------------------------------
@@ -1189,6 +1251,61 @@ int fs_graph_free(fs_ctx *ctx, int graph_id)
         FS_HIP(hipGraphExecDestroy(ctx->graphs[graph_id]));
         ctx->graphs[graph_id] = nullptr;
     }
+    return FS_OK;
+}
+
+// ---- command tapes: the N > 1 counterpart of the hipGraph replay -------------------------------------------------------------
+// A hipGraph cannot hold the RCCL ghost-row exchange of a slab run portably, so the launch sequence of a slab step (kernels on
+// the compute stream + mark / begin / wait of the exchanges) is recorded as a list of host closures instead and re-issued by
+// fs_tape_replay in a C++ loop: no Python, no ctypes marshalling and no validity bookkeeping between two launches (a 130 us
+// slab step is otherwise driven by ~25 Python calls of 10-20 us each).
+int fs_tape_begin(fs_ctx *ctx, int execute)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(!ctx->tape_rec && !ctx->capturing, "already recording / capturing");
+    int rc = prof_drain(ctx); if (rc) return rc;
+    ctx->tape_rec = new Tape();
+    ctx->tape_execute = execute != 0;
+    return FS_OK;
+}
+
+int fs_tape_end(fs_ctx *ctx, int *tape_id)
+{
+    FS_REQUIRE(ctx && tape_id, "null argument");
+    FS_REQUIRE(ctx->tape_rec, "not recording");
+    ctx->tapes.push_back(ctx->tape_rec);
+    ctx->tape_rec = nullptr;
+    ctx->tape_execute = true;
+    *tape_id = (int)ctx->tapes.size() - 1;
+    return FS_OK;
+}
+
+int fs_tape_length(fs_ctx *ctx, int tape_id, int *nops)
+{
+    FS_REQUIRE(ctx && nops, "null argument");
+    FS_REQUIRE(tape_id >= 0 && tape_id < (int)ctx->tapes.size() && ctx->tapes[tape_id], "bad tape id");
+    *nops = (int)ctx->tapes[tape_id]->ops.size();
+    return FS_OK;
+}
+
+int fs_tape_replay(fs_ctx *ctx, int tape_id, int times)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(tape_id >= 0 && tape_id < (int)ctx->tapes.size() && ctx->tapes[tape_id], "bad tape id");
+    FS_REQUIRE(!ctx->tape_rec && !ctx->capturing, "replay while recording / capturing");
+    FS_HIP(hipSetDevice(ctx->device));
+    const Tape *t = ctx->tapes[tape_id];
+    for (int n = 0; n < times; ++n)
+        for (const auto &op : t->ops) { int rc = op(); if (rc) return rc; }
+    return FS_OK;
+}
+
+int fs_tape_free(fs_ctx *ctx, int tape_id)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(tape_id >= 0 && tape_id < (int)ctx->tapes.size(), "bad tape id");
+    delete ctx->tapes[tape_id];
+    ctx->tapes[tape_id] = nullptr;
     return FS_OK;
 }
 

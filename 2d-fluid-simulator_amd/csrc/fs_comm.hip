@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "fs_host.h"
 
@@ -279,6 +280,20 @@ static int begin(fs_ctx *ctx, fs_field *const *fields, const int *valid, int nfi
     int rc = check_exchange_args(ctx, fields, valid, nfields, depth); if (rc) return rc;
     Comm *cm = ctx->comm;
     if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
+    if (ctx->tape_rec) {      // recorded like a kernel launch (fs_tape_*): the closure owns copies of the argument arrays
+        std::vector<fs_field *> fv(fields, fields + nfields);
+        std::vector<int> vv;
+        if (valid) vv.assign(valid, valid + nfields);
+        Tape *t = ctx->tape_rec;
+        ctx->tape_rec = nullptr;                       // the closure re-enters begin() at replay time with no tape open
+        t->ops.emplace_back([=]() -> int { return begin(ctx, fv.data(), vv.empty() ? nullptr : vv.data(), (int)fv.size(), depth, self); });
+        ctx->tape_rec = t;
+        if (!ctx->tape_execute) return FS_OK;
+        ctx->tape_rec = nullptr;
+        rc = begin(ctx, fields, valid, nfields, depth, self);
+        ctx->tape_rec = t;
+        return rc;
+    }
     FS_REQUIRE(!cm->in_flight, "fs_halo_exchange_begin while another exchange is in flight (call fs_halo_exchange_wait first)");
     FS_REQUIRE(!ctx->capturing, "halo exchange during graph capture");
     if (self && cm->nranks != 1) { set_error("loop-back exchange needs a 1-rank communicator"); return FS_ERR_COMM; }
@@ -310,6 +325,10 @@ int fs_halo_exchange_mark(fs_ctx *ctx)
     FS_REQUIRE(ctx, "ctx is null");
     Comm *cm = ctx->comm;
     if (!cm) { set_error("fs_halo_exchange without fs_comm_init"); return FS_ERR_COMM; }
+    if (ctx->tape_rec) {
+        ctx->tape_rec->ops.emplace_back([=]() -> int { return fs_halo_exchange_mark(ctx); });     // replay runs with no tape open
+        if (!ctx->tape_execute) return FS_OK;
+    }
     FS_REQUIRE(!cm->in_flight, "fs_halo_exchange_mark while an exchange is in flight");
     FS_HIP(hipEventRecord(cm->ev_compute, ctx->stream));
     cm->marked = true;
@@ -320,6 +339,10 @@ int fs_halo_exchange_wait(fs_ctx *ctx)
 {
     FS_REQUIRE(ctx, "ctx is null");
     Comm *cm = ctx->comm;
+    if (ctx->tape_rec && cm) {
+        ctx->tape_rec->ops.emplace_back([=]() -> int { return fs_halo_exchange_wait(ctx); });
+        if (!ctx->tape_execute) return FS_OK;
+    }
     if (!cm || !cm->in_flight) return FS_OK;
     cm->in_flight = false;
     if (cm->armed) FS_HIP(hipStreamWaitEvent(ctx->stream, cm->ev_comm, 0));   // later compute-stream work sees the filled ghost rows
@@ -361,6 +384,7 @@ int fs_allreduce_sum(fs_ctx *ctx, double *values, int n)
     Comm *cm = ctx->comm;
     if (!cm || cm->nranks == 1 || n == 0) return FS_OK;
     FS_REQUIRE(!cm->in_flight, "fs_allreduce_sum while a halo exchange is in flight");
+    FS_REQUIRE(!ctx->tape_rec, "fs_allreduce_sum while recording a tape");
     FS_HIP(hipStreamSynchronize(ctx->stream));                      // host-side collective: the compute stream drains first
     FS_HIP(hipMemcpyAsync(cm->d_red, values, n * sizeof(double), hipMemcpyHostToDevice, cm->stream));
     FS_NCCL(g_rccl.AllReduce(cm->d_red, cm->d_red, n, ncclFloat64, ncclSum, cm->comm, cm->stream));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -47,6 +48,11 @@ struct ProfRec {
 
 struct Comm;  // fs_comm.hip
 
+// recorded launch sequence (fs_tape_*): closures that re-issue a kernel launch / an exchange step with the arguments of the recording
+struct Tape {
+    std::vector<std::function<int()>> ops;
+};
+
 }  // namespace fs
 
 struct fs_ctx {
@@ -68,6 +74,10 @@ struct fs_ctx {
     // graphs
     bool capturing = false;
     std::vector<hipGraphExec_t> graphs;
+    // tapes
+    fs::Tape *tape_rec = nullptr;      // open recording
+    bool tape_execute = true;          // ... that also executes what it records (false: record only)
+    std::vector<fs::Tape *> tapes;
     // profiling
     bool prof_on = false;
     std::vector<std::string> prof_names;

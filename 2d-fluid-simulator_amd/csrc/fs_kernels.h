@@ -374,6 +374,41 @@ __global__ __launch_bounds__(256) void k_clamp(Grid g, int jb, T lo, T hi, T *f)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Visualisation kernels (fs/fluid_simulator.py:38-58, 121-126; colour maps fs/visualization.py:8-22), all cells:
+//   MODE 0  _to_norm       rgb = 0.2 * (|v|, |v|, |v|);  rgb += 0.002 * (max(p, 0), 0, max(-p, 0))
+//   MODE 1  _to_pressure   rgb = 0.04 * (max(p, 0), 0, max(-p, 0))
+//   MODE 2  _to_vorticity  rgb = 0.005 * (max(w, 0), 0, max(-w, 0)),  w = diff_x(v).y - diff_y(v).x
+//   MODE 3  _to_dye        rgb = dye
+// then wall cells take the wall colour (0.5, 0.7, 0.5) (fs/fluid_simulator.py:17).  The scale factors are Python floats in
+// the reference, i.e. constants of the field type.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void k_visualize(Grid g, Konst<T> k, int jb, T *rgb, const T *a, const T *b)
+{
+    FS_CELL_PROLOGUE
+    T r, gg, bb;
+    if (mask_at(g, i, j) == 1) { r = (T)0.5; gg = (T)0.7; bb = (T)0.5; }
+    else if (MODE == 0) {
+        const T x = at<2>(a, g, 0, i, j), y = at<2>(a, g, 1, i, j), pv = at<1>(b, g, 0, i, j);
+        const T c = tsqrt(x * x + y * y);
+        r = (T)0.2 * c + (T)0.002 * tmax(pv, (T)0.0);
+        gg = (T)0.2 * c + (T)0.002 * (T)0.0;
+        bb = (T)0.2 * c + (T)0.002 * tmax(-pv, (T)0.0);
+    } else if (MODE == 1) {
+        const T pv = at<1>(a, g, 0, i, j);
+        r = (T)0.04 * tmax(pv, (T)0.0); gg = (T)0.04 * (T)0.0; bb = (T)0.04 * tmax(-pv, (T)0.0);
+    } else if (MODE == 2) {
+        const T w = diff_x<2>(a, g, k, 1, i, j) - diff_y<2>(a, g, k, 0, i, j);
+        r = (T)0.005 * tmax(w, (T)0.0); gg = (T)0.005 * (T)0.0; bb = (T)0.005 * tmax(-w, (T)0.0);
+    } else {
+        r = at<3>(a, g, 0, i, j); gg = at<3>(a, g, 1, i, j); bb = at<3>(a, g, 2, i, j);
+    }
+    rgb[idx<3, T>(g, 0, i, j)] = r;
+    rgb[idx<3, T>(g, 1, i, j)] = gg;
+    rgb[idx<3, T>(g, 2, i, j)] = bb;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Boundary-condition kernels as op lists.
 //
 // The reference's BC kernels (fs/boundary_condition.py:16-65, 94-99) touch only boundary cells, but do so

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfs_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -62,6 +62,10 @@ _PROTOS = {
     "fs_clamp_field": [_c_vp, _c_dbl, _c_dbl, _c_vp] + _ROWS,
     "fs_cip_advect_dye_clamped": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
     "fs_clamp_inflow": [_c_vp, _c_dbl, _c_dbl, _c_vp] + _ROWS,
+    "fs_vis_norm": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_vis_pressure": [_c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_vis_vorticity": [_c_vp, _c_dbl, _c_vp, _c_vp] + _ROWS,
+    "fs_vis_dye": [_c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_comm_unique_id": [_c_vp],
     "fs_comm_init": [_c_vp, _c_int, _c_int, _c_vp],
     "fs_comm_destroy": [_c_vp],
@@ -78,6 +82,11 @@ _PROTOS = {
     "fs_graph_end": [_c_vp, _P(_c_int)],
     "fs_graph_launch": [_c_vp, _c_int, _c_int],
     "fs_graph_free": [_c_vp, _c_int],
+    "fs_tape_begin": [_c_vp, _c_int],
+    "fs_tape_end": [_c_vp, _P(_c_int)],
+    "fs_tape_length": [_c_vp, _c_int, _P(_c_int)],
+    "fs_tape_replay": [_c_vp, _c_int, _c_int],
+    "fs_tape_free": [_c_vp, _c_int],
     "fs_prof_enable": [_c_vp, _c_int],
     "fs_prof_reset": [_c_vp],
     "fs_prof_count": [_c_vp, _P(_c_int)],

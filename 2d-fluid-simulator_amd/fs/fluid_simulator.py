@@ -5,16 +5,13 @@
 `pressure_updater=` is an extension (the reference hard-codes RB-SOR): ("jacobi", n_iter) or
 ("rbsor", omega, n_iter) or a ready PressureUpdater factory.
 """
-import numpy as np
-
-from . import visualization as _vis
 from .advection import advect_kk_scheme, advect_upwind
 from .boundary_condition import get_boundary_condition
 from .pressure_updater import JacobiPressureUpdater, RedBlackSorPressureUpdater
 from .solver import CipMacSolver, DyeCipMacSolver, DyeMacSolver, MacSolver
 from .vorticity_confinement import VorticityConfinement
 
-_WALL_COLOR = np.array([0.5, 0.7, 0.5], np.float32)   # fs/fluid_simulator.py:17
+_WALL_COLOR = (0.5, 0.7, 0.5)   # fs/fluid_simulator.py:17 (applied by the visualisation kernels, csrc/fs_kernels.h k_visualize)
 
 
 def _make_updater(spec, bc, dt, dx):
@@ -48,29 +45,95 @@ def _compose(num, resolution, dt, dx, re, vor_eps, scheme, enable_dye, pressure_
 class FluidSimulator:
     def __init__(self, solver):
         self._solver = solver
+        self._dev = solver._dev
+        self.rgb_buf = self._dev.alloc(3)      # image buffer (fs/fluid_simulator.py:16), device resident
         self._wall_color = _WALL_COLOR
+        self._graph = None
+        self._tape = None
+        self._steps = 0
 
     def step(self):
         self._solver.update()
+
+    def _counted_step(self):
+        self.step()
+        self._steps += 1
+
+    # -- replay of the step as a hipGraph (new; the reference steps from a Python GUI loop) --------------------------
+    def _signature(self):
+        """Identity of every device buffer behind the solver's DoubleBuffers + the flags that select kernel variants: a
+        captured launch sequence is valid exactly while this is what it was at capture time."""
+        s, sig = self._solver, []
+        for name in ("v", "p", "vx", "vy", "dye", "dyex", "dyey"):
+            db = getattr(s, name, None)
+            if db is not None:
+                for f in (db.current, db.next):
+                    sig.append((id(f), f.user_data))
+        spare = getattr(s, "_v_spare", None)
+        sig.append(id(spare) if spare is not None else 0)
+        return tuple(sig)
+
+    def run(self, nsteps, graph=True):
+        """`nsteps` x step().  With graph=True (single GPU) the launches of a whole number of steps are captured once into a
+        hipGraph and replayed, so no Python runs between kernels - for small grids (res 200: 8 kernels of ~3 us per step) that
+        is the difference between launch-bound and GPU-bound.  Results are identical to calling step() nsteps times."""
+        dev = self._dev
+        if graph and dev.nranks > 1 and nsteps >= 24:
+            # slab run: a hipGraph cannot carry the RCCL exchange; the period of the step (launches + exchanges) is logged
+            # once and replayed from C++ instead (runtime.py tape_period / replay_tape)
+            if self._tape is None or self._tape[0] != (self._signature(), dev._state_signature()):
+                before = self._steps
+                tape = dev.tape_period(self._counted_step, nsteps=2)
+                nsteps -= self._steps - before
+                self._tape = ((self._signature(), dev._state_signature()), tape) if tape is not None else None
+            if self._tape is not None:
+                per = self._tape[1]["nsteps"]
+                dev.replay_tape(self._tape[1], nsteps // per)
+                self._steps += nsteps - nsteps % per
+                nsteps %= per
+        if not graph or dev.nranks > 1 or not hasattr(dev, "capture") or nsteps < 4:
+            for _ in range(nsteps):
+                self._counted_step()
+            return
+        sig = self._signature()
+        if self._graph is None or self._graph[0] != sig:
+            self._graph = None
+            for period in (2, 6):      # 2 steps return every DoubleBuffer to its parity; 6 also covers a 3-buffer rotation
+                if nsteps < 2 * period:
+                    break
+                gid = dev.capture(lambda: [self.step() for _ in range(period)])      # host-side swaps happen, nothing executes
+                back = self._signature() == sig
+                dev.replay(gid, 1)                                                   # now the captured steps run once
+                nsteps -= period
+                if back:
+                    self._graph = (sig, gid, period)
+                    break
+                dev.free_graph(gid)
+                sig = self._signature()
+        if self._graph is not None:
+            _, gid, period = self._graph
+            dev.replay(gid, nsteps // period)
+            nsteps %= period
+        for _ in range(nsteps):
+            self.step()
 
     def field_to_numpy(self):
         fields = self._solver.get_fields()
         return {"v": fields[0].to_numpy(), "p": fields[1].to_numpy()}
 
-    # -- visualisation (GUI side of the reference, fs/fluid_simulator.py:22-58): host-side NumPy on a download --
-    def _wall(self, rgb):
-        rgb[self._solver._bc.mask == 1] = self._wall_color
-        return rgb
-
+    # -- visualisation (fs/fluid_simulator.py:22-58): device kernels; like the reference these return the image FIELD ----
     def get_norm_field(self):
-        f = self.field_to_numpy()
-        return self._wall(0.2 * _vis.visualize_norm(f["v"]) + 0.002 * _vis.visualize_pressure(f["p"]))
+        v, p = self._solver.get_fields()[:2]
+        self._dev.vis_norm(self.rgb_buf, v, p)
+        return self.rgb_buf
 
     def get_pressure_field(self):
-        return self._wall(0.04 * _vis.visualize_pressure(self.field_to_numpy()["p"]))
+        self._dev.vis_pressure(self.rgb_buf, self._solver.get_fields()[1])
+        return self.rgb_buf
 
     def get_vorticity_field(self):
-        return self._wall(0.005 * _vis.visualize_vorticity(self.field_to_numpy()["v"], self._solver.dx))
+        self._dev.vis_vorticity(self._solver.dx, self.rgb_buf, self._solver.get_fields()[0])
+        return self.rgb_buf
 
     @staticmethod
     def create(num, resolution, dt, dx, re, vor_eps, scheme, pressure_updater=None):
@@ -83,7 +146,8 @@ class DyeFluidSimulator(FluidSimulator):
         return {"v": fields[0].to_numpy(), "p": fields[1].to_numpy(), "dye": fields[2].to_numpy()}
 
     def get_dye_field(self):
-        return self._wall(self.field_to_numpy()["dye"].copy())
+        self._dev.vis_dye(self.rgb_buf, self._solver.get_fields()[2])
+        return self.rgb_buf
 
     @staticmethod
     def create(num, resolution, dt, dx, re, vor_eps, scheme, pressure_updater=None):

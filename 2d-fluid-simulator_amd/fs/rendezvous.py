@@ -7,17 +7,52 @@ of the timings) goes through the communicator itself (Device.barrier / Device.al
 benchmark process needs no torch / MPI import at all.
 """
 import os
+import stat
 import time
+
+
+def _private_dir():
+    """A directory only this user can write: $FS_RDZV_DIR, else /tmp/fs_rdzv_<uid> (mode 0700, owned by us, not a symlink) -
+    nobody else can pre-create or redirect the rendezvous files."""
+    d = os.environ.get("FS_RDZV_DIR")
+    if d:
+        return d
+    d = os.path.join("/tmp", f"fs_rdzv_{os.getuid()}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError(f"rendezvous directory {d} is not a private directory of this user")
+    return d
+
+
+def _launcher_start_time():
+    """Wall-clock start of the parent process (the launcher all ranks share): a rendezvous file older than the launcher is a
+    leftover of an earlier job whose key happens to repeat."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError):
+        return None
 
 
 class FileRendezvous:
     def __init__(self, rank, world, key=None, timeout=300.0):
         self.rank, self.world, self.timeout = rank, world, timeout
-        if key is None:
-            key = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-        self.base = os.path.join(os.environ.get("FS_RDZV_DIR", "/tmp"), f"fs_rdzv_{key}")
+        if key is None:      # launcher identity + restart generation: a worker group restarted by the same launcher gets new files
+            key = "_".join([os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "0"),
+                            str(os.getppid()), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")])
+        self.base = os.path.join(_private_dir(), f"fs_rdzv_{key}")
         self.calls = 0
-        self.t_start = time.time()
+        t_launch = _launcher_start_time()
+        # files written before this job's launcher existed are stale; without /proc fall back to "not much older than me"
+        # (rank 0 may be well ahead of a rank whose first import is still paging in)
+        self.t_valid = t_launch - 1.0 if t_launch is not None else time.time() - 120.0
 
     def bcast(self, payload):
         """Rank 0's bytes on every rank.  Collective: every rank must call it the same number of times."""
@@ -31,8 +66,8 @@ class FileRendezvous:
             return payload
         t0 = time.time()
         while True:
-            try:    # a leftover file of an earlier job with a recycled key is older than this process: ignore it
-                if os.path.getmtime(path) >= self.t_start - 120.0:
+            try:    # a leftover file of an earlier job with a recycled key is older than this job's launcher: ignore it
+                if os.path.getmtime(path) >= self.t_valid:
                     break
             except OSError:
                 pass

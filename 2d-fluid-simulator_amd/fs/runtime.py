@@ -150,11 +150,14 @@ class DeviceBase:
         self.bcast, self.allgather = bcast, allgather
         self.y0, self.nyl = slab_rows(self.ny, rank, nranks)
         if halo is None:
-            halo = 0 if nranks == 1 else int(os.environ.get("FS_HALO", self.DEFAULT_HALO if self.nyl >= 128 else min(8, self.nyl)))
+            # the default must be the SAME number on every rank (neighbours exchange `halo` rows with each other and run the
+            # same validity bookkeeping): derive it from the thinnest slab of the decomposition, not from this rank's own height
+            thinnest = self.ny // nranks
+            halo = 0 if nranks == 1 else int(os.environ.get("FS_HALO", self.DEFAULT_HALO if thinnest >= 128 else min(8, thinnest)))
         self.halo = int(halo)
         if nranks > 1 and self.halo < self.MIN_HALO:
             raise ValueError(f"slab decomposition needs halo >= {self.MIN_HALO}")
-        if nranks > 1 and self.nyl < self.halo:
+        if nranks > 1 and self.ny // nranks < self.halo:      # rank-independent test: every rank raises, or none does
             raise ValueError("slab thinner than its halo: use fewer ranks or a larger grid")
         self.rows = self.nyl + 2 * self.halo
         # global rows covered by local rows (ghost rows included), clipped to the domain
@@ -165,6 +168,9 @@ class DeviceBase:
         self.n_exchanged_fields = 0   # fields refreshed by them
         self.n_exchanged_bytes = 0    # payload sent to ONE neighbour by them (an interior rank sends twice that)
         self.n_overlapped = 0         # exchanges that ran behind the interior rows of the kernel that needed them
+        self._oplog = None            # list of primitive operations while a period is being logged (see tape_period)
+        self._cur_writes = ()
+        self._fields = weakref.WeakSet()
         self.overlap = nranks > 1 and os.environ.get("FS_OVERLAP", "1") != "0"
         self.partial = os.environ.get("FS_PARTIAL_HALO", "1") != "0"     # send only the ghost rows beyond a field's validity
 
@@ -187,6 +193,8 @@ class DeviceBase:
         """Refresh the ghost rows of several fields with ONE grouped send/recv (one launch, one latency)."""
         depth = self.halo if depth is None else depth
         handles = self._handles(fields, depth)
+        if self._oplog is not None:       # a logged period keeps the two halves apart (the tape moves the begin up)
+            self._oplog += [("begin", handles, depth), ("wait",)]
         self._p_exchange_many(handles, depth)
         self._account(fields, handles, depth)
 
@@ -238,9 +246,10 @@ class DeviceBase:
         """
         multi = self.nranks > 1
         off = self.y0 - self.halo
+        self._cur_writes = list(writes) + list(full_writes)
         if pointwise or not multi:      # pointwise: all in-domain local rows, ghost rows included -> validity preserved
             lo, hi = (self.g_lo - off, self.g_hi - off) if pointwise else (self.halo, self.halo + self.nyl)
-            self._p_kernel(name, *args, lo, hi)
+            self._kernel(name, args, lo, hi)
             return
         H = self.halo
         for f, radius in reads:
@@ -267,7 +276,7 @@ class DeviceBase:
                 # and their outputs are not among the rows being sent: launch them FIRST (the GPU is busy while the host issues
                 # the exchange), the two edge strips after the exchange has landed.
                 self._p_exchange_mark()
-                self._p_kernel(name, *args, 2 * H, self.nyl)
+                self._kernel(name, args, 2 * H, self.nyl)
                 self.exchange_begin(need)
                 pending = True
             else:
@@ -278,16 +287,141 @@ class DeviceBase:
         hi = min(H + self.nyl + e, self.g_hi - off)
         if pending:
             self.exchange_wait()
-            self._p_kernel(name, *args, lo, 2 * H)
-            self._p_kernel(name, *args, self.nyl, hi)
+            self._kernel(name, args, lo, 2 * H)
+            self._kernel(name, args, self.nyl, hi)
         else:
-            self._p_kernel(name, *args, lo, hi)
+            self._kernel(name, args, lo, hi)
         for f in list(writes) + list(full_writes):      # full_writes: every cell of the computed rows is overwritten
             f.valid = e
         self._after_kernel(name, list(writes) + list(full_writes), lo, hi)
 
     def alloc(self, nchan):
-        return Field(self, nchan)
+        f = Field(self, nchan)
+        self._fields.add(f)
+        return f
+
+    # ---- command tapes: a logged period of primitive operations, replayed without the bookkeeping above --------------------
+    def _kernel(self, name, args, lo, hi):
+        if self._oplog is not None:
+            self._oplog.append(("k", name, tuple(args) + (lo, hi), tuple(id(f._h) for f in self._cur_writes)))
+        self._p_kernel(name, *args, lo, hi)
+
+    def _state_signature(self):
+        return tuple(sorted((id(f), f.valid, f.user_data) for f in self._fields))
+
+    @staticmethod
+    def _op_key(op):
+        """Hashable identity of a logged operation (handles by object identity: a Field keeps its handle for life)."""
+        if op[0] == "k":
+            return ("k", op[1], tuple(a if isinstance(a, (int, float, type(None))) else id(a) for a in op[2]))
+        if op[0] == "begin":
+            return ("begin", tuple((id(h), c, v) for h, c, v in op[1]), op[2])
+        return (op[0],)
+
+    def tape_period(self, step_fn, nsteps=2, tries=10, hoist=True, max_blocks=3):
+        """Log blocks of `nsteps` x step_fn() (executed normally) until the last P blocks (P = 1 .. max_blocks) repeat the P blocks
+        before them - the same primitive operations from the same bookkeeping state - then compile those P blocks into a tape of
+        P * nsteps steps (see replay_tape).  Returns None if nothing repeated within `tries` blocks (the caller keeps stepping
+        eagerly).  nsteps = 2 returns every DoubleBuffer to its parity; the ghost-row bookkeeping settles into a period of 1, 2 or
+        4 steps after a transient of up to ~8 steps, depending on halo depth and solver.  Collective on slab runs: every rank
+        takes the same decisions because every rank runs the same validity tracker."""
+        saved_overlap, self.overlap = self.overlap, False       # blocking begin + wait pairs: the tape moves the begins itself
+        try:
+            blocks = []          # (state signature before the block, op keys, op log, exchange counters spent)
+            for _ in range(tries):
+                sig0 = self._state_signature()
+                self._oplog = []
+                c0 = (self.n_exchanges, self.n_exchanged_fields, self.n_exchanged_bytes)
+                for _ in range(nsteps):
+                    step_fn()
+                log, self._oplog = self._oplog, None
+                c1 = (self.n_exchanges, self.n_exchanged_fields, self.n_exchanged_bytes)
+                blocks.append((sig0, [self._op_key(op) for op in log], log, tuple(b - a for a, b in zip(c0, c1))))
+                for P in range(1, max_blocks + 1):
+                    if len(blocks) < 2 * P:
+                        break
+                    a, b = blocks[-2 * P:-P], blocks[-P:]
+                    if (all(x[0] == y[0] and x[1] == y[1] for x, y in zip(a, b)) and self._state_signature() == b[0][0]):
+                        log = [op for blk in b for op in blk[2]]
+                        per_period = tuple(sum(blk[3][k] for blk in b) for k in range(3))
+                        return self._compile_tape(log, P * nsteps, per_period, hoist)
+            return None
+        finally:
+            self._oplog = None
+            self.overlap = saved_overlap
+
+    @staticmethod
+    def hoist_exchanges(log):
+        """Order a logged period for replay -> (ops, prologue).
+
+        A blocking exchange (begin, wait) sits right in front of the kernel that needed it.  Its `begin` only depends on the last
+        kernel that WROTE one of its fields (it sends owned rows of those fields; the ghost rows it fills lie beyond the fields'
+        validity, which no kernel in between reads - the tracker sized their row ranges from that validity), so it is moved up
+        to just behind that kernel, or behind the previous exchange: the pack / RCCL / unpack chain then runs on the
+        communication stream behind several kernels instead of in front of one.  The `wait` stays where it was.  The period is
+        cyclic: a begin that moves past the start of the period is issued at its END, for the next period; it is returned in
+        `prologue` (issued once before the first replay - the last replay then leaves one exchange in flight, which
+        replay_tape completes).  At most one begin crosses the boundary (one exchange in flight per context)."""
+        ops = list(log)
+        prologue = []
+        for b in [op for op in ops if op[0] == "begin"]:
+            n = next(i for i, op in enumerate(ops) if op is b)
+            L = len(ops)
+            fields = {id(h) for h, _, _ in b[1]}
+            k = 0
+            for d in range(1, L - 1):
+                if d > n and prologue:
+                    break
+                o = ops[(n - d) % L]
+                if o[0] != "k" or fields & set(o[3]):
+                    break
+                k = d
+            if k == 0:
+                continue
+            ops.pop(n)
+            if k <= n:
+                ops.insert(n - k, b)
+            else:                         # crossed the start of the period: in front of the op that was at cyclic index n - k
+                ops.insert(L + n - k - 1, b)
+                prologue.append(b)
+        return ops, prologue
+
+    def _compile_tape(self, log, nsteps, per_period, hoist):
+        ops, prologue = self.hoist_exchanges(log) if hoist else (list(log), [])
+        return {"ops": ops, "prologue": prologue, "nsteps": nsteps, "per_period": per_period, "id": self._p_tape_build(ops)}
+
+    def _issue(self, op):
+        if op[0] == "k":
+            self._p_kernel(op[1], *op[2])
+        elif op[0] == "begin":
+            self._p_exchange_begin(op[1], op[2])
+        elif op[0] == "wait":
+            self._p_exchange_wait()
+        elif op[0] == "mark":
+            self._p_exchange_mark()
+
+    def _p_tape_build(self, ops):       # backends without a native tape: replay issues the operations one by one
+        return None
+
+    def _p_tape_replay(self, tape, times):
+        for _ in range(times):
+            for op in tape["ops"]:
+                self._issue(op)
+
+    def replay_tape(self, tape, times):
+        """`times` periods (= times * tape['nsteps'] steps) of the logged operation sequence."""
+        if times <= 0:
+            return
+        for op in tape["prologue"]:
+            self._issue(op)
+        self._p_tape_replay(tape, times)
+        if tape["prologue"]:
+            self._p_exchange_wait()       # the exchange the last period started for its successor: complete it (the ghost rows it
+                                          # filled are valid deeper than the tracker assumes - harmless)
+        e, f, b = tape["per_period"]
+        self.n_exchanges += e * times
+        self.n_exchanged_fields += f * times
+        self.n_exchanged_bytes += b * times
 
     # ---- scene --------------------------------------------------------------------------------------
     def upload_scene(self, bc_mask, bc_const, bc_dye=None):
@@ -389,10 +523,10 @@ class DeviceBase:
         self._run("rbsor_halfsweep_src", (omega, parity, pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
 
     def limit_field(self, limit, v):                            # fs/solver.py:38-43
-        self._run("limit_field", (limit, v._h), pointwise=True)
+        self._run("limit_field", (limit, v._h), pointwise=True, writes=[v])
 
     def clamp_field(self, low, high, f):                        # fs/solver.py:46-49
-        self._run("clamp_field", (low, high, f._h), pointwise=True)
+        self._run("clamp_field", (low, high, f._h), pointwise=True, writes=[f])
 
     def cip_advect_dye_clamped(self, dt, dx, fn, fxn, fyn, fc, fxc, fyc, v):
         """CIP advection of the dye with clamp_field(dye, 0, 1) folded into the store (fluid cells)."""
@@ -400,7 +534,20 @@ class DeviceBase:
                   reads=[(fc, 1), (fxc, 1), (fyc, 1), (v, 1)], writes=[fn, fxn, fyn])
 
     def clamp_inflow(self, low, high, dye):
-        self._run("clamp_inflow", (low, high, dye._h), pointwise=True)
+        self._run("clamp_inflow", (low, high, dye._h), pointwise=True, writes=[dye])
+
+    # visualisation kernels (fs/fluid_simulator.py:38-58, 121-126): every cell of the computed rows is written
+    def vis_norm(self, rgb, v, p):
+        self._run("vis_norm", (rgb._h, v._h, p._h), reads=[(v, 0), (p, 0)], full_writes=[rgb])
+
+    def vis_pressure(self, rgb, p):
+        self._run("vis_pressure", (rgb._h, p._h), reads=[(p, 0)], full_writes=[rgb])
+
+    def vis_vorticity(self, dx, rgb, v):
+        self._run("vis_vorticity", (dx, rgb._h, v._h), reads=[(v, 1)], full_writes=[rgb])
+
+    def vis_dye(self, rgb, dye):
+        self._run("vis_dye", (rgb._h, dye._h), reads=[(dye, 0)], full_writes=[rgb])
 
     def poisson_residual(self, dt, dx, p, vc):
         """(sum of squared Jacobi residuals, cell count) over all not-wall cells of the GLOBAL grid."""
@@ -542,6 +689,23 @@ class Device(DeviceBase):
 
     def replay(self, graph_id, times=1):
         _lib.call("fs_graph_launch", self._ctx, graph_id, times)
+
+    def free_graph(self, graph_id):
+        _lib.call("fs_graph_free", self._ctx, graph_id)
+
+    # -- command tape (slab runs): the logged period as C++ closures inside libfs_hip, replayed without Python ----------
+    def _p_tape_build(self, ops):
+        _lib.call("fs_tape_begin", self._ctx, 0)          # record only: nothing executes while the operations are re-issued
+        try:
+            for op in ops:
+                self._issue(op)
+        finally:
+            tid = ctypes.c_int(-1)
+            _lib.call("fs_tape_end", self._ctx, ctypes.byref(tid))
+        return tid.value
+
+    def _p_tape_replay(self, tape, times):
+        _lib.call("fs_tape_replay", self._ctx, tape["id"], times)
 
     # -- per-kernel HIP-event timing ---------------------------------------------------------------------
     def profile(self, on=True):

@@ -1,25 +1,16 @@
-"""Colour maps for the reference's viewer (fs/visualization.py:8-22), as host-side NumPy on downloaded
-fields.  GUI-side code: not on the step() hot path, no GPU kernel spent on it."""
-import numpy as np
+"""Colour maps of the reference's viewer (fs/visualization.py:8-22).
 
+In the reference these are `@ti.func`s inlined into the `_to_*` kernels of FluidSimulator; here they live in the
+device kernel `k_visualize` (csrc/fs_kernels.h) behind `fs_vis_norm / fs_vis_pressure / fs_vis_vorticity /
+fs_vis_dye` (include/fs_hip.h).  This module only names the maps and their scale factors so that callers can
+introspect what `FluidSimulator.get_*_field()` renders; there is no host-side implementation.
+"""
 
-def visualize_norm(v):
-    c = np.sqrt(v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1])
-    return np.stack([c, c, c], axis=-1)
-
-
-def visualize_pressure(p):
-    z = np.zeros_like(p)
-    return np.stack([np.maximum(p, 0.0), z, np.maximum(-p, 0.0)], axis=-1)
-
-
-def _central(f, axis, dx):
-    g = np.take(f, np.clip(np.arange(f.shape[axis]) + 1, 0, f.shape[axis] - 1), axis=axis) \
-        - np.take(f, np.clip(np.arange(f.shape[axis]) - 1, 0, f.shape[axis] - 1), axis=axis)
-    return (np.float32(0.5) * g / np.float32(dx)).astype(f.dtype)
-
-
-def visualize_vorticity(v, dx):
-    w = _central(v[..., 1], 0, dx) - _central(v[..., 0], 1, dx)
-    z = np.zeros_like(w)
-    return np.stack([np.maximum(w, 0.0), z, np.maximum(-w, 0.0)], axis=-1)
+# (C-ABI entry point, scale factors) per reference function - fs/fluid_simulator.py:38-58, 121-126
+RENDERERS = {
+    "norm": ("fs_vis_norm", {"visualize_norm": 0.2, "visualize_pressure": 0.002}),
+    "pressure": ("fs_vis_pressure", {"visualize_pressure": 0.04}),
+    "vorticity": ("fs_vis_vorticity", {"visualize_vorticity": 0.005}),
+    "dye": ("fs_vis_dye", {}),
+}
+WALL_COLOR = (0.5, 0.7, 0.5)   # fs/fluid_simulator.py:17

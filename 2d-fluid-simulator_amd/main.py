@@ -42,10 +42,18 @@ def build_parser():
     p.add_argument("--f64", action="store_true", help="double precision (the reference is f32 only)")
     p.add_argument("--dump-every", type=int, default=0, help="np.savez v, p[, dye] every N steps (reference key 'd')")
     p.add_argument("--frame-every", type=int, default=0, help="write the -vis image as PNG every N steps")
+    p.add_argument("--graph", action="store_true",
+                   help="replay the steps between two dumps / frames as a hipGraph (no Python between kernels; same results)")
     p.add_argument("--out", type=str, default="output")
     p.add_argument("--save-state", type=str, default=None, help="write a full-state checkpoint (.npz) after the last step")
     p.add_argument("--load-state", type=str, default=None, help="resume from a checkpoint written by --save-state")
     return p
+
+
+def _npz_path(path):
+    """np.savez appends '.npz' to a name without it; use the same name for writing and reading."""
+    path = str(path)
+    return path if path.endswith(".npz") else path + ".npz"
 
 
 def save_state(sim, path, step):
@@ -59,12 +67,12 @@ def save_state(sim, path, step):
     if vc is not None:
         arrays["vorticity"] = vc.vorticity.to_numpy()
         arrays["vorticity_abs"] = vc.vorticity_abs.to_numpy()
-    np.savez(path, **arrays)
+    np.savez(_npz_path(path), **arrays)
 
 
 def load_state(sim, path):
     s = sim._solver
-    z = np.load(path)
+    z = np.load(_npz_path(path))
     for name in _STATE:
         if hasattr(s, name):
             getattr(s, name).current.from_numpy(z[f"{name}.current"])
@@ -77,17 +85,19 @@ def load_state(sim, path):
 
 
 def frame(sim, vis):
+    """The image the reference's window would show (main.py:93-107), downloaded as an (X, Y, 3) array."""
     if vis == 0:
-        return sim.get_norm_field()
+        return sim.get_norm_field().to_numpy()
     if vis == 1:
-        return sim.get_pressure_field()
+        return sim.get_pressure_field().to_numpy()
     if vis == 2:
-        return sim.get_vorticity_field()
-    return sim.get_dye_field()
+        return sim.get_vorticity_field().to_numpy()
+    return sim.get_dye_field().to_numpy()
 
 
 def main(argv=None):
-    args = build_parser().parse_args(argv)
+    parser = build_parser()
+    args = parser.parse_args(argv)
     if args.cpu:
         print("note: -cpu ignored; this build runs on the GPU only", file=sys.stderr)
     res = args.resolution
@@ -97,6 +107,12 @@ def main(argv=None):
     enable_dye = not args.no_dye
     if args.visualization == 3 and not enable_dye:
         raise SystemExit("-vis 3 (dye) needs dye transport (drop -no_dye)")
+    if args.boundary_condition == 6:
+        from fs.boundary_condition import _find_obstacle_image
+        try:
+            _find_obstacle_image()
+        except FileNotFoundError as e:      # the obstacle image is an asset of the reference repository and is not shipped here
+            parser.error(f"-bc 6: {e}")
     print(f"Boundary Condition: {args.boundary_condition}\ndt: {dt}\nRe: {args.reynolds_num}\nResolution: {res}\n"
           f"Scheme: {args.advection_scheme}\nVorticity confinement: {vor_eps}")
     fs.runtime.init(gpu=args.gpu, dtype="f64" if args.f64 else "f32")
@@ -106,16 +122,24 @@ def main(argv=None):
     step0 = load_state(sim, args.load_state) if args.load_state else 0
     dev = sim._solver._bc.device
     t0 = time.perf_counter()
-    for step in range(step0, step0 + args.steps):
+    step, last = step0, step0 + args.steps
+    while step < last:
         if args.frame_every and step % args.frame_every == 0:
             from PIL import Image
             out.mkdir(exist_ok=True)
             img = np.clip(frame(sim, args.visualization), 0.0, 1.0)
             Image.fromarray((np.flip(img.transpose(1, 0, 2), axis=0) * 255).astype(np.uint8)).save(out / f"{step:06}.png")
-        sim.step()
-        if args.dump_every and (step + 1) % args.dump_every == 0:
+        # steps until the next frame / dump / end: one chunk (a hipGraph replay with --graph, a plain loop otherwise)
+        nxt = last
+        if args.frame_every:
+            nxt = min(nxt, (step // args.frame_every + 1) * args.frame_every)
+        if args.dump_every:
+            nxt = min(nxt, (step // args.dump_every + 1) * args.dump_every)
+        sim.run(nxt - step, graph=args.graph)
+        step = nxt
+        if args.dump_every and step % args.dump_every == 0:
             out.mkdir(exist_ok=True)
-            np.savez(str(out / f"step_{step + 1:06}.npz"), **sim.field_to_numpy())
+            np.savez(str(out / f"step_{step:06}.npz"), **sim.field_to_numpy())
     dev.sync()
     el = time.perf_counter() - t0
     print(f"{args.steps} steps in {el:.3f} s = {args.steps / el:.1f} steps/s")

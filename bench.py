@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--scheme", default="cip")
     ap.add_argument("--vc", type=float, default=5.0)
     ap.add_argument("--re", type=float, default=1.0e6)
+    ap.add_argument("--dt", type=float, default=0.0, help="time step (default 0.05 / res, like the reference's main.py)")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f64: the build's double-precision instantiation (BASELINE configs[4])")
+    ap.add_argument("--no-tape", action="store_true", help="N > 1: keep Python in the timed loop instead of replaying the recorded period")
     ap.add_argument("--dye", action="store_true", help="DyeFluidSimulator (what the reference's main.py runs by default)")
     ap.add_argument("--jacobi", type=int, default=0, help="use JacobiPressureUpdater with this many sweeps/step (BASELINE configs[1])")
     ap.add_argument("--sweeps", type=int, default=200, help="isolated Jacobi sweeps for the roofline leg")
@@ -82,28 +85,41 @@ def algorithmic_bytes(mask, esize=4):
     }, {"cells": n, "fluid": fl, "not_wall": nw}
 
 
-def cpu_baseline(args, scene):
-    """The CPU oracle (C restatement of the reference algorithm, OpenMP) on this host's cores: same workload,
-    zero initial state, as many steps as fit in ~cpu_seconds (>= 2)."""
+def cpu_baseline(args, scene, sim, dt, abytes_step):
+    """The CPU oracle (C restatement of the reference algorithm, OpenMP on the race-free kernels) on this host's cores, on a
+    BOUNDED sample of the same workload: it takes over the GPU's developed state (every internal buffer), runs as many steps as
+    fit in ~cpu_seconds (>= 2), and the GPU then advances by the same steps - the two must agree bit for bit (parity in the
+    same run)."""
     import numpy as np
     from oracle import oracle as O
-    const, mask, _ = scene
+    const, mask, dye = scene
     res = args.res
-    sim = O.make_simulator(const, mask, None, scheme=args.scheme, dt=0.05 / res, dx=1.0 / res, re=1.0e6,
-                           vor_eps=args.vc if args.vc else None)
-    sim.update()   # first touch of every buffer (page faults) is not timed
+    ref = O.make_simulator(const, mask, dye if args.dye else None, scheme=args.scheme, dt=dt, dx=1.0 / res, re=args.re,
+                           vor_eps=args.vc if args.vc else None, updater=("jacobi", args.jacobi) if args.jacobi else ("rbsor", 1.3, 2),
+                           dtype=np.float32 if args.dtype == "f32" else np.float64)
+    s = sim._solver
+    for name in ("v", "p", "vx", "vy", "dye", "dyex", "dyey"):
+        if hasattr(s, name) and getattr(ref, name, None) is not None:
+            getattr(ref, name).current[...] = getattr(s, name).current.to_numpy()
+            getattr(ref, name).next[...] = getattr(s, name).next.to_numpy()
     t0 = time.perf_counter()
     n = 0
     while n < 2 or (time.perf_counter() - t0) < args.cpu_seconds:
-        sim.update()
+        ref.update()
         n += 1
-        if n >= args.steps:
+        if n >= 200:
             break
-    dt = time.perf_counter() - t0
+    el = time.perf_counter() - t0
+    for _ in range(n):
+        sim.step()
+    out = sim.field_to_numpy()
+    same = all(np.array_equal(out[k], e, equal_nan=True) for k, e in ref.fields().items())
     cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or len(os.sched_getaffinity(0))
-    return {"value": n / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of the same workload (bc{args.bc} res{res} {args.scheme}) from the zero state, "
-                      f"{dt:.1f} s, OpenMP C oracle"}
+    return {"value": n / el, "unit": "steps/s", "cores": cores, "kind": "port",
+            "GBps": round(abytes_step * n / el / 1e9, 1),
+            "sample": f"{n} steps of the same workload (bc{args.bc} res{res} {args.scheme}{' +dye' if args.dye else ''}) continuing from the "
+                      f"GPU's state after the timed run, {el:.1f} s, OpenMP C oracle (boundary kernels serial over the boundary cells)",
+            "parity_in_run": {"steps": n, "fields": sorted(ref.fields()), "bit_identical": bool(same)}}
 
 
 def main():
@@ -135,30 +151,57 @@ def main():
             os.environ["FS_TEST_COMM"] = "1"
 
     res = args.res
-    dt, dx, re = 0.05 / res, 1.0 / res, args.re
+    dt, dx, re = (args.dt or 0.05 / res), 1.0 / res, args.re
     vc = args.vc if args.vc else None
-    fs.runtime.init(gpu=local_rank, dtype="f32", rank=rank, nranks=world, bcast=bcast)
+    esize = 4 if args.dtype == "f32" else 8
+    fs.runtime.init(gpu=local_rank, dtype=args.dtype, rank=rank, nranks=world, bcast=bcast)
     sim = (fs.DyeFluidSimulator if args.dye else fs.FluidSimulator).create(args.bc, res, dt, dx, re, vc, args.scheme,
                                    pressure_updater=("jacobi", args.jacobi) if args.jacobi else None)
     dev = sim._solver._bc.device
     mask = sim._solver._bc.mask
 
     # ---- warm-up, then EXACTLY K timed steps between barrier + device sync --------------------------------
-    use_graph = world == 1 and not args.force_dist and not args.no_graph and args.steps % 2 == 0 and args.warmup % 2 == 0
+    # No Python between two launches of the timed region when it can be avoided:
+    #   N = 1: the launches of a PAIR of steps (two steps return every DoubleBuffer to its parity) are captured into a hipGraph
+    #          after the warm-up and replayed K // 2 times (+ one eager step if K is odd);
+    #   N > 1: a hipGraph cannot carry the RCCL exchange, so the period of the slab step (kernels + exchange begin / wait, 2-4
+    #          steps) is logged after the warm-up and replayed from C++ (fs_tape_replay); K mod period steps run eagerly.
+    # Every mode advances the state by the same number of steps, so `state_checksum` is comparable across modes and N.
     for _ in range(args.warmup):
         sim.step()
-    graph = None
-    aligned = args.steps % 2 == 0 and args.warmup % 2 == 0
-    if aligned and not use_graph:
-        sim.step(), sim.step()         # the graph mode runs its captured pair once: keep every mode on the same trajectory
-    if use_graph:
-        # two consecutive steps return every DoubleBuffer to its starting parity, so the captured pair replays
+    graph = tape = None
+    launch = "eager (python per step)"
+    settle = 24                        # steps spent finding / capturing the replayable period (untimed, the same in every mode)
+    if world == 1 and not args.force_dist and not args.no_graph:
+        for _ in range(settle - 2):
+            sim.step()
         graph = dev.capture(lambda: (sim.step(), sim.step()))
-        dev.replay(graph, 1)   # capture does not execute: run the pair once so the state advances like eager
+        dev.replay(graph, 1)           # capture does not execute: run the pair once so the state advances like eager
+        launch = "hipGraph replay of 2-step pairs"
+    elif (world > 1 or args.force_dist) and not args.no_tape:
+        done = [0]
+
+        def counted():
+            sim.step()
+            done[0] += 1
+        tape = dev.tape_period(counted, nsteps=2, tries=settle // 2)
+        for _ in range(settle - done[0]):
+            sim.step()
+        if tape is not None:
+            launch = f"tape replay of {tape['nsteps']}-step periods ({len(tape['ops'])} operations, C++ loop)"
+    else:
+        for _ in range(settle):
+            sim.step()
     dev.barrier()                      # device sync + all ranks arrived
     t0 = time.perf_counter()
     if graph is not None:
         dev.replay(graph, args.steps // 2)
+        for _ in range(args.steps % 2):
+            sim.step()
+    elif tape is not None:
+        dev.replay_tape(tape, args.steps // tape["nsteps"])
+        for _ in range(args.steps % tape["nsteps"]):
+            sim.step()
     else:
         for _ in range(args.steps):
             sim.step()
@@ -176,7 +219,7 @@ def main():
     dev.profile(False)
     # order-independent exact checksum of the final state (sum of the f32 bit patterns mod 2^64 over the whole grid):
     # equal numbers from the --gpus 1/2/4/8 runs of the same command line mean the slab runs are bit-identical.
-    total_steps = args.warmup + (2 if aligned else 0) + args.steps + prof_steps
+    total_steps = args.warmup + settle + args.steps + prof_steps
     checksum = {"after_steps": total_steps}
     for name, f in zip(("v", "p", "dye"), sim._solver.get_fields()):
         local = int(np.ascontiguousarray(f.to_numpy(local=True)).view(np.uint32).astype(np.uint64).sum(dtype=np.uint64))
@@ -188,12 +231,13 @@ def main():
     v_f, p_f = sim._solver.get_fields()[:2]
     r_sum, r_cnt = dev.poisson_residual(dt, dx, p_f, v_f)
     residual = {"rms": float(np.sqrt(r_sum / max(r_cnt, 1.0))), "cells": int(r_cnt)}
-    abytes, counts = algorithmic_bytes(mask)
+    abytes, counts = algorithmic_bytes(mask, esize)
     # HBM bytes per launch from rocprofv3 PMC passes of this same workload (tools/profile.sh -> profiles/*.json), if present
-    pmc_traffic = {}
+    pmc_traffic, traffic_source = {}, None
     pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_file) and (res, args.bc, args.scheme, args.dye) == (4096, 5, "cip", False) and world == 1:
+    if os.path.exists(pmc_file) and (res, args.bc, args.scheme, args.dye, args.dtype) == (4096, 5, "cip", False, "f32") and world == 1:
         pmc_traffic = json.load(open(pmc_file)).get("bytes_per_launch", {})
+        traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this workload (tools/profile.sh), NOT measured in this run"
     frac_rows = dev.nyl / dev.ny
     kernels = {}
     for name, (launches, ms) in rep.items():
@@ -231,47 +275,57 @@ def main():
 
         def leg(name, label):
             n_, ms_ = rj[name]
-            avg_s = max(dev.allgather_scalars(ms_ / n_ * 1e-3))     # slowest slab; bytes are those of the whole grid
-            gbs = abytes[name] / avg_s / 1e9
-            return {"kernel": label, "sweeps": n_, "avg_us": round(avg_s * 1e6, 2), "alg_MB": round(abytes[name] / 1e6, 2),
+            avg_s = max(dev.allgather_scalars(ms_ / n_ * 1e-3))     # slowest slab
+            slab_bytes = abytes[name] * frac_rows                     # PER DEVICE: this slab's share of the grid against ONE GPU's peak
+            gbs = slab_bytes / avg_s / 1e9
+            return {"kernel": label, "sweeps": n_, "avg_us": round(avg_s * 1e6, 2), "alg_MB": round(slab_bytes / 1e6, 2),
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic.get(name)}
+                    "per": "device" if world > 1 else "grid", "traffic": pmc_traffic.get(name)}
         jac = leg("jacobi_sweep_src", "jacobi_sweep_src (k_jacobi_ov<SRC>: p + precomputed source pair, S=8)")
+        # SURVEY.md 8d credits a sweep that reads a precomputed source S = 4 bytes per cell; the pair (s2, s3) this build stores to
+        # stay bit-exact is 8.  Both accountings, so that nobody has to argue about the second plane:
+        s4_bytes = (counts["cells"] + counts["not_wall"] * 3 * esize) * frac_rows
+        jac["S4_equiv_alg_MB"] = round(s4_bytes / 1e6, 2)
+        jac["S4_equiv_frac"] = round(s4_bytes / (jac["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         jac["reads_v_like_reference"] = leg("jacobi_sweep", "jacobi_sweep (k_jacobi_ov: p + v, S=8)")
 
     out = {
         # BASELINE.json's metric string for the headline configuration; `value` is its steps/sec part, the Poisson-sweep
         # GB/s (% of the HBM roofline) part is in `poisson_jacobi_sweep` (and per kernel in `kernels`)
         "metric": "simulation steps/sec + Poisson-sweep HBM GB/s (% roofline), res 4096\u00b2, 1/2/4/8 GPU"
-                  if (res, args.bc, args.scheme, args.jacobi, args.dye) == (4096, 5, "cip", 0, False)
-                  else f"simulation steps/sec (bc{args.bc} res {res} {args.scheme}{' jacobi' + str(args.jacobi) if args.jacobi else ''}{' +dye' if args.dye else ''})",
+                  if (res, args.bc, args.scheme, args.jacobi, args.dye, args.dtype) == (4096, 5, "cip", 0, False, "f32")
+                  else f"simulation steps/sec (bc{args.bc} res {res} {args.scheme}{' jacobi' + str(args.jacobi) if args.jacobi else ''}{' +dye' if args.dye else ''}{' f64' if args.dtype == 'f64' else ''})",
         "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 / steps_per_s, 4), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"bc={args.bc} res={res} ({2 * res}x{res} cells) scheme={args.scheme} vc={vc} "
-                               f"{'Jacobi(' + str(args.jacobi) + ')' if args.jacobi else 'RB-SOR(1.3, 2 iters)'} Re={re:g} dt=0.05/res"
+                               f"{'Jacobi(' + str(args.jacobi) + ')' if args.jacobi else 'RB-SOR(1.3, 2 iters)'} Re={re:g} dt={'0.05/res' if not args.dt else args.dt}"
                                + ("; BASELINE.json configs[2]" if (res, args.bc, args.scheme, args.jacobi) == (4096, 5, "cip", 0) else ""),
                    "cells": counts["cells"], "fluid_cells": counts["fluid"], "parallelism": f"y-slab x{world}",
-                   "launch": "hipGraph replay of 2-step pairs" if graph is not None else "eager (python per step)"},
+                   "launch": launch},
         "state_checksum": checksum,
         "poisson_residual": residual,
         "halo_exchanges_per_step": None if world == 1 else {
-            "grouped_launches": round(dev.n_exchanges / max(args.warmup + args.steps + prof_steps, 1), 2),
-            "fields": round(dev.n_exchanged_fields / max(args.warmup + args.steps + prof_steps, 1), 2),
-            "KB_per_neighbour": round(dev.n_exchanged_bytes / max(args.warmup + args.steps + prof_steps, 1) / 1024, 1),
+            "grouped_launches": round(dev.n_exchanges / max(total_steps, 1), 2),
+            "fields": round(dev.n_exchanged_fields / max(total_steps, 1), 2),
+            "KB_per_neighbour": round(dev.n_exchanged_bytes / max(total_steps, 1) / 1024, 1),
             "overlapped_fraction": round(dev.n_overlapped / max(dev.n_exchanges, 1), 2),
             "halo_rows": dev.halo},
     }
     if dominant:
         kd = kernels[dominant]
         out["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": kd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(kd["GBps"] / HBM_PEAK_GBS, 4), "traffic": pmc_traffic.get(dominant),
+                           "frac": round(kd["GBps"] / HBM_PEAK_GBS, 4), "traffic": pmc_traffic.get(dominant), "traffic_source": traffic_source,
                            "alg_bytes_per_launch": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"]}
     if jac:
         out["poisson_jacobi_sweep"] = jac
     out["kernels"] = kernels
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args, create_scene_arrays(args.bc, res))
+        # algorithmic bytes of one step as launched (sum over the profiled kernels), for the CPU leg's GB/s
+        step_bytes = sum(abytes[k] * kernels[k]["launches_per_step"] for k in kernels if k in abytes)
+        out["cpu_baseline"] = cpu_baseline(args, create_scene_arrays(args.bc, res), sim, dt, step_bytes)
+        if not out["cpu_baseline"]["parity_in_run"]["bit_identical"]:
+            raise SystemExit("bench: GPU and CPU oracle disagree after the same steps from the same state: " + json.dumps(out["cpu_baseline"]))
     dev.barrier()
     dev.close()
     if rdzv is not None:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 1
+#define FS_ABI_VERSION 2
 
 typedef struct fs_ctx fs_ctx;
 typedef struct fs_field fs_field;
@@ -178,6 +178,16 @@ int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, f
                               int row_begin, int row_end);
 int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row_begin, int row_end);
 
+/* ---- visualisation (the image buffers main.py:93-107 shows; all cells, wall cells take the wall colour) ---------------- */
+/* FluidSimulator._to_norm        fs/fluid_simulator.py:38-44   0.2 * visualize_norm(v) + 0.002 * visualize_pressure(p)    */
+int fs_vis_norm(fs_ctx *ctx, fs_field *rgb, const fs_field *v, const fs_field *p, int row_begin, int row_end);
+/* FluidSimulator._to_pressure    fs/fluid_simulator.py:46-51   0.04 * visualize_pressure(p)   (fs/visualization.py:14-16) */
+int fs_vis_pressure(fs_ctx *ctx, fs_field *rgb, const fs_field *p, int row_begin, int row_end);
+/* FluidSimulator._to_vorticity   fs/fluid_simulator.py:53-58   0.005 * visualize_vorticity(v) (fs/visualization.py:19-22) */
+int fs_vis_vorticity(fs_ctx *ctx, double dx, fs_field *rgb, const fs_field *v, int row_begin, int row_end);
+/* DyeFluidSimulator._to_dye      fs/fluid_simulator.py:121-126                                                            */
+int fs_vis_dye(fs_ctx *ctx, fs_field *rgb, const fs_field *dye, int row_begin, int row_end);
+
 /* ---- multi-GPU: y-slab halo exchange over RCCL (new; the reference is single-device) ---------- */
 #define FS_UNIQUE_ID_BYTES 128
 int fs_comm_unique_id(void *out_128_bytes);
@@ -212,6 +222,18 @@ int fs_graph_begin(fs_ctx *ctx);
 int fs_graph_end(fs_ctx *ctx, int *graph_id);
 int fs_graph_launch(fs_ctx *ctx, int graph_id, int times);
 int fs_graph_free(fs_ctx *ctx, int graph_id);
+
+/* ---- command tapes: replay of a recorded launch sequence INCLUDING the RCCL ghost-row exchanges (slab runs) ---------------
+ * Between begin and end every kernel entry point and fs_halo_exchange_begin* / _mark / _wait appends a closure holding its
+ * arguments (execute = 1: and runs as usual; execute = 0: records only).  fs_tape_replay re-issues the closures `times` times
+ * from a C++ loop - the fused driver of SURVEY.md 8b for N > 1, where a hipGraph cannot carry the exchange.  The caller
+ * guarantees that the recorded sequence is valid to repeat (fs/runtime.py records a whole period of the buffer rotation and
+ * of its ghost-row bookkeeping).                                                                                          */
+int fs_tape_begin(fs_ctx *ctx, int execute);
+int fs_tape_end(fs_ctx *ctx, int *tape_id);
+int fs_tape_length(fs_ctx *ctx, int tape_id, int *nops);
+int fs_tape_replay(fs_ctx *ctx, int tape_id, int times);
+int fs_tape_free(fs_ctx *ctx, int tape_id);
 
 /* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) --------------- */
 int fs_prof_enable(fs_ctx *ctx, int on);          /* record an event pair around every launch      */

@@ -117,30 +117,40 @@ static inline REAL FN(adv)(int scheme, const FN(consts) *k, const REAL *vc, cons
  * K1  BoundaryCondition.set_velocity_boundary_condition   (boundary_condition.py:16-39)
  * in place, serial (i, j) order: mirror scatter into the 2nd wall layer / inflow const / outflow floor
  * ------------------------------------------------------------------------------------------- */
+#define M(i, j) mask[(size_t)(i) * Y + (j)]
+static inline void FN(velocity_bc_cell)(int X, int Y, const uint8_t *mask, const REAL *bc_const, REAL *v, int i, int j)
+{
+    uint8_t m = M(i, j);
+    if (m == 1 && 1 <= i && i < X - 1 && 1 <= j && j < Y - 1) {
+        if (M(i - 1, j) == 0 && M(i, j - 1) == 1 && M(i, j + 1) == 1) {
+            for (int c = 0; c < 2; ++c) AT(v, 2, i + 1, j, c) = -S(v, 2, i - 1, j, c);
+        } else if (M(i + 1, j) == 0 && M(i, j - 1) == 1 && M(i, j + 1) == 1) {
+            for (int c = 0; c < 2; ++c) AT(v, 2, i - 1, j, c) = -S(v, 2, i + 1, j, c);
+        } else if (M(i, j - 1) == 0 && M(i - 1, j) == 1 && M(i + 1, j) == 1) {
+            for (int c = 0; c < 2; ++c) AT(v, 2, i, j + 1, c) = -S(v, 2, i, j - 1, c);
+        } else if (M(i, j + 1) == 0 && M(i - 1, j) == 1 && M(i + 1, j) == 1) {
+            for (int c = 0; c < 2; ++c) AT(v, 2, i, j - 1, c) = -S(v, 2, i, j + 1, c);
+        }
+    } else if (m == 2) {
+        AT(v, 2, i, j, 0) = AT(bc_const, 2, i, j, 0);
+        AT(v, 2, i, j, 1) = AT(bc_const, 2, i, j, 1);
+    } else if (m == 3) {
+        REAL l = S(v, 2, i - 1, j, 0);
+        AT(v, 2, i, j, 0) = FMAX(l, (REAL)0.05);
+    }
+}
+
 void FN(oracle_velocity_bc)(int X, int Y, const uint8_t *mask, const REAL *bc_const, REAL *v)
 {
-#define M(i, j) mask[(size_t)(i) * Y + (j)]
     for (int i = 0; i < X; ++i)
-        for (int j = 0; j < Y; ++j) {
-            uint8_t m = M(i, j);
-            if (m == 1 && 1 <= i && i < X - 1 && 1 <= j && j < Y - 1) {
-                if (M(i - 1, j) == 0 && M(i, j - 1) == 1 && M(i, j + 1) == 1) {
-                    for (int c = 0; c < 2; ++c) AT(v, 2, i + 1, j, c) = -S(v, 2, i - 1, j, c);
-                } else if (M(i + 1, j) == 0 && M(i, j - 1) == 1 && M(i, j + 1) == 1) {
-                    for (int c = 0; c < 2; ++c) AT(v, 2, i - 1, j, c) = -S(v, 2, i + 1, j, c);
-                } else if (M(i, j - 1) == 0 && M(i - 1, j) == 1 && M(i + 1, j) == 1) {
-                    for (int c = 0; c < 2; ++c) AT(v, 2, i, j + 1, c) = -S(v, 2, i, j - 1, c);
-                } else if (M(i, j + 1) == 0 && M(i - 1, j) == 1 && M(i + 1, j) == 1) {
-                    for (int c = 0; c < 2; ++c) AT(v, 2, i, j - 1, c) = -S(v, 2, i, j + 1, c);
-                }
-            } else if (m == 2) {
-                AT(v, 2, i, j, 0) = AT(bc_const, 2, i, j, 0);
-                AT(v, 2, i, j, 1) = AT(bc_const, 2, i, j, 1);
-            } else if (m == 3) {
-                REAL l = S(v, 2, i - 1, j, 0);
-                AT(v, 2, i, j, 0) = FMAX(l, (REAL)0.05);
-            }
-        }
+        for (int j = 0; j < Y; ++j) FN(velocity_bc_cell)(X, Y, mask, bc_const, v, i, j);
+}
+
+/* The same kernel over a precomputed list of the cells that can act at all (oracle_bc_cells: serial (i, j) order is kept, so
+ * the result is the serial one) - O(perimeter) instead of a serial walk over every cell; used for the large-grid CPU baseline. */
+void FN(oracle_velocity_bc_list)(int X, int Y, const uint8_t *mask, const REAL *bc_const, REAL *v, const int64_t *cells, int n)
+{
+    for (int q = 0; q < n; ++q) FN(velocity_bc_cell)(X, Y, mask, bc_const, v, (int)(cells[q] / Y), (int)(cells[q] % Y));
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -151,29 +161,37 @@ void FN(oracle_velocity_bc)(int X, int Y, const uint8_t *mask, const REAL *bc_co
 static inline int FN(mask_at)(const uint8_t *mask, int X, int Y, int i, int j)
 { return (i < 0 || i >= X || j < 0 || j >= Y) ? 1 : mask[(size_t)i * Y + j]; }
 
+#define MM(i, j) FN(mask_at)(mask, X, Y, i, j)
+static inline void FN(pressure_bc_cell)(int X, int Y, const uint8_t *mask, REAL *p, int i, int j)
+{
+    uint8_t m = M(i, j);
+    if (m == 1) {
+        if (MM(i - 1, j) == 0 && MM(i, j - 1) == 1 && MM(i, j + 1) == 1) AT(p, 1, i, j, 0) = S(p, 1, i - 1, j, 0);
+        else if (MM(i + 1, j) == 0 && MM(i, j - 1) == 1 && MM(i, j + 1) == 1) AT(p, 1, i, j, 0) = S(p, 1, i + 1, j, 0);
+        else if (MM(i, j - 1) == 0 && MM(i - 1, j) == 1 && MM(i + 1, j) == 1) AT(p, 1, i, j, 0) = S(p, 1, i, j - 1, 0);
+        else if (MM(i, j + 1) == 0 && MM(i - 1, j) == 1 && MM(i + 1, j) == 1) AT(p, 1, i, j, 0) = S(p, 1, i, j + 1, 0);
+        else if (MM(i - 1, j) == 0 && MM(i, j + 1) == 0) AT(p, 1, i, j, 0) = (S(p, 1, i - 1, j, 0) + S(p, 1, i, j + 1, 0)) / (REAL)2.0;
+        else if (MM(i + 1, j) == 0 && MM(i, j + 1) == 0) AT(p, 1, i, j, 0) = (S(p, 1, i + 1, j, 0) + S(p, 1, i, j + 1, 0)) / (REAL)2.0;
+        else if (MM(i - 1, j) == 0 && MM(i, j - 1) == 0) AT(p, 1, i, j, 0) = (S(p, 1, i - 1, j, 0) + S(p, 1, i, j - 1, 0)) / (REAL)2.0;
+        else if (MM(i + 1, j) == 0 && MM(i, j - 1) == 0) AT(p, 1, i, j, 0) = (S(p, 1, i + 1, j, 0) + S(p, 1, i, j - 1, 0)) / (REAL)2.0;
+    } else if (m == 2) {
+        AT(p, 1, i, j, 0) = S(p, 1, i + 1, j, 0);
+    } else if (m == 3) {
+        AT(p, 1, i, j, 0) = (REAL)0.0;
+    }
+}
+
 void FN(oracle_pressure_bc)(int X, int Y, const uint8_t *mask, REAL *p)
 {
-#define MM(i, j) FN(mask_at)(mask, X, Y, i, j)
     for (int i = 0; i < X; ++i)
-        for (int j = 0; j < Y; ++j) {
-            uint8_t m = M(i, j);
-            if (m == 1) {
-                if (MM(i - 1, j) == 0 && MM(i, j - 1) == 1 && MM(i, j + 1) == 1) AT(p, 1, i, j, 0) = S(p, 1, i - 1, j, 0);
-                else if (MM(i + 1, j) == 0 && MM(i, j - 1) == 1 && MM(i, j + 1) == 1) AT(p, 1, i, j, 0) = S(p, 1, i + 1, j, 0);
-                else if (MM(i, j - 1) == 0 && MM(i - 1, j) == 1 && MM(i + 1, j) == 1) AT(p, 1, i, j, 0) = S(p, 1, i, j - 1, 0);
-                else if (MM(i, j + 1) == 0 && MM(i - 1, j) == 1 && MM(i + 1, j) == 1) AT(p, 1, i, j, 0) = S(p, 1, i, j + 1, 0);
-                else if (MM(i - 1, j) == 0 && MM(i, j + 1) == 0) AT(p, 1, i, j, 0) = (S(p, 1, i - 1, j, 0) + S(p, 1, i, j + 1, 0)) / (REAL)2.0;
-                else if (MM(i + 1, j) == 0 && MM(i, j + 1) == 0) AT(p, 1, i, j, 0) = (S(p, 1, i + 1, j, 0) + S(p, 1, i, j + 1, 0)) / (REAL)2.0;
-                else if (MM(i - 1, j) == 0 && MM(i, j - 1) == 0) AT(p, 1, i, j, 0) = (S(p, 1, i - 1, j, 0) + S(p, 1, i, j - 1, 0)) / (REAL)2.0;
-                else if (MM(i + 1, j) == 0 && MM(i, j - 1) == 0) AT(p, 1, i, j, 0) = (S(p, 1, i + 1, j, 0) + S(p, 1, i, j - 1, 0)) / (REAL)2.0;
-            } else if (m == 2) {
-                AT(p, 1, i, j, 0) = S(p, 1, i + 1, j, 0);
-            } else if (m == 3) {
-                AT(p, 1, i, j, 0) = (REAL)0.0;
-            }
-        }
-#undef MM
+        for (int j = 0; j < Y; ++j) FN(pressure_bc_cell)(X, Y, mask, p, i, j);
 }
+
+void FN(oracle_pressure_bc_list)(int X, int Y, const uint8_t *mask, REAL *p, const int64_t *cells, int n)
+{
+    for (int q = 0; q < n; ++q) FN(pressure_bc_cell)(X, Y, mask, p, (int)(cells[q] / Y), (int)(cells[q] % Y));
+}
+#undef MM
 
 /* K10  DyeBoundaryCondition.set_dye_boundary_condition   (boundary_condition.py:94-99) */
 void FN(oracle_dye_bc)(int X, int Y, const uint8_t *mask, const REAL *bc_dye, REAL *dye)

@@ -86,23 +86,42 @@ class Buf2:
 
 
 class OracleBC:
-    """fs/boundary_condition.py:12-112 (BoundaryCondition / DyeBoundaryCondition)."""
+    """fs/boundary_condition.py:12-112 (BoundaryCondition / DyeBoundaryCondition).
 
-    def __init__(self, bc_const, bc_mask, bc_dye=None, dtype=np.float32):
+    `cell_list`: run the velocity / pressure kernels over the precomputed list of cells that can act at all (non-fluid cells
+    that are inflow / outflow or touch a fluid cell), in the same serial (i, j) order, instead of walking every cell of the
+    grid serially - identical results (tests/test_oracle_golden.py), O(perimeter) work.  Default: on for grids above 1 M cells
+    (the CPU-baseline sizes); the small parity grids keep the literal full scan."""
+
+    def __init__(self, bc_const, bc_mask, bc_dye=None, dtype=np.float32, cell_list=None):
         self.dtype = np.dtype(dtype)
         self.bc_const = np.ascontiguousarray(bc_const, dtype=self.dtype)
         self.mask = np.ascontiguousarray(bc_mask, dtype=np.uint8)
         self.bc_dye = None if bc_dye is None else np.ascontiguousarray(bc_dye, dtype=self.dtype)
         self.X, self.Y = self.mask.shape
+        self.cells = None
+        if cell_list if cell_list is not None else self.mask.size > (1 << 20):
+            m = self.mask
+            fluid = m == 0
+            near = np.zeros_like(fluid)
+            near[1:, :] |= fluid[:-1, :]; near[:-1, :] |= fluid[1:, :]
+            near[:, 1:] |= fluid[:, :-1]; near[:, :-1] |= fluid[:, 1:]
+            self.cells = np.ascontiguousarray(np.flatnonzero((m >= 2) | ((m == 1) & near)), dtype=np.int64)   # ascending = (i, j) order
 
     def get_resolution(self):
         return (self.X, self.Y)
 
     def set_velocity_boundary_condition(self, v):
-        _call("oracle_velocity_bc", self.dtype, self.X, self.Y, self.mask, self.bc_const, v)
+        if self.cells is not None:
+            _call("oracle_velocity_bc_list", self.dtype, self.X, self.Y, self.mask, self.bc_const, v, self.cells, len(self.cells))
+        else:
+            _call("oracle_velocity_bc", self.dtype, self.X, self.Y, self.mask, self.bc_const, v)
 
     def set_pressure_boundary_condition(self, p):
-        _call("oracle_pressure_bc", self.dtype, self.X, self.Y, self.mask, p)
+        if self.cells is not None:
+            _call("oracle_pressure_bc_list", self.dtype, self.X, self.Y, self.mask, p, self.cells, len(self.cells))
+        else:
+            _call("oracle_pressure_bc", self.dtype, self.X, self.Y, self.mask, p)
 
     def set_dye_boundary_condition(self, dye):
         _call("oracle_dye_bc", self.dtype, self.X, self.Y, self.mask, self.bc_dye, dye)
@@ -275,3 +294,54 @@ def make_simulator(bc_const, bc_mask, bc_dye, *, scheme, dt, dx, re, vor_eps, up
     if scheme in ("upwind", "kk"):
         return OracleMacSolver(bc, pu, scheme, dt, dx, re, vc, dye=dye)
     raise ValueError(f"Unknown scheme: {scheme}")
+
+
+# ------------------------------------------------------------------------------------------------
+# Visualisation maps (fluid_simulator.py:38-58, 121-126; visualization.py:8-22): element-wise IEEE
+# arithmetic in the field dtype, so plain NumPy is an exact restatement (no C needed).
+# ------------------------------------------------------------------------------------------------
+WALL_COLOR = (0.5, 0.7, 0.5)          # fluid_simulator.py:17
+
+
+def _visualize_pressure(val):
+    """visualization.py:14-16: (max(val, 0), 0, max(-val, 0)) with NaN-ignoring max (shim: np.fmax)."""
+    z = np.zeros_like(val)
+    return np.stack([np.fmax(val, z), z, np.fmax(-val, z)], axis=-1)
+
+
+def _central(f, axis, dx):
+    """differentiation.py:41-50 through sample() (clamp-to-edge): 0.5 * (f[+1] - f[-1]) / dx."""
+    n = f.shape[axis]
+    up = np.take(f, np.clip(np.arange(n) + 1, 0, n - 1), axis=axis)
+    dn = np.take(f, np.clip(np.arange(n) - 1, 0, n - 1), axis=axis)
+    return (f.dtype.type(0.5) * (up - dn)) / f.dtype.type(dx)
+
+
+def _wall(rgb, mask):
+    rgb[mask == 1] = np.asarray(WALL_COLOR, rgb.dtype)
+    return rgb
+
+
+def vis_norm(v, p, mask):
+    """_to_norm, fluid_simulator.py:38-44: 0.2 * visualize_norm(v), then += 0.002 * visualize_pressure(p)."""
+    t = v.dtype.type
+    c = np.sqrt(v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1])      # Vector.norm(): sqrt of the left-to-right sum of squares
+    rgb = t(0.2) * np.stack([c, c, c], axis=-1)
+    rgb = rgb + t(0.002) * _visualize_pressure(p)
+    return _wall(rgb, mask)
+
+
+def vis_pressure(p, mask):
+    """_to_pressure, fluid_simulator.py:46-51."""
+    return _wall(p.dtype.type(0.04) * _visualize_pressure(p), mask)
+
+
+def vis_vorticity(v, dx, mask):
+    """_to_vorticity, fluid_simulator.py:53-58; visualize_vorticity visualization.py:19-22."""
+    w = _central(v[..., 1], 0, dx) - _central(v[..., 0], 1, dx)
+    return _wall(v.dtype.type(0.005) * _visualize_pressure(w), mask)
+
+
+def vis_dye(dye, mask):
+    """_to_dye, fluid_simulator.py:121-126."""
+    return _wall(dye.copy(), mask)

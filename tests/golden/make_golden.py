@@ -14,6 +14,7 @@ Fixture families
   scenes.npz / scene_hashes.json : outputs of create_boundary_condition1..6 (boundary_condition.py:222-524)
   kernels_bc{n}.npz              : single-call I/O of every @ti.kernel on the step() path, res 16
   traj_*.npz                     : FluidSimulator.step() trajectories (field_to_numpy + internal buffers)
+  vis_*.npz                      : a state + the RGB buffers of get_norm/pressure/vorticity/dye_field() for it
 """
 import hashlib
 import json
@@ -297,8 +298,34 @@ def job_traj(job):
     return job["name"], round(time.time() - t0, 1)
 
 
+# --------------------------------------------------------------------------------------------
+# visualisation buffers (fluid_simulator.py:22-58, 112-126)
+# --------------------------------------------------------------------------------------------
+def job_vis(job):
+    """State after a few steps + the four image buffers the reference's getters produce from it."""
+    np, ti = _setup()
+    from fs.fluid_simulator import DyeFluidSimulator
+
+    bcn, res, scheme, steps = job
+    dt, dx = 0.05 / res, 1 / res
+    sim = DyeFluidSimulator.create(bcn, res, dt, dx, 1.0e6, 5.0, scheme)
+    for _ in range(steps):
+        sim.step()
+    out = {"params": np.array([bcn, res, dt, dx, 1.0e6, 5.0], dtype=np.float64), "scheme": np.array(scheme), "steps": np.array(steps)}
+    out.update(_scene_arrays(sim._solver._bc))
+    for k, a in sim.field_to_numpy().items():
+        out[f"state.{k}"] = a
+    out["rgb.norm"] = sim.get_norm_field().to_numpy().copy()
+    out["rgb.pressure"] = sim.get_pressure_field().to_numpy().copy()
+    out["rgb.vorticity"] = sim.get_vorticity_field().to_numpy().copy()
+    out["rgb.dye"] = sim.get_dye_field().to_numpy().copy()
+    name = f"vis_bc{bcn}_res{res}_{scheme}"
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    return name
+
+
 def main():
-    what = set(sys.argv[1:]) or {"scenes", "kernels", "traj", "bighash"}
+    what = set(sys.argv[1:]) or {"scenes", "kernels", "traj", "bighash", "vis"}
     ctx = mp.get_context("spawn")
     meta_path = os.path.join(HERE, "scene_hashes.json")
     meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
@@ -313,6 +340,9 @@ def main():
         if "kernels" in what:
             for n in range(1, 7):
                 pending.append(("kernels", pool.apply_async(job_kernels, (n,))))
+        if "vis" in what:
+            for job in [(1, 32, "cip", 4), (2, 32, "kk", 3), (5, 32, "cip", 5), (3, 48, "upwind", 3)]:
+                pending.append(("vis", pool.apply_async(job_vis, (job,))))
         if "traj" in what:
             for job in sorted(_traj_jobs(), key=lambda j: -j["res"] * (3 if j["scheme"] == "cip" else 1)):
                 pending.append(("traj", pool.apply_async(job_traj, (job,))))

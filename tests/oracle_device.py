@@ -191,6 +191,20 @@ class OracleSlabDevice(DeviceBase):
                 f._h.a[:, :a_lo] = np.nan
                 f._h.a[:, a_hi:] = np.nan
 
+    def _p_tape_replay(self, tape, times):
+        """Replay through the same primitives, with the same poisoning as the eager path: rows of a kernel's outputs outside its
+        computed range become NaN, so an exchange moved too far up (or dropped) by the tape compiler fails the comparison."""
+        for _ in range(times):
+            for op in tape["ops"]:
+                self._issue(op)
+                if op[0] == "k" and self.poison and op[3]:
+                    lo, hi = op[2][-2:]
+                    a_lo, a_hi = max(lo - self.r_off, 0), max(hi - self.r_off, 0)
+                    for a in op[2]:
+                        if isinstance(a, _Arr) and id(a) in op[3]:
+                            a.a[:, :a_lo] = np.nan
+                            a.a[:, a_hi:] = np.nan
+
     def sync(self):
         pass
 

@@ -53,7 +53,56 @@ def test_visualisation_buffers(hip_lib):
     for _ in range(3):
         sim.step()
     wall = sim._solver._bc.mask == 1
-    for img in (sim.get_norm_field(), sim.get_pressure_field(), sim.get_vorticity_field(), sim.get_dye_field()):
+    for field in (sim.get_norm_field(), sim.get_pressure_field(), sim.get_vorticity_field(), sim.get_dye_field()):
+        img = field.to_numpy()
         assert img.shape == (64, 32, 3) and np.isfinite(img).all()
         assert np.allclose(img[wall], [0.5, 0.7, 0.5])                   # wall colour, fluid_simulator.py:17
     sim._solver._bc.device.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_dump_contents_equal_the_reference_trajectory(tmp_path, hip_lib, graph):
+    """the `d`-key dump (main.py:129-132) of `-bc 2 -res 32 -no_dye` (defaults: cip, vc 5, Re 1e6, dt 0.05/res)
+    holds exactly the fields the reference's own run produces (tests/golden/traj_bc2_cip_vc5.npz), with and without --graph."""
+    from conftest import golden
+    g = golden("traj_bc2_cip_vc5.npz")
+    cli = _cli()
+    cli.main("-bc 2 -res 32 -no_dye --steps 10 --dump-every 5".split() + ["--out", str(tmp_path)] + (["--graph"] if graph else []))
+    for step in (5, 10):
+        z = np.load(tmp_path / f"step_{step:06}.npz")
+        assert sorted(z.files) == ["p", "v"]
+        for k in ("v", "p"):
+            assert z[k].dtype == g[f"step{step}.{k}"].dtype and np.array_equal(z[k], g[f"step{step}.{k}"]), (step, k)
+
+
+@pytest.mark.gpu
+def test_dye_dump_equals_the_reference_trajectory(tmp_path, hip_lib):
+    """The reference's default mode (dye on): `-bc 5 -res 32 -scheme kk` dump vs traj_dye_bc5_kk_vc5.npz."""
+    from conftest import golden
+    g = golden("traj_dye_bc5_kk_vc5.npz")
+    _cli().main("-bc 5 -res 32 -scheme kk --steps 5 --dump-every 5".split() + ["--out", str(tmp_path)])
+    z = np.load(tmp_path / "step_000005.npz")
+    assert sorted(z.files) == ["dye", "p", "v"]
+    for k in z.files:
+        assert np.array_equal(z[k], g[f"step5.{k}"]), k
+
+
+@pytest.mark.gpu
+def test_checkpoint_name_without_extension(tmp_path, hip_lib):
+    """`--save-state ckpt` writes ckpt.npz (np.savez appends the suffix); `--load-state ckpt` must find it."""
+    cli = _cli()
+    cli.main("-bc 1 -res 32 -no_dye --steps 2".split() + ["--out", str(tmp_path), "--save-state", str(tmp_path / "ckpt")])
+    assert (tmp_path / "ckpt.npz").exists()
+    cli.main("-bc 1 -res 32 -no_dye --steps 1".split() + ["--out", str(tmp_path), "--load-state", str(tmp_path / "ckpt")])
+
+
+def test_scene6_without_asset_is_an_argparse_error(monkeypatch, tmp_path, capsys):
+    """`-bc 6` is an accepted choice but needs the reference's dragon.png: a clear usage error, not a traceback."""
+    from fs import boundary_condition as B
+    monkeypatch.setattr(B, "_find_obstacle_image", lambda name="dragon.png": (_ for _ in ()).throw(
+        FileNotFoundError("scene 6 needs the obstacle image images/bc_mask/dragon.png; set FS_ASSET_DIR")))
+    with pytest.raises(SystemExit) as e:
+        _cli().main(["-bc", "6", "-res", "32", "--steps", "1", "--out", str(tmp_path)])
+    assert e.value.code == 2
+    assert "FS_ASSET_DIR" in capsys.readouterr().err

@@ -45,7 +45,7 @@ def _device_cls():
     return LoopbackSlab
 
 
-def _run(res, halo, overlap, scheme, updater, steps):
+def _run(res, halo, overlap, scheme, updater, steps, tape=False):
     import fs
     from fs.boundary_condition import BoundaryCondition, create_scene_arrays
     const, mask, _ = create_scene_arrays(5, res)
@@ -58,8 +58,22 @@ def _run(res, halo, overlap, scheme, updater, steps):
         solver = fs.CipMacSolver(bc, pu, dt, dx, 1e6, vc)
     else:
         solver = fs.MacSolver(bc, pu, fs.advect_kk_scheme, dt, dx, 1e6, vc)
-    for _ in range(steps):
-        solver.update()
+    if tape:
+        # the N > 1 timed loop of bench.py: log the period of the step, compile it into a C++ tape (fs_tape_*), replay it
+        done = [0]
+
+        def counted():
+            solver.update()
+            done[0] += 1
+        t = dev.tape_period(counted, nsteps=2)
+        assert t is not None and t["id"] is not None, "no steady period / no native tape"
+        dev.replay_tape(t, 3)
+        steps = done[0] + 3 * t["nsteps"] + 1
+        solver.update()                   # the eager path carries on from the replayed state
+        tape.append((steps, len(t["ops"]), t["nsteps"]))
+    else:
+        for _ in range(steps):
+            solver.update()
     out = {n: getattr(solver, n).current.local_window() for n in ("v", "p", "vx", "vy") if hasattr(solver, n)}
     out.update({n + ".next": getattr(solver, n).next.local_window() for n in ("v", "p") if hasattr(solver, n)})
     stats = (dev.n_exchanges, dev.n_overlapped)
@@ -79,3 +93,18 @@ def test_overlapped_equals_blocking(res, halo, scheme, updater, steps, hip_lib):
         for k in blocking:
             assert np.array_equal(hidden[k], blocking[k], equal_nan=True), (k, rep)
     assert float(np.nanmax(np.abs(blocking["p"]))) > 0
+
+
+@pytest.mark.parametrize("res,halo,scheme,updater", [(256, 8, "cip", "rbsor"), (256, 2, "cip", "rbsor"), (1024, 16, "cip", "rbsor"),
+                                                     (1024, 4, "kk", "jacobi"), (4096, 16, "cip", "rbsor")])
+def test_tape_replay_equals_eager(res, halo, scheme, updater, hip_lib):
+    """fs_tape_*: the recorded period (kernel launches + RCCL exchange begin / wait as C++ closures) replayed without Python
+    advances the slab exactly like eager stepping through the same RCCL path."""
+    info = []
+    taped, (nt, _) = _run(res, halo, False, scheme, updater, 0, tape=info)
+    steps, nops, period = info[0]
+    eager, (ne, _) = _run(res, halo, False, scheme, updater, steps)
+    assert nt == ne, "the replay must account for the exchanges it issues"
+    for k in eager:
+        assert np.array_equal(taped[k], eager[k], equal_nan=True), (k, steps, nops, period)
+    assert float(np.nanmax(np.abs(eager["p"]))) > 0

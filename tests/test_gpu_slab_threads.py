@@ -125,7 +125,7 @@ def _run_slabs(g, cfg, world, halo):
         threads.append(t)
         t.start()
     for t in threads:
-        t.join(timeout=300)
+        t.join(timeout=900)
     assert not errors, errors
     return results
 
@@ -149,6 +149,7 @@ def test_slabs_on_one_gpu_are_bit_identical(fname, world, halo, hip_lib):
     (5, 4096, "cip", 5.0, ("rbsor", 1.3, 2), 8, 8),      # configs[2] itself, as the driver's --gpus 8 run cuts it
     (2, 1024, "cip", None, ("jacobi", 12), 8, 8),        # configs[3]'s scene (bc2 CIP) with Jacobi
     (3, 1000, "kk", 10.0, ("rbsor", 1.3, 2), 4, 16),     # configs[4]: 4 slabs, 250 rows each (not a multiple of 4)
+    (2, 8192, "cip", 5.0, ("rbsor", 1.3, 2), 8, 16),     # configs[3] ITSELF: bc2 res 8192 (16384 x 8192 cells), 8 slabs of 1024 rows, default halo
 ])
 def test_slabs_at_size_equal_single_domain(bc, res, scheme, vc, updater, world, halo, hip_lib):
     """Grids wide enough for many waves per row and many tile rows per slab (the XCD band mapping, the overlapped-wave
@@ -157,7 +158,7 @@ def test_slabs_at_size_equal_single_domain(bc, res, scheme, vc, updater, world, 
     from fs.boundary_condition import create_scene_arrays
     const, mask, _ = create_scene_arrays(bc, res)
     g = {"bc_const": const, "bc_mask": mask}
-    steps = 4
+    steps = 4 if res < 8192 else 3
     cfg = dict(bc=bc, res=res, dt=0.05 / res, dx=1.0 / res, re=1e6, vor_eps=vc, scheme=scheme, updater=updater,
                dye=False, fp64=False, snaps=[steps])
     results = _run_slabs(g, cfg, world, halo)

@@ -127,3 +127,29 @@ def test_known_answers_uniform_flow_and_limit():
     O.limit_field(big)
     assert np.all(big[..., 0] == np.float32(10.0) * (np.float32(12.0) / np.float32(20.0)))
     small = v.copy(); O.limit_field(small); assert np.array_equal(small, v)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bc_cell_list_equals_full_scan(seed):
+    """The O(perimeter) form of the velocity / pressure boundary kernels (OracleBC(cell_list=True), used for the large-grid CPU
+    baseline) against the literal full scan, on the reference scenes and on random masks with thin walls / hazards."""
+    rng = np.random.default_rng(seed)
+    if seed < 3:
+        g = golden(f"kernels_bc{(3, 5, 6)[seed]}.npz")
+        const, mask = g["bc_const"], g["bc_mask"]
+    else:
+        X, Y = int(rng.integers(8, 60)), int(rng.integers(8, 40))
+        mask = (rng.random((X, Y)) < 0.25).astype(np.uint8)
+        mask[rng.integers(0, X, 6), :] = 1
+        mask[:2, :] = 2; mask[-2:, :] = 3
+        mask[:, [0, 1, Y - 2, Y - 1]] = 1
+        const = rng.uniform(-1, 1, (X, Y, 2)).astype(np.float32)
+    a, b = O.OracleBC(const, mask, cell_list=False), O.OracleBC(const, mask, cell_list=True)
+    assert a.cells is None and b.cells is not None
+    for _ in range(3):
+        v = rng.uniform(-1, 1, mask.shape + (2,)).astype(np.float32)
+        p = rng.uniform(-10, 10, mask.shape).astype(np.float32)
+        v2, p2 = v.copy(), p.copy()
+        a.set_velocity_boundary_condition(v); b.set_velocity_boundary_condition(v2)
+        a.set_pressure_boundary_condition(p); b.set_pressure_boundary_condition(p2)
+        assert np.array_equal(v, v2) and np.array_equal(p, p2)

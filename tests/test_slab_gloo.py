@@ -83,3 +83,78 @@ def test_single_rank_never_exchanges():
     d.velocity_bc(v); d.cip_nonadv(0.1, 0.1, 1.0, d.alloc(2), v, p); d.limit_field(10.0, v)
     assert d.halo == 0 and d.n_exchanges == 0 and (d.bc_radius_v, d.bc_radius_p) == (2, 1)
     assert [c[1] for c in d.calls] == [(0, 32)] * 3
+
+
+def test_default_halo_is_the_same_on_every_rank():
+    """the default depth used to come from the rank's OWN slab height, so ranks on either side of the 128-row
+    threshold disagreed (res 1020 on 8 ranks: 128-row slabs took 16, 127-row slabs took 8)."""
+    import numpy as np
+    from fs.runtime import DeviceBase
+    for ny, n in [(1020, 8), (510, 4), (255, 2), (4096, 8), (129 * 3 - 1, 3), (64, 8), (33, 4)]:
+        hs = {DeviceBase(2 * ny, ny, np.float32, rank=r, nranks=n).halo for r in range(n)}
+        assert len(hs) == 1, (ny, n, hs)
+    assert DeviceBase(2040, 1020, np.float32, rank=0, nranks=8).halo == 8      # thinnest slab: 127 rows
+    assert DeviceBase(2048, 1024, np.float32, rank=7, nranks=8).halo == 16
+
+
+def test_default_halo_slab_run_straddling_the_threshold(tmp_path):
+    """ny = 255 on 2 ranks: slabs of 128 and 127 rows, default halo; equal to the single-domain oracle run."""
+    from slab_worker import run_default_halo
+    mp.spawn(run_default_halo, args=(2, _free_port(), 255, str(tmp_path)), nprocs=2, join=True)
+    nbad, halos, rows = open(os.path.join(tmp_path, "result.txt")).read().split(" ", 2)
+    assert int(nbad) == 0
+    assert halos == "[8]" and rows.strip() == "[127, 128]"
+
+
+TAPE_CASES = [
+    ("traj_bc5_cip_vc5.npz", 2, 8),                          # snaps up to step 10
+    ("traj_bc5_cip_vc5.npz", 2, 2),                          # shallow halo: an exchange in front of nearly every kernel
+    ("traj_cfg1_bc1_upwind_re1000.npz", 3, 4),               # 20 steps, MacSolver without VC (one v swap per step)
+    ("traj_cfg1_bc1_upwind_re1000.npz", 2, 12),              # deep halo: the bookkeeping repeats only every 4 steps
+    ("traj_bc3_kk_vc5.npz", 2, 4),
+    ("traj_bc2_cip_vc5.npz", 3, 6),
+]
+
+
+@pytest.mark.parametrize("fname,world,halo", TAPE_CASES)
+def test_tape_replay_with_hoisted_exchanges_is_bit_identical(fname, world, halo, tmp_path):
+    """The N > 1 timed loop of bench.py: a logged 2-step period replayed as a tape, exchange begins moved up to the last writer
+    of their fields.  Ghost rows are NaN-poisoned during the replay as well, so an exchange moved too far fails."""
+    from slab_worker import run
+    mp.spawn(run, args=(world, _free_port(), fname, halo, str(tmp_path), True), nprocs=world, join=True)
+    lines = open(os.path.join(tmp_path, "result.txt")).read().splitlines()
+    nbad, per_step, *names = lines[0].split()
+    assert int(nbad) == 0, f"{fname}: tape replay differs from the single-domain result in {names}"
+    print("exchange begins moved up:", lines[1])
+
+
+def test_hoist_exchanges_unit():
+    """hoist_exchanges on synthetic logs: a begin moves up to just behind the last writer of its fields / the previous exchange,
+    never past them, and at most one begin crosses the period boundary."""
+    from fs.runtime import DeviceBase
+    A, B, C = object(), object(), object()
+
+    def k(name, writes):
+        return ("k", name, (), tuple(id(w) for w in writes))
+
+    def ex(*fields):
+        return ("begin", [(f, 1, 0) for f in fields], 4), ("wait",)
+
+    b1, w1 = ex(A)
+    b2, w2 = ex(B)
+    log = [k("k0", [A]), k("k1", [B]), k("k2", [C]), b1, w1, k("k3", [C]), k("k4", [C]), b2, w2, k("k5", [A, B])]
+    ops, pro = DeviceBase.hoist_exchanges(log)
+    names = [o[1] if o[0] == "k" else ("b1" if o is b1 else "b2" if o is b2 else "w") for o in ops]
+    # b1 (field A, last written by k0) moves in front of k1; b2 (field B, written by k1 - but k1 is beyond b1's wait) stops at w1
+    assert names == ["k0", "b1", "k1", "k2", "w", "b2", "k3", "k4", "w", "k5"] and pro == []
+    # cyclic: the first begin's field was last written at the END of the previous period -> it moves across the boundary
+    b3, w3 = ex(A)
+    log = [k("k0", [C]), b3, w3, k("k1", [C]), k("k2", [A]), k("k3", [C])]
+    ops, pro = DeviceBase.hoist_exchanges(log)
+    names = [o[1] if o[0] == "k" else ("b3" if o is b3 else "w") for o in ops]
+    assert names == ["k0", "w", "k1", "k2", "b3", "k3"] and pro == [b3]
+    # a writer immediately in front: nothing moves
+    b4, w4 = ex(A)
+    log = [k("k0", [A]), b4, w4, k("k1", [A])]
+    ops, pro = DeviceBase.hoist_exchanges(log)
+    assert ops == log and pro == []

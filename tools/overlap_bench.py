@@ -52,16 +52,20 @@ def main():
     const, mask, _ = create_scene_arrays(5, res)
     dt, dx = 0.05 / res, 1.0 / res
     for halo in [int(a) for a in sys.argv[1:]] or [4, 8, 16]:
-        for mode in ("none", "blocking", "overlap"):
+        for mode in ("none", "blocking", "overlap", "tape"):
             dev = LoopbackSlab(mask.shape[0], mask.shape[1], rank, world, halo, mode)
             bc = BoundaryCondition(const, mask, device=dev)
             solver = fs.CipMacSolver(bc, fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2), dt, dx, 1e6, fs.VorticityConfinement(bc, dt, dx, 5.0))
             for _ in range(40):
                 solver.update()
+            tape = dev.tape_period(solver.update, nsteps=2) if mode == "tape" else None
             dev.sync()
             n0, t0, steps = dev.n_exchanges, time.perf_counter(), 400
-            for _ in range(steps):
-                solver.update()
+            if tape is not None:
+                dev.replay_tape(tape, steps // tape["nsteps"])
+            else:
+                for _ in range(steps):
+                    solver.update()
             dev.sync()
             el = time.perf_counter() - t0
             print(f"halo {halo:2d} {mode:9s}: {el / steps * 1e6:7.1f} us/step   {(dev.n_exchanges - n0) / steps:.2f} exchanges/step, "
