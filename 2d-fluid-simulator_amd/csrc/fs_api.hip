@@ -3,7 +3,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
+#include <type_traits>
 #include <unordered_map>
 
 #include "fs_host.h"
@@ -18,6 +20,42 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
     g_err = buf;
     return FS_ERR_HIP;
+}
+
+// ---- reciprocal-FMA division: exhaustive check of a divisor on the device (fs_device.h rdiv) -----------------------------------
+__global__ __launch_bounds__(256) static void k_verify_rcp(float d, float r, unsigned *bad)
+{
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;          // all 2^23 significands of x in [1, 2): the sequence and the quotient
+    const float x = __uint_as_float(0x3f800000u | m);            // scale exactly with the exponent of x (range-checked in the kernels)
+    DivGuard G;
+    const float q = rdiv(x, d, r, G), t = x / d;
+    const float qn = rdiv(-x, d, r, G), tn = (-x) / d;
+    if (__float_as_uint(q) != __float_as_uint(t) || __float_as_uint(qn) != __float_as_uint(tn)) atomicOr(bad, 1u);
+}
+
+bool rcp_verified(fs_ctx *ctx, float d, bool may_verify)
+{
+    static std::mutex mu;
+    static std::unordered_map<uint32_t, bool> cache;
+    uint32_t key;
+    memcpy(&key, &d, 4);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (!may_verify) return false;
+    bool ok = false;
+    unsigned *flag = nullptr, h = 1u;
+    if (hipMalloc(&flag, sizeof(unsigned)) == hipSuccess) {
+        if (hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream) == hipSuccess) {
+            hipLaunchKernelGGL(k_verify_rcp, dim3(1u << 15), dim3(256), 0, ctx->stream, d, 1.0f / d, flag);
+            if (hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess)
+                ok = h == 0u;
+        }
+        hipFree(flag);
+    }
+    cache[key] = ok;
+    return ok;
 }
 
 // ---- launch helper: optional HIP-event pair around every launch (fs_prof_*) --------------------
@@ -95,7 +133,14 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
     const bool stacked = (c->stack_mask & family) != 0;    // the 4 waves of a workgroup: 4 tile rows of one wave column
     o.nbx = stacked ? waves : (waves + 3) / 4;
     o.nby = stacked ? (tiles + 3) / 4 : tiles;
-    if (c->xcd_mask & family) {
+    if ((c->tile2d_mask & family) && (c->xcd_mask & family)) {
+        // 2-D XCD tiles (fs_march.h band_coords): tile_waves wave columns x tile_rows field rows
+        const int rows_per_block = rt * (stacked ? 4 : 1), waves_per_block = stacked ? 1 : 4;
+        const int tbx = std::min(255, std::max(1, c->tile_waves / waves_per_block)), tby = std::min(256, std::max(1, c->tile_rows / rows_per_block));
+        o.grid = dim3(tile2d_blocks(o.nbx, o.nby, tbx, tby), zgroups, 1);
+        o.nbx |= tbx << 16;
+        o.nby |= (tby - 1) << 24;
+    } else if (c->xcd_mask & family) {
         const int group = stacked ? std::max(1, c->xcd_group / 4) : c->xcd_group;     // the same number of rows per XCD group
         o.grid = dim3(band_blocks(o.nbx, o.nby, group), zgroups, 1);
         o.nby |= (group - 1) << 24;
@@ -104,12 +149,34 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
     return o;
 }
 
+// Division-mode dispatch (fs_device.h DM_*): CALL(DM) is expanded for the modes a kernel family distinguishes; the reciprocal-FMA
+// modes (2, 3) exist for f32 only.
+#define FS_DM2(dm, CALL)      /* modes 0 / 2 : no dx-derived divisor                */ \
+    do { if constexpr (std::is_same<T, float>::value) { if ((dm) & 2) { CALL(2); break; } } CALL(0); } while (0)
+#define FS_DM3(dm, CALL)      /* modes 0 / 1 / 2 : dx-derived divisors only         */ \
+    do { if ((dm) & 1) { CALL(1); break; } if constexpr (std::is_same<T, float>::value) { if ((dm) & 2) { CALL(2); break; } } CALL(0); } while (0)
+#define FS_DM4(dm, CALL)      /* modes 0 / 1 / 2 / 3 : both kinds                   */ \
+    do { if constexpr (std::is_same<T, float>::value) { if (((dm) & 3) == 3) { CALL(3); break; } if ((dm) & 2) { CALL(2); break; } } \
+         if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
+
 template <bool SRC, typename T>
 static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
 {
     // overlapped-wave register tiles of 1, 2 or 4 rows (FS_JACOBI=21/22/24), 30 = LDS halo tile.  Default (0): the source-pair
     // form streams best with 1-row tiles at 8 waves/SIMD (76 vs 79 us), the v-reading form with 2-row tiles (89 vs 95 us)
     const int v = ctx->jacobi_variant ? ctx->jacobi_variant : (SRC ? 21 : 22);
+    if (v >= 100) {      // row-streaming form: FS_JACOBI = 100 * RING + rows per strip (e.g. 632 = ring of 6 slots, 32-row strips)
+        const int ring = v / 100, S = std::min(v % 100 ? v % 100 : 32, 62);
+        const int nwx = ctx->nwx, strips = (je - jb + S - 1) / S;       // S <= 62 (the activity masks are 64 bits)
+        const dim3 grid((nwx * strips + 3) / 4, 1, 1);
+        const uint8_t *act = ctx->d_rowact;
+        return launch(ctx, name, [=] {
+            if (ring == 4) hipLaunchKernelGGL((k_jacobi_stream<SRC, 4, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, nwx, S, jb, je, act, pn, pc, vs);
+            else if (ring == 5) hipLaunchKernelGGL((k_jacobi_stream<SRC, 5, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, nwx, S, jb, je, act, pn, pc, vs);
+            else if (ring == 8) hipLaunchKernelGGL((k_jacobi_stream<SRC, 8, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, nwx, S, jb, je, act, pn, pc, vs);
+            else hipLaunchKernelGGL((k_jacobi_stream<SRC, 6, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, nwx, S, jb, je, act, pn, pc, vs);
+        });
+    }
     if (v == 30) {
         constexpr int TY = 16;
         const dim3 grid((ctx->X + 255) / 256, (je - jb + TY - 1) / TY, 1);
@@ -119,11 +186,12 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
     }
     const int rt = v == 24 ? 4 : (v == 21 ? 1 : 2);
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
-    return launch(ctx, name, [=] {
-        if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
-        else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
-        else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs);
-    });
+    const int dm = SRC ? 0 : dm_const(ctx, k, RCP_JACOBI);           // the source-pair form divides nothing
+#define FS_JAC(DM) do { \
+        if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
+    return launch(ctx, name, [=] { FS_DM2(dm, FS_JAC); });
 }
 
 static int check_rows(const fs_ctx *c, int jb, int je)
@@ -183,13 +251,17 @@ struct DSU {
 
 static void free_ops(BcOpsDev &o)
 {
-    int **ptrs[] = {&o.comp_begin, &o.comp_rlo, &o.comp_rhi, &o.kind, &o.tgt, &o.s1, &o.s2};
+    int **ptrs[] = {&o.comp_begin, &o.comp_rlo, &o.comp_rhi, &o.kind, &o.tgt, &o.s1, &o.s2, &o.row, &o.srow};
     for (auto pp : ptrs) { if (*pp) hipFree(*pp); *pp = nullptr; }
-    o.ncomp = o.nops = 0;
+    if (o.simple) hipFree(o.simple);
+    o.simple = nullptr;
+    o.nsimple = o.ncomp = o.nops = 0;
 }
 
 // Group the serial-order op list into hazard components and upload it in local cell offsets.
-static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, int &reach, int min_radius)
+// `rows_in_z`: the simple-op record carries the ROW of source 1 in .z (velocity field: 2 channels, element offsets need the row)
+// instead of source 2 (pressure: offsets are element offsets as they are).
+static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, int &reach, int min_radius, bool rows_in_z)
 {
     free_ops(out);
     const int n = (int)ops.size();
@@ -226,7 +298,8 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
     auto local_row = [&](long long cell) { return (int)(cell % Y) - c->y0 + c->halo; };
     auto local_off = [&](long long cell) { return local_row(cell) * c->P + (int)(cell / Y); };
 
-    std::vector<int> h_begin, h_rlo, h_rhi, h_kind, h_tgt, h_s1, h_s2;
+    std::vector<int> h_begin, h_rlo, h_rhi, h_kind, h_tgt, h_s1, h_s2, h_row, h_srow;
+    std::vector<int4> h_simple;
     int pos = 0;
     while (pos < n) {
         int end = pos;
@@ -285,7 +358,16 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
             const int depth = r < c->halo ? c->halo - r : (r >= c->halo + c->nyl ? r - (c->halo + c->nyl) + 1 : 0);
             if (depth <= c->halo - min_radius) c->bc_incomplete = true;   // an owned row, or a ghost row the tracker may rely on
         }
-        if (!kept.empty()) {
+        if (kept.size() == 1) {        // the common case: one assignment, no hazard -> a flat 16-byte record
+            const HostOp &op = ops[kept[0]];
+            const int tr = local_row(op.t);
+            int4 r;
+            r.x = local_off(op.t);
+            r.y = op.s1 >= 0 ? local_off(op.s1) : -1;
+            r.z = rows_in_z ? (op.s1 >= 0 ? local_row(op.s1) : 0) : (op.s2 >= 0 ? local_off(op.s2) : -1);
+            r.w = op.kind | (tr << 2);
+            h_simple.push_back(r);
+        } else if (!kept.empty()) {
             int klo = INT32_MAX, khi = INT32_MIN;
             for (int o : kept) { const int tr = local_row(ops[o].t); klo = std::min(klo, tr); khi = std::max(khi, tr); }
             h_begin.push_back((int)h_kind.size());
@@ -297,6 +379,8 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
                 h_tgt.push_back(local_off(op.t));
                 h_s1.push_back(op.s1 >= 0 ? local_off(op.s1) : -1);
                 h_s2.push_back(op.s2 >= 0 ? local_off(op.s2) : -1);
+                h_row.push_back(local_row(op.t));
+                h_srow.push_back(op.s1 >= 0 ? local_row(op.s1) : 0);
             }
         }
         pos = end;
@@ -319,6 +403,11 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
     if ((rc = up(out.tgt, h_tgt))) return rc;
     if ((rc = up(out.s1, h_s1))) return rc;
     if ((rc = up(out.s2, h_s2))) return rc;
+    if ((rc = up(out.row, h_row))) return rc;
+    if ((rc = up(out.srow, h_srow))) return rc;
+    out.nsimple = (int)h_simple.size();
+    FS_HIP(hipMalloc(&out.simple, std::max<size_t>(h_simple.size(), 1) * sizeof(int4)));
+    if (!h_simple.empty()) FS_HIP(hipMemcpyAsync(out.simple, h_simple.data(), h_simple.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
     return FS_OK;
 }
@@ -371,9 +460,9 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
     c->bc_radius_vel = c->bc_radius_prs = 0;
     int rc, dummy = 0;
     // min_radius: the least radius the host tracker charges for the kernel (fs/runtime.py: max(2, .) / max(1, .) / 0)
-    if ((rc = upload_ops(c, vel, c->ops_vel, c->bc_radius_vel, 2))) return rc;
-    if ((rc = upload_ops(c, prs, c->ops_prs, c->bc_radius_prs, 1))) return rc;
-    if ((rc = upload_ops(c, dye, c->ops_dye, dummy, 0))) return rc;
+    if ((rc = upload_ops(c, vel, c->ops_vel, c->bc_radius_vel, 2, true))) return rc;
+    if ((rc = upload_ops(c, prs, c->ops_prs, c->bc_radius_prs, 1, false))) return rc;
+    if ((rc = upload_ops(c, dye, c->ops_dye, dummy, 0, true))) return rc;
     return FS_OK;
 }
 
@@ -412,8 +501,13 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     e = hipMalloc(&c->d_mask, (size_t)c->rows * c->Pm);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_mask, 1, (size_t)c->rows * c->Pm, c->stream);   // never the null stream: see upload_ops
     if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
+    c->nwx = (nx / 4 + 61) / 62;
+    if (e == hipSuccess) e = hipMalloc(&c->d_rowact, (size_t)std::max(c->nwx, 1) * c->rows);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_rowact, 0, (size_t)std::max(c->nwx, 1) * c->rows, c->stream);
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
+    if (const char *s = getenv("FS_RCP")) c->use_rcp = atoi(s);
+    if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
@@ -421,6 +515,9 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     c->stack_mask = XCD_RBSOR | XCD_ADVECT | XCD_GRAD;      // measured per family: K4 313 -> 301 us, K3 246 -> 243, RB-SOR 129 -> 127.5; the others lose 1 %
     if (const char *s = getenv("FS_STACK")) c->stack_mask = atoi(s);
     if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
+    if (const char *s = getenv("FS_TILE2D")) c->tile2d_mask = atoi(s);
+    if (const char *s = getenv("FS_TILE_ROWS")) { int v = atoi(s); if (v >= 1 && v <= 1024) c->tile_rows = v; }
+    if (const char *s = getenv("FS_TILE_WAVES")) { int v = atoi(s); if (v >= 1 && v <= 255) c->tile_waves = v; }
     if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows
     *out = c;
     return FS_OK;
@@ -438,13 +535,14 @@ int fs_destroy(fs_ctx *ctx)
     for (auto &r : ctx->prof_recs) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
     for (auto e : ctx->prof_pool) hipEventDestroy(e);
     free_ops(ctx->ops_vel); free_ops(ctx->ops_prs); free_ops(ctx->ops_dye);
-    for (fs_field *f : ctx->fields) { if (f->d) hipFree(f->d); delete f; }
+    for (fs_field *f : ctx->fields) { if (f->d) hipFree(f->d); if (f->hot) hipFree(f->hot); delete f; }
     ctx->fields.clear();
     if (ctx->d_mask) hipFree(ctx->d_mask);
     if (ctx->d_bc_const) hipFree(ctx->d_bc_const);
     if (ctx->d_bc_dye) hipFree(ctx->d_bc_dye);
     if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->d_acc) hipFree(ctx->d_acc);
+    if (ctx->d_rowact) hipFree(ctx->d_rowact);
     if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -523,6 +621,10 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     if (rc) return rc;
     rc = build_bc_ops(ctx, mask_xy);
     if (rc) return rc;
+    if (ctx->X % 4 == 0) {      // row-activity map of the row-streaming kernels
+        hipLaunchKernelGGL(k_row_activity, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_rowact);
+        FS_HIP(hipGetLastError());
+    }
     ctx->mask_set = true;
     return FS_OK;
 }
@@ -562,7 +664,9 @@ int fs_field_alloc(fs_ctx *ctx, int nchan, fs_field **out)
     f->bytes = (size_t)ctx->rows * nchan * ctx->P * ctx->esize;
     hipError_t e = hipMalloc(&f->d, f->bytes);
     if (e == hipSuccess) e = hipMemsetAsync(f->d, 0, f->bytes, ctx->stream);
-    if (e != hipSuccess) { delete f; return hip_fail(e, "hipMalloc(field)", __FILE__, __LINE__); }
+    if (e == hipSuccess) e = hipMalloc(&f->hot, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(f->hot, 0, sizeof(unsigned), ctx->stream);
+    if (e != hipSuccess) { if (f->d) hipFree(f->d); if (f->hot) hipFree(f->hot); delete f; return hip_fail(e, "hipMalloc(field)", __FILE__, __LINE__); }
     ctx->fields.insert(f);
     *out = f;
     return FS_OK;
@@ -575,6 +679,7 @@ int fs_field_free(fs_field *f)
     hipStreamSynchronize(f->ctx->stream);
     f->ctx->fields.erase(f);
     if (f->d) hipFree(f->d);
+    if (f->hot) hipFree(f->hot);
     delete f;
     return FS_OK;
 }
@@ -586,16 +691,27 @@ int fs_field_fill(fs_field *f, double value)
     FS_REQUIRE(f, "field is null");
     fs_ctx *ctx = f->ctx;
     const size_t n = f->bytes / ctx->esize;
+    const unsigned hot = 2.0 * value * value > (double)FS_HOT_SQ ? 1u : 0u;      // every channel takes `value`
     FS_DISPATCH(ctx, {
-        return launch(ctx, "fill", [=] { hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value); });
+        return launch(ctx, "fill", [=] {
+            hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value);
+            hipLaunchKernelGGL(k_fill<unsigned>, dim3(1), dim3(64), 0, ctx->stream, f->hot, (size_t)1, hot);
+        });
     })
 }
 
 int fs_field_upload(fs_field *f, const void *host_xrc, int row_begin, int nrows)
 {
     FS_REQUIRE(f, "field is null");
-    FS_HIP(hipSetDevice(f->ctx->device));
-    return upload_window(f->ctx, f->d, f->C, f->ctx->esize, host_xrc, row_begin, nrows, f->ctx->P);
+    fs_ctx *ctx = f->ctx;
+    FS_HIP(hipSetDevice(ctx->device));
+    int rc = upload_window(ctx, f->d, f->C, ctx->esize, host_xrc, row_begin, nrows, ctx->P);
+    if (rc || f->C != 2 || nrows == 0) return rc;
+    FS_DISPATCH(ctx, {      // what came in may exceed the speed the limit_field gate assumes: look at it (fs_device.h "hot" flag)
+        hipLaunchKernelGGL(k_scan_hot<T>, cells_grid(ctx, row_begin, row_begin + nrows), dim3(256), 0, ctx->stream, ctx->grid(), row_begin, (const T *)f->d, f->hot);
+    })
+    FS_HIP(hipGetLastError());
+    return FS_OK;
 }
 
 int fs_field_download(const fs_field *f, void *host_xrc, int row_begin, int nrows)
@@ -624,6 +740,7 @@ int fs_field_copy(fs_field *dst, const fs_field *src)
 {
     FS_REQUIRE(dst && src && dst->ctx == src->ctx && dst->C == src->C, "copy needs two fields of one context and shape");
     FS_HIP(hipMemcpyAsync(dst->d, src->d, src->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
+    FS_HIP(hipMemcpyAsync(dst->hot, src->hot, sizeof(unsigned), hipMemcpyDeviceToDevice, dst->ctx->stream));
     return FS_OK;
 }
 
@@ -652,11 +769,11 @@ int fs_velocity_bc(fs_ctx *ctx, fs_field *v, int row_begin, int row_end)
     FS_ROWS();
     if (!ctx->d_bc_const) { set_error("bc_const not uploaded"); return FS_ERR_STATE; }
     int rc = bc_guard(ctx); if (rc) return rc;
-    if (ctx->ops_vel.ncomp == 0) return FS_OK;
+    if (ctx->ops_vel.lanes() == 0) return FS_OK;
     FS_DISPATCH(ctx, {
         return launch(ctx, "velocity_bc", [=] {
-            hipLaunchKernelGGL(k_velocity_bc<T>, dim3((ctx->ops_vel.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
-                               ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, (T *)v->d, (const T *)ctx->d_bc_const);
+            hipLaunchKernelGGL(k_velocity_bc<T>, dim3((ctx->ops_vel.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, (T *)v->d, (const T *)ctx->d_bc_const, v->hot);
         });
     })
 }
@@ -667,10 +784,10 @@ int fs_pressure_bc(fs_ctx *ctx, fs_field *p, int row_begin, int row_end)
     FS_FIELD(p, 1);
     FS_ROWS();
     int rc = bc_guard(ctx); if (rc) return rc;
-    if (ctx->ops_prs.ncomp == 0) return FS_OK;
+    if (ctx->ops_prs.lanes() == 0) return FS_OK;
     FS_DISPATCH(ctx, {
         return launch(ctx, "pressure_bc", [=] {
-            hipLaunchKernelGGL(k_pressure_bc<T>, dim3((ctx->ops_prs.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_pressure_bc<T>, dim3((ctx->ops_prs.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_prs.view(), row_begin, row_end, (T *)p->d);
         });
     })
@@ -682,10 +799,10 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
     FS_FIELD(dye, 3);
     FS_ROWS();
     if (!ctx->d_bc_dye) { set_error("bc_dye not uploaded"); return FS_ERR_STATE; }
-    if (ctx->ops_dye.ncomp == 0) return FS_OK;
+    if (ctx->ops_dye.lanes() == 0) return FS_OK;
     FS_DISPATCH(ctx, {
         return launch(ctx, "dye_bc", [=] {
-            hipLaunchKernelGGL(k_dye_bc<T>, dim3((ctx->ops_dye.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_dye_bc<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T *)dye->d, (const T *)ctx->d_bc_dye);
         });
     })
@@ -698,7 +815,7 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
     });
 
 #define FS_K2M(SS, PP) hipLaunchKernelGGL((k_mac_update_quad<SS, PP, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
-            (T *)vn->d, (const T *)vc->d, (const T *)pc->d)
+            (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot)
 int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_field *vn, const fs_field *vc,
                   const fs_field *pc, int row_begin, int row_end)
 {
@@ -708,16 +825,17 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
     FS_REQUIRE(vn != vc, "vn must not alias vc");
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, re);
+        auto k = make_konst<T>(ctx, dt, dx, re);
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
-                if (scheme == FS_UPWIND) { if (k.p2) FS_K2M(0, true); else FS_K2M(0, false); }
-                else { if (k.p2) FS_K2M(1, true); else FS_K2M(1, false); }
+#define FS_K2M_UP(DM) FS_K2M(0, DM)
+#define FS_K2M_KK(DM) FS_K2M(1, DM)
+                if (scheme == FS_UPWIND) FS_DM4(dm_all(ctx, k, RCP_MAC), FS_K2M_UP); else FS_DM4(dm_all(ctx, k, RCP_MAC), FS_K2M_KK);
             });
         }
-        if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_update_upwind", (k_mac_update<0, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d) }
-        else { FS_LAUNCH_CELLS("mac_update_kk", (k_mac_update<1, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d) }
+        if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_update_upwind", (k_mac_update<0, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot) }
+        else { FS_LAUNCH_CELLS("mac_update_kk", (k_mac_update<1, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot) }
     })
 }
 
@@ -730,7 +848,7 @@ int fs_mac_dye(fs_ctx *ctx, int scheme, double dt, double dx, fs_field *dn, cons
     FS_REQUIRE(dn != dc, "dn must not alias dc");
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0);
         if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_dye_upwind", (k_mac_dye<0, T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d, (const T *)vc->d) }
         else { FS_LAUNCH_CELLS("mac_dye_kk", (k_mac_dye<1, T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d, (const T *)vc->d) }
     })
@@ -744,7 +862,7 @@ int fs_cip_set_grad(fs_ctx *ctx, double dx, fs_field *fx, fs_field *fy, const fs
     FS_FIELD(fx, C); FS_FIELD(fy, C); FS_FIELD(f, C);
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(1.0, dx, 1.0);
+        auto k = make_konst<T>(ctx, 1.0, dx, 1.0);
         if (C == 2) { FS_LAUNCH_CELLS("cip_set_grad", (k_cip_set_grad<2, T>), ctx->grid(), k, row_begin, (T *)fx->d, (T *)fy->d, (const T *)f->d) }
         else { FS_LAUNCH_CELLS("cip_set_grad_c3", (k_cip_set_grad<3, T>), ctx->grid(), k, row_begin, (T *)fx->d, (T *)fy->d, (const T *)f->d) }
     })
@@ -758,16 +876,16 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
     FS_REQUIRE(fn != fc, "fn must not alias fc");
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, re);
+        auto k = make_konst<T>(ctx, dt, dx, re);
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, "cip_nonadv", [=] {
-                if (k.p2) hipLaunchKernelGGL((k_cip_nonadv_quad<true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d);
-                else hipLaunchKernelGGL((k_cip_nonadv_quad<false, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d);
+#define FS_K2Q(DM) hipLaunchKernelGGL((k_cip_nonadv_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
+                FS_DM4(dm_all(ctx, k, RCP_K2), FS_K2Q);
             });
         }
-        if (k.p2) { FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<true, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d) }
-        FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<false, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d)
+        if (k.p2) { FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<true, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot) }
+        FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<false, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
     })
 }
 
@@ -778,12 +896,12 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
     FS_REQUIRE(dn != dc, "dn must not alias dc");
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, re);
+        auto k = make_konst<T>(ctx, dt, dx, re);
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, "cip_nonadv_dye", [=] {
-                if (k.p2) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d);
-                else hipLaunchKernelGGL((k_cip_nonadv_dye_quad<false, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d);
+#define FS_K12Q(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
+                FS_DM4(dm_all(ctx, k, RCP_DYE), FS_K12Q);
             });
         }
         FS_LAUNCH_CELLS("cip_nonadv_dye", (k_cip_nonadv_dye<T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d)
@@ -802,12 +920,13 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
     FS_FIELD(fxn, C); FS_FIELD(fyn, C); FS_FIELD(fxc, C); FS_FIELD(fyc, C); FS_FIELD(fc, C); FS_FIELD(fn, C);
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(1.0, dx, 1.0);
+        auto k = make_konst<T>(ctx, 1.0, dx, 1.0);
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, C == 2 ? 1 : 3, XCD_GRAD);
             return launch(ctx, C == 2 ? "cip_nonadv_grad" : "cip_nonadv_grad_c3", [=] {
-                if (C == 2) { if (k.p2) FS_K3Q(2, 2, true); else FS_K3Q(2, 2, false); }
-                else { if (k.p2) FS_K3Q(3, 1, true); else FS_K3Q(3, 1, false); }
+#define FS_K3Q_V(DM) FS_K3Q(2, 2, DM)
+#define FS_K3Q_D(DM) FS_K3Q(3, 1, DM)
+                if (C == 2) FS_DM3(dm_dx(ctx, k, RCP_K3), FS_K3Q_V); else FS_DM3(dm_dx(ctx, k, RCP_K3), FS_K3Q_D);
             });
         }
         if (C == 2 && k.p2) FS_K3(2, true, "cip_nonadv_grad")
@@ -818,11 +937,11 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
 }
 
 #define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, false, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
+        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
 #define FS_K4D(PP) hipLaunchKernelGGL((k_cip_advect_dye<PP, false, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
+        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
 #define FS_K4N(CC, PP) hipLaunchKernelGGL((k_cip_advect<CC, PP, T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, \
-        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d)
+        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
 int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
                   const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
 {
@@ -833,15 +952,17 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
     FS_REQUIRE(fn != fc && fxn != fxc && fyn != fyc, "outputs must not alias inputs");
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0);
         const bool self = (v == fc);
         const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, (C == 2 && !self) ? 2 : 1, XCD_ADVECT);   // C == 3: one pass over the channels
         const dim3 qgrid = og.grid;
         return launch(ctx, C == 2 ? "cip_advect" : "cip_advect_c3", [=] {
             if (ctx->use_march) {
-                if (C == 2 && self) { if (k.p2) FS_K4Q(2, 2, true, true); else FS_K4Q(2, 2, true, false); }
-                else if (C == 2) { if (k.p2) FS_K4Q(2, 1, false, true); else FS_K4Q(2, 1, false, false); }
-                else { if (k.p2) FS_K4D(true); else FS_K4D(false); }
+#define FS_K4Q_SELF(DM) FS_K4Q(2, 2, true, DM)
+#define FS_K4Q_OTHER(DM) FS_K4Q(2, 1, false, DM)
+                if (C == 2 && self) FS_DM3(dm_dx(ctx, k, RCP_K4), FS_K4Q_SELF);
+                else if (C == 2) FS_DM3(dm_dx(ctx, k, RCP_K4), FS_K4Q_OTHER);
+                else FS_DM3(dm_dx(ctx, k, RCP_K4), FS_K4D);
             } else {
                 if (C == 2) { if (k.p2) FS_K4N(2, true); else FS_K4N(2, false); }
                 else { if (k.p2) FS_K4N(3, true); else FS_K4N(3, false); }
@@ -851,7 +972,7 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
 }
 
 #define FS_K34(PP, EE) hipLaunchKernelGGL((k_cip_grad_advect<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
-                (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d)
+                (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
 int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
                               const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
 {
@@ -862,12 +983,11 @@ int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, f
     FS_ROWS();
     const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_ADVECT);
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0);
         return launch(ctx, "cip_advect_c3_clamped", [=] {
-            if (k.p2) hipLaunchKernelGGL((k_cip_advect_dye<true, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
-                                         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d);
-            else hipLaunchKernelGGL((k_cip_advect_dye<false, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
-                                    (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d);
+#define FS_K4DC(DM) hipLaunchKernelGGL((k_cip_advect_dye<DM, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+                                         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
+            FS_DM3(dm_dx(ctx, k, RCP_K4), FS_K4DC);
         });
     })
 }
@@ -878,17 +998,17 @@ int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row
     FS_FIELD(dye, 3);
     FS_ROWS();
     if (!ctx->d_bc_dye) { set_error("bc_dye not uploaded"); return FS_ERR_STATE; }
-    if (ctx->ops_dye.ncomp == 0) return FS_OK;
+    if (ctx->ops_dye.lanes() == 0) return FS_OK;
     FS_DISPATCH(ctx, {
         return launch(ctx, "clamp_inflow", [=] {
-            hipLaunchKernelGGL(k_clamp_inflow<T>, dim3((ctx->ops_dye.ncomp + 255) / 256), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_clamp_inflow<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T)low, (T)high, (T *)dye->d);
         });
     })
 }
 
 #define FS_K23(PP, EE) hipLaunchKernelGGL((k_cip_nonadv_fused<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
-                (T *)fn->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d)
+                (T *)fn->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, fn->hot)
 int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, fs_field *gx_out, fs_field *gy_out,
                         const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int row_begin, int row_end)
 {
@@ -900,7 +1020,7 @@ int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *
     const Grid gg = ctx->grid();
     const int in_lo = std::min(std::max(row_begin, gg.jlo + 2), row_end), in_hi = std::max(std::min(row_end, gg.jhi - 1), in_lo);
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, re);
+        auto k = make_konst<T>(ctx, dt, dx, re);
         auto run = [&](int jb, int je, bool edge) -> int {
             if (jb >= je) return FS_OK;
             const OvGrid og = ov_grid(ctx, jb, je, 1, 2, XCD_NONADV);
@@ -928,7 +1048,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
     const Grid gg = ctx->grid();
     const int in_lo = std::min(std::max(row_begin, gg.jlo + 2), row_end), in_hi = std::max(std::min(row_end, gg.jhi - 1), in_lo);
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0);
         auto run = [&](int jb, int je, bool edge) -> int {
             if (jb >= je) return FS_OK;
             const OvGrid og = ov_grid(ctx, jb, je, 1, 2, XCD_ADVECT);
@@ -951,7 +1071,7 @@ int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, con
     FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1); FS_FIELD(vc, 2);
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(1.0, dx, 1.0);
+        auto k = make_konst<T>(ctx, 1.0, dx, 1.0);
         FS_LAUNCH_CELLS("vort_calc", (k_vort_calc<T>), ctx->grid(), k, row_begin, (T *)vort->d, (T *)vort_abs->d, (const T *)vc->d)
     })
 }
@@ -963,8 +1083,8 @@ int fs_vort_add(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, 
     FS_FIELD(vn, 2); FS_FIELD(vc, 2); FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1);
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0, weight);
-        FS_LAUNCH_CELLS("vort_add", (k_vort_add<T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)vort->d, (const T *)vort_abs->d)
+        auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
+        FS_LAUNCH_CELLS("vort_add", (k_vort_add<T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)vort->d, (const T *)vort_abs->d, vn->hot)
     })
 }
 
@@ -987,14 +1107,14 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
     const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 1, XCD_VORT);
     const dim3 grid = og.grid;
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0, weight);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
         const bool p2 = k.p2 != 0;
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
         return launch(ctx, "vort_confine", [=] {
-            if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
-            else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
-            else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
-            else hipLaunchKernelGGL((k_vort_fused<RT, false, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa);
+            if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot);
+            else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot);
+            else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot);
+            else hipLaunchKernelGGL((k_vort_fused<RT, false, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot);
         });
     })
 }
@@ -1007,7 +1127,7 @@ int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_fi
     FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0);
         if (ctx->use_march) return launch_jacobi<false, T>(ctx, "jacobi_sweep", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
         FS_LAUNCH_CELLS("jacobi_sweep", (k_jacobi<false, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
     })
@@ -1020,7 +1140,7 @@ int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(1.0, 1.0, 1.0);
+        auto k = make_konst<T>(ctx, 1.0, 1.0, 1.0);
         if (ctx->use_march) return launch_jacobi<true, T>(ctx, "jacobi_sweep_src", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
         FS_LAUNCH_CELLS("jacobi_sweep_src", (k_jacobi<true, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
     })
@@ -1036,7 +1156,7 @@ int fs_rbsor_halfsweep(fs_ctx *ctx, double dt, double dx, double omega, int pari
     FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(vc, 2);
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0, 0.0, omega);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
         return launch(ctx, parity ? "rbsor_odd" : "rbsor_even", [=] {
             hipLaunchKernelGGL((k_rbsor<false, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
                                row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
@@ -1059,11 +1179,10 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
     constexpr int RT = 2;
     const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 1, XCD_RBSOR);
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0, 0.0, omega);
-        return launch(ctx, "rbsor_iteration", [=] {
-            hipLaunchKernelGGL((k_rbsor_fused<RT, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end,
-                               (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
-        });
+        auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
+#define FS_RBF(DM) hipLaunchKernelGGL((k_rbsor_fused<RT, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+                               (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
+        return launch(ctx, "rbsor_iteration", [=] { FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF); });
     })
 }
 
@@ -1075,7 +1194,7 @@ int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, 
     FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(1.0, 1.0, 1.0, 0.0, omega);
+        auto k = make_konst<T>(ctx, 1.0, 1.0, 1.0, 0.0, omega);
         return launch(ctx, parity ? "rbsor_odd_src" : "rbsor_even_src", [=] {
             hipLaunchKernelGGL((k_rbsor<true, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
                                row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
@@ -1090,7 +1209,7 @@ int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs
     FS_REQUIRE(src != vc, "src must not alias vc");
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0);
         FS_LAUNCH_CELLS("poisson_source", (k_poisson_source<T>), ctx->grid(), k, row_begin, (T *)src->d, (const T *)vc->d)
     })
 }
@@ -1111,7 +1230,7 @@ int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, co
     }
     int rc;
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(dt, dx, 1.0);
+        auto k = make_konst<T>(ctx, dt, dx, 1.0);
         rc = launch(ctx, "poisson_residual", [=] {
             hipLaunchKernelGGL((k_residual<T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end,
                                (const T *)p->d, (const T *)vc->d, ctx->d_partial);
@@ -1134,11 +1253,15 @@ int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int ro
     FS_FIELD(v, 2);
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        if (ctx->use_march)
+        if (ctx->use_march) {
+            // gated by the buffer's "hot" flag (fs_device.h): while no writer has stored a speed above 8 the pass has nothing to do
+            const int gated = (T)limit * (T)limit > (T)FS_HOT_SQ && ctx->limit_gate ? 1 : 0;
+            const int lanes = std::min(row_end - row_begin, 256);
             return launch(ctx, "limit_field", [=] {
-                hipLaunchKernelGGL((k_limit_quad<T>), dim3((ctx->X / 4 + 255) / 256, row_end - row_begin), dim3(256), 0, ctx->stream,
-                                   ctx->grid(), row_begin, (T)limit, (T *)v->d);
+                hipLaunchKernelGGL((k_limit_quad<T>), dim3((ctx->X / 4 + 255) / 256, lanes), dim3(256), 0, ctx->stream,
+                                   ctx->grid(), row_begin, row_end, (T)limit, (T *)v->d, v->hot, gated);
             });
+        }
         FS_LAUNCH_CELLS("limit_field", (k_limit<T>), ctx->grid(), row_begin, (T)limit, (T *)v->d)
     })
 }
@@ -1161,7 +1284,7 @@ static int visualize(fs_ctx *ctx, int mode, double dx, fs_field *rgb, const fs_f
 {
     static const char *names[4] = {"vis_norm", "vis_pressure", "vis_vorticity", "vis_dye"};
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(1.0, dx, 1.0);
+        auto k = make_konst<T>(ctx, 1.0, dx, 1.0);
         const T *pa = (const T *)a->d, *pb = b ? (const T *)b->d : nullptr;
         return launch(ctx, names[mode], [=] {
             const dim3 grid = cells_grid(ctx, row_begin, row_end);

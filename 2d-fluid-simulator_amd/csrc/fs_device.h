@@ -40,7 +40,57 @@ struct Konst {
     // x / d == x * (1/d) bit for bit (exact scaling); p2 switches those divisions to multiplications.
     int p2;
     T inv_dx, inv_two_dx, inv_dx_sq, inv_dx2_fold, inv_dx3_fold;
+    // Correctly rounded reciprocals RN(1/d) of the remaining loop-invariant divisors, and `rcp`: every divisor of this set (the
+    // dx-derived ones included) passed the exhaustive check that  q0 = x*r; e = fma(-q0, d, x); q = fma(e, r, q0)  equals the
+    // IEEE quotient x / d for all 2^23 significands of x (fs_api.hip rcp_verified; f32 only).  See rdiv() below.
+    int rcp;
+    T inv_six_dx, inv_eight_dt, inv_re;
 };
+
+// ---- division by loop-invariant divisors --------------------------------------------------------------------------------
+// HIP's IEEE f32 division expands to ~13 instructions (div_scale x2, rcp, 5 fma, div_fmas, div_fixup).  For a divisor d that
+// is constant over the launch three of them suffice: with r = RN(1/d), q0 = RN(x r), the remainder e = x - q0 d is exact in
+// an FMA and q = RN(q0 + e r) is the correctly rounded quotient (Markstein's division theorem; here additionally VERIFIED for
+// every significand of x on the device for each divisor actually used, fs_api.hip).  The identity needs x/d and e to be
+// normal numbers, so DivGuard tracks the smallest exponent among the dividends of a tile (zero is fine: the sign of a zero
+// quotient is taken from q0) and whether an output came out non-finite (inf / NaN dividends, overflow); a tile that saw
+// either is recomputed with the IEEE division before anything is stored - one wave-uniform branch per tile, never taken in
+// a healthy run.  Large finite dividends are exact as long as nothing overflows.
+// Mode bits of the kernels' DM template parameter:
+//   bit 0: the dx-derived divisors are powers of two  -> x * (1/d) is exact
+//   bit 1: reciprocal-FMA sequence for every other loop-invariant divisor (and for the dx-derived ones unless bit 0)
+constexpr int DM_IEEE = 0, DM_P2 = 1, DM_RCP = 2;
+struct DivGuard {
+    int emin;          // smallest binary exponent (frexp) among the dividends seen; zero, inf and NaN report 0
+    unsigned nonfin;   // an OUTPUT was inf / NaN (an inf dividend gives NaN here but inf in IEEE arithmetic; overflow of x * r likewise)
+    __device__ __forceinline__ DivGuard() : emin(0), nonfin(0u) {}
+    __device__ __forceinline__ void see(float x)
+    {
+        const int e = __builtin_amdgcn_frexp_expf(x);      // one instruction; 0 for +-0 (fine: the quotient is a zero of the right sign)
+        emin = e < emin ? e : emin;
+    }
+    __device__ __forceinline__ void out(float o) { nonfin |= (__float_as_uint(o) & 0x7f800000u) == 0x7f800000u ? 1u : 0u; }
+    __device__ __forceinline__ void see(double) {}
+    __device__ __forceinline__ void out(double) {}
+    // a dividend below 2^-60 in magnitude (denormals included): the remainder / the quotient may leave the normal range
+    __device__ __forceinline__ bool bad() const { return emin < -59 || nonfin != 0u; }
+};
+__device__ __forceinline__ float rdiv(float x, float d, float r, DivGuard &G)
+{
+    G.see(x);
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-q0, d, x);
+    const float q1 = __builtin_fmaf(e, r, q0);
+    // magnitude of q1, sign of q0 (x = -0 gives q1 = +0 but the quotient is -0): one v_bfi_b32
+    return __uint_as_float((__float_as_uint(q1) & 0x7fffffffu) | (__float_as_uint(q0) & 0x80000000u));
+}
+__device__ __forceinline__ double rdiv(double x, double d, double, DivGuard &) { return x / d; }   // f64: never selected (no exhaustive check)
+// x / d for a dx-derived divisor / for any other loop-invariant divisor
+template <int DM, typename T>
+__device__ __forceinline__ T xdiv(T x, T d, T inv_d, DivGuard &G) { return (DM & DM_P2) ? x * inv_d : ((DM & DM_RCP) ? rdiv(x, d, inv_d, G) : x / d); }
+template <int DM, typename T>
+__device__ __forceinline__ T cdiv(T x, T d, T inv_d, DivGuard &G) { return (DM & DM_RCP) ? rdiv(x, d, inv_d, G) : x / d; }
+
 
 template <typename T> __device__ __forceinline__ T tmin(T a, T b);
 template <typename T> __device__ __forceinline__ T tmax(T a, T b);
@@ -52,6 +102,18 @@ __device__ __forceinline__ float tsqrt(float a) { return sqrtf(a); }
 __device__ __forceinline__ double tsqrt(double a) { return sqrt(a); }
 __device__ __forceinline__ float tabs(float a) { return fabsf(a); }
 __device__ __forceinline__ double tabs(double a) { return fabs(a); }
+
+// ---- "hot" flag of a velocity buffer --------------------------------------------------------------------------------------
+// limit_field (fs/solver.py:38-43) rewrites the cells whose speed exceeds 10 - in a healthy run none, yet the pass reads the whole
+// velocity field every step (268 MB at res 4096).  Every kernel that writes a 2-channel field raises the buffer's flag word when
+// it stores a value with x*x + y*y > 64 (the same expression limit_field takes the square root of, so speed <= 8 is certain
+// otherwise); the flag is never cleared.  fs_limit_field exits at once while the flag is down (and the limit is above 8): the
+// result is the same for every input, the common case costs a 3 us launch instead of 47 us.  Uploads scan what they bring in,
+// ghost-row exchanges check what they unpack.  NaN never raises the flag - limit_field ignores NaN as well (NaN > limit is false).
+constexpr float FS_HOT_SQ = 64.0f;
+template <typename T> __device__ __forceinline__ bool hot2(T x, T y) { return x * x + y * y > (T)FS_HOT_SQ; }
+template <typename T> __device__ __forceinline__ bool hot1(T x) { return x * x > (T)(0.5f * FS_HOT_SQ); }      // one component alone
+__device__ __forceinline__ void raise_hot(unsigned *hot, bool h) { if (h) atomicOr(hot, 1u); }                  // rare: no wave logic
 
 // x / d with the exact-reciprocal shortcut (see Konst::p2)
 // P2 is a COMPILE-TIME switch: a run-time branch per division splits the kernel into basic blocks and

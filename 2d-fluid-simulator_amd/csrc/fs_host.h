@@ -35,10 +35,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
     } while (0)
 
 struct BcOpsDev {
-    int ncomp = 0, nops = 0;
+    int nsimple = 0, ncomp = 0, nops = 0;
+    int4 *simple = nullptr;
     int *comp_begin = nullptr, *comp_rlo = nullptr, *comp_rhi = nullptr;
-    int *kind = nullptr, *tgt = nullptr, *s1 = nullptr, *s2 = nullptr;
-    BcOps view() const { return BcOps{ncomp, comp_begin, comp_rlo, comp_rhi, kind, tgt, s1, s2}; }
+    int *kind = nullptr, *tgt = nullptr, *s1 = nullptr, *s2 = nullptr, *row = nullptr, *srow = nullptr;
+    int lanes() const { return nsimple + ncomp; }
+    BcOps view() const { return BcOps{nsimple, simple, ncomp, comp_begin, comp_rlo, comp_rhi, kind, tgt, s1, s2, row, srow}; }
 };
 
 struct ProfRec {
@@ -62,6 +64,8 @@ struct fs_ctx {
     size_t esize = 4;
     hipStream_t stream = nullptr;
     uint8_t *d_mask = nullptr;
+    uint8_t *d_rowact = nullptr;   // [nwx][rows] row-activity map of the row-streaming kernels (fs_march.h k_row_activity)
+    int nwx = 0;                   // wave columns of 62 quads across a row
     void *d_bc_const = nullptr, *d_bc_dye = nullptr;
     bool mask_set = false, bc_incomplete = false;
     int bc_radius_vel = 0, bc_radius_prs = 0;   // rows of pre-kernel data a rewritten boundary cell depends on
@@ -91,9 +95,18 @@ struct fs_ctx {
     std::set<fs_field *> fields;  // live fields, released with the context
     // tuning knobs (env FS_MARCH=0: one-cell-per-lane kernels only)
     bool use_march = true;
+    // Kernel families that use the reciprocal-FMA division for loop-invariant divisors (fs_device.h rdiv; env FS_RCP = bit mask).
+    // HIP's IEEE f32 division is ~10 instructions here, the sequence + range guard 6: measured on MI355X it only pays where the
+    // kernel is issue-bound - Kawamura-Kuwahara MAC update 227 -> 207 us (8 divisions by 6dx / Re per cell) - and is neutral to
+    // slightly negative for the bandwidth-bound kernels (RB-SOR 136 -> 134, K2 116 -> 122, Jacobi 88 -> 91; K4 at a
+    // non-power-of-two dx 78 -> 105 us: 244 VGPRs).  Default: the MAC update only.
+    int use_rcp = 1;           // RCP_MAC
+    bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int stack_mask = 0;       // env FS_STACK: kernel families (XCD_* bits) launched with stacked workgroups
+    int tile2d_mask = 0;      // env FS_TILE2D: kernel families dealt to the XCDs as 2-D tiles (tile_waves wave columns x tile_rows rows)
+    int tile_rows = 32, tile_waves = 4;   // env FS_TILE_ROWS / FS_TILE_WAVES
     bool pack_halo = true;    // env FS_PACK_HALO=0: one ncclSend/ncclRecv per field instead of one packed message per neighbour
     int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default, 22 / 24 / 21 = overlapped-wave tiles of 2 / 4 / 1 rows, 30 = LDS tile
 
@@ -115,6 +128,7 @@ struct fs_field {
     int C = 1;
     void *d = nullptr;
     size_t bytes = 0;
+    unsigned *hot = nullptr;   // device word: "may hold a speed above 8" (fs_device.h); meaningful for 2-channel fields
 };
 
 namespace fs {
@@ -127,8 +141,14 @@ inline bool is_pow2(T x)
     return x > 0 && std::frexp(x, &e) == (T)0.5;
 }
 
+// f32: is  q0 = x*r; e = fma(-q0, d, x); q = fma(e, r, q0)  (r = RN(1/d)) bit-identical to x / d for EVERY significand of x on
+// this device?  Checked exhaustively by a kernel once per divisor value and cached (fs_api.hip).  `may_verify` = false (graph
+// capture in progress) answers from the cache only.
+bool rcp_verified(fs_ctx *ctx, float d, bool may_verify);
+inline bool rcp_verified(fs_ctx *, double, bool) { return false; }     // f64: 2^52 significands - keeps the IEEE division
+
 template <typename T>
-inline Konst<T> make_konst(double dt, double dx, double re, double weight = 0.0, double omega = 0.0)
+inline Konst<T> make_konst(fs_ctx *ctx, double dt, double dx, double re, double weight = 0.0, double omega = 0.0)
 {
     Konst<T> k;
     k.dt = (T)dt; k.dx = (T)dx; k.re = (T)re;
@@ -148,8 +168,30 @@ inline Konst<T> make_konst(double dt, double dx, double re, double weight = 0.0,
     k.inv_dx_sq = (T)1 / k.dx_sq;
     k.inv_dx2_fold = (T)1 / k.dx2_fold;
     k.inv_dx3_fold = (T)1 / k.dx3_fold;
+    k.inv_six_dx = (T)1 / k.six_dx;
+    k.inv_eight_dt = (T)1 / k.eight_dt;
+    k.inv_re = (T)1 / k.re;
+    // reciprocal-FMA division (fs_device.h rdiv): every divisor of the set must be a normal number of moderate magnitude (the
+    // range check of the dividends assumes 2^-66 <= |d| <= 2^66) and must have passed the exhaustive check on the device
+    k.rcp = 0;
+    if (ctx && ctx->use_rcp != 0 && sizeof(T) == 4) {
+        const T ds[8] = {k.dx, k.two_dx, k.dx_sq, k.dx2_fold, k.dx3_fold, k.six_dx, k.eight_dt, k.re};
+        bool ok = true;
+        for (T d : ds) {
+            const double a = std::fabs((double)d);
+            ok = ok && a >= 0x1p-66 && a <= 0x1p66 && rcp_verified(ctx, d, !ctx->capturing);
+        }
+        k.rcp = ok ? 1 : 0;
+    }
     return k;
 }
+
+// division mode of a launch (fs_device.h): which kernels have which kinds of divisors decides how many modes they instantiate
+enum { RCP_MAC = 1, RCP_K2 = 2, RCP_K3 = 4, RCP_K4 = 8, RCP_RBSOR = 16, RCP_JACOBI = 32, RCP_DYE = 64 };
+template <typename T> inline bool rcp_on(const fs_ctx *c, const Konst<T> &k, int family) { return k.rcp && (c->use_rcp & family); }
+template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k, int f) { return (k.p2 ? DM_P2 : 0) | (rcp_on(c, k, f) ? DM_RCP : 0); }      // dx-derived AND other divisors
+template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k, int f) { return k.p2 ? DM_P2 : (rcp_on(c, k, f) ? DM_RCP : DM_IEEE); }       // dx-derived divisors only
+template <typename T> inline int dm_const(const fs_ctx *c, const Konst<T> &k, int f) { return rcp_on(c, k, f) ? DM_RCP : DM_IEEE; }                     // no dx-derived divisor
 
 
 }  // namespace fs

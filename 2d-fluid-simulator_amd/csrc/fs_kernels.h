@@ -62,18 +62,21 @@ __device__ __forceinline__ T advect(const T *phi, const Grid &g, const Konst<T> 
 // K2'  MacSolver._update_velocities, fs/solver.py:94-107  (fluid cells)
 // ------------------------------------------------------------------------------------------------
 template <int SCHEME, typename T>
-__global__ __launch_bounds__(256) void k_mac_update(Grid g, Konst<T> k, int jb, T *vn, const T *vc, const T *pc)
+__global__ __launch_bounds__(256) void k_mac_update(Grid g, Konst<T> k, int jb, T *vn, const T *vc, const T *pc, unsigned *hot)
 {
     FS_CELL_PROLOGUE
     if (mask_at(g, i, j) != 0) return;
     const T ux = at<2>(vc, g, 0, i, j), uy = at<2>(vc, g, 1, i, j);
     const T gp[2] = {diff_x<1>(pc, g, k, 0, i, j), diff_y<1>(pc, g, k, 0, i, j)};
+    T o[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         T a = advect<SCHEME, 2>(vc, g, k, ux, uy, c, i, j);
         T lap = (diff2_x<2>(vc, g, k, c, i, j) + diff2_y<2>(vc, g, k, c, i, j)) / k.re;
-        vn[idx<2, T>(g, c, i, j)] = (c == 0 ? ux : uy) + k.dt * (((-a) - gp[c]) + lap);
+        o[c] = (c == 0 ? ux : uy) + k.dt * (((-a) - gp[c]) + lap);
+        vn[idx<2, T>(g, c, i, j)] = o[c];
     }
+    raise_hot(hot, hot2(o[0], o[1]));
 }
 
 // K11  DyeMacSolver._update_dye, fs/solver.py:157-161
@@ -104,17 +107,20 @@ __global__ __launch_bounds__(256) void k_cip_set_grad(Grid g, Konst<T> k, int jb
 
 // K2  CipMacSolver._non_advection_phase (+ _calc_diffusion), fs/solver.py:229-240, 263-265  (not-wall cells)
 template <bool P2, typename T>
-__global__ __launch_bounds__(256) void k_cip_nonadv(Grid g, Konst<T> k, int jb, T *fn, const T *fc, const T *pc)
+__global__ __launch_bounds__(256) void k_cip_nonadv(Grid g, Konst<T> k, int jb, T *fn, const T *fc, const T *pc, unsigned *hot)
 {
     FS_CELL_PROLOGUE
     if (mask_at(g, i, j) == 1) return;
     const T gp[2] = {diff_x<1, P2>(pc, g, k, 0, i, j), diff_y<1, P2>(pc, g, k, 0, i, j)};
+    T o[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         T dif = (diff2_x<2, P2>(fc, g, k, c, i, j) + diff2_y<2, P2>(fc, g, k, c, i, j)) / k.re;
         T gg = (-gp[c]) + dif;
-        fn[idx<2, T>(g, c, i, j)] = at<2>(fc, g, c, i, j) + gg * k.dt;
+        o[c] = at<2>(fc, g, c, i, j) + gg * k.dt;
+        fn[idx<2, T>(g, c, i, j)] = o[c];
     }
+    raise_hot(hot, hot2(o[0], o[1]));
 }
 
 // K12  DyeCipMacSolver._non_advection_phase_dye, fs/solver.py:378-383
@@ -150,26 +156,26 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad(Grid g, Konst<T> k, int
 // _cip_advect for one cell and one channel, fs/solver.py:282-332, on already-gathered values:
 //   f00 = f[i,j], f0m = f[i,j_m], fm0 = f[i_m,j], fmm = f[i_m,j_m]  with the upwind cell (i_m, j_m) = (i - sign(u), j - sign(v));
 //   likewise the x- / y-gradient fields; (vx, vy) the advecting velocity, d?? its central differences.
-template <bool P2, typename T>
+template <int DM, typename T>
 __device__ __forceinline__ void cip_point(const Konst<T> &k, T vx, T vy, T dxx, T dxy, T dyx, T dyy,
                                           T f00, T f0m, T fm0, T fmm, T fx00, T fxm0, T fx0m, T fy00, T fy0m, T fym0,
-                                          T &out_f, T &out_fx, T &out_fy)
+                                          T &out_f, T &out_fx, T &out_fy, DivGuard &G)
 {
     const T is = vx < (T)0.0 ? (T)-1 : (T)1;   // sign(0) = +1, fs/differentiation.py:12-14
     const T js = vy < (T)0.0 ? (T)-1 : (T)1;
     const T i_s_denom = is * k.dx3_fold, j_s_denom = js * k.dx3_fold, is_dx = is * k.dx;
-    const T i_s_inv = is * k.inv_dx3_fold, j_s_inv = js * k.inv_dx3_fold, is_dx_inv = is * k.inv_dx;   // exact when p2
+    const T i_s_inv = is * k.inv_dx3_fold, j_s_inv = js * k.inv_dx3_fold, is_dx_inv = is * k.inv_dx;   // +-1 times the reciprocal: exact
     const T Xd = (-vx) * k.dt, Yd = (-vy) * k.dt;
     const T tmp1 = ((f00 - f0m) - fm0) + fmm;
     const T tmp2 = fm0 - f00;
     const T tmp3 = f0m - f00;
-    const T a = qdiv<P2>((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2), i_s_denom, i_s_inv);
-    const T b = qdiv<P2>((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3), j_s_denom, j_s_inv);
-    const T cc = qdiv<P2>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv);
-    const T d = qdiv<P2>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv);
-    const T e = qdiv<P2>((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold);
-    const T f = qdiv<P2>((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold);
-    const T gq = qdiv<P2>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv);
+    const T a = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2), i_s_denom, i_s_inv, G);
+    const T b = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3), j_s_denom, j_s_inv, G);
+    const T cc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv, G);
+    const T d = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv, G);
+    const T e = xdiv<DM>((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, G);
+    const T f = xdiv<DM>((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, G);
+    const T gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, G);
     out_f = (((((a * Xd + cc * Yd) + e) * Xd + gq * Yd) + fx00) * Xd + (((b * Yd + d * Xd) + f) * Yd + fy00) * Yd) + f00;
     const T Fx = ((((T)3.0 * a) * Xd + ((T)2.0 * cc) * Yd) + (T)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
     const T Fy = ((((T)3.0 * b) * Yd + ((T)2.0 * d) * Xd) + (T)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;
@@ -180,7 +186,7 @@ __device__ __forceinline__ void cip_point(const Konst<T> &k, T vx, T vy, T dxx, 
 // K4  _advection_phase / _cip_advect, fs/solver.py:267-332  (fluid cells; C channels advected by v), one cell per lane
 template <int C, bool P2, typename T>
 __global__ __launch_bounds__(256) void k_cip_advect(Grid g, Konst<T> k, int jb, T *fn, T *fxn, T *fyn,
-                                                    const T *fc, const T *fxc, const T *fyc, const T *v)
+                                                    const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
 {
     FS_CELL_PROLOGUE
     if (mask_at(g, i, j) != 0) return;
@@ -191,13 +197,15 @@ __global__ __launch_bounds__(256) void k_cip_advect(Grid g, Konst<T> k, int jb, 
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         T of, ofx, ofy;
-        cip_point<P2>(k, vx, vy, dxx, dxy, dyx, dyy,
+        DivGuard G;      // unused: the one-cell-per-lane kernels divide by IEEE division or exact multiplication only
+        cip_point<P2 ? DM_P2 : DM_IEEE>(k, vx, vy, dxx, dxy, dyx, dyy,
                   at<C>(fc, g, c, i, j), smp<C>(fc, g, c, i, jm), smp<C>(fc, g, c, im, j), smp<C>(fc, g, c, im, jm),
                   at<C>(fxc, g, c, i, j), smp<C>(fxc, g, c, im, j), smp<C>(fxc, g, c, i, jm),
-                  at<C>(fyc, g, c, i, j), smp<C>(fyc, g, c, i, jm), smp<C>(fyc, g, c, im, j), of, ofx, ofy);
+                  at<C>(fyc, g, c, i, j), smp<C>(fyc, g, c, i, jm), smp<C>(fyc, g, c, im, j), of, ofx, ofy, G);
         fn[idx<C, T>(g, c, i, j)] = of;
         fxn[idx<C, T>(g, c, i, j)] = ofx;
         fyn[idx<C, T>(g, c, i, j)] = ofy;
+        if (C == 2) raise_hot(hot, hot1(of));      // (velocity field; the dye passes hot = nullptr-free C == 3)
     }
 }
 
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void k_vort_calc(Grid g, Konst<T> k, int jb, T
 // K6  _add_vorticity + _vorticity_vec, fs/vorticity_confinement.py:34-55.  |grad| == 0 gives 0/0 = NaN and the
 // NaN-ignoring min/max (fminf/fmaxf) turn it into +0.1 on both components.
 template <typename T>
-__global__ __launch_bounds__(256) void k_vort_add(Grid g, Konst<T> k, int jb, T *vn, const T *vc, const T *vort, const T *vort_abs)
+__global__ __launch_bounds__(256) void k_vort_add(Grid g, Konst<T> k, int jb, T *vn, const T *vc, const T *vort, const T *vort_abs, unsigned *hot)
 {
     FS_CELL_PROLOGUE
     if (mask_at(g, i, j) != 0) return;
@@ -229,8 +237,10 @@ __global__ __launch_bounds__(256) void k_vort_add(Grid g, Konst<T> k, int jb, T 
     T f0 = gy * w, f1 = (-gx) * w;
     f0 = tmax(tmin(f0, (T)0.1), (T)-0.1);
     f1 = tmax(tmin(f1, (T)0.1), (T)-0.1);
-    vn[idx<2, T>(g, 0, i, j)] = at<2>(vc, g, 0, i, j) + k.dtw * f0;
-    vn[idx<2, T>(g, 1, i, j)] = at<2>(vc, g, 1, i, j) + k.dtw * f1;
+    const T ox = at<2>(vc, g, 0, i, j) + k.dtw * f0, oy = at<2>(vc, g, 1, i, j) + k.dtw * f1;
+    vn[idx<2, T>(g, 0, i, j)] = ox;
+    vn[idx<2, T>(g, 1, i, j)] = oy;
+    raise_hot(hot, hot2(ox, oy));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,6 +372,14 @@ __global__ __launch_bounds__(256) void k_limit(Grid g, int jb, T lim, T *v)
     }
 }
 
+// raise the flag of a 2-channel field for what is stored in rows [jb, je) (after an upload / a direct ghost-row transfer)
+template <typename T>
+__global__ __launch_bounds__(256) void k_scan_hot(Grid g, int jb, const T *v, unsigned *hot)
+{
+    FS_CELL_PROLOGUE
+    raise_hot(hot, hot2(at<2>(v, g, 0, i, j), at<2>(v, g, 1, i, j)));
+}
+
 template <int C, typename T>
 __global__ __launch_bounds__(256) void k_clamp(Grid g, int jb, T lo, T hi, T *f)
 {
@@ -420,6 +438,11 @@ __global__ __launch_bounds__(256) void k_visualize(Grid g, Konst<T> k, int jb, T
 // exactly the serial one for any mask.
 // ------------------------------------------------------------------------------------------------
 struct BcOps {
+    // components of ONE assignment (nearly all of them): {target cell, source 1, source 2, kind | row << 2} - one 16-byte load per
+    // lane, then the data, then the store: two dependent memory round trips instead of four (the kernels are pure latency)
+    int nsimple;
+    const int4 *simple;
+    // hazard components (several assignments that must run in serial order)
     int ncomp;
     const int *comp_begin;  // [ncomp + 1] into the op arrays
     const int *comp_rlo;    // [ncomp] min / max local target row of the component
@@ -427,42 +450,69 @@ struct BcOps {
     const int *kind;        // per op
     const int *tgt;         // per op: cell offset j*P + i (channel 0 of a C=1 field; scaled by the kernels)
     const int *s1, *s2;     // per op: source cell offsets (or -1)
+    const int *row;         // per op: local row of the target (saves the kernels a division by the pitch)
+    const int *srow;        // per op: local row of source 1
 };
 
-__device__ __forceinline__ size_t cell_off(const Grid &g, int cell, int C, int c)
-{
-    int j = cell / g.P, i = cell - j * g.P;
-    return ((size_t)j * C + c) * g.P + i;
-}
+// element offset of channel c of the cell at C=1 offset `cell` in local row `row`, for a C-channel field
+__device__ __forceinline__ size_t cell_off(const Grid &g, int cell, int row, int C, int c)
+{ return ((size_t)row * C + c) * g.P + (cell - row * g.P); }
 
 // K1  set_velocity_boundary_condition, fs/boundary_condition.py:16-39
 //   kind 0: v[t] = -v[s1] (mirror into the 2nd wall layer), 1: v[t] = bc_const[t], 2: v[t].x = max(v[s1].x, 0.05)
 template <typename T>
-__global__ __launch_bounds__(256) void k_velocity_bc(Grid g, BcOps ops, int jb, int je, T *v, const T *bc_const)
+__device__ __forceinline__ void velocity_bc_op(const Grid &g, int kind, int t, int trow, int s, int srow, T *v, const T *bc_const, unsigned *hot)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kind == 0) {             // a copy (negated) of a cell of the same buffer: cannot raise the buffer's maximum speed
+        v[cell_off(g, t, trow, 2, 0)] = -v[cell_off(g, s, srow, 2, 0)];
+        v[cell_off(g, t, trow, 2, 1)] = -v[cell_off(g, s, srow, 2, 1)];
+    } else if (kind == 1) {
+        const T x = bc_const[cell_off(g, t, trow, 2, 0)], y = bc_const[cell_off(g, t, trow, 2, 1)];
+        v[cell_off(g, t, trow, 2, 0)] = x;
+        v[cell_off(g, t, trow, 2, 1)] = y;
+        raise_hot(hot, hot2(x, y));
+    } else {                     // x from the neighbour, y stays: a NEW pair
+        const T x = tmax(v[cell_off(g, s, srow, 2, 0)], (T)0.05);
+        v[cell_off(g, t, trow, 2, 0)] = x;
+        raise_hot(hot, hot2(x, v[cell_off(g, t, trow, 2, 1)]));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_velocity_bc(Grid g, BcOps ops, int jb, int je, T *v, const T *bc_const, unsigned *hot)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < ops.nsimple) {
+        const int4 o = ops.simple[n];
+        const int trow = o.w >> 2;
+        if (trow < jb || trow >= je) return;
+        // a simple mirror / outflow op reads a cell of the same row or of the row +-2 / +-1 next to it: its row travels in .z
+        velocity_bc_op(g, o.w & 3, o.x, trow, o.y, o.z, v, bc_const, hot);
+        return;
+    }
+    n -= ops.nsimple;
     if (n >= ops.ncomp) return;
     if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
-    for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {
-        const int kind = ops.kind[o], t = ops.tgt[o], s = ops.s1[o];
-        if (kind == 0) {
-            v[cell_off(g, t, 2, 0)] = -v[cell_off(g, s, 2, 0)];
-            v[cell_off(g, t, 2, 1)] = -v[cell_off(g, s, 2, 1)];
-        } else if (kind == 1) {
-            v[cell_off(g, t, 2, 0)] = bc_const[cell_off(g, t, 2, 0)];
-            v[cell_off(g, t, 2, 1)] = bc_const[cell_off(g, t, 2, 1)];
-        } else {
-            v[cell_off(g, t, 2, 0)] = tmax(v[cell_off(g, s, 2, 0)], (T)0.05);
-        }
-    }
+    for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o)
+        velocity_bc_op(g, ops.kind[o], ops.tgt[o], ops.row[o], ops.s1[o], ops.srow[o], v, bc_const, hot);
 }
 
 // K7  set_pressure_boundary_condition, fs/boundary_condition.py:41-65
-//   kind 0: p[t] = p[s1], 1: p[t] = (p[s1] + p[s2]) / 2, 2: p[t] = 0
+//   kind 0: p[t] = p[s1], 1: p[t] = (p[s1] + p[s2]) / 2, 2: p[t] = 0          (C = 1: cell offsets are element offsets)
 template <typename T>
 __global__ __launch_bounds__(256) void k_pressure_bc(Grid g, BcOps ops, int jb, int je, T *p)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < ops.nsimple) {
+        const int4 o = ops.simple[n];
+        const int trow = o.w >> 2, kind = o.w & 3;
+        if (trow < jb || trow >= je) return;
+        T val = (T)0.0;
+        if (kind == 0) val = p[o.y];
+        else if (kind == 1) val = (p[o.y] + p[o.z]) / (T)2.0;
+        p[o.x] = val;
+        return;
+    }
+    n -= ops.nsimple;
     if (n >= ops.ncomp) return;
     if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
     for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {
@@ -475,18 +525,17 @@ __global__ __launch_bounds__(256) void k_pressure_bc(Grid g, BcOps ops, int jb, 
     }
 }
 
-// K10  set_dye_boundary_condition, fs/boundary_condition.py:94-99:  dye[t] = bc_dye[t] on inflow cells
+// K10  set_dye_boundary_condition, fs/boundary_condition.py:94-99:  dye[t] = bc_dye[t] on inflow cells (never hazardous: all simple)
 template <typename T>
 __global__ __launch_bounds__(256) void k_dye_bc(Grid g, BcOps ops, int jb, int je, T *dye, const T *bc_dye)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= ops.ncomp) return;
-    if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
-    for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {
-        const int t = ops.tgt[o];
+    if (n >= ops.nsimple) return;
+    const int4 o = ops.simple[n];
+    const int trow = o.w >> 2;
+    if (trow < jb || trow >= je) return;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dye[cell_off(g, t, 3, c)] = bc_dye[cell_off(g, t, 3, c)];
-    }
+    for (int c = 0; c < 3; ++c) dye[cell_off(g, o.x, trow, 3, c)] = bc_dye[cell_off(g, o.x, trow, 3, c)];
 }
 
 // ------------------------------------------------------------------------------------------------

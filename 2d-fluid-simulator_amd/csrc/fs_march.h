@@ -24,6 +24,10 @@ template <typename T> struct Quad;
 template <> struct Quad<float> { using type = float4; };
 template <> struct Quad<double> { using type = double4; };
 
+// an address the optimiser knows nothing about (same value): loads through it are not merged with earlier loads of the same data
+template <typename P>
+__device__ __forceinline__ P *opaque(P *p) { asm volatile("" : "+s"(p)); return p; }
+
 // value of the previous / next lane (undefined in lane 0 / lane 63: the caller patches those)
 __device__ __forceinline__ float lane_prev(float x)
 { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, false)); }   // wave_shr:1
@@ -82,12 +86,12 @@ template <typename T>
 __device__ __forceinline__ T predict_from(T pE, T pW, T pN, T pS, T s2, T s3)
 { return ((T)0.25 * (((pE + pW) + pN) + pS) + s2) - s3; }
 
-template <typename T>
-__device__ __forceinline__ void source_from(const Konst<T> &k, T vxE, T vxW, T vyE, T vyW, T vxN, T vxS, T vyN, T vyS, T &s2, T &s3)
+template <int DM, typename T>
+__device__ __forceinline__ void source_from(const Konst<T> &k, T vxE, T vxW, T vyE, T vyW, T vxN, T vxS, T vyN, T vyS, T &s2, T &s3, DivGuard &G)
 {
     T sxx = vxE - vxW, sxy = vyE - vyW, syx = vxN - vxS, syy = vyN - vyS;
     s2 = ((sxx * sxx + syy * syy) + (syx * sxy)) / (T)8.0;
-    s3 = (k.dx * (sxx + syy)) / k.eight_dt;
+    s3 = cdiv<DM>(k.dx * (sxx + syy), k.eight_dt, k.inv_eight_dt, G);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -118,6 +122,26 @@ __device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, in
         return by < nby;
     }
     const int id = blockIdx.x, xcd = id & 7, t = id >> 3;
+    const int tbx = (nbx >> 16) & 0xff;
+    if (tbx) {
+        // 2-D XCD tiles: the block grid is cut into tiles of tbx x tby blocks (x fastest), tile T runs on XCD T % 8 as that XCD's
+        // (T / 8)-th tile, row-major inside the tile.  A tile is tall (tby block rows = 32 field rows or more) and narrow, so the
+        // halo rows that vertically adjacent tile rows re-read stay in the XCD's 4 MiB L2, and only the 1 - 2 rows at the top and
+        // bottom EDGE of a tile are fetched by two XCDs: (32 + 2) / 32 of the rows instead of the (8 + 2) / 8 of full-width groups
+        // of 8 rows - which is what the rocprof traffic counters showed (1.21x - 1.32x the algorithmic bytes).  Tiles are small
+        // (32 blocks) and dealt cyclically, so walls stay balanced across the XCDs.
+        nbx &= 0xffff;
+        const int tby = FS_XCD_GROUP, per_tile = tbx * tby;
+        const int ntx = (nbx + tbx - 1) / tbx, nty = (nby + tby - 1) / tby;
+        const int tl = t / per_tile, rem = t - tl * per_tile;
+        const int T = tl * 8 + xcd;
+        if (T >= ntx * nty) return false;
+        const int ty = T / ntx, tx = T - ty * ntx;
+        const int ly = rem / tbx, lx = rem - ly * tbx;
+        bx = tx * tbx + lx;
+        by = ty * tby + ly;
+        return bx < nbx && by < nby;
+    }
     const int per_group = FS_XCD_GROUP * nbx;
     const int lg = t / per_group, rem = t - lg * per_group;
     const int ly = rem / nbx;
@@ -137,6 +161,11 @@ __device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_pack
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }
     return wave_x * 62 < (g.X >> 2) && jb + tile_y * rt < je;
+}
+static inline int tile2d_blocks(int nbx, int nby, int tbx, int tby)
+{
+    const int ntx = (nbx + tbx - 1) / tbx, nty = (nby + tby - 1) / tby;
+    return 8 * ((ntx * nty + 7) / 8) * tbx * tby;
 }
 static inline int band_blocks(int nbx, int nby, int FS_XCD_GROUP)
 {
@@ -180,7 +209,7 @@ __device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return P2 ? x * k.
 // VorticityConfinement; the unfused pair of kernels remains available and is what parity tests compare with).
 // ------------------------------------------------------------------------------------------------
 template <int RT, bool P2, bool STORE_W, typename T>
-__global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs)
+__global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot)
 {
     using V = typename Quad<T>::type;
     int bx, by;
@@ -258,6 +287,7 @@ __global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx,
         FS_VC_CELL(w, ar, a.z)
 #undef FS_VC_CELL
         if (lm.owner && f) {
+            raise_hot(hot, ((f & 1u) && hot2(ox.x, oy.x)) || ((f & 2u) && hot2(ox.y, oy.y)) || ((f & 4u) && hot2(ox.z, oy.z)) || ((f & 8u) && hot2(ox.w, oy.w)));
             store_quad_sel<T>(vn + idx<2, T>(g, 0, i0, j), ox, f);
             store_quad_sel<T>(vn + idx<2, T>(g, 1, i0, j), oy, f);
         }
@@ -288,8 +318,8 @@ struct Q4 {
 };
 
 // one colour of one row: cells k with ((k + PAR) & 1) == COLOR ... relax from centre row C, neighbours M (j-1), P (j+1)
-template <int PAR, int COLOR, typename T>
-__device__ __forceinline__ void rb_relax_row(const Konst<T> &k, const LaneMap &lm, unsigned fluid,
+template <int PAR, int COLOR, int DM, typename T>
+__device__ __forceinline__ void rb_relax_row(const Konst<T> &k, DivGuard &G, const LaneMap &lm, unsigned fluid,
                                              const Q4<T> &pm, const Q4<T> &pc, const Q4<T> &pp,     // pressure rows j-1, j, j+1
                                              const Q4<T> &xm, const Q4<T> &xc, const Q4<T> &xp,     // v.x rows
                                              const Q4<T> &ym, const Q4<T> &yc, const Q4<T> &yp,     // v.y rows
@@ -306,17 +336,18 @@ __device__ __forceinline__ void rb_relax_row(const Konst<T> &k, const LaneMap &l
         const T xE = c == 3 ? xr : xc.a[c == 3 ? 3 : c + 1], xW = c == 0 ? xl : xc.a[c == 0 ? 0 : c - 1];
         const T yE = c == 3 ? yr : yc.a[c == 3 ? 3 : c + 1], yW = c == 0 ? yl : yc.a[c == 0 ? 0 : c - 1];
         T s2, s3;
-        source_from(k, xE, xW, yE, yW, xp.a[c], xm.a[c], yp.a[c], ym.a[c], s2, s3);
+        source_from<DM>(k, xE, xW, yE, yW, xp.a[c], xm.a[c], yp.a[c], ym.a[c], s2, s3, G);
         const T pred = predict_from(pE, pW, pp.a[c], pm.a[c], s2, s3);
         out.a[c] = k.om1 * pc.a[c] + k.om * pred;
     }
 }
 
-template <int RT, typename T>
-__global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
+template <int RT, int DM, typename T>
+__device__ __forceinline__ bool rbsor_fused_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
 {
+    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return false;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j0 = jb + by * RT;
@@ -328,7 +359,7 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx
         fl[r] = sel_fluid(mask_quad(g, i0, clampy(g, j0 - 1 + r)));
         if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
     }
-    if (!__any(any)) return;
+    if (!__any(any)) return false;
 
     Q4<T> PC[RT + 4], VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1 (clamped)
 #pragma unroll
@@ -348,10 +379,13 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx
         const int j = j0 - 1 + r;
         if (j < g.jlo || j > g.jhi) continue;    // virtual row outside the domain: never consumed
         const int par = (g.ybase + j) & 1;
-        if (par) rb_relax_row<1, 1>(k, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
-        else     rb_relax_row<0, 1>(k, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
+        if (par) rb_relax_row<1, 1, DM>(k, G, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
+        else     rb_relax_row<0, 1, DM>(k, G, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
     }
-    // even pass on rows j0 .. j0+RT-1, in place on pnO; the clamped neighbour of the first / last domain row is the row itself
+    // even pass on rows j0 .. j0+RT-1, in place on pnO; the clamped neighbour of the first / last domain row is the row itself.
+    // All rows are relaxed BEFORE anything is stored: pn is input and output of this kernel, and a tile whose reciprocal divisions
+    // left their exact range is redone from the untouched buffers.
+    Q4<T> OUT[RT];
 #pragma unroll
     for (int r = 1; r <= RT; ++r) {
         const int j = j0 - 1 + r;
@@ -361,10 +395,35 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx
         const Q4<T> ctr = PO[r];
         Q4<T> out = ctr;
         const int par = (g.ybase + j) & 1;
-        if (par) rb_relax_row<1, 0>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
-        else     rb_relax_row<0, 0>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
-        if (lm.owner && fl[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), out.quad(), fl[r]);
+        if (par) rb_relax_row<1, 0, DM>(k, G, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
+        else     rb_relax_row<0, 0, DM>(k, G, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
+        OUT[r - 1] = out;
+        if (DM & DM_RCP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) G.out(out.a[q]);
+        }
     }
+    if ((DM & DM_RCP) && __any(G.bad())) return true;
+#pragma unroll
+    for (int r = 1; r <= RT; ++r) {
+        const int j = j0 - 1 + r;
+        if (j >= je) break;
+        if (lm.owner && fl[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), OUT[r - 1].quad(), fl[r]);
+    }
+    return false;
+}
+// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
+// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
+template <int RT, int DM, typename T>
+__device__ __forceinline__ void rbsor_fused_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
+{
+    rbsor_fused_tile<RT, DM_IEEE, T>(g, k, nbx, nby, jb, je, opaque(pn), opaque(pc), opaque(vc));
+}
+template <int RT, int DM, typename T>
+__global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
+{
+    if (DM & DM_RCP) { if (rbsor_fused_tile<RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vc)) rbsor_fused_tile_redo<RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vc); }
+    else rbsor_fused_tile<RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vc);
 }
 
 
@@ -376,18 +435,19 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx
 // (i - sign(u), j - sign(v)) becomes a per-cell select among the 3x3 gathered values.  blockIdx.z selects the
 // channel group (dye: 3 single-channel passes sharing the advecting velocity).
 // ------------------------------------------------------------------------------------------------
-template <int C, int NC, bool SELF, bool P2, bool CLAMP01, typename T>
-__global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
-                                                         const T *fc, const T *fxc, const T *fyc, const T *v)
+template <int C, int NC, bool SELF, int DM, bool CLAMP01, typename T>
+__device__ __forceinline__ bool cip_advect_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+                                                         const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
 {
+    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j = jb + by;
     const int c0 = blockIdx.y * NC;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
-    if (!__any(fl != 0u)) return;
+    if (!__any(fl != 0u)) return false;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
 
     Q4<T> F[NC][3], FX[NC][3], FY[NC][3];      // rows j-1, j, j+1
@@ -423,8 +483,8 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
         const bool nx = vx < (T)0.0, ny = vy < (T)0.0;       // upwind cell is E / N when the velocity is negative
         const T vxE = q == 3 ? vxr : VX[1].a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VX[1].a[q == 0 ? 0 : q - 1];
         const T vyE = q == 3 ? vyr : VY[1].a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VY[1].a[q == 0 ? 0 : q - 1];
-        const T dxx = qdiv<P2>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx), dxy = qdiv<P2>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx);
-        const T dyx = qdiv<P2>((T)0.5 * (VX[2].a[q] - VX[0].a[q]), k.dx, k.inv_dx), dyy = qdiv<P2>((T)0.5 * (VY[2].a[q] - VY[0].a[q]), k.dx, k.inv_dx);
+        const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, G);
+        const T dyx = xdiv<DM>((T)0.5 * (VX[2].a[q] - VX[0].a[q]), k.dx, k.inv_dx, G), dyy = xdiv<DM>((T)0.5 * (VY[2].a[q] - VY[0].a[q]), k.dx, k.inv_dx, G);
         const int ru = ny ? 2 : 0;                             // row of the upwind cell
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -440,8 +500,8 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
             const T fx00 = FX[c][1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? FX[c][2].a[q] : FX[c][0].a[q];
             const T fy00 = FY[c][1].a[q], fy0m = ny ? FY[c][2].a[q] : FY[c][0].a[q], fym0 = nx ? fyE : fyW;
             (void)ru;
-            cip_point<P2>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
-                      OF[c].a[q], OFX[c].a[q], OFY[c].a[q]);
+            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
+                      OF[c].a[q], OFX[c].a[q], OFY[c].a[q], G);
         }
     }
     if (CLAMP01) {      // clamp_field(dye, 0, 1) (fs/solver.py:46-49) folded into the store of the advected value
@@ -450,7 +510,19 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) OF[c].a[q] = tmin(tmax(OF[c].a[q], (T)0.0), (T)1.0);
     }
+    if (DM & DM_RCP) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { G.out(OF[c].a[q]); G.out(OFX[c].a[q]); G.out(OFY[c].a[q]); }
+        if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
+    }
     if (lm.owner && fl) {
+        if (C == 2) {       // the advected field is a velocity: keep its "hot" flag honest (per component when the pass holds one)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                raise_hot(hot, ((fl >> q) & 1u) && (NC == 2 ? hot2(OF[0].a[q], OF[NC - 1].a[q]) : hot1(OF[0].a[q])));
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             store_quad_sel<T>(fn + idx<C, T>(g, c0 + c, i0, j), OF[c].quad(), fl);
@@ -458,6 +530,22 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
             store_quad_sel<T>(fyn + idx<C, T>(g, c0 + c, i0, j), OFY[c].quad(), fl);
         }
     }
+    return false;
+}
+// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
+// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
+template <int C, int NC, bool SELF, int DM, bool CLAMP01, typename T>
+__device__ __forceinline__ void cip_advect_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+                                                         const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
+{
+    cip_advect_quad_tile<C, NC, SELF, DM & DM_P2, CLAMP01, T>(g, k, nbx, nby, jb, je, opaque(fn), opaque(fxn), opaque(fyn), opaque(fc), opaque(fxc), opaque(fyc), opaque(v), hot);
+}
+template <int C, int NC, bool SELF, int DM, bool CLAMP01, typename T>
+__global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+                                                         const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
+{
+    if (DM & DM_RCP) { if (cip_advect_quad_tile<C, NC, SELF, DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot)) cip_advect_quad_tile_redo<C, NC, SELF, DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot); }
+    else cip_advect_quad_tile<C, NC, SELF, DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot);
 }
 
 
@@ -465,15 +553,16 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
 // K2  CipMacSolver._non_advection_phase (fs/solver.py:229-240, 263-265), quad form: rows j-1, j, j+1 of v (2 planes)
 // and p are requested up front; not-wall cells get  fn = fc + ((-grad p) + lap(fc)/re) * dt.
 // ------------------------------------------------------------------------------------------------
-template <bool P2, typename T>
-__global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc)
+template <int DM, typename T>
+__device__ __forceinline__ bool cip_nonadv_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
 {
+    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
-    if (!__any(nw != 0u)) return;
+    if (!__any(nw != 0u)) return false;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> F[2][3], P[3];
 #pragma unroll
@@ -488,40 +577,58 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int
         for (int q = 0; q < 4; ++q) {
             const T fE = q == 3 ? r : F[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : F[c][1].a[q == 0 ? 0 : q - 1];
             const T f0 = F[c][1].a[q];
-            const T d2x = qdiv<P2>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq);
-            const T d2y = qdiv<P2>((F[c][2].a[q] - (T)2.0 * f0) + F[c][0].a[q], k.dx_sq, k.inv_dx_sq);
-            const T dif = (d2x + d2y) / k.re;
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, G);
+            const T d2y = xdiv<DM>((F[c][2].a[q] - (T)2.0 * f0) + F[c][0].a[q], k.dx_sq, k.inv_dx_sq, G);
+            const T dif = cdiv<DM>(d2x + d2y, k.re, k.inv_re, G);
             T gp;
             if (c == 0) {
                 const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
-                gp = qdiv<P2>((T)0.5 * (pE - pW), k.dx, k.inv_dx);
+                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, G);
             } else {
-                gp = qdiv<P2>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx);
+                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, G);
             }
             const T gg = (-gp) + dif;
             O[c].a[q] = f0 + gg * k.dt;
         }
     }
+    if ((DM & DM_RCP) && __any(G.bad())) return true;      // a dividend outside the range the reciprocal division is exact for: redo
     if (lm.owner && nw) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raise_hot(hot, ((nw >> q) & 1u) && hot2(O[0].a[q], O[1].a[q]));
         store_quad_sel<T>(fn + idx<2, T>(g, 0, i0, j), O[0].quad(), nw);
         store_quad_sel<T>(fn + idx<2, T>(g, 1, i0, j), O[1].quad(), nw);
     }
+    return false;
+}
+// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
+// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
+template <int DM, typename T>
+__device__ __forceinline__ void cip_nonadv_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
+{
+    cip_nonadv_quad_tile<DM & DM_P2, T>(g, k, nbx, nby, jb, je, opaque(fn), opaque(fc), opaque(pc), hot);
+}
+template <int DM, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
+{
+    if (DM & DM_RCP) { if (cip_nonadv_quad_tile<DM, T>(g, k, nbx, nby, jb, je, fn, fc, pc, hot)) cip_nonadv_quad_tile_redo<DM, T>(g, k, nbx, nby, jb, je, fn, fc, pc, hot); }
+    else cip_nonadv_quad_tile<DM, T>(g, k, nbx, nby, jb, je, fn, fc, pc, hot);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3  _non_advection_phase_grad (fs/solver.py:242-261), quad form, NC channels [c0, c0+NC) per lane (blockIdx.y = group).
 // Out-of-range neighbours are clamped (SURVEY.md H2 policy), as in the one-cell-per-lane kernel.
 // ------------------------------------------------------------------------------------------------
-template <int C, int NC, bool P2, typename T>
-__global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
+template <int C, int NC, int DM, typename T>
+__device__ __forceinline__ bool cip_nonadv_grad_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
                                                               const T *fxc, const T *fyc, const T *fc, const T *fn)
 {
+    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by, c0 = blockIdx.y * NC;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
-    if (!__any(nw != 0u)) return;
+    if (!__any(nw != 0u)) return false;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> N[NC][3], Fc[NC][3], GX[NC], GY[NC];
 #pragma unroll
@@ -542,14 +649,35 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k
             const T cE = q == 3 ? cr : Fc[c][1].a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : Fc[c][1].a[q == 0 ? 0 : q - 1];
             const T sx = ((nE - cE) - nW) + cW;
             const T sy = ((N[c][2].a[q] - Fc[c][2].a[q]) - N[c][0].a[q]) + Fc[c][0].a[q];
-            OX.a[q] = GX[c].a[q] + qdiv<P2>(sx, k.two_dx, k.inv_two_dx);
-            OY.a[q] = GY[c].a[q] + qdiv<P2>(sy, k.two_dx, k.inv_two_dx);
+            OX.a[q] = GX[c].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, G);
+            OY.a[q] = GY[c].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, G);
+        }
+        if (DM & DM_RCP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { G.out(OX.a[q]); G.out(OY.a[q]); }
+            if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
         }
         if (lm.owner && nw) {
             store_quad_sel<T>(fxn + idx<C, T>(g, c0 + c, i0, j), OX.quad(), nw);
             store_quad_sel<T>(fyn + idx<C, T>(g, c0 + c, i0, j), OY.quad(), nw);
         }
     }
+    return false;
+}
+// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
+// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
+template <int C, int NC, int DM, typename T>
+__device__ __forceinline__ void cip_nonadv_grad_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
+                                                              const T *fxc, const T *fyc, const T *fc, const T *fn)
+{
+    cip_nonadv_grad_quad_tile<C, NC, DM & DM_P2, T>(g, k, nbx, nby, jb, je, opaque(fxn), opaque(fyn), opaque(fxc), opaque(fyc), opaque(fc), opaque(fn));
+}
+template <int C, int NC, int DM, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
+                                                              const T *fxc, const T *fyc, const T *fc, const T *fn)
+{
+    if (DM & DM_RCP) { if (cip_nonadv_grad_quad_tile<C, NC, DM, T>(g, k, nbx, nby, jb, je, fxn, fyn, fxc, fyc, fc, fn)) cip_nonadv_grad_quad_tile_redo<C, NC, DM, T>(g, k, nbx, nby, jb, je, fxn, fyn, fxc, fyc, fc, fn); }
+    else cip_nonadv_grad_quad_tile<C, NC, DM, T>(g, k, nbx, nby, jb, je, fxn, fyn, fxc, fyc, fc, fn);
 }
 
 
@@ -587,8 +715,9 @@ __device__ __forceinline__ Q4<T> pick5(Q4<T> a0, Q4<T> a1, Q4<T> a2, Q4<T> a3, Q
 template <int c, bool P2, bool EDGE, typename T>
 __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                      T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                     const T *gxc, const T *gyc)
+                                                     const T *gxc, const T *gyc, unsigned *hot)
 {
+    DivGuard G;      // unused here: exact multiplication or IEEE division only
     int bx, by;
     if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
@@ -643,8 +772,8 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
                 const T sx = ((nE - cE) - nW) + cW;
                 const T sy = ((nN.a[q] - cN.a[q]) - nS.a[q]) + cS.a[q];
                 const bool live = (nw[s] >> q) & 1u;
-                NX[s].a[q] = live ? GX[s].a[q] + qdiv<P2>(sx, k.two_dx, k.inv_two_dx) : GX[s].a[q];
-                NY[s].a[q] = live ? GY[s].a[q] + qdiv<P2>(sy, k.two_dx, k.inv_two_dx) : GY[s].a[q];
+                NX[s].a[q] = live ? GX[s].a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sx, k.two_dx, k.inv_two_dx, G) : GX[s].a[q];
+                NY[s].a[q] = live ? GY[s].a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sy, k.two_dx, k.inv_two_dx, G) : GY[s].a[q];
             }
         }
         // ---- K4 on row j ----
@@ -664,8 +793,8 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
             const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
             const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
             const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = qdiv<P2>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx), dxy = qdiv<P2>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx);
-            const T dyx = qdiv<P2>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx), dyy = qdiv<P2>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx);
+            const T dxx = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, G), dxy = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, G);
+            const T dyx = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, G), dyy = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, G);
             const T fE1 = q == 3 ? fr_[1] : N[2].a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl_[1] : N[2].a[q == 0 ? 0 : q - 1];
             const T fE0 = q == 3 ? fr_[0] : N[1].a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl_[0] : N[1].a[q == 0 ? 0 : q - 1];
             const T fE2 = q == 3 ? fr_[2] : N[3].a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl_[2] : N[3].a[q == 0 ? 0 : q - 1];
@@ -678,11 +807,12 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
             const T fx00 = NX[1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[2].a[q] : NX[0].a[q];
             const T fy00 = NY[1].a[q], fy0m = ny ? NY[2].a[q] : NY[0].a[q], fym0 = nx ? fyE : fyW;
             T of, ofx, ofy;
-            cip_point<P2>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
+            cip_point<P2 ? DM_P2 : DM_IEEE>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy, G);
             if ((fl >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
         }
     }
     if (lm.owner) {
+        raise_hot(hot, hot1(OV.a[0]) || hot1(OV.a[1]) || hot1(OV.a[2]) || hot1(OV.a[3]));     // one component per pass: conservative
         *reinterpret_cast<typename Quad<T>::type *>(vo + idx<2, T>(g, c, i0, j)) = OV.quad();     // every cell: result or carried value
         if (nw[1]) {
             store_quad_sel<T>(gxo + idx<2, T>(g, c, i0, j), OX.quad(), nw[1]);                  // fluid: result, inflow/outflow: carried
@@ -696,10 +826,10 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
 template <bool P2, bool EDGE, typename T>
 __global__ __launch_bounds__(256) void k_cip_grad_advect(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                          T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                         const T *gxc, const T *gyc)
+                                                         const T *gxc, const T *gyc, unsigned *hot)
 {
-    if (blockIdx.y == 0) cip_grad_advect_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc);
-    else cip_grad_advect_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc);
+    if (blockIdx.y == 0) cip_grad_advect_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
+    else cip_grad_advect_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
 }
 
 
@@ -707,11 +837,12 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect(Grid g, Konst<T> k, int
 // K8J  JacobiPressureUpdater._update (fs/pressure_updater.py:62-66), overlapped-wave register tile: x-neighbours of the wave-edge quads come
 // from halo lanes (DPP) instead of per-row edge loads, and blocks are dealt to the XCDs in groups of tile rows.
 // ------------------------------------------------------------------------------------------------
-template <bool SRC, int RT, typename T>
-__global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
+template <bool SRC, int RT, int DM, typename T>
+__device__ __forceinline__ bool jacobi_ov_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
 {
+    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return false;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j0 = jb + by * RT;
@@ -723,7 +854,7 @@ __global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, 
         sel[r] = j0 + r < je ? sel_not_wall(mask_quad(g, i0, j0 + r)) : 0u;
         any |= sel[r];
     }
-    if (!__any(any != 0u)) return;
+    if (!__any(any != 0u)) return false;
 
     Q4<T> P[RT + 2], VX[RT + 2], VY[RT + 2], S2[RT], S3[RT];
 #pragma unroll
@@ -760,12 +891,145 @@ __global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, 
                 const Q4<T> &xc = VX[r + 1], &yc = VY[r + 1];
                 const T xE = q == 3 ? xr : xc.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : xc.a[q == 0 ? 0 : q - 1];
                 const T yE = q == 3 ? yr : yc.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : yc.a[q == 0 ? 0 : q - 1];
-                source_from(k, xE, xW, yE, yW, VX[r + 2].a[q], VX[r].a[q], VY[r + 2].a[q], VY[r].a[q], s2, s3);
+                source_from<DM>(k, xE, xW, yE, yW, VX[r + 2].a[q], VX[r].a[q], VY[r + 2].a[q], VY[r].a[q], s2, s3, G);
             }
             const T pE = q == 3 ? pr : c.a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : c.a[q == 0 ? 0 : q - 1];
             o.a[q] = predict_from(pE, pW, n.a[q], m.a[q], s2, s3);
         }
+        if (DM & DM_RCP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) G.out(o.a[q]);
+        }
+        if ((DM & DM_RCP) && __any(G.bad())) return true;      // (pn is not an input: rows already stored are exact and get rewritten identically)
         if (lm.owner && sel[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o.quad(), sel[r]);
+    }
+    return false;
+}
+// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
+// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
+template <bool SRC, int RT, int DM, typename T>
+__device__ __forceinline__ void jacobi_ov_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
+{
+    jacobi_ov_tile<SRC, RT, DM_IEEE, T>(g, k, nbx, nby, jb, je, opaque(pn), opaque(pc), opaque(vs));
+}
+template <bool SRC, int RT, int DM, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
+{
+    if (DM & DM_RCP) { if (jacobi_ov_tile<SRC, RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vs)) jacobi_ov_tile_redo<SRC, RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vs); }
+    else jacobi_ov_tile<SRC, RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vs);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K8J, row-STREAMING form.  A wave owns a column strip of 62 quads x S rows and walks down it; every input row is requested
+// exactly once per strip, RING - 2 rows ahead of the row being relaxed, into a ring of RING row slots held in registers (the
+// loop is unrolled RING times, so every slot index is a compile-time constant and the ring never leaves the register file).
+// Against the register-TILE form above (RT output rows from RT + 2 input rows per field): 3 instead of 6 16-byte loads per
+// output row of the v-reading sweep, no vertical halo re-reads except the two rows a strip shares with its neighbours
+// (S = 32: 6 %), at the price of a longer dependent loop per wave - hidden by the RING - 3 rows (x 3 KiB per wave) that are
+// always in flight.  The first attempt at row marching (round 1: three rolling rows, nothing in flight beyond the next row)
+// was latency-bound; the prefetch ring is what was missing.  Same arithmetic, same bits.
+// ------------------------------------------------------------------------------------------------
+// Row-activity map for the row-streaming kernels: act[wx * rows + r] = bit 0: the 62 owner quads of wave column wx hold a
+// not-wall cell in local row r, bit 1: ... a fluid cell.  Built once per mask upload (fs_upload_mask).  A streaming wave reads
+// the bytes of its strip with one load per lane and turns them into two 64-bit scalar masks (ballot): skipping all-wall rows -
+// their compute AND the HBM traffic of the rows only they would need - is then pure scalar work.
+static __global__ __launch_bounds__(256) void k_row_activity(Grid g, int nwx, uint8_t *act)
+{
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wx = wid % nwx, r = wid / nwx;
+    if (r >= g.rows) return;
+    const int q = wx * 62 + lane;                       // owner quads only (lanes 62, 63 idle)
+    uint32_t m4 = 0x01010101u;
+    if (lane < 62 && q < (g.X >> 2)) m4 = mask_quad(g, q << 2, r);
+    const bool nw = sel_not_wall(m4) != 0u, fl = sel_fluid(m4) != 0u;
+    const unsigned a = (__any(nw) ? 1u : 0u) | (__any(fl) ? 2u : 0u);
+    if (lane == 0) act[(size_t)wx * g.rows + r] = (uint8_t)a;
+}
+
+// 64-bit activity masks of the rows j0 - 1 .. j0 + 62 of wave column wx (bit t <-> local row j0 - 1 + t; rows outside the slab: 0)
+__device__ __forceinline__ void strip_activity(const Grid &g, const uint8_t *act, int wx, int j0, unsigned long long &not_wall, unsigned long long &fluid)
+{
+    const int lane = threadIdx.x & 63, r = j0 - 1 + lane;
+    unsigned a = 0u;
+    if (r >= 0 && r < g.rows) a = act[(size_t)wx * g.rows + r];
+    not_wall = __ballot(a & 1u);
+    fluid = __ballot(a & 2u);
+}
+
+template <bool SRC, typename T>
+struct JacRow {
+    Q4<T> p, a, b;      // p; v.x, v.y (reads v) or s2, s3 (precomputed source pair)
+    uint32_t m;
+};
+
+template <bool SRC, typename T>
+__device__ __forceinline__ JacRow<SRC, T> jac_load_row(const Grid &g, const T *pc, const T *vs, int i0, int j)
+{
+    JacRow<SRC, T> r;
+    const int jc = clampy(g, j);
+    r.p = Q4<T>(load_quad<1>(pc, g, 0, i0, jc));
+    r.a = Q4<T>(load_quad<2>(vs, g, 0, i0, jc));
+    r.b = Q4<T>(load_quad<2>(vs, g, 1, i0, jc));
+    r.m = mask_quad(g, i0, jc);
+    return r;
+}
+
+template <bool SRC, int RING, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_stream(Grid g, Konst<T> k, int nwx, int S, int jb, int je, const uint8_t *act, T *pn, const T *pc, const T *vs)
+{
+    const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wx = wid % nwx, sy = wid / nwx;
+    const int j0 = jb + sy * S;
+    if (j0 >= je) return;
+    const int j1 = j0 + S < je ? j0 + S : je;
+    unsigned long long nwbits, flbits;
+    strip_activity(g, act, wx, j0, nwbits, flbits);            // bit t <-> row j0 - 1 + t
+    if (((nwbits >> 1) & ((1ull << (j1 - j0)) - 1ull)) == 0ull) return;      // no not-wall cell in the whole strip
+    const LaneMap lm = lane_map_wave(g, wx);
+    const int i0 = lm.i0;
+    const int jdummy = clampy(g, j0);
+    // row r is read by the relaxation of rows r - 1, r, r + 1: fetch it only if one of them has work, otherwise re-read a row that
+    // is already in cache (the load is still ISSUED: a branch around it would make the compiler drain the prefetch ring at the join)
+    auto row_or_dummy = [&](int r) { const int t = r - (j0 - 1); return ((t > 0 ? nwbits >> (t - 1) : nwbits << 1) & 7ull) ? r : jdummy; };
+
+    DivGuard G;                  // unused (IEEE division)
+    JacRow<SRC, T> R[RING];      // R[(r + 1) % RING] holds row j0 + r of the strip (slot 0: row j0 - 1)
+#pragma unroll
+    for (int r = 0; r < RING; ++r) R[r] = jac_load_row<SRC, T>(g, pc, vs, i0, row_or_dummy(j0 - 1 + r));
+
+    for (int jj = j0; jj < j1; jj += RING) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            const int j = jj + u;
+            if (j >= j1) break;
+            const JacRow<SRC, T> &rm = R[u], &rc = R[(u + 1) % RING], &rp = R[(u + 2) % RING];
+            if ((nwbits >> (j - (j0 - 1))) & 1ull) {
+                const unsigned sel = sel_not_wall(rc.m);
+                const T pl = quad_left<T>(lm, rc.p.quad()), pr = quad_right<T>(lm, rc.p.quad());
+                T xl = 0, xr = 0, yl = 0, yr = 0;
+                if (!SRC) {
+                    xl = quad_left<T>(lm, rc.a.quad()); xr = quad_right<T>(lm, rc.a.quad());
+                    yl = quad_left<T>(lm, rc.b.quad()); yr = quad_right<T>(lm, rc.b.quad());
+                }
+                Q4<T> o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    T s2, s3;
+                    if (SRC) { s2 = rc.a.a[q]; s3 = rc.b.a[q]; }
+                    else {
+                        const T xE = q == 3 ? xr : rc.a.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : rc.a.a[q == 0 ? 0 : q - 1];
+                        const T yE = q == 3 ? yr : rc.b.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : rc.b.a[q == 0 ? 0 : q - 1];
+                        source_from<DM_IEEE>(k, xE, xW, yE, yW, rp.a.a[q], rm.a.a[q], rp.b.a[q], rm.b.a[q], s2, s3, G);
+                    }
+                    const T pE = q == 3 ? pr : rc.p.a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : rc.p.a[q == 0 ? 0 : q - 1];
+                    o.a[q] = predict_from(pE, pW, rp.p.a[q], rm.p.a[q], s2, s3);
+                }
+                if (lm.owner && sel) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o.quad(), sel);
+            }
+            // row j - 1 is done with: its slot takes row j - 1 + RING (needed RING - 2 steps from now)
+            R[u] = jac_load_row<SRC, T>(g, pc, vs, i0, j - 1 + RING <= j1 ? row_or_dummy(j - 1 + RING) : jdummy);
+        }
     }
 }
 
@@ -774,17 +1038,18 @@ __global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, 
 // K2'  MacSolver._update_velocities (fs/solver.py:94-107), quad form: upwind (fs/advection.py:12-24, +-1 stencil) or
 // Kawamura-Kuwahara (fs/advection.py:27-60, +-2 stencil: two DPP hops give the cells i0-2 .. i0+5 of a row).
 // ------------------------------------------------------------------------------------------------
-template <int SCHEME, bool P2, typename T>
-__global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc)
+template <int SCHEME, int DM, typename T>
+__device__ __forceinline__ bool mac_update_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
 {
+    DivGuard G;
     constexpr int R = SCHEME == 0 ? 1 : 2;          // stencil radius
     constexpr int NR = 2 * R + 1;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
-    if (!__any(fl != 0u)) return;
+    if (!__any(fl != 0u)) return false;
     Q4<T> V[2][NR], P[3];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -812,8 +1077,8 @@ __global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int
             const T fN = V[c][R + 1].a[q], fS = V[c][R - 1].a[q];
             T adv;
             if (SCHEME == 0) {
-                const T ax = ux * qdiv<P2>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx);
-                const T ay = uy * qdiv<P2>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx);
+                const T ax = ux * xdiv<DM>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx, G);
+                const T ay = uy * xdiv<DM>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx, G);
                 adv = ax + ay;
             } else {
                 // cells i+2 / i-2 of the row: inside the quad, or one of the two DPP'd neighbours; at the domain edge sample() clamps
@@ -824,31 +1089,52 @@ __global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int
                 T w0 = nx ? (T)-2 : (T)1, w1 = nx ? (T)10 : (T)-2, w2 = nx ? (T)-9 : (T)9, w3 = nx ? (T)2 : (T)-10, w4 = nx ? (T)-1 : (T)2;
                 T acc = fEE * w0;
                 acc = acc + fE * w1; acc = acc + f0 * w2; acc = acc + fW * w3; acc = acc + fWW * w4;
-                const T a = acc / k.six_dx;
+                const T a = cdiv<DM>(acc, k.six_dx, k.inv_six_dx, G);
                 const bool ny = uy < (T)0;
                 w0 = ny ? (T)-2 : (T)1; w1 = ny ? (T)10 : (T)-2; w2 = ny ? (T)-9 : (T)9; w3 = ny ? (T)2 : (T)-10; w4 = ny ? (T)-1 : (T)2;
                 acc = V[c][R + 2 > NR - 1 ? NR - 1 : R + 2].a[q] * w0;
                 acc = acc + fN * w1; acc = acc + f0 * w2; acc = acc + fS * w3; acc = acc + V[c][R - 2 < 0 ? 0 : R - 2].a[q] * w4;
-                const T b = acc / k.six_dx;
+                const T b = cdiv<DM>(acc, k.six_dx, k.inv_six_dx, G);
                 adv = ux * a + uy * b;
             }
             T gp;
             if (c == 0) {
                 const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
-                gp = qdiv<P2>((T)0.5 * (pE - pW), k.dx, k.inv_dx);
+                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, G);
             } else {
-                gp = qdiv<P2>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx);
+                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, G);
             }
-            const T d2x = qdiv<P2>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq);
-            const T d2y = qdiv<P2>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq);
-            const T lap = (d2x + d2y) / k.re;
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, G);
+            const T d2y = xdiv<DM>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq, G);
+            const T lap = cdiv<DM>(d2x + d2y, k.re, k.inv_re, G);
             O[c].a[q] = f0 + k.dt * (((-adv) - gp) + lap);
         }
     }
+    if (DM & DM_RCP) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { G.out(O[0].a[q]); G.out(O[1].a[q]); }
+        if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
+    }
     if (lm.owner && fl) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raise_hot(hot, ((fl >> q) & 1u) && hot2(O[0].a[q], O[1].a[q]));
         store_quad_sel<T>(vn + idx<2, T>(g, 0, i0, j), O[0].quad(), fl);
         store_quad_sel<T>(vn + idx<2, T>(g, 1, i0, j), O[1].quad(), fl);
     }
+    return false;
+}
+// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
+// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
+template <int SCHEME, int DM, typename T>
+__device__ __forceinline__ void mac_update_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
+{
+    mac_update_quad_tile<SCHEME, DM & DM_P2, T>(g, k, nbx, nby, jb, je, opaque(vn), opaque(vc), opaque(pc), hot);
+}
+template <int SCHEME, int DM, typename T>
+__global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
+{
+    if (DM & DM_RCP) { if (mac_update_quad_tile<SCHEME, DM, T>(g, k, nbx, nby, jb, je, vn, vc, pc, hot)) mac_update_quad_tile_redo<SCHEME, DM, T>(g, k, nbx, nby, jb, je, vn, vc, pc, hot); }
+    else mac_update_quad_tile<SCHEME, DM, T>(g, k, nbx, nby, jb, je, vn, vc, pc, hot);
 }
 
 
@@ -863,8 +1149,9 @@ __global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int
 // ------------------------------------------------------------------------------------------------
 template <int c, bool P2, bool EDGE, typename T>
 __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
-                                                      T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc)
+                                                      T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc, unsigned *hot)
 {
+    DivGuard G;      // unused here: exact multiplication or IEEE division only
     int bx, by;
     if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
@@ -907,15 +1194,15 @@ __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst
         for (int q = 0; q < 4; ++q) {
             const T f0 = row.a[q];
             const T fE = q == 3 ? r : row.a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : row.a[q == 0 ? 0 : q - 1];
-            const T d2x = qdiv<P2>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq);
-            const T d2y = qdiv<P2>((fN.a[q] - (T)2.0 * f0) + fS.a[q], k.dx_sq, k.inv_dx_sq);
+            const T d2x = xdiv<P2 ? DM_P2 : DM_IEEE>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, G);
+            const T d2y = xdiv<P2 ? DM_P2 : DM_IEEE>((fN.a[q] - (T)2.0 * f0) + fS.a[q], k.dx_sq, k.inv_dx_sq, G);
             const T dif = (d2x + d2y) / k.re;
             T gp;
             if (c == 0) {
                 const T pE = q == 3 ? pr : P[s + 1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[s + 1].a[q == 0 ? 0 : q - 1];
-                gp = qdiv<P2>((T)0.5 * (pE - pW), k.dx, k.inv_dx);
+                gp = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (pE - pW), k.dx, k.inv_dx, G);
             } else {
-                gp = qdiv<P2>((T)0.5 * (pN.a[q] - pS.a[q]), k.dx, k.inv_dx);
+                gp = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (pN.a[q] - pS.a[q]), k.dx, k.inv_dx, G);
             }
             const T gg = (-gp) + dif;
             const T val = f0 + gg * k.dt;
@@ -932,10 +1219,12 @@ __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst
         const T cE = q == 3 ? cr : F[2].a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : F[2].a[q == 0 ? 0 : q - 1];
         const T sx = ((nE - cE) - nW) + cW;
         const T sy = ((N[2].a[q] - F[3].a[q]) - N[0].a[q]) + F[1].a[q];
-        OX.a[q] = GX.a[q] + qdiv<P2>(sx, k.two_dx, k.inv_two_dx);
-        OY.a[q] = GY.a[q] + qdiv<P2>(sy, k.two_dx, k.inv_two_dx);
+        OX.a[q] = GX.a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sx, k.two_dx, k.inv_two_dx, G);
+        OY.a[q] = GY.a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sy, k.two_dx, k.inv_two_dx, G);
     }
     if (lm.owner && nw[1]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raise_hot(hot, ((nw[1] >> q) & 1u) && hot1(N[1].a[q]));
         store_quad_sel<T>(fn + idx<2, T>(g, c, i0, j), N[1].quad(), nw[1]);
         store_quad_sel<T>(gxn + idx<2, T>(g, c, i0, j), OX.quad(), nw[1]);
         store_quad_sel<T>(gyn + idx<2, T>(g, c, i0, j), OY.quad(), nw[1]);
@@ -944,10 +1233,10 @@ __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst
 
 template <bool P2, bool EDGE, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
-                                                          T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc)
+                                                          T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc, unsigned *hot)
 {
-    if (blockIdx.y == 0) cip_nonadv_fused_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc);
-    else cip_nonadv_fused_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc);
+    if (blockIdx.y == 0) cip_nonadv_fused_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc, hot);
+    else cip_nonadv_fused_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc, hot);
 }
 
 
@@ -957,19 +1246,25 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_fused(Grid g, Konst<T> k, in
 // where the norm exceeds the limit (never in a healthy run), so the pass is read-only in practice.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, T lim, T *v)
+__global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, int je, T lim, T *v, unsigned *hot, int gated)
 {
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) << 2, j = jb + blockIdx.y;
+    // `gated`: the buffer's flag is authoritative for this limit (fs_device.h) - while it is down no cell can exceed it: done.
+    // A fixed grid of gridDim.y row lanes keeps the common case a ~3 us launch; the rare full pass strides over the rows.
+    if (gated && *hot == 0u) return;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) << 2;
     if (i0 >= g.X) return;
-    T *px = v + idx<2, T>(g, 0, i0, j), *py = v + idx<2, T>(g, 1, i0, j);
-    const Q4<T> X(*reinterpret_cast<const typename Quad<T>::type *>(px)), Y(*reinterpret_cast<const typename Quad<T>::type *>(py));
+    for (int j = jb + blockIdx.y; j < je; j += gridDim.y) {
+        T *px = v + idx<2, T>(g, 0, i0, j), *py = v + idx<2, T>(g, 1, i0, j);
+        const Q4<T> X(*reinterpret_cast<const typename Quad<T>::type *>(px)), Y(*reinterpret_cast<const typename Quad<T>::type *>(py));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const T x = X.a[q], y = Y.a[q];
-        const T nrm = tsqrt(x * x + y * y);
-        if (nrm > lim) {
-            px[q] = lim * (x / nrm);
-            py[q] = lim * (y / nrm);
+        for (int q = 0; q < 4; ++q) {
+            const T x = X.a[q], y = Y.a[q];
+            const T nrm = tsqrt(x * x + y * y);
+            if (nrm > lim) {
+                px[q] = lim * (x / nrm);
+                py[q] = lim * (y / nrm);
+            }
+            raise_hot(hot, hot2(x, y));      // (ungated calls - a limit of 8 or less - keep the flag's meaning intact)
         }
     }
 }
@@ -977,15 +1272,16 @@ __global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, T lim, T *v)
 // ------------------------------------------------------------------------------------------------
 // K12  DyeCipMacSolver._non_advection_phase_dye (fs/solver.py:378-383), quad form: dn = dc + (lap(dc)/re) dt on not-wall cells.
 // ------------------------------------------------------------------------------------------------
-template <bool P2, typename T>
-__global__ __launch_bounds__(256) void k_cip_nonadv_dye_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
+template <int DM, typename T>
+__device__ __forceinline__ bool cip_nonadv_dye_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
 {
+    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
-    if (!__any(nw != 0u)) return;
+    if (!__any(nw != 0u)) return false;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> D[3][3];
 #pragma unroll
@@ -1002,13 +1298,32 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_dye_quad(Grid g, Konst<T> k,
         for (int q = 0; q < 4; ++q) {
             const T f0 = D[c][1].a[q];
             const T fE = q == 3 ? r : D[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : D[c][1].a[q == 0 ? 0 : q - 1];
-            const T d2x = qdiv<P2>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq);
-            const T d2y = qdiv<P2>((D[c][2].a[q] - (T)2.0 * f0) + D[c][0].a[q], k.dx_sq, k.inv_dx_sq);
-            const T dif = (d2x + d2y) / k.re;
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, G);
+            const T d2y = xdiv<DM>((D[c][2].a[q] - (T)2.0 * f0) + D[c][0].a[q], k.dx_sq, k.inv_dx_sq, G);
+            const T dif = cdiv<DM>(d2x + d2y, k.re, k.inv_re, G);
             O.a[q] = f0 + dif * k.dt;
+        }
+        if (DM & DM_RCP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) G.out(O.a[q]);
+            if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
         }
         if (lm.owner && nw) store_quad_sel<T>(dn + idx<3, T>(g, c, i0, j), O.quad(), nw);
     }
+    return false;
+}
+// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
+// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
+template <int DM, typename T>
+__device__ __forceinline__ void cip_nonadv_dye_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
+{
+    cip_nonadv_dye_quad_tile<DM & DM_P2, T>(g, k, nbx, nby, jb, je, opaque(dn), opaque(dc));
+}
+template <int DM, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_dye_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
+{
+    if (DM & DM_RCP) { if (cip_nonadv_dye_quad_tile<DM, T>(g, k, nbx, nby, jb, je, dn, dc)) cip_nonadv_dye_quad_tile_redo<DM, T>(g, k, nbx, nby, jb, je, dn, dc); }
+    else cip_nonadv_dye_quad_tile<DM, T>(g, k, nbx, nby, jb, je, dn, dc);
 }
 
 // clamp_field restricted to the inflow cells (op list of the dye boundary kernel): with the clamp folded into the advection
@@ -1018,15 +1333,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_clamp_inflow(Grid g, BcOps ops, int jb, int je, T lo, T hi, T *dye)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= ops.ncomp) return;
-    if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
-    for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {
-        const int t = ops.tgt[o];
+    if (n >= ops.nsimple) return;
+    const int4 o = ops.simple[n];
+    const int trow = o.w >> 2;
+    if (trow < jb || trow >= je) return;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const size_t a = cell_off(g, t, 3, c);
-            dye[a] = tmin(tmax(dye[a], lo), hi);
-        }
+    for (int c = 0; c < 3; ++c) {
+        const size_t a = cell_off(g, o.x, trow, 3, c);
+        dye[a] = tmin(tmax(dye[a], lo), hi);
     }
 }
 
@@ -1037,16 +1351,17 @@ __global__ __launch_bounds__(256) void k_clamp_inflow(Grid g, BcOps ops, int jb,
 // kept in registers; the channels are then streamed one after the other (nine 16-byte loads each), re-using the same
 // registers.  Replaces three single-channel launches slices that each re-read the velocity.
 // ------------------------------------------------------------------------------------------------
-template <bool P2, bool CLAMP01, typename T>
-__global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
-                                                        const T *fc, const T *fxc, const T *fyc, const T *v)
+template <int DM, bool CLAMP01, typename T>
+__device__ __forceinline__ bool cip_advect_dye_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+                                                        const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
 {
+    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
-    if (!__any(fl != 0u)) return;
+    if (!__any(fl != 0u)) return false;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
 
     T vx[4], vy[4], dxx[4], dxy[4], dyx[4], dyy[4];
@@ -1060,8 +1375,8 @@ __global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int 
             vx[q] = X1.a[q]; vy[q] = Y1.a[q];
             const T xE = q == 3 ? xr : X1.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : X1.a[q == 0 ? 0 : q - 1];
             const T yE = q == 3 ? yr : Y1.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : Y1.a[q == 0 ? 0 : q - 1];
-            dxx[q] = qdiv<P2>((T)0.5 * (xE - xW), k.dx, k.inv_dx); dxy[q] = qdiv<P2>((T)0.5 * (yE - yW), k.dx, k.inv_dx);
-            dyx[q] = qdiv<P2>((T)0.5 * (X2.a[q] - X0.a[q]), k.dx, k.inv_dx); dyy[q] = qdiv<P2>((T)0.5 * (Y2.a[q] - Y0.a[q]), k.dx, k.inv_dx);
+            dxx[q] = xdiv<DM>((T)0.5 * (xE - xW), k.dx, k.inv_dx, G); dxy[q] = xdiv<DM>((T)0.5 * (yE - yW), k.dx, k.inv_dx, G);
+            dyx[q] = xdiv<DM>((T)0.5 * (X2.a[q] - X0.a[q]), k.dx, k.inv_dx, G); dyy[q] = xdiv<DM>((T)0.5 * (Y2.a[q] - Y0.a[q]), k.dx, k.inv_dx, G);
         }
     }
 #pragma unroll 1
@@ -1088,9 +1403,14 @@ __global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int 
             const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
             const T fx00 = FX[1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? FX[2].a[q] : FX[0].a[q];
             const T fy00 = FY[1].a[q], fy0m = ny ? FY[2].a[q] : FY[0].a[q], fym0 = nx ? fyE : fyW;
-            cip_point<P2>(k, vx[q], vy[q], dxx[q], dxy[q], dyx[q], dyy[q], f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
-                          OF.a[q], OFX.a[q], OFY.a[q]);
+            cip_point<DM>(k, vx[q], vy[q], dxx[q], dxy[q], dyx[q], dyy[q], f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
+                          OF.a[q], OFX.a[q], OFY.a[q], G);
             if (CLAMP01) OF.a[q] = tmin(tmax(OF.a[q], (T)0.0), (T)1.0);     // clamp_field(dye, 0, 1), fs/solver.py:46-49
+        }
+        if (DM & DM_RCP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { G.out(OF.a[q]); G.out(OFX.a[q]); G.out(OFY.a[q]); }
+            if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
         }
         if (lm.owner && fl) {
             store_quad_sel<T>(fn + idx<3, T>(g, c, i0, j), OF.quad(), fl);
@@ -1098,6 +1418,22 @@ __global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int 
             store_quad_sel<T>(fyn + idx<3, T>(g, c, i0, j), OFY.quad(), fl);
         }
     }
+    return false;
+}
+// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
+// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
+template <int DM, bool CLAMP01, typename T>
+__device__ __forceinline__ void cip_advect_dye_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+                                                        const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
+{
+    cip_advect_dye_tile<DM & DM_P2, CLAMP01, T>(g, k, nbx, nby, jb, je, opaque(fn), opaque(fxn), opaque(fyn), opaque(fc), opaque(fxc), opaque(fyc), opaque(v), hot);
+}
+template <int DM, bool CLAMP01, typename T>
+__global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+                                                        const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
+{
+    if (DM & DM_RCP) { if (cip_advect_dye_tile<DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot)) cip_advect_dye_tile_redo<DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot); }
+    else cip_advect_dye_tile<DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot);
 }
 
 
@@ -1115,6 +1451,7 @@ __global__ __launch_bounds__(256) void k_jacobi_lds(Grid g, Konst<T> k, int jb, 
     constexpr int NP = SRC ? 1 : 3;                 // planes staged: p [, v.x, v.y]
     constexpr int W = 256 + 8;                      // tile row: 4 pad + 256 cells + 4 pad (keeps 16-byte alignment; halo cells at [3], [260])
     __shared__ __attribute__((aligned(16))) T tile[NP][TY + 2][W];
+    DivGuard G;                                     // unused (IEEE division)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * 256;                // first cell of the tile
     const int j0 = jb + blockIdx.y * TY;
@@ -1161,10 +1498,10 @@ __global__ __launch_bounds__(256) void k_jacobi_lds(Grid g, Konst<T> k, int jb, 
             const V yn = *reinterpret_cast<const V *>(&tile[2][r + 2][o]), ym = *reinterpret_cast<const V *>(&tile[2][r][o]);
             T xl = tile[1][r + 1][o - 1], xr = tile[1][r + 1][o + 4], yl = tile[2][r + 1][o - 1], yr = tile[2][r + 1][o + 4];
             if (i0 + 4 >= g.X) { xr = xc.w; yr = yc.w; }
-            source_from(k, xc.y, xl, yc.y, yl, xn.x, xm.x, yn.x, ym.x, s2.x, s3.x);
-            source_from(k, xc.z, xc.x, yc.z, yc.x, xn.y, xm.y, yn.y, ym.y, s2.y, s3.y);
-            source_from(k, xc.w, xc.y, yc.w, yc.y, xn.z, xm.z, yn.z, ym.z, s2.z, s3.z);
-            source_from(k, xr, xc.z, yr, yc.z, xn.w, xm.w, yn.w, ym.w, s2.w, s3.w);
+            source_from<DM_IEEE>(k, xc.y, xl, yc.y, yl, xn.x, xm.x, yn.x, ym.x, s2.x, s3.x, G);
+            source_from<DM_IEEE>(k, xc.z, xc.x, yc.z, yc.x, xn.y, xm.y, yn.y, ym.y, s2.y, s3.y, G);
+            source_from<DM_IEEE>(k, xc.w, xc.y, yc.w, yc.y, xn.z, xm.z, yn.z, ym.z, s2.z, s3.z, G);
+            source_from<DM_IEEE>(k, xr, xc.z, yr, yc.z, xn.w, xm.w, yn.w, ym.w, s2.w, s3.w, G);
         }
         V out;
         out.x = predict_from(c.y, pl_, n.x, m.x, s2.x, s3.x);

@@ -171,7 +171,8 @@ def main():
         sim.step()
     graph = tape = None
     launch = "eager (python per step)"
-    settle = 24                        # steps spent finding / capturing the replayable period (untimed, the same in every mode)
+    settle = 24                        # untimed steps reserved for finding / capturing the replayable period; what the search does not
+    later = 0                          # use is stepped AFTER the timed region, so every mode and every N takes the same total
     if world == 1 and not args.force_dist and not args.no_graph:
         for _ in range(settle - 2):
             sim.step()
@@ -184,9 +185,8 @@ def main():
         def counted():
             sim.step()
             done[0] += 1
-        tape = dev.tape_period(counted, nsteps=2, tries=settle // 2)
-        for _ in range(settle - done[0]):
-            sim.step()
+        tape = dev.tape_period(counted, nsteps=2, tries=settle // 2)      # returns AT the start of a period: replay must follow directly
+        later = settle - done[0]
         if tape is not None:
             launch = f"tape replay of {tape['nsteps']}-step periods ({len(tape['ops'])} operations, C++ loop)"
     else:
@@ -208,6 +208,8 @@ def main():
     dev.barrier()
     elapsed = max(dev.allgather_scalars(time.perf_counter() - t0))      # max over ranks
     steps_per_s = args.steps / elapsed
+    for _ in range(later):
+        sim.step()
 
     # ---- per-kernel durations with HIP events on the kernels' own stream (same K steps again) -------------
     dev.profile(True)

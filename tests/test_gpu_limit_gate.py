@@ -1,0 +1,110 @@
+"""limit_field behind the "hot" flag (csrc/fs_device.h): the pass over the whole velocity field is skipped while no kernel has
+stored a speed above 8 into the buffer.  The result must be the reference's for EVERY input, so these cases drive the speed over
+the limit through each kind of writer - boundary values, the transport kernels, uploads, fills - and compare with the CPU
+oracle bit for bit; plus gate on == gate off on a regular run."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(const, mask, scheme, vc, dt, dx, re=1e6, dtype="f32"):
+    import fs
+    from fs.boundary_condition import BoundaryCondition
+    from oracle import oracle as O
+    fs.runtime.init(gpu=0, dtype=dtype)
+    bc = BoundaryCondition(const, mask)
+    pu = fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2)
+    v = fs.VorticityConfinement(bc, dt, dx, vc) if vc else None
+    if scheme == "cip":
+        solver = fs.CipMacSolver(bc, pu, dt, dx, re, v)
+    else:
+        solver = fs.MacSolver(bc, pu, fs.advect_upwind if scheme == "upwind" else fs.advect_kk_scheme, dt, dx, re, v)
+    ref = O.make_simulator(const, mask, None, scheme=scheme, dt=dt, dx=dx, re=re, vor_eps=vc,
+                           dtype=np.float32 if dtype == "f32" else np.float64)
+    return fs.FluidSimulator(solver), ref
+
+
+def _compare(sim, ref, steps, tag):
+    for step in range(1, steps + 1):
+        sim.step()
+        ref.update()
+        out = sim.field_to_numpy()
+        for k, e in ref.fields().items():
+            assert np.array_equal(out[k], e, equal_nan=True), f"{tag}: step {step} {k}"
+    return out
+
+
+@pytest.mark.parametrize("scheme,vc", [("cip", 5.0), ("upwind", None), ("kk", 5.0)])
+@pytest.mark.parametrize("res", [32, 130])
+def test_inflow_faster_than_the_limit(scheme, vc, res, hip_lib):
+    """bc_const asks for an inflow speed of 30: the velocity BC writes it every step, limit_field cuts it back to 10."""
+    from fs.boundary_condition import create_scene_arrays
+    const, mask, _ = create_scene_arrays(2, res)
+    const = const.copy()
+    const[mask == 2] *= np.float32(30.0) / max(float(np.abs(const[mask == 2]).max()), 1e-6)
+    sim, ref = _pair(const, mask, scheme, vc, 0.05 / res, 1.0 / res)
+    try:
+        out = _compare(sim, ref, 4, f"inflow30 {scheme}")
+        speed = np.sqrt((out["v"] ** 2).sum(-1))
+        assert speed.max() <= 10.0001 and speed.max() > 9.99         # the limiter did act
+    finally:
+        sim._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("scheme", ["cip", "upwind"])
+def test_transport_kernels_push_the_speed_over_the_limit(scheme, hip_lib):
+    """A huge pressure gradient uploaded into p: the first transport kernel of the step produces speeds far above 10."""
+    from fs.boundary_condition import create_scene_arrays
+    res = 64
+    const, mask, _ = create_scene_arrays(5, res)
+    sim, ref = _pair(const, mask, scheme, 5.0, 0.05 / res, 1.0 / res)
+    try:
+        X, Y = mask.shape
+        p0 = (np.linspace(0, 4.0e4, X, dtype=np.float32)[:, None] * np.ones((1, Y), np.float32)).astype(np.float32)
+        sim._solver.p.current.from_numpy(p0)
+        ref.p.current[...] = p0
+        out = _compare(sim, ref, 2, f"pgrad {scheme}")          # (a third step of this abuse turns CIP into NaN - on both sides alike)
+        assert np.nanmax(np.sqrt((out["v"] ** 2).sum(-1))) > 9.99
+    finally:
+        sim._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("how", ["upload", "fill"])
+def test_uploaded_and_filled_fields_are_limited(how, hip_lib):
+    from fs.boundary_condition import create_scene_arrays
+    res = 48
+    const, mask, _ = create_scene_arrays(1, res)
+    sim, ref = _pair(const, mask, "cip", None, 0.05 / res, 1.0 / res)
+    try:
+        if how == "upload":
+            rng = np.random.default_rng(5)
+            v0 = rng.uniform(-14, 14, mask.shape + (2,)).astype(np.float32)
+            sim._solver.v.current.from_numpy(v0)
+            ref.v.current[...] = v0
+        else:
+            sim._solver.v.current.fill(9.0)          # speed 12.7 everywhere
+            ref.v.current[...] = np.float32(9.0)
+        _compare(sim, ref, 3, how)
+    finally:
+        sim._solver._bc.device.close()
+
+
+def test_gate_on_equals_gate_off(hip_lib, monkeypatch):
+    """The same 30 steps with the gate disabled (FS_LIMIT_GATE=0: full pass every step): identical state, every buffer."""
+    import fs
+    res = 256
+    outs = []
+    for gate in ("1", "0"):
+        monkeypatch.setenv("FS_LIMIT_GATE", gate)
+        fs.runtime.init(gpu=0)
+        sim = fs.FluidSimulator.create(5, res, 0.05 / res, 1.0 / res, 1e6, 5.0, "cip")
+        sim.run(30, graph=(gate == "1"))
+        s = sim._solver
+        outs.append({n + w: getattr(getattr(s, n), w).to_numpy() for n in ("v", "p", "vx", "vy") for w in ("current", "next")})
+        s._bc.device.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert float(np.abs(outs[0]["vcurrent"]).max()) < 8.0      # a healthy run never comes near the gate's threshold

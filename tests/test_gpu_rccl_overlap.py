@@ -49,7 +49,9 @@ def _run(res, halo, overlap, scheme, updater, steps, tape=False):
     import fs
     from fs.boundary_condition import BoundaryCondition, create_scene_arrays
     const, mask, _ = create_scene_arrays(5, res)
+    os.environ["FS_OVERLAP"] = "1" if overlap else "0"      # read by fs_comm_init: exchanges on the communication stream / in line
     dev = _device_cls()(mask.shape[0], mask.shape[1], halo, overlap)
+    os.environ.pop("FS_OVERLAP")
     dt, dx = 0.05 / res, 1.0 / res
     bc = BoundaryCondition(const, mask, device=dev)
     vc = fs.VorticityConfinement(bc, dt, dx, 5.0)
@@ -58,7 +60,7 @@ def _run(res, halo, overlap, scheme, updater, steps, tape=False):
         solver = fs.CipMacSolver(bc, pu, dt, dx, 1e6, vc)
     else:
         solver = fs.MacSolver(bc, pu, fs.advect_kk_scheme, dt, dx, 1e6, vc)
-    if tape:
+    if tape is not False:
         # the N > 1 timed loop of bench.py: log the period of the step, compile it into a C++ tape (fs_tape_*), replay it
         done = [0]
 

@@ -21,6 +21,7 @@ from fs.runtime import Device, DeviceBase  # noqa: E402
 class LoopbackSlab(Device):
     def __init__(self, nx, ny, rank, world, halo, mode):
         DeviceBase.__init__(self, nx, ny, np.float32, 0, rank, world, halo, None, None)
+        os.environ["FS_OVERLAP"] = "1" if mode in ("overlap", "blocking-commstream") else "0"      # fs_comm_init: communication stream or in line
         self.overlap = mode == "overlap"
         self.mode = mode
         self._lib = _lib.load()
@@ -52,7 +53,7 @@ def main():
     const, mask, _ = create_scene_arrays(5, res)
     dt, dx = 0.05 / res, 1.0 / res
     for halo in [int(a) for a in sys.argv[1:]] or [4, 8, 16]:
-        for mode in ("none", "blocking", "overlap", "tape"):
+        for mode in ("none", "blocking-commstream", "blocking", "overlap", "tape"):
             dev = LoopbackSlab(mask.shape[0], mask.shape[1], rank, world, halo, mode)
             bc = BoundaryCondition(const, mask, device=dev)
             solver = fs.CipMacSolver(bc, fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2), dt, dx, 1e6, fs.VorticityConfinement(bc, dt, dx, 5.0))
