@@ -508,6 +508,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_RCP")) c->use_rcp = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
+    if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 ? 2 : (v >= 4 ? 4 : 0); }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
@@ -1057,8 +1058,23 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
                 else { if (edge) FS_K34(false, true); else FS_K34(false, false); }
             });
         };
+        // whole register tiles of RT rows in the interior (env FS_K34_RT = 0 / 2 / 4); what is left over, row by row
+        const int RT = sizeof(T) == 4 ? ctx->k34_rt : 0;      // f64: 256 VGPRs at one wave per SIMD - the one-row form stays
+        int tiled_end = in_lo;
         int rc = run(row_begin, in_lo, true);
-        if (!rc) rc = run(in_lo, in_hi, false);
+        if (!rc && RT > 1 && in_hi - in_lo >= RT) {
+            tiled_end = in_lo + (in_hi - in_lo) / RT * RT;
+            const int jb = in_lo, je = tiled_end;
+            OvGrid og = ov_grid(ctx, jb, je, RT, 1, XCD_ADVECT);
+            og.grid.x = (og.grid.x + 7) / 8 * 16;      // both component passes in one 1-D grid (k_cip_grad_advect_rt pairs them per XCD)
+#define FS_K34RT(R, PP) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, PP, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
+                (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
+            rc = launch(ctx, "cip_grad_advect_rt", [=] {
+                if (RT == 2) { if (k.p2) FS_K34RT(2, true); else FS_K34RT(2, false); }
+                else { if (k.p2) FS_K34RT(4, true); else FS_K34RT(4, false); }
+            });
+        }
+        if (!rc) rc = run(tiled_end, in_hi, false);
         if (!rc) rc = run(in_hi, row_end, true);
         return rc;
     })

@@ -112,16 +112,17 @@ struct LaneMap {
 // other's halo rows, then run on the same XCD close in time and the re-read is a local L2 hit.  Groups are dealt
 // to the XCDs cyclically, so regions with little work (solid walls) are spread evenly - one contiguous band per
 // XCD measured 15 % slower on scene 5 because the dispatcher does not rebalance.  Placement only affects speed.
-__device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by)
+__device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by, int block_id = -1)
 {
+    if (block_id < 0) block_id = blockIdx.x;
     const int nby = nby_packed & 0x7fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked
     if (nbx < 0) {   // plain row-major decode (rows of one tile row spread over the XCDs)
         nbx = -nbx;
-        by = blockIdx.x / nbx;
-        bx = blockIdx.x - by * nbx;
+        by = block_id / nbx;
+        bx = block_id - by * nbx;
         return by < nby;
     }
-    const int id = blockIdx.x, xcd = id & 7, t = id >> 3;
+    const int id = block_id, xcd = id & 7, t = id >> 3;
     const int tbx = (nbx >> 16) & 0xff;
     if (tbx) {
         // 2-D XCD tiles: the block grid is cut into tiles of tbx x tby blocks (x fastest), tile T runs on XCD T % 8 as that XCD's
@@ -153,10 +154,10 @@ __device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, in
 // nby_packed): they are consecutive tile rows of ONE wave column, so the halo rows a tile shares with the tile below are re-read
 // by the same CU within microseconds (L1 / local L2 hits).  Returns this wave's column and tile row, false if it has no work.
 constexpr int FS_STACKED = 1 << 23;
-__device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y)
+__device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int block_id = -1)
 {
     int bx, by;
-    if (!band_coords(nbx, nby_packed, bx, by)) return false;
+    if (!band_coords(nbx, nby_packed, bx, by, block_id)) return false;
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }
@@ -819,6 +820,143 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
             store_quad_sel<T>(gyo + idx<2, T>(g, c, i0, j), OY.quad(), nw[1]);
         }
     }
+}
+
+// The same fused pass on a register tile of RT rows (interior rows only: every row j0 - 2 .. j0 + RT + 1 lies inside the domain, so
+// no clamped duplicates).  The gradient update is evaluated for RT + 2 rows per RT output rows instead of 3 per 1 - at RT = 4 the
+// recompute overhead that made the one-row form issue-bound drops from 3x to 1.5x - and the five input planes are requested up front
+// as 5 RT + 14 16-byte loads per lane.  Rows that do not fill a whole tile, and the rows next to the domain edge, take the one-row
+// kernels below.
+template <int c, int RT, bool P2, typename T>
+__device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+                                                        T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                        const T *gxc, const T *gyc, unsigned *hot, int block_id)
+{
+    constexpr int DM = P2 ? DM_P2 : DM_IEEE;
+    DivGuard G;      // unused: exact multiplication or IEEE division only
+    int wx, ty;
+    if (!tile_coords(g, nbx, nby, jb, je, RT, wx, ty, block_id)) return;
+    const LaneMap lm = lane_map_wave(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    constexpr int o = 1 - c;
+
+    unsigned nw[RT + 2], fl[RT];                 // not-wall selectors of rows j0-1 .. j0+RT, fluid selectors of rows j0 .. j0+RT-1
+    bool any_fl = false;
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const uint32_t m4 = mask_quad(g, i0, j0 - 1 + s);
+        nw[s] = sel_not_wall(m4);
+        if (s >= 1 && s <= RT) { fl[s - 1] = sel_fluid(m4); any_fl |= fl[s - 1] != 0u; }
+    }
+    if (!__any(any_fl)) {
+        // no fluid cell in this wave's tile: every output is a carried value (vo = fc everywhere, old gradients on inflow / outflow cells)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int j = j0 + t;
+            const typename Quad<T>::type f = load_quad<2>(fc, g, c, i0, j);
+            if (lm.owner) {
+                raise_hot(hot, hot1(f.x) || hot1(f.y) || hot1(f.z) || hot1(f.w));
+                *reinterpret_cast<typename Quad<T>::type *>(vo + idx<2, T>(g, c, i0, j)) = f;
+                if (nw[t + 1]) {
+                    store_quad_sel<T>(gxo + idx<2, T>(g, c, i0, j), load_quad<2>(gxc, g, c, i0, j), nw[t + 1]);
+                    store_quad_sel<T>(gyo + idx<2, T>(g, c, i0, j), load_quad<2>(gyc, g, c, i0, j), nw[t + 1]);
+                }
+            }
+        }
+        return;
+    }
+
+    // slot u of N / Fc <-> row j0 - 2 + u;   slot s of NO / GX / GY / NX / NY <-> row j0 - 1 + s
+    Q4<T> N[RT + 4], Fc[RT + 4], NO[RT + 2], GX[RT + 2], GY[RT + 2];
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        N[u] = Q4<T>(load_quad<2>(fn, g, c, i0, j0 - 2 + u));
+        Fc[u] = Q4<T>(load_quad<2>(fc, g, c, i0, j0 - 2 + u));
+    }
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        NO[s] = Q4<T>(load_quad<2>(fn, g, o, i0, j0 - 1 + s));
+        GX[s] = Q4<T>(load_quad<2>(gxc, g, c, i0, j0 - 1 + s));
+        GY[s] = Q4<T>(load_quad<2>(gyc, g, c, i0, j0 - 1 + s));
+    }
+    // ---- K3 on rows j0-1 .. j0+RT: wall cells keep the stored gradient ----
+    Q4<T> NX[RT + 2], NY[RT + 2];
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const Q4<T> &n1 = N[s + 1], &c1 = Fc[s + 1];
+        const T nl = quad_left<T>(lm, n1.quad()), nr = quad_right<T>(lm, n1.quad());
+        const T cl = quad_left<T>(lm, c1.quad()), cr = quad_right<T>(lm, c1.quad());
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T nE = q == 3 ? nr : n1.a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : n1.a[q == 0 ? 0 : q - 1];
+            const T cE = q == 3 ? cr : c1.a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : c1.a[q == 0 ? 0 : q - 1];
+            const T sx = ((nE - cE) - nW) + cW;
+            const T sy = ((N[s + 2].a[q] - Fc[s + 2].a[q]) - N[s].a[q]) + Fc[s].a[q];
+            const bool live = (nw[s] >> q) & 1u;
+            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, G) : GX[s].a[q];
+            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, G) : GY[s].a[q];
+        }
+    }
+    // ---- K4 on rows j0 .. j0+RT-1 ----
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        const Q4<T> &Nm = N[t + 1], &Nc = N[t + 2], &Np = N[t + 3];                                // value field rows j-1, j, j+1
+        const Q4<T> &VXr = c == 0 ? Nc : NO[t + 1], &VYr = c == 0 ? NO[t + 1] : Nc;                 // advecting velocity, row j
+        const Q4<T> &VXm = c == 0 ? Nm : NO[t], &VXp = c == 0 ? Np : NO[t + 2];
+        const Q4<T> &VYm = c == 0 ? NO[t] : Nm, &VYp = c == 0 ? NO[t + 2] : Np;
+        const T vxl = quad_left<T>(lm, VXr.quad()), vxr = quad_right<T>(lm, VXr.quad());
+        const T vyl = quad_left<T>(lm, VYr.quad()), vyr = quad_right<T>(lm, VYr.quad());
+        const T fl0 = quad_left<T>(lm, Nm.quad()), fr0 = quad_right<T>(lm, Nm.quad());
+        const T fl1 = quad_left<T>(lm, Nc.quad()), fr1 = quad_right<T>(lm, Nc.quad());
+        const T fl2 = quad_left<T>(lm, Np.quad()), fr2 = quad_right<T>(lm, Np.quad());
+        const T fxl = quad_left<T>(lm, NX[t + 1].quad()), fxr = quad_right<T>(lm, NX[t + 1].quad());
+        const T fyl = quad_left<T>(lm, NY[t + 1].quad()), fyr = quad_right<T>(lm, NY[t + 1].quad());
+        Q4<T> OV = Fc[t + 2], OX = GX[t + 1], OY = GY[t + 1];       // carry values; fluid cells are replaced below
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T vx = VXr.a[q], vy = VYr.a[q];
+            const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
+            const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
+            const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
+            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, G);
+            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, G), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, G);
+            const T fE1 = q == 3 ? fr1 : Nc.a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
+            const T fE0 = q == 3 ? fr0 : Nm.a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
+            const T fE2 = q == 3 ? fr2 : Np.a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
+            const T fxE = q == 3 ? fxr : NX[t + 1].a[q == 3 ? 3 : q + 1], fxW = q == 0 ? fxl : NX[t + 1].a[q == 0 ? 0 : q - 1];
+            const T fyE = q == 3 ? fyr : NY[t + 1].a[q == 3 ? 3 : q + 1], fyW = q == 0 ? fyl : NY[t + 1].a[q == 0 ? 0 : q - 1];
+            const T f00 = Nc.a[q];
+            const T f0m = ny ? Np.a[q] : Nm.a[q];
+            const T fm0 = nx ? fE1 : fW1;
+            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
+            const T fx00 = NX[t + 1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[t + 2].a[q] : NX[t].a[q];
+            const T fy00 = NY[t + 1].a[q], fy0m = ny ? NY[t + 2].a[q] : NY[t].a[q], fym0 = nx ? fyE : fyW;
+            T of, ofx, ofy;
+            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy, G);
+            if ((fl[t] >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
+        }
+        if (lm.owner) {
+            raise_hot(hot, hot1(OV.a[0]) || hot1(OV.a[1]) || hot1(OV.a[2]) || hot1(OV.a[3]));     // one component per pass: conservative
+            *reinterpret_cast<typename Quad<T>::type *>(vo + idx<2, T>(g, c, i0, j)) = OV.quad();     // every cell: result or carried value
+            if (nw[t + 1]) {
+                store_quad_sel<T>(gxo + idx<2, T>(g, c, i0, j), OX.quad(), nw[t + 1]);              // fluid: result, inflow/outflow: carried
+                store_quad_sel<T>(gyo + idx<2, T>(g, c, i0, j), OY.quad(), nw[t + 1]);
+            }
+        }
+    }
+}
+
+template <int RT, bool P2, typename T>
+__global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+                                                            T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                            const T *gxc, const T *gyc, unsigned *hot)
+{
+    // The two component passes of a tile run back to back on the SAME XCD (block ids 16 m + x and 16 m + 8 + x): the second one finds
+    // the velocity rows both passes read in that XCD's L2 instead of fetching them from HBM again.
+    const int b = blockIdx.x, block_id = ((b >> 4) << 3) | (b & 7);
+    if (((b >> 3) & 1) == 0) cip_grad_advect_rt_body<0, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, block_id);
+    else cip_grad_advect_rt_body<1, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, block_id);
 }
 
 // EDGE = false: rows at least two rows away from the domain's first / last row (static register slots, branch-free);

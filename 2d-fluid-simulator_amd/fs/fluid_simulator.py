@@ -95,27 +95,40 @@ class FluidSimulator:
             for _ in range(nsteps):
                 self._counted_step()
             return
-        sig = self._signature()
-        if self._graph is None or self._graph[0] != sig:
-            self._graph = None
-            for period in (2, 6):      # 2 steps return every DoubleBuffer to its parity; 6 also covers a 3-buffer rotation
-                if nsteps < 2 * period:
-                    break
-                gid = dev.capture(lambda: [self.step() for _ in range(period)])      # host-side swaps happen, nothing executes
-                back = self._signature() == sig
-                dev.replay(gid, 1)                                                   # now the captured steps run once
-                nsteps -= period
-                if back:
-                    self._graph = (sig, gid, period)
-                    break
-                dev.free_graph(gid)
-                sig = self._signature()
+        if self._graph is None or self._graph[0] != self._signature():
+            done = self.capture_period(budget=nsteps)
+            nsteps -= done
         if self._graph is not None:
             _, gid, period = self._graph
             dev.replay(gid, nsteps // period)
             nsteps %= period
         for _ in range(nsteps):
             self.step()
+
+    def capture_period(self, budget=24):
+        """Capture the launches of one PERIOD of the step into a hipGraph -> number of steps this took (they are executed).
+
+        A replayed graph re-issues kernels on fixed device buffers, so it must cover a whole period of the solver's buffer
+        rotation: 2 steps when every DoubleBuffer just swaps (two swaps restore it), 6 steps for the CIP solver with its fused
+        gradient + advection pass and vorticity confinement (the velocity rotates through three buffers, the gradients through
+        two).  Periods are tried in increasing order; a capture whose steps do not bring every buffer back to its place is still
+        executed once (the host-side swaps have happened) and discarded.  Leaves self._graph = (signature, graph id, period) or
+        None if nothing within the budget repeats."""
+        dev, done = self._dev, 0
+        self._graph = None
+        for period in (1, 2, 3, 4, 6):
+            if done + period > budget:
+                break
+            sig = self._signature()
+            gid = dev.capture(lambda: [self.step() for _ in range(period)])       # host-side swaps happen, nothing executes
+            back = self._signature() == sig
+            dev.replay(gid, 1)                                                    # now the captured steps run once
+            done += period
+            if back:
+                self._graph = (sig, gid, period)
+                break
+            dev.free_graph(gid)
+        return done
 
     def field_to_numpy(self):
         fields = self._solver.get_fields()

@@ -114,12 +114,13 @@ class CipMacSolver(Solver):
         self.vy = DoubleBuffer(self.resolution, 2, self._dev)
         self.p = DoubleBuffer(self.resolution, 1, self._dev)
         self._set_grad(self.vx.current, self.vy.current, self.v.current)
-        # Optional fused gradient-update + advection pass (same observable bits, 66 instead of 96 B/cell of HBM traffic;
-        # needs a third velocity buffer because the reference's in-place result buffer is still an input of neighbouring
-        # tiles).  Measured on MI355X at res 4096: 544 us against 331 + 238 us for the two kernels - the recomputed
-        # gradient rows make it issue-bound, so it is OFF by default (fused_transport=True or FS_FUSE_TRANSPORT=1 enables).
+        # Fused gradient-update + advection pass (same observable bits, 64 instead of 98 B/cell of HBM traffic; needs a third
+        # velocity buffer because the reference's in-place result buffer is still an input of neighbouring tiles).  The first,
+        # one-row form was issue-bound (544 us against 231 + 287 us for the two kernels at res 4096: three gradient rows
+        # recomputed per output row); on 2-row register tiles it takes 456 us -> ON by default since round 2
+        # (fused_transport=False or FS_FUSE_TRANSPORT=0 gives the reference's two launches and its intermediate buffers).
         if fused_transport is None:
-            fused_transport = os.environ.get("FS_FUSE_TRANSPORT", "0") == "1"
+            fused_transport = os.environ.get("FS_FUSE_TRANSPORT", "1") == "1"
         self._fused_transport = (bool(fused_transport) and self.resolution[0] % 4 == 0
                                  and os.environ.get("FS_MARCH", "1") != "0")
         self._v_spare = self._dev.alloc(2) if self._fused_transport else None
