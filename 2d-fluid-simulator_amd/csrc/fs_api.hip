@@ -133,16 +133,11 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
     const bool stacked = (c->stack_mask & family) != 0;    // the 4 waves of a workgroup: 4 tile rows of one wave column
     o.nbx = stacked ? waves : (waves + 3) / 4;
     o.nby = stacked ? (tiles + 3) / 4 : tiles;
-    if ((c->tile2d_mask & family) && (c->xcd_mask & family)) {
-        // 2-D XCD tiles (fs_march.h band_coords): tile_waves wave columns x tile_rows field rows
-        const int rows_per_block = rt * (stacked ? 4 : 1), waves_per_block = stacked ? 1 : 4;
-        const int tbx = std::min(255, std::max(1, c->tile_waves / waves_per_block)), tby = std::min(256, std::max(1, c->tile_rows / rows_per_block));
-        o.grid = dim3(tile2d_blocks(o.nbx, o.nby, tbx, tby), zgroups, 1);
-        o.nbx |= tbx << 16;
-        o.nby |= (tby - 1) << 24;
-    } else if (c->xcd_mask & family) {
-        const int group = stacked ? std::max(1, c->xcd_group / 4) : c->xcd_group;     // the same number of rows per XCD group
-        o.grid = dim3(band_blocks(o.nbx, o.nby, group), zgroups, 1);
+    if (c->xcd_mask & family) {
+        // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords)
+        const int group = stacked ? std::max(1, c->xcd_group / 4) : c->xcd_group;     // the same number of field rows per XCD group
+        const int groups = (o.nby + group - 1) / group;
+        o.grid = dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
         o.nby |= (group - 1) << 24;
     } else { o.grid = dim3(o.nbx * o.nby, zgroups, 1); o.nbx = -o.nbx; }   // negative nbx = row-major decode
     if (stacked) o.nby |= FS_STACKED;
@@ -184,11 +179,12 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
             hipLaunchKernelGGL((k_jacobi_lds<SRC, TY, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
         });
     }
-    const int rt = v == 24 ? 4 : (v == 21 ? 1 : 2);
+    const int rt = v == 24 ? 4 : (v == 21 ? 1 : (v == 23 ? 3 : 2));
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
     const int dm = SRC ? 0 : dm_const(ctx, k, RCP_JACOBI);           // the source-pair form divides nothing
 #define FS_JAC(DM) do { \
         if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else if (rt == 3) hipLaunchKernelGGL((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
         else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
         else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
     return launch(ctx, name, [=] { FS_DM2(dm, FS_JAC); });
@@ -516,9 +512,6 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     c->stack_mask = XCD_RBSOR | XCD_ADVECT | XCD_GRAD;      // measured per family: K4 313 -> 301 us, K3 246 -> 243, RB-SOR 129 -> 127.5; the others lose 1 %
     if (const char *s = getenv("FS_STACK")) c->stack_mask = atoi(s);
     if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
-    if (const char *s = getenv("FS_TILE2D")) c->tile2d_mask = atoi(s);
-    if (const char *s = getenv("FS_TILE_ROWS")) { int v = atoi(s); if (v >= 1 && v <= 1024) c->tile_rows = v; }
-    if (const char *s = getenv("FS_TILE_WAVES")) { int v = atoi(s); if (v >= 1 && v <= 255) c->tile_waves = v; }
     if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows
     *out = c;
     return FS_OK;
@@ -1065,8 +1058,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
         if (!rc && RT > 1 && in_hi - in_lo >= RT) {
             tiled_end = in_lo + (in_hi - in_lo) / RT * RT;
             const int jb = in_lo, je = tiled_end;
-            OvGrid og = ov_grid(ctx, jb, je, RT, 1, XCD_ADVECT);
-            og.grid.x = (og.grid.x + 7) / 8 * 16;      // both component passes in one 1-D grid (k_cip_grad_advect_rt pairs them per XCD)
+            const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT);
 #define FS_K34RT(R, PP) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, PP, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
             rc = launch(ctx, "cip_grad_advect_rt", [=] {

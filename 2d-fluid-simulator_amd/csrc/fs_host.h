@@ -106,8 +106,6 @@ struct fs_ctx {
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int stack_mask = 0;       // env FS_STACK: kernel families (XCD_* bits) launched with stacked workgroups
-    int tile2d_mask = 0;      // env FS_TILE2D: kernel families dealt to the XCDs as 2-D tiles (tile_waves wave columns x tile_rows rows)
-    int tile_rows = 32, tile_waves = 4;   // env FS_TILE_ROWS / FS_TILE_WAVES
     bool pack_halo = true;    // env FS_PACK_HALO=0: one ncclSend/ncclRecv per field instead of one packed message per neighbour
     int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default, 22 / 24 / 21 = overlapped-wave tiles of 2 / 4 / 1 rows, 30 = LDS tile
 

@@ -112,66 +112,53 @@ struct LaneMap {
 // other's halo rows, then run on the same XCD close in time and the re-read is a local L2 hit.  Groups are dealt
 // to the XCDs cyclically, so regions with little work (solid walls) are spread evenly - one contiguous band per
 // XCD measured 15 % slower on scene 5 because the dispatcher does not rebalance.  Placement only affects speed.
-__device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by, int block_id = -1)
+// Launch geometry of the tile kernels: grid = (8 * nbx, G * ZG, ceil(groups / 8)) with
+//   blockIdx.x = 8 * bx + xcd      bx: block column, xcd: which XCD runs it (the dispatcher deals consecutive workgroups of the
+//                                  linearised grid to the XCDs round-robin, and the x extent is a multiple of 8)
+//   blockIdx.y = ly * ZG + cg      ly: tile row inside the group of G rows, cg: channel group (ZG = 1, 2 or 3 passes over the same
+//                                  rows, adjacent in dispatch order: the second pass finds the shared planes in that XCD's L2)
+//   blockIdx.z = lg                the lg-th group of this XCD:  by = (lg * 8 + xcd) * G + ly
+// No integer division in the decode (the first version, a 1-D grid decoded with two divisions per wave, spent ~70 of the ~700
+// instructions of a one-row K2 tile on them).
+template <int ZG = 1>
+__device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by, int &cg)
 {
-    if (block_id < 0) block_id = blockIdx.x;
     const int nby = nby_packed & 0x7fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked
-    if (nbx < 0) {   // plain row-major decode (rows of one tile row spread over the XCDs)
+    if (nbx < 0) {   // plain row-major decode (FS_XCD=0: rows of one tile row spread over the XCDs): grid = (nbx * nby, ZG)
         nbx = -nbx;
-        by = block_id / nbx;
-        bx = block_id - by * nbx;
+        by = blockIdx.x / nbx;
+        bx = blockIdx.x - by * nbx;
+        cg = blockIdx.y;
         return by < nby;
     }
-    const int id = block_id, xcd = id & 7, t = id >> 3;
-    const int tbx = (nbx >> 16) & 0xff;
-    if (tbx) {
-        // 2-D XCD tiles: the block grid is cut into tiles of tbx x tby blocks (x fastest), tile T runs on XCD T % 8 as that XCD's
-        // (T / 8)-th tile, row-major inside the tile.  A tile is tall (tby block rows = 32 field rows or more) and narrow, so the
-        // halo rows that vertically adjacent tile rows re-read stay in the XCD's 4 MiB L2, and only the 1 - 2 rows at the top and
-        // bottom EDGE of a tile are fetched by two XCDs: (32 + 2) / 32 of the rows instead of the (8 + 2) / 8 of full-width groups
-        // of 8 rows - which is what the rocprof traffic counters showed (1.21x - 1.32x the algorithmic bytes).  Tiles are small
-        // (32 blocks) and dealt cyclically, so walls stay balanced across the XCDs.
-        nbx &= 0xffff;
-        const int tby = FS_XCD_GROUP, per_tile = tbx * tby;
-        const int ntx = (nbx + tbx - 1) / tbx, nty = (nby + tby - 1) / tby;
-        const int tl = t / per_tile, rem = t - tl * per_tile;
-        const int T = tl * 8 + xcd;
-        if (T >= ntx * nty) return false;
-        const int ty = T / ntx, tx = T - ty * ntx;
-        const int ly = rem / tbx, lx = rem - ly * tbx;
-        bx = tx * tbx + lx;
-        by = ty * tby + ly;
-        return bx < nbx && by < nby;
-    }
-    const int per_group = FS_XCD_GROUP * nbx;
-    const int lg = t / per_group, rem = t - lg * per_group;
-    const int ly = rem / nbx;
-    bx = rem - ly * nbx;
-    by = (lg * 8 + xcd) * FS_XCD_GROUP + ly;
+    const int xcd = blockIdx.x & 7;
+    bx = blockIdx.x >> 3;
+    const int ly = ZG == 1 ? (int)blockIdx.y : (int)blockIdx.y / ZG;        // division by a compile-time 2 or 3
+    cg = ZG == 1 ? 0 : (int)blockIdx.y - ly * ZG;
+    by = ((int)blockIdx.z * 8 + xcd) * FS_XCD_GROUP + ly;
     return by < nby;
 }
 // Workgroup shape.  Side by side (default): the waves of a workgroup are consecutive wave columns of ONE tile row.  Stacked (bit 23 of
 // nby_packed): they are consecutive tile rows of ONE wave column, so the halo rows a tile shares with the tile below are re-read
 // by the same CU within microseconds (L1 / local L2 hits).  Returns this wave's column and tile row, false if it has no work.
+// Everything here is wave-uniform and SAID to be (readfirstlane on the wave index): row numbers, and with them the row part of
+// every address, then live in scalar registers - the loads take a scalar base + one 32-bit lane offset instead of a 64-bit
+// multiply-add per load and lane.
 constexpr int FS_STACKED = 1 << 23;
-__device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int block_id = -1)
+template <int ZG = 1>
+__device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg)
 {
     int bx, by;
-    if (!band_coords(nbx, nby_packed, bx, by, block_id)) return false;
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (!band_coords<ZG>(nbx, nby_packed, bx, by, cg)) return false;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }
     return wave_x * 62 < (g.X >> 2) && jb + tile_y * rt < je;
 }
-static inline int tile2d_blocks(int nbx, int nby, int tbx, int tby)
+__device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y)
 {
-    const int ntx = (nbx + tbx - 1) / tbx, nty = (nby + tby - 1) / tby;
-    return 8 * ((ntx * nty + 7) / 8) * tbx * tby;
-}
-static inline int band_blocks(int nbx, int nby, int FS_XCD_GROUP)
-{
-    const int groups = (nby + FS_XCD_GROUP - 1) / FS_XCD_GROUP;
-    return 8 * ((groups + 7) / 8) * FS_XCD_GROUP * nbx;
+    int cg;
+    return tile_coords<1>(g, nbx, nby_packed, jb, je, rt, wave_x, tile_y, cg);
 }
 
 __device__ __forceinline__ LaneMap lane_map_wave(const Grid &g, int wave)
@@ -441,12 +428,12 @@ __device__ __forceinline__ bool cip_advect_quad_tile(Grid g, Konst<T> k, int nbx
                                                          const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
 {
     DivGuard G;
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
+    int bx, by, cg;
+    if (!tile_coords<C / NC>(g, nbx, nby, jb, je, 1, bx, by, cg)) return false;   // bx: wave column, by: tile row, cg: channel group
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j = jb + by;
-    const int c0 = blockIdx.y * NC;
+    const int c0 = cg * NC;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
     if (!__any(fl != 0u)) return false;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
@@ -624,10 +611,10 @@ __device__ __forceinline__ bool cip_nonadv_grad_quad_tile(Grid g, Konst<T> k, in
                                                               const T *fxc, const T *fyc, const T *fc, const T *fn)
 {
     DivGuard G;
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
+    int bx, by, cg;
+    if (!tile_coords<C / NC>(g, nbx, nby, jb, je, 1, bx, by, cg)) return false;   // bx: wave column, by: tile row, cg: channel group
     const LaneMap lm = lane_map_wave(g, bx);
-    const int i0 = lm.i0, j = jb + by, c0 = blockIdx.y * NC;
+    const int i0 = lm.i0, j = jb + by, c0 = cg * NC;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
     if (!__any(nw != 0u)) return false;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
@@ -719,8 +706,8 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
                                                      const T *gxc, const T *gyc, unsigned *hot)
 {
     DivGuard G;      // unused here: exact multiplication or IEEE division only
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    int bx, by, cg;
+    if (!tile_coords<2>(g, nbx, nby, jb, je, 1, bx, by, cg)) return;   // bx: wave column, by: tile row (cg == c: the wrapper picked this instantiation)
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     constexpr int o = 1 - c;                        // c: this pass's component (compile time: runtime selection among the
@@ -830,12 +817,12 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
 template <int c, int RT, bool P2, typename T>
 __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                         T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                        const T *gxc, const T *gyc, unsigned *hot, int block_id)
+                                                        const T *gxc, const T *gyc, unsigned *hot)
 {
     constexpr int DM = P2 ? DM_P2 : DM_IEEE;
     DivGuard G;      // unused: exact multiplication or IEEE division only
-    int wx, ty;
-    if (!tile_coords(g, nbx, nby, jb, je, RT, wx, ty, block_id)) return;
+    int wx, ty, cg;
+    if (!tile_coords<2>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
     const LaneMap lm = lane_map_wave(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     constexpr int o = 1 - c;
@@ -952,11 +939,10 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, 
                                                             T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
                                                             const T *gxc, const T *gyc, unsigned *hot)
 {
-    // The two component passes of a tile run back to back on the SAME XCD (block ids 16 m + x and 16 m + 8 + x): the second one finds
-    // the velocity rows both passes read in that XCD's L2 instead of fetching them from HBM again.
-    const int b = blockIdx.x, block_id = ((b >> 4) << 3) | (b & 7);
-    if (((b >> 3) & 1) == 0) cip_grad_advect_rt_body<0, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, block_id);
-    else cip_grad_advect_rt_body<1, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, block_id);
+    // blockIdx.y = (tile row in the XCD group) * 2 + component: the two component passes of a tile are adjacent in dispatch order on
+    // the SAME XCD, so the second one finds the velocity rows both passes read in that XCD's L2 instead of fetching them again.
+    if ((blockIdx.y & 1) == 0) cip_grad_advect_rt_body<0, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
+    else cip_grad_advect_rt_body<1, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
 }
 
 // EDGE = false: rows at least two rows away from the domain's first / last row (static register slots, branch-free);
@@ -966,7 +952,7 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect(Grid g, Konst<T> k, int
                                                          T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
                                                          const T *gxc, const T *gyc, unsigned *hot)
 {
-    if (blockIdx.y == 0) cip_grad_advect_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
+    if ((blockIdx.y & 1) == 0) cip_grad_advect_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
     else cip_grad_advect_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
 }
 
@@ -1290,8 +1276,8 @@ __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst
                                                       T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc, unsigned *hot)
 {
     DivGuard G;      // unused here: exact multiplication or IEEE division only
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    int bx, by, cg;
+    if (!tile_coords<2>(g, nbx, nby, jb, je, 1, bx, by, cg)) return;   // bx: wave column, by: tile row (cg == c: the wrapper picked this instantiation)
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const int rows5[5] = {clampy(g, j - 2), clampy(g, j - 1), j, clampy(g, j + 1), clampy(g, j + 2)};
@@ -1373,7 +1359,7 @@ template <bool P2, bool EDGE, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                           T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc, unsigned *hot)
 {
-    if (blockIdx.y == 0) cip_nonadv_fused_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc, hot);
+    if ((blockIdx.y & 1) == 0) cip_nonadv_fused_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc, hot);
     else cip_nonadv_fused_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc, hot);
 }
 

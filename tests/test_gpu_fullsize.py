@@ -173,22 +173,43 @@ def test_against_oracle_at_baseline_size(hip_lib):
 
 
 def test_f64_vs_f32_tolerance_sweep(hip_lib, capsys):
-    """BASELINE configs[4] asks for an fp64-vs-fp32 sweep (bc3, KK, Re 1e8, VC 10).  f64 is the build's own truth
-    (the reference is f32 only)."""
-    res, steps = 1024, 20
+    """BASELINE configs[4] at its own size: bc3, res 4096 (8192 x 4096 cells), Kawamura-Kuwahara, Re 1e8, f32 against the build's
+    f64 instantiation (the reference is f32 only) after 1, 2, 5, 10, 20 steps.  Vorticity confinement off: asserted <= 1e-5
+    rel-L2 on v and p; VC = 10 (the configuration's value): reported, not asserted - the confinement force is discontinuous
+    (hazard H4), a one-ulp difference flips whole cells.  The curve is printed and written to gpurun_out/ (copied to profiles/)."""
+    import json
+    res, snaps = 4096, (1, 2, 5, 10, 20)
     curves = {}
     for vc in (None, 10.0):
         sims = {d: _build(3, res, "kk", vc, 1e8, None, True, dtype=d) for d in ("f32", "f64")}
         curve = []
-        for step in range(1, steps + 1):
+        for step in range(1, max(snaps) + 1):
             for s in sims.values():
                 s.step()
-            if step in (1, 2, 5, 10, 20):
-                a, b = sims["f32"].field_to_numpy(), sims["f64"].field_to_numpy()
-                curve.append((step, rel_l2(a["v"], b["v"]), rel_l2(a["p"], b["p"])))
+            if step in snaps:
+                ev = ep = None
+                for name, key in (("v", 0), ("p", 1)):
+                    a = sims["f32"]._solver.get_fields()[key].to_numpy()
+                    b = sims["f64"]._solver.get_fields()[key].to_numpy()
+                    e = rel_l2(a, b)
+                    del a, b
+                    if name == "v":
+                        ev = e
+                    else:
+                        ep = e
+                curve.append((step, ev, ep))
         for s in sims.values():
             s._solver._bc.device.close()
         curves[vc] = curve
+    report = {"config": "BASELINE.json configs[4]: bc=3 res=4096 (8192x4096 cells) scheme=kk Re=1e8 dt=0.05/res RB-SOR(1.3, 2)",
+              "metric": "rel-L2 of the f32 run against the f64 run (same kernels, double instantiation)",
+              "curves": {("vc_off" if vc is None else f"vc_{vc:g}"): [{"step": s_, "v": ev, "p": ep} for s_, ev, ep in c]
+                         for vc, c in curves.items()},
+              "asserted": "vc_off: v, p <= 1e-5 at every snapshot; vc_10: reported only (discontinuous confinement force, SURVEY.md H4)"}
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "f64_vs_f32_bc3_res4096.json"), "w") as f:
+            json.dump(report, f, indent=1)
     with capsys.disabled():
         for vc, curve in curves.items():
             print(f"\n[f64-vs-f32 bc3 res{res} kk Re1e8 vc={vc}] " + "  ".join(f"step{s}: v {ev:.2e} p {ep:.2e}" for s, ev, ep in curve))
