@@ -12,7 +12,7 @@ CSRC = os.path.join(REPO, "2d-fluid-simulator_amd", "csrc")
 
 def main():
     asm = "/tmp/fs_api_isa.s"
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w",
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w",
                     "-I/opt/rocm/include", "--cuda-device-only", "-S", os.path.join(CSRC, "fs_api.hip"), "-o", asm], check=True)
     lines = open(asm).read().split("\n")
     subs = sys.argv[1:] or ["k_rbsor_fused", "k_cip_advect_quad", "k_vort_fused", "k_cip_nonadv_grad_quad", "k_cip_nonadv_quad", "k_jacobi_ov", "k_limit_quad"]
