@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (gpurun -- 'bash tools/profile.sh <tag>'): rocprofv3 kernel-trace stats + PMC passes for bench.py.
 # Outputs land in gpurun_out/prof_<tag>/; copy the summaries you want judged into profiles/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
