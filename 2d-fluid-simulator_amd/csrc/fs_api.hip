@@ -452,6 +452,28 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
                 prs.push_back({2, id(i, j), -1, -1});                              // :64-65  p = 0
             }
         }
+    // "lazy" pressure boundary condition (fs_march.h k_jacobi_lazy): the recipe of every K7 assignment as one byte per cell, and the
+    // preconditions under which evaluating it from the raw sweep output is exactly what K7 followed by the sweep computes
+    {
+        std::vector<uint8_t> map((size_t)X * Y, 0);
+        bool ok = true;
+        auto dir = [&](long long t, long long s) -> int {      // 0: i-1, 1: i+1, 2: j-1, 3: j+1, -1: anything else
+            const long long d = s - t;
+            return d == -(long long)Y ? 0 : (d == (long long)Y ? 1 : (d == -1 ? 2 : (d == 1 ? 3 : -1)));
+        };
+        for (const HostOp &op : prs) {
+            if (op.kind == 2) { map[op.t] = 1 | (2 << 1); continue; }
+            if (op.s1 == op.t) continue;                                   // clamped onto itself: p[t] = p[t]
+            const int d1 = dir(op.t, op.s1), d2 = op.kind == 1 ? dir(op.t, op.s2) : 0;
+            if (d1 < 0 || d2 < 0) { ok = false; continue; }
+            if (mask[op.s1] == 1 || (op.kind == 1 && mask[op.s2] == 1)) ok = false;      // a wall source would be read from the buffer's history
+            map[op.t] = (uint8_t)(1 | (op.kind << 1) | (d1 << 3) | (d2 << 5));
+        }
+        for (int i = 0; i < X && ok; ++i)                                  // no computed cell may sample a clamped y neighbour
+            if (M(i, 0) != 1 || M(i, Y - 1) != 1) ok = false;
+        c->lazy_ok = ok && X % 4 == 0;
+        c->h_bcmap.swap(map);            // uploaded by fs_upload_mask (same transpose path as the mask), then dropped
+    }
     c->bc_incomplete = false;
     c->bc_radius_vel = c->bc_radius_prs = 0;
     int rc, dummy = 0;
@@ -504,6 +526,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_RCP")) c->use_rcp = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
+    if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
     if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 ? 2 : (v >= 4 ? 4 : 0); }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
@@ -537,6 +560,8 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->d_acc) hipFree(ctx->d_acc);
     if (ctx->d_rowact) hipFree(ctx->d_rowact);
+    if (ctx->d_bcmap) hipFree(ctx->d_bcmap);
+    if (ctx->d_lazyflags) hipFree(ctx->d_lazyflags);
     if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -615,8 +640,16 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     if (rc) return rc;
     rc = build_bc_ops(ctx, mask_xy);
     if (rc) return rc;
-    if (ctx->X % 4 == 0) {      // row-activity map of the row-streaming kernels
+    if (!ctx->d_bcmap) FS_HIP(hipMalloc(&ctx->d_bcmap, (size_t)ctx->rows * ctx->Pm));
+    if (!ctx->d_lazyflags) FS_HIP(hipMalloc(&ctx->d_lazyflags, (size_t)std::max(ctx->nwx, 1) * ctx->rows));
+    FS_HIP(hipMemsetAsync(ctx->d_bcmap, 0, (size_t)ctx->rows * ctx->Pm, ctx->stream));
+    FS_HIP(hipMemsetAsync(ctx->d_lazyflags, 1, (size_t)std::max(ctx->nwx, 1) * ctx->rows, ctx->stream));
+    rc = upload_global(ctx, ctx->d_bcmap, 1, 1, ctx->h_bcmap.data(), ctx->Pm);
+    std::vector<uint8_t>().swap(ctx->h_bcmap);
+    if (rc) return rc;
+    if (ctx->X % 4 == 0) {      // row-activity map of the row-streaming kernels; per-tile flags of the lazy pressure BC
         hipLaunchKernelGGL(k_row_activity, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_rowact);
+        hipLaunchKernelGGL(k_lazy_flags, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_bcmap, ctx->d_lazyflags);
         FS_HIP(hipGetLastError());
     }
     ctx->mask_set = true;
@@ -1056,7 +1089,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
         int tiled_end = in_lo;
         int rc = run(row_begin, in_lo, true);
         if (!rc && RT > 1 && in_hi - in_lo >= RT) {
-            tiled_end = in_lo + (in_hi - in_lo) / RT * RT;
+            tiled_end = in_lo + (in_hi - in_lo) / (RT > 1 ? RT : 1) * RT;
             const int jb = in_lo, je = tiled_end;
             const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT);
 #define FS_K34RT(R, PP) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, PP, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
@@ -1151,6 +1184,29 @@ int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
         auto k = make_konst<T>(ctx, 1.0, 1.0, 1.0);
         if (ctx->use_march) return launch_jacobi<true, T>(ctx, "jacobi_sweep_src", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
         FS_LAUNCH_CELLS("jacobi_sweep_src", (k_jacobi<true, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
+    })
+}
+
+int fs_lazy_bc_ok(const fs_ctx *ctx, int *ok)
+{
+    FS_REQUIRE(ctx && ok, "null argument");
+    *ok = ctx->mask_set && ctx->lazy_ok && ctx->use_march && ctx->use_lazy ? 1 : 0;
+    return FS_OK;
+}
+
+int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
+    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
+    FS_ROWS();
+    if (!(ctx->lazy_ok && ctx->use_march)) { set_error("this mask does not admit the lazy pressure boundary condition (fs_lazy_bc_ok)"); return FS_ERR_UNSUPPORTED; }
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_JACOBI);
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "jacobi_sweep_lazy", [=] {
+            hipLaunchKernelGGL((k_jacobi_lazy<T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end,
+                               (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
+        });
     })
 }
 

@@ -64,6 +64,10 @@ struct fs_ctx {
     size_t esize = 4;
     hipStream_t stream = nullptr;
     uint8_t *d_mask = nullptr;
+    uint8_t *d_bcmap = nullptr;    // [rows][Pm] recipe byte of the pressure boundary condition per cell (fs_march.h k_jacobi_lazy)
+    uint8_t *d_lazyflags = nullptr;   // [nwx][rows] tile needs the lazy evaluation
+    std::vector<uint8_t> h_bcmap;  // host copy between build_bc_ops and the upload
+    bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
     uint8_t *d_rowact = nullptr;   // [nwx][rows] row-activity map of the row-streaming kernels (fs_march.h k_row_activity)
     int nwx = 0;                   // wave columns of 62 quads across a row
     void *d_bc_const = nullptr, *d_bc_dye = nullptr;

@@ -1159,6 +1159,124 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(Grid g, Konst<T> k, int n
 
 
 // ------------------------------------------------------------------------------------------------
+// K8J with the pressure boundary condition evaluated ON THE FLY ("lazy" K7), for long Jacobi runs (BASELINE configs[1]: 50 sweeps
+// per step, where the separate boundary kernel - two dependent HBM round trips + a launch, 6.6 us - is 28 % of the step).
+//
+// K7 (fs/boundary_condition.py:41-65) is a pure gather from the buffer the previous sweep wrote: a wall cell takes the value (or the
+// mean of two values) of FLUID neighbours, an outflow cell 0, an inflow cell the old value of its right neighbour; no assignment reads
+// a cell an earlier assignment of the same call wrote (sources are fluid, or lie later in the serial order).  So the value K7 would
+// have stored in a cell is a function of the RAW sweep output around it, and the next sweep can evaluate it when it needs it:
+//     p_bc(c) = not a target ? raw(c) : recipe(c)(raw)         recipe = copy of a 4-neighbour | mean of two | 0
+// `bcmap` (one byte per cell, built with the op lists at mask upload) holds the recipe; `flags` (one byte per wave-tile row) says
+// whether any not-wall cell of the tile has a target among its 4 neighbours - only those tiles load the two extra rows of p and the
+// three rows of bcmap, every other tile is the plain source-pair sweep.  The host runs n - 2 lazy sweeps and then the last two with
+// the real K7, which leaves both physical p buffers exactly as the reference's n x (K7, sweep, swap) does (fs/pressure_updater.py).
+// Host-checked preconditions (fs_api.hip lazy_ok): every source is a not-wall cell (an inflow cell whose right neighbour is a wall
+// would read that buffer's history), and rows 0 / Y-1 hold no not-wall cell (no clamped y neighbour of a computed cell).
+// bcmap byte: bit 0 target, bits 1-2 kind (0 copy, 1 mean, 2 zero), bits 3-4 direction of source 1, bits 5-6 of source 2
+// (0 = i-1, 1 = i+1, 2 = j-1, 3 = j+1).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T lazy_value(unsigned code, T raw, T sL, T sR, T sD, T sU)
+{
+    if (!(code & 1u)) return raw;
+    const unsigned kind = (code >> 1) & 3u, d1 = (code >> 3) & 3u, d2 = (code >> 5) & 3u;
+    const T a = d1 == 0u ? sL : (d1 == 1u ? sR : (d1 == 2u ? sD : sU));
+    const T b = d2 == 0u ? sL : (d2 == 1u ? sR : (d2 == 2u ? sD : sU));
+    return kind == 0u ? a : (kind == 1u ? (a + b) / (T)2.0 : (T)0.0);
+}
+
+// flags[wx * rows + r] = 1 if a not-wall owner cell of wave column wx in row r has a boundary-condition target among its 4 neighbours
+static __global__ __launch_bounds__(256) void k_lazy_flags(Grid g, int nwx, const uint8_t *bcmap, uint8_t *flags)
+{
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wx = wid % nwx, r = wid / nwx;
+    if (r >= g.rows) return;
+    const LaneMap lm = lane_map_wave(g, wx);
+    const int i0 = lm.i0;
+    auto bq = [&](int row) { return *reinterpret_cast<const uint32_t *>(bcmap + (size_t)clampy(g, row) * g.Pm + i0); };
+    const uint32_t m4 = mask_quad(g, i0, r), bm = bq(r - 1), bc = bq(r), bp = bq(r + 1);
+    // codes of cells i0-1 / i0+4 (the shifts sit OUTSIDE the conditional: inside an arm of ?: only the lanes taking that arm would execute
+    // them, and a DPP read from a lane that is switched off returns 0)
+    const uint32_t bc_prev = lane_prev_u(bc), bc_next = lane_next_u(bc);
+    const uint32_t bl = lm.at_lo ? (bc << 24) : bc_prev, br = lm.at_hi ? (bc >> 24) : bc_next;
+    bool hit = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (((m4 >> (8 * q)) & 0xffu) == 1u) continue;                                   // wall cells are not computed
+        const unsigned cE = q == 3 ? (br & 0xffu) : ((bc >> (8 * (q + 1))) & 0xffu), cW = q == 0 ? (bl >> 24) : ((bc >> (8 * (q - 1))) & 0xffu);
+        hit |= ((cE | cW | (bm >> (8 * q)) | (bp >> (8 * q))) & 1u) != 0u;
+    }
+    const bool any = __any(hit && lm.owner);
+    if (lane == 0) flags[(size_t)wx * g.rows + r] = any ? 1 : 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_jacobi_lazy(Grid g, int nbx, int nby, int jb, int je, const uint8_t *bcmap, const uint8_t *flags,
+                                                     T *pn, const T *pc, const T *src)
+{
+    int bx, by;
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
+    const int i0 = lm.i0, j = jb + by;
+    const uint32_t m4 = mask_quad(g, i0, j);
+    const unsigned sel = sel_not_wall(m4);
+    if (!__any(sel != 0u)) return;
+    const bool lazy = flags[(size_t)bx * g.rows + j] != 0;      // wave-uniform (scalar load)
+    const Q4<T> S2(load_quad<2>(src, g, 0, i0, j)), S3(load_quad<2>(src, g, 1, i0, j));
+    Q4<T> o;
+    if (!lazy) {      // nothing around this tile takes a boundary value: the plain sweep
+        const Q4<T> m(load_quad<1>(pc, g, 0, i0, clampy(g, j - 1))), c(load_quad<1>(pc, g, 0, i0, j)), n(load_quad<1>(pc, g, 0, i0, clampy(g, j + 1)));
+        const T pl = quad_left<T>(lm, c.quad()), pr = quad_right<T>(lm, c.quad());
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T pE = q == 3 ? pr : c.a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : c.a[q == 0 ? 0 : q - 1];
+            o.a[q] = predict_from(pE, pW, n.a[q], m.a[q], S2.a[q], S3.a[q]);
+        }
+    } else {
+        Q4<T> P[5];                                              // rows j-2 .. j+2 of the raw buffer
+#pragma unroll
+        for (int r = 0; r < 5; ++r) P[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, clampy(g, j - 2 + r)));
+        auto bq = [&](int row) { return *reinterpret_cast<const uint32_t *>(bcmap + (size_t)clampy(g, row) * g.Pm + i0); };
+        const uint32_t bm = bq(j - 1), bc = bq(j), bp = bq(j + 1);
+        const uint32_t bc_prev = lane_prev_u(bc), bc_next = lane_next_u(bc);       // unconditionally, see k_lazy_flags
+        const uint32_t bl = lm.at_lo ? (bc << 24) : bc_prev, br = lm.at_hi ? (bc >> 24) : bc_next;
+        // x-neighbours of the quad: columns i0-1, i0-2 / i0+4, i0+5 of row j (sample() clamps both onto the edge column), i0-1 / i0+4 of rows j+-1
+        const T c_l1 = quad_left<T>(lm, P[2].quad()), c_r1 = quad_right<T>(lm, P[2].quad());
+        T c_l2 = lane_prev(P[2].a[2]), c_r2 = lane_next(P[2].a[1]);
+        if (lm.at_lo) c_l2 = P[2].a[0];
+        if (lm.at_hi) c_r2 = P[2].a[3];
+        const T m_l1 = quad_left<T>(lm, P[1].quad()), m_r1 = quad_right<T>(lm, P[1].quad());
+        const T p_l1 = quad_left<T>(lm, P[3].quad()), p_r1 = quad_right<T>(lm, P[3].quad());
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // raw values of row j at columns i-2 .. i+2, of rows j-1 / j+1 at i-1 .. i+1, of rows j-2 / j+2 at i   (i = i0 + q)
+            const T a0 = P[2].a[q];
+            const T a1 = q == 3 ? c_r1 : P[2].a[q == 3 ? 3 : q + 1], a2 = q == 3 ? c_r2 : (q == 2 ? c_r1 : P[2].a[q >= 2 ? 3 : q + 2]);
+            const T am1 = q == 0 ? c_l1 : P[2].a[q == 0 ? 0 : q - 1], am2 = q == 0 ? c_l2 : (q == 1 ? c_l1 : P[2].a[q <= 1 ? 0 : q - 2]);
+            const T bm0 = P[1].a[q], bm1 = q == 3 ? m_r1 : P[1].a[q == 3 ? 3 : q + 1], bmm1 = q == 0 ? m_l1 : P[1].a[q == 0 ? 0 : q - 1];
+            const T bp0 = P[3].a[q], bp1 = q == 3 ? p_r1 : P[3].a[q == 3 ? 3 : q + 1], bpm1 = q == 0 ? p_l1 : P[3].a[q == 0 ? 0 : q - 1];
+            const T cm = P[0].a[q], cp = P[4].a[q];
+            const unsigned kC = (bc >> (8 * q)) & 0xffu;
+            const unsigned kE = q == 3 ? (br & 0xffu) : ((bc >> (8 * (q == 3 ? 3 : q + 1))) & 0xffu);
+            const unsigned kW = q == 0 ? (bl >> 24) : ((bc >> (8 * (q == 0 ? 0 : q - 1))) & 0xffu);
+            const unsigned kN = (bp >> (8 * q)) & 0xffu, kS = (bm >> (8 * q)) & 0xffu;
+            // the value the boundary kernel would have left in each stencil neighbour; at the domain's first / last column the
+            // clamped neighbour is the cell itself
+            const T vC = lazy_value(kC, a0, am1, a1, bm0, bp0);
+            const bool edgeE = lm.at_hi && q == 3, edgeW = lm.at_lo && q == 0;
+            const T pE = edgeE ? vC : lazy_value(kE, a1, a0, a2, bm1, bp1);
+            const T pW = edgeW ? vC : lazy_value(kW, am1, am2, a0, bmm1, bpm1);
+            const T pN = lazy_value(kN, bp0, bpm1, bp1, a0, cp);
+            const T pS = lazy_value(kS, bm0, bmm1, bm1, cm, a0);
+            o.a[q] = predict_from(pE, pW, pN, pS, S2.a[q], S3.a[q]);
+        }
+    }
+    if (lm.owner && sel) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o.quad(), sel);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // K2'  MacSolver._update_velocities (fs/solver.py:94-107), quad form: upwind (fs/advection.py:12-24, +-1 stencil) or
 // Kawamura-Kuwahara (fs/advection.py:27-60, +-2 stencil: two DPP hops give the cells i0-2 .. i0+5 of a row).
 // ------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libfs_hip.so")     # FS_LIB: A/B builds (tools/)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -56,6 +56,8 @@ _PROTOS = {
     "fs_rbsor_iteration": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_poisson_source": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp] + _ROWS,
     "fs_jacobi_sweep_src": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_lazy_bc_ok": [_c_vp, _P(_c_int)],
+    "fs_jacobi_sweep_lazy": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_rbsor_halfsweep_src": [_c_vp, _c_dbl, _c_int, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_poisson_residual": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _P(_c_dbl), _P(_c_dbl)],
     "fs_limit_field": [_c_vp, _c_dbl, _c_vp] + _ROWS,

@@ -164,6 +164,7 @@ class DeviceBase:
         self.g_lo = max(0, self.y0 - self.halo)
         self.g_hi = min(self.ny, self.y0 + self.nyl + self.halo)
         self.bc_radius_v, self.bc_radius_p = 2, 1
+        self.lazy_bc_ok = False
         self.n_exchanges = 0          # grouped send/recv launches issued
         self.n_exchanged_fields = 0   # fields refreshed by them
         self.n_exchanged_bytes = 0    # payload sent to ONE neighbour by them (an interior rank sends twice that)
@@ -228,6 +229,9 @@ class DeviceBase:
 
     def _p_exchange_mark(self):
         pass
+
+    def _p_lazy_bc_ok(self):        # backends without the lazy pressure boundary condition
+        return False
 
     def _p_max_over_ranks(self, values):
         """Element-wise maximum of a short list of non-negative numbers over all ranks (collective)."""
@@ -444,7 +448,9 @@ class DeviceBase:
         rv, rp = self._p_upload_scene(bc_mask, bc_const, bc_dye)
         # every slab analysed its own rows of the mask: the reach of chained thin walls differs from slab to slab, but the
         # ranks must run the SAME validity bookkeeping (same exchanges, same message sizes) -> one global pair of radii
-        rv, rp = self._p_max_over_ranks([rv, rp])
+        # (and one answer to "may the pressure boundary condition be evaluated lazily?")
+        rv, rp, no_lazy = self._p_max_over_ranks([rv, rp, 0 if self._p_lazy_bc_ok() else 1])
+        self.lazy_bc_ok = not no_lazy
         self.bc_radius_v, self.bc_radius_p = max(2, int(rv)), max(1, int(rp))
         if self.nranks > 1 and max(self.bc_radius_v, self.bc_radius_p) > self.halo:
             raise RuntimeError(
@@ -525,6 +531,12 @@ class DeviceBase:
 
     def jacobi_sweep_src(self, pn, pc, src):
         self._run("jacobi_sweep_src", (pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
+
+    def jacobi_sweep_lazy(self, pn, pc, src):
+        """Source-pair sweep that evaluates the pressure boundary condition on the fly from the raw buffer (csrc/fs_march.h
+        k_jacobi_lazy): the boundary value of a stencil neighbour may come from two cells away -> radius 2 (plus the reach of the
+        boundary kernel on this mask, were it larger)."""
+        self._run("jacobi_sweep_lazy", (pn._h, pc._h, src._h), reads=[(pc, max(2, 1 + self.bc_radius_p)), (src, 0)], writes=[pn])
 
     def rbsor_halfsweep_src(self, omega, parity, pn, pc, src):
         self._run("rbsor_halfsweep_src", (omega, parity, pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
@@ -630,6 +642,11 @@ class Device(DeviceBase):
 
     def _p_kernel(self, name, *args):
         _lib.check(getattr(self._lib, "fs_" + name)(self._ctx, *args))
+
+    def _p_lazy_bc_ok(self):
+        ok = ctypes.c_int()
+        _lib.call("fs_lazy_bc_ok", self._ctx, ctypes.byref(ok))
+        return bool(ok.value)
 
     def _p_exchange(self, h, nchan, depth):
         _lib.call("fs_halo_exchange", self._ctx, h, depth)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 2
+#define FS_ABI_VERSION 3
 
 typedef struct fs_ctx fs_ctx;
 typedef struct fs_field fs_field;
@@ -158,6 +158,12 @@ int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs
                       int row_begin, int row_end);
 int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src,
                         int row_begin, int row_end);
+/* Jacobi sweep on the source pair with the pressure boundary condition evaluated on the fly from the RAW output of the previous
+ * sweep (build-side optimisation for long Jacobi runs, same bits): replaces fs_pressure_bc + fs_jacobi_sweep_src for all but the
+ * last two sweeps of a JacobiPressureUpdater.update (fs/pressure_updater.py:56-66).  fs_lazy_bc_ok: does this mask admit it
+ * (every K7 source a not-wall cell, no computed cell in the first / last row)?                                                */
+int fs_lazy_bc_ok(const fs_ctx *ctx, int *ok);
+int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end);
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc,
                            const fs_field *src, int row_begin, int row_end);
 /* Residual diagnostic (new; the reference never measures convergence): sum over owned not-wall cells of

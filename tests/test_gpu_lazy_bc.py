@@ -1,0 +1,118 @@
+"""The "lazy" pressure boundary condition of long Jacobi runs (csrc/fs_march.h k_jacobi_lazy): all but the last two sweeps of
+JacobiPressureUpdater.update evaluate K7 (fs/boundary_condition.py:41-65) on the fly from the raw output of the previous sweep
+instead of launching the boundary kernel.  Bit for bit against the CPU oracle, which runs the reference's n x (BC, sweep, swap) -
+including the internal p.next buffer, whose non-fluid cells only the last two real boundary passes define."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(const, mask, scheme, n_iter, res, dtype="f32", lazy=True, vc=5.0):
+    import fs
+    from fs.boundary_condition import BoundaryCondition
+    from oracle import oracle as O
+    dt, dx, re = 0.05 / res, 1.0 / res, 1.0e4
+    fs.runtime.init(gpu=0, dtype=dtype)
+    bc = BoundaryCondition(const, mask)
+    pu = fs.JacobiPressureUpdater(bc, dt, dx, n_iter, precompute_source=True, lazy_bc=lazy)
+    v = fs.VorticityConfinement(bc, dt, dx, vc) if vc else None
+    if scheme == "cip":
+        solver = fs.CipMacSolver(bc, pu, dt, dx, re, v)
+    else:
+        solver = fs.MacSolver(bc, pu, fs.advect_upwind if scheme == "upwind" else fs.advect_kk_scheme, dt, dx, re, v)
+    ref = O.make_simulator(const, mask, None, scheme=scheme, dt=dt, dx=dx, re=re, vor_eps=vc, updater=("jacobi", n_iter),
+                           dtype=np.float32 if dtype == "f32" else np.float64)
+    return solver, ref, pu
+
+
+def _run(solver, ref, steps, tag, rng=None):
+    if rng is not None:
+        X, Y = solver.resolution
+        t = solver.v.current.dev.dtype
+        v0 = rng.uniform(-1, 1, (X, Y, 2)).astype(t)
+        p0 = rng.uniform(-3, 3, (X, Y)).astype(t)
+        p1 = rng.uniform(-3, 3, (X, Y)).astype(t)              # the stale buffer matters too (never-written wall cells)
+        solver.v.current.from_numpy(v0); ref.v.current[...] = v0
+        solver.p.current.from_numpy(p0); ref.p.current[...] = p0
+        solver.p.next.from_numpy(p1); ref.p.next[...] = p1
+    for step in range(1, steps + 1):
+        solver.update()
+        ref.update()
+        for name, a, e in (("v", solver.v.current.to_numpy(), ref.v.current), ("p", solver.p.current.to_numpy(), ref.p.current),
+                           ("p.next", solver.p.next.to_numpy(), ref.p.next)):
+            assert np.array_equal(a, e, equal_nan=True), f"{tag}: step {step} {name}: max|d| {np.nanmax(np.abs(a - e))}"
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("res,scheme,n_iter", [(64, "cip", 7), (128, "upwind", 6), (32, "kk", 3)])
+def test_reference_scenes(n, res, scheme, n_iter, hip_lib):
+    from fs.boundary_condition import create_scene_arrays
+    const, mask, _ = create_scene_arrays(n, res)
+    solver, ref, pu = _pair(const, mask, scheme, n_iter, res)
+    try:
+        assert solver._dev.lazy_bc_ok and pu._lazy, "every reference scene admits the lazy boundary condition"
+        _run(solver, ref, 4, f"bc{n} res{res} {scheme}", np.random.default_rng(n * 100 + res))
+    finally:
+        solver._dev.close()
+
+
+def _framed_scene(rng, X, Y, wall_p, io_inside):
+    """Walls on rows 0, 1, Y-2, Y-1; inflow columns 0-1, outflow column(s) at the right edge; random interior walls (thin ones
+    included), optionally stray inflow / outflow cells inside (an inflow cell left of a wall makes the mask NOT admit laziness)."""
+    mask = (rng.random((X, Y)) < wall_p).astype(np.uint8)
+    for _ in range(5):
+        i, j, w, h = rng.integers(2, X - 6), rng.integers(2, Y - 6), rng.integers(1, 7), rng.integers(1, 7)
+        mask[i:i + w, j:j + h] = 1
+    if io_inside:
+        io = rng.random((X, Y))
+        mask[(io < 0.02) & (mask == 0)] = 2
+        mask[(io > 0.98) & (mask == 0)] = 3
+    mask[:2, :] = 2
+    if not io_inside:
+        mask[2, :] = 0                       # an inflow cell left of a wall makes the mask refuse laziness
+    mask[-(1 + int(rng.integers(0, 2))):, :] = 3
+    mask[:, [0, 1, Y - 2, Y - 1]] = 1
+    const = np.zeros((X, Y, 2), np.float32)
+    const[mask == 2] = rng.uniform(0.2, 1, (int((mask == 2).sum()), 2)).astype(np.float32) * np.float32([1, 0.1])
+    return const, mask
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_framed_masks(seed, hip_lib):
+    rng = np.random.default_rng(7000 + seed)
+    X, Y = [(64, 32), (248, 20), (252, 24), (496, 12), (1000, 10), (128, 64), (72, 40), (244, 16), (992, 9), (1240, 12)][seed]
+    const, mask = _framed_scene(rng, X, Y, wall_p=[0.0, 0.03, 0.1, 0.05, 0.02, 0.2, 0.3, 0.08, 0.04, 0.06][seed], io_inside=seed % 3 == 2)
+    solver, ref, pu = _pair(const, mask, ["cip", "upwind", "kk"][seed % 3], 3 + seed % 5, 32 if seed % 2 else 30)
+    try:
+        if seed % 3 != 2:
+            assert pu._lazy, "a framed mask whose only inflow cells are columns 0-1 admits the lazy boundary condition"
+        _run(solver, ref, 3, f"seed {seed} lazy={pu._lazy}", rng)
+    finally:
+        solver._dev.close()
+
+
+def test_f64_and_long_run(hip_lib):
+    from fs.boundary_condition import create_scene_arrays
+    const, mask, _ = create_scene_arrays(2, 100)
+    solver, ref, pu = _pair(const, mask, "cip", 50, 100, dtype="f64")
+    try:
+        assert pu._lazy
+        _run(solver, ref, 3, "f64 bc2 res100 jacobi50")
+    finally:
+        solver._dev.close()
+
+
+def test_inflow_next_to_a_wall_is_refused(hip_lib):
+    """An inflow cell whose right neighbour is a wall would make K7 read that buffer's history: fs_lazy_bc_ok says no, the updater
+    keeps launching the boundary kernel, results stay those of the oracle."""
+    from fs.boundary_condition import create_scene_arrays
+    const, mask, _ = create_scene_arrays(1, 32)
+    mask = mask.copy()
+    mask[2, 10:14] = 1                       # a wall stub right of the inflow column 1
+    solver, ref, pu = _pair(const, mask, "cip", 6, 32)
+    try:
+        assert not solver._dev.lazy_bc_ok and not pu._lazy
+        _run(solver, ref, 3, "refused", np.random.default_rng(3))
+    finally:
+        solver._dev.close()
