@@ -154,6 +154,18 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
     do { if constexpr (std::is_same<T, float>::value) { if (((dm) & 3) == 3) { CALL(3); break; } if ((dm) & 2) { CALL(2); break; } } \
          if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
 
+#define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end, \
+                               (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, (const uint32_t *)ctx->d_pairlist, ctx->n_pairlist, zoff, \
+                               (T *)pn->d, (const T *)pc->d, (const T *)src->d)
+template <bool SW, typename T>
+static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, int row_end, fs_field *pn, const fs_field *pc, const fs_field *src)
+{
+    // the general rows ride in front: `zoff` leading z slices of the same launch, one wave per listed row
+    const int per_slice = (int)(og.grid.x * og.grid.y), blocks = (ctx->n_pairlist + 3) / 4, zoff = (blocks + per_slice - 1) / per_slice;
+    const dim3 grid(og.grid.x, og.grid.y, og.grid.z + zoff);
+    if (rt == 1) FS_PAIR(1); else if (rt == 4) FS_PAIR(4); else if (rt == 3) FS_PAIR(3); else FS_PAIR(2);
+}
+
 template <bool SRC, typename T>
 static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
 {
@@ -527,6 +539,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_RCP")) c->use_rcp = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
+    if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 ? 2 : (v >= 4 ? 4 : 0); }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
@@ -562,6 +575,7 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_rowact) hipFree(ctx->d_rowact);
     if (ctx->d_bcmap) hipFree(ctx->d_bcmap);
     if (ctx->d_lazyflags) hipFree(ctx->d_lazyflags);
+    if (ctx->d_pairlist) hipFree(ctx->d_pairlist);
     if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -643,7 +657,7 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     if (!ctx->d_bcmap) FS_HIP(hipMalloc(&ctx->d_bcmap, (size_t)ctx->rows * ctx->Pm));
     if (!ctx->d_lazyflags) FS_HIP(hipMalloc(&ctx->d_lazyflags, (size_t)std::max(ctx->nwx, 1) * ctx->rows));
     FS_HIP(hipMemsetAsync(ctx->d_bcmap, 0, (size_t)ctx->rows * ctx->Pm, ctx->stream));
-    FS_HIP(hipMemsetAsync(ctx->d_lazyflags, 1, (size_t)std::max(ctx->nwx, 1) * ctx->rows, ctx->stream));
+    FS_HIP(hipMemsetAsync(ctx->d_lazyflags, 31, (size_t)std::max(ctx->nwx, 1) * ctx->rows, ctx->stream));
     rc = upload_global(ctx, ctx->d_bcmap, 1, 1, ctx->h_bcmap.data(), ctx->Pm);
     std::vector<uint8_t>().swap(ctx->h_bcmap);
     if (rc) return rc;
@@ -651,6 +665,17 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
         hipLaunchKernelGGL(k_row_activity, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_rowact);
         hipLaunchKernelGGL(k_lazy_flags, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_bcmap, ctx->d_lazyflags);
         FS_HIP(hipGetLastError());
+        // the rows the two-sweep kernel hands to its general path: list + count (read back once per mask)
+        if (!ctx->d_pairlist) FS_HIP(hipMalloc(&ctx->d_pairlist, ((size_t)ctx->nwx * ctx->rows + 1) * sizeof(uint32_t)));
+        unsigned *d_count = (unsigned *)(ctx->d_pairlist + (size_t)ctx->nwx * ctx->rows);
+        FS_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(k_pair_list, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, (uint8_t *)ctx->d_lazyflags,
+                           ctx->d_pairlist, d_count);
+        FS_HIP(hipGetLastError());
+        unsigned n = 0;
+        FS_HIP(hipMemcpyAsync(&n, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->n_pairlist = (int)n;
     }
     ctx->mask_set = true;
     return FS_OK;
@@ -1206,6 +1231,25 @@ int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs
         return launch(ctx, "jacobi_sweep_lazy", [=] {
             hipLaunchKernelGGL((k_jacobi_lazy<T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end,
                                (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
+        });
+    })
+}
+
+// two lazily-bounded sweeps in one pass (fs_march.h k_jacobi_pair): pn <- sweep(sweep(pc)); pn's wall cells are read (the intermediate
+// buffer of the two-buffer rotation is pn itself)
+int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int swapped, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
+    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
+    FS_ROWS();
+    if (!(ctx->lazy_ok && ctx->use_march)) { set_error("this mask does not admit the lazy pressure boundary condition (fs_lazy_bc_ok)"); return FS_ERR_UNSUPPORTED; }
+    const int rt = ctx->pair_rt;
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_JACOBI);
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "jacobi_pair_lazy", [=] {
+            if (swapped) launch_pair<true, T>(ctx, og, rt, row_begin, row_end, pn, pc, src);
+            else launch_pair<false, T>(ctx, og, rt, row_begin, row_end, pn, pc, src);
         });
     })
 }

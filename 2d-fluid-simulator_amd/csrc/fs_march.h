@@ -36,9 +36,30 @@ __device__ __forceinline__ float lane_next(float x)
 __device__ __forceinline__ double lane_prev(double x) { return __shfl_up(x, 1, 64); }
 __device__ __forceinline__ double lane_next(double x) { return __shfl_down(x, 1, 64); }
 
+// Addressing of the quad accesses: wave-uniform row base (an SGPR pair) + ONE 32-bit lane offset shared by every access of the lane - the
+// `saddr` form of global_load / global_store.  Left to itself the compiler reassociates base + row + lane into (base + lane), a 64-bit
+// VGPR pair, + row: one v_lshl_add_u64 and two more live VGPRs per access (a CIP tile has ~40).  Passing the row base through
+// readfirstlane (it IS uniform: every row index here derives from tile_coords' wave index) pins the split.  Rows must be wave-uniform.
+typedef __attribute__((address_space(1))) const char *fs_gcptr;
+typedef __attribute__((address_space(1))) char *fs_gptr;
+__device__ __forceinline__ uint64_t uniform64(uint64_t u)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename Q, typename T>
+__device__ __forceinline__ Q load_row_quad(const T *row, int i0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<__attribute__((address_space(1))) const Q *>((fs_gcptr)uniform64((uint64_t)row) + (unsigned)i0 * (unsigned)sizeof(T));
+#else       // (the host pass only parses device code; it has no address spaces)
+    return *reinterpret_cast<const Q *>(row + i0);
+#endif
+}
+
 template <int C, typename T>
 __device__ __forceinline__ typename Quad<T>::type load_quad(const T *f, const Grid &g, int c, int i0, int j)
-{ return *reinterpret_cast<const typename Quad<T>::type *>(f + idx<C, T>(g, c, i0, j)); }
+{ return load_row_quad<typename Quad<T>::type, T>(f + ((size_t)j * C + c) * g.P, i0); }
 
 // predicated load: lanes whose quad (and whose neighbours' quads) are solid wall fetch nothing
 template <int C, typename T>
@@ -56,7 +77,7 @@ __device__ __forceinline__ unsigned lane_next_u(unsigned x) { return (unsigned)_
 __device__ __forceinline__ bool lane_needed(unsigned active) { return (active | lane_prev_u(active) | lane_next_u(active)) != 0u; }
 
 __device__ __forceinline__ uint32_t mask_quad(const Grid &g, int i0, int j)
-{ return *reinterpret_cast<const uint32_t *>(g.mask + (size_t)j * g.Pm + i0); }
+{ return load_row_quad<uint32_t, uint8_t>(g.mask + (size_t)j * g.Pm, i0); }
 
 // store the components of `v` whose mask byte satisfies the predicate encoded in `sel` (bit k = cell k)
 template <typename T>
@@ -121,7 +142,7 @@ struct LaneMap {
 // No integer division in the decode (the first version, a 1-D grid decoded with two divisions per wave, spent ~70 of the ~700
 // instructions of a one-row K2 tile on them).
 template <int ZG = 1>
-__device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by, int &cg)
+__device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by, int &cg, int zoff = 0)
 {
     const int nby = nby_packed & 0x7fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked
     if (nbx < 0) {   // plain row-major decode (FS_XCD=0: rows of one tile row spread over the XCDs): grid = (nbx * nby, ZG)
@@ -135,7 +156,7 @@ __device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, in
     bx = blockIdx.x >> 3;
     const int ly = ZG == 1 ? (int)blockIdx.y : (int)blockIdx.y / ZG;        // division by a compile-time 2 or 3
     cg = ZG == 1 ? 0 : (int)blockIdx.y - ly * ZG;
-    by = ((int)blockIdx.z * 8 + xcd) * FS_XCD_GROUP + ly;
+    by = (((int)blockIdx.z - zoff) * 8 + xcd) * FS_XCD_GROUP + ly;       // zoff: leading z slices that belong to someone else
     return by < nby;
 }
 // Workgroup shape.  Side by side (default): the waves of a workgroup are consecutive wave columns of ONE tile row.  Stacked (bit 23 of
@@ -146,10 +167,10 @@ __device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, in
 // multiply-add per load and lane.
 constexpr int FS_STACKED = 1 << 23;
 template <int ZG = 1>
-__device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg)
+__device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg, int zoff = 0)
 {
     int bx, by;
-    if (!band_coords<ZG>(nbx, nby_packed, bx, by, cg)) return false;
+    if (!band_coords<ZG>(nbx, nby_packed, bx, by, cg, zoff)) return false;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }
@@ -1186,7 +1207,12 @@ __device__ __forceinline__ T lazy_value(unsigned code, T raw, T sL, T sR, T sD, 
     return kind == 0u ? a : (kind == 1u ? (a + b) / (T)2.0 : (T)0.0);
 }
 
-// flags[wx * rows + r] = 1 if a not-wall owner cell of wave column wx in row r has a boundary-condition target among its 4 neighbours
+__device__ __forceinline__ uint32_t bcmap_quad(const Grid &g, const uint8_t *bcmap, int i0, int row)
+{ return load_row_quad<uint32_t, uint8_t>(bcmap + (size_t)clampy(g, row) * g.Pm, i0); }
+
+// flags[wx * rows + r]: bit 0 - a not-wall owner cell of wave column wx in row r has a boundary-condition target among its 4 neighbours;
+// (bit 4 is added by k_pair_list) bit 1 - a wall or a target lies in row r within 2 columns of the wave's owner cells; within 4 columns of them: bit 3 - a target with a
+// source in another row, bit 2 - such a target in a wall one cell thick, or a wall cell WITHOUT a recipe that a not-wall cell reads (k_jacobi_pair)
 static __global__ __launch_bounds__(256) void k_lazy_flags(Grid g, int nwx, const uint8_t *bcmap, uint8_t *flags)
 {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1194,8 +1220,7 @@ static __global__ __launch_bounds__(256) void k_lazy_flags(Grid g, int nwx, cons
     if (r >= g.rows) return;
     const LaneMap lm = lane_map_wave(g, wx);
     const int i0 = lm.i0;
-    auto bq = [&](int row) { return *reinterpret_cast<const uint32_t *>(bcmap + (size_t)clampy(g, row) * g.Pm + i0); };
-    const uint32_t m4 = mask_quad(g, i0, r), bm = bq(r - 1), bc = bq(r), bp = bq(r + 1);
+    const uint32_t m4 = mask_quad(g, i0, r), bm = bcmap_quad(g, bcmap, i0, r - 1), bc = bcmap_quad(g, bcmap, i0, r), bp = bcmap_quad(g, bcmap, i0, r + 1);
     // codes of cells i0-1 / i0+4 (the shifts sit OUTSIDE the conditional: inside an arm of ?: only the lanes taking that arm would execute
     // them, and a DPP read from a lane that is switched off returns 0)
     const uint32_t bc_prev = lane_prev_u(bc), bc_next = lane_next_u(bc);
@@ -1207,8 +1232,87 @@ static __global__ __launch_bounds__(256) void k_lazy_flags(Grid g, int nwx, cons
         const unsigned cE = q == 3 ? (br & 0xffu) : ((bc >> (8 * (q + 1))) & 0xffu), cW = q == 0 ? (bl >> 24) : ((bc >> (8 * (q - 1))) & 0xffu);
         hit |= ((cE | cW | (bm >> (8 * q)) | (bp >> (8 * q))) & 1u) != 0u;
     }
-    const bool any = __any(hit && lm.owner);
-    if (lane == 0) flags[(size_t)wx * g.rows + r] = any ? 1 : 0;
+    // per cell: wall or target
+    uint32_t d4 = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (((m4 >> (8 * q)) & 0xffu) == 1u || ((bc >> (8 * q)) & 1u)) d4 |= 1u << q;
+    // per cell, v4: a target with a source in another row (copy of the cell below / above, mean).  x4: such a target whose OTHER vertical
+    // neighbour is computed too (a wall one cell thick: the reader on one side needs the row beyond the other side), or a wall cell
+    // without a recipe that a not-wall cell reads (its content is history, and the two buffers' histories differ)
+    const uint32_t mm = mask_quad(g, i0, clampy(g, r - 1)), mp = mask_quad(g, i0, clampy(g, r + 1));
+    const uint32_t m_prev = lane_prev_u(m4), m_next = lane_next_u(m4);
+    const uint32_t ml = lm.at_lo ? (m4 << 24) : m_prev, mr = lm.at_hi ? (m4 >> 24) : m_next;
+    uint32_t x4 = 0u, v4 = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned code = (bc >> (8 * q)) & 0xffu, kind = (code >> 1) & 3u, d1 = (code >> 3) & 3u, d2 = (code >> 5) & 3u;
+        const unsigned mE = q == 3 ? (mr & 0xffu) : ((m4 >> (8 * (q + 1))) & 0xffu), mW = q == 0 ? (ml >> 24) : ((m4 >> (8 * (q - 1))) & 0xffu);
+        const unsigned mS = (mm >> (8 * q)) & 0xffu, mN = (mp >> (8 * q)) & 0xffu;
+        const bool wall = ((m4 >> (8 * q)) & 0xffu) == 1u;
+        if (code & 1u) {
+            const unsigned dv = kind == 0u ? d1 : (kind == 1u ? d2 : 0u);       // the vertical source, if any: 2 = the cell below, 3 = above
+            if (kind != 2u && dv >= 2u) {
+                v4 |= 1u << q;
+                if ((dv == 2u ? mN : mS) != 1u) x4 |= 1u << q;
+            }
+        } else if (wall && (mE != 1u || mW != 1u || mS != 1u || mN != 1u)) x4 |= 1u << q;
+    }
+    const uint32_t d_prev = lane_prev_u(d4), d_next = lane_next_u(d4), x_prev = lane_prev_u(x4), x_next = lane_next_u(x4);
+    const uint32_t v_prev = lane_prev_u(v4), v_next = lane_next_u(v4);
+    const bool near = d4 != 0u || (!lm.at_lo && (d_prev & 0xcu)) || (!lm.at_hi && (d_next & 0x3u));
+    const bool hard = x4 != 0u || (!lm.at_lo && x_prev) || (!lm.at_hi && x_next);
+    const bool vert = v4 != 0u || (!lm.at_lo && v_prev) || (!lm.at_hi && v_next);
+    const bool any = __any(hit && lm.owner), any2 = __any(near && lm.owner), any4 = __any(hard && lm.owner), any8 = __any(vert && lm.owner);
+    if (lane == 0) flags[(size_t)wx * g.rows + r] = (any ? 1 : 0) | (any2 ? 2 : 0) | (any4 ? 4 : 0) | (any8 ? 8 : 0);
+}
+
+// One row of the plain source-pair sweep on register rows: m / c / n = rows j-1 / j / j+1 of the previous iterate.
+template <typename T>
+__device__ __forceinline__ Q4<T> plain_row(const LaneMap &lm, const Q4<T> &m, const Q4<T> &c, const Q4<T> &n, const Q4<T> &S2, const Q4<T> &S3)
+{
+    const T pl = quad_left<T>(lm, c.quad()), pr = quad_right<T>(lm, c.quad());
+    Q4<T> o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const T pE = q == 3 ? pr : c.a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : c.a[q == 0 ? 0 : q - 1];
+        o.a[q] = predict_from(pE, pW, n.a[q], m.a[q], S2.a[q], S3.a[q]);
+    }
+    return o;
+}
+
+// K7 on one register row whose targets are all "0" or "copy of the left / right neighbour" (inflow / outflow columns): no other row involved
+template <typename T>
+__device__ __forceinline__ Q4<T> bc_row_h(const LaneMap &lm, const Q4<T> &c, uint32_t code)
+{
+    const T cl = quad_left<T>(lm, c.quad()), cr = quad_right<T>(lm, c.quad());
+    Q4<T> o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned k = (code >> (8 * q)) & 0xffu;
+        const T sL = q == 0 ? cl : c.a[q == 0 ? 0 : q - 1], sR = q == 3 ? cr : c.a[q == 3 ? 3 : q + 1];
+        const T v = (k & 4u) ? (T)0.0 : ((k & 8u) ? sR : sL);            // kind 2 (bit 2 of the byte) = zero; direction bit 3: 0 left, 1 right
+        o.a[q] = (k & 1u) ? v : c.a[q];
+    }
+    return o;
+}
+
+// One row of the buffer as K7 would leave it, from RAW rows: m / c / n = rows j-1 / j / j+1, code = recipe bytes of row j.  Each cell's
+// boundary value is evaluated ONCE here and the stencil then runs on the finished rows (evaluating it per stencil neighbour costs 5x the
+// selects).  At the domain's first / last column sample() clamps onto the cell itself - no recipe points outside (fs_api.hip build_bc_ops).
+// Must be called by the whole wave (cross-lane shifts).
+template <typename T>
+__device__ __forceinline__ Q4<T> bc_row(const LaneMap &lm, const Q4<T> &m, const Q4<T> &c, const Q4<T> &n, uint32_t code)
+{
+    if (!__any((code & 0x01010101u) != 0u)) return c;            // wave-uniform: no target in this row of the wave
+    const T cl = quad_left<T>(lm, c.quad()), cr = quad_right<T>(lm, c.quad());
+    Q4<T> o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const T sL = q == 0 ? cl : c.a[q == 0 ? 0 : q - 1], sR = q == 3 ? cr : c.a[q == 3 ? 3 : q + 1];
+        o.a[q] = lazy_value((code >> (8 * q)) & 0xffu, c.a[q], sL, sR, m.a[q], n.a[q]);
+    }
+    return o;
 }
 
 template <typename T>
@@ -1222,57 +1326,179 @@ __global__ __launch_bounds__(256) void k_jacobi_lazy(Grid g, int nbx, int nby, i
     const uint32_t m4 = mask_quad(g, i0, j);
     const unsigned sel = sel_not_wall(m4);
     if (!__any(sel != 0u)) return;
-    const bool lazy = flags[(size_t)bx * g.rows + j] != 0;      // wave-uniform (scalar load)
+    const bool lazy = (flags[(size_t)bx * g.rows + j] & 1u) != 0;      // wave-uniform (scalar load)
     const Q4<T> S2(load_quad<2>(src, g, 0, i0, j)), S3(load_quad<2>(src, g, 1, i0, j));
     Q4<T> o;
     if (!lazy) {      // nothing around this tile takes a boundary value: the plain sweep
         const Q4<T> m(load_quad<1>(pc, g, 0, i0, clampy(g, j - 1))), c(load_quad<1>(pc, g, 0, i0, j)), n(load_quad<1>(pc, g, 0, i0, clampy(g, j + 1)));
-        const T pl = quad_left<T>(lm, c.quad()), pr = quad_right<T>(lm, c.quad());
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T pE = q == 3 ? pr : c.a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : c.a[q == 0 ? 0 : q - 1];
-            o.a[q] = predict_from(pE, pW, n.a[q], m.a[q], S2.a[q], S3.a[q]);
-        }
+        o = plain_row<T>(lm, m, c, n, S2, S3);
     } else {
         Q4<T> P[5];                                              // rows j-2 .. j+2 of the raw buffer
 #pragma unroll
         for (int r = 0; r < 5; ++r) P[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, clampy(g, j - 2 + r)));
-        auto bq = [&](int row) { return *reinterpret_cast<const uint32_t *>(bcmap + (size_t)clampy(g, row) * g.Pm + i0); };
-        const uint32_t bm = bq(j - 1), bc = bq(j), bp = bq(j + 1);
-        const uint32_t bc_prev = lane_prev_u(bc), bc_next = lane_next_u(bc);       // unconditionally, see k_lazy_flags
-        const uint32_t bl = lm.at_lo ? (bc << 24) : bc_prev, br = lm.at_hi ? (bc >> 24) : bc_next;
-        // x-neighbours of the quad: columns i0-1, i0-2 / i0+4, i0+5 of row j (sample() clamps both onto the edge column), i0-1 / i0+4 of rows j+-1
-        const T c_l1 = quad_left<T>(lm, P[2].quad()), c_r1 = quad_right<T>(lm, P[2].quad());
-        T c_l2 = lane_prev(P[2].a[2]), c_r2 = lane_next(P[2].a[1]);
-        if (lm.at_lo) c_l2 = P[2].a[0];
-        if (lm.at_hi) c_r2 = P[2].a[3];
-        const T m_l1 = quad_left<T>(lm, P[1].quad()), m_r1 = quad_right<T>(lm, P[1].quad());
-        const T p_l1 = quad_left<T>(lm, P[3].quad()), p_r1 = quad_right<T>(lm, P[3].quad());
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // raw values of row j at columns i-2 .. i+2, of rows j-1 / j+1 at i-1 .. i+1, of rows j-2 / j+2 at i   (i = i0 + q)
-            const T a0 = P[2].a[q];
-            const T a1 = q == 3 ? c_r1 : P[2].a[q == 3 ? 3 : q + 1], a2 = q == 3 ? c_r2 : (q == 2 ? c_r1 : P[2].a[q >= 2 ? 3 : q + 2]);
-            const T am1 = q == 0 ? c_l1 : P[2].a[q == 0 ? 0 : q - 1], am2 = q == 0 ? c_l2 : (q == 1 ? c_l1 : P[2].a[q <= 1 ? 0 : q - 2]);
-            const T bm0 = P[1].a[q], bm1 = q == 3 ? m_r1 : P[1].a[q == 3 ? 3 : q + 1], bmm1 = q == 0 ? m_l1 : P[1].a[q == 0 ? 0 : q - 1];
-            const T bp0 = P[3].a[q], bp1 = q == 3 ? p_r1 : P[3].a[q == 3 ? 3 : q + 1], bpm1 = q == 0 ? p_l1 : P[3].a[q == 0 ? 0 : q - 1];
-            const T cm = P[0].a[q], cp = P[4].a[q];
-            const unsigned kC = (bc >> (8 * q)) & 0xffu;
-            const unsigned kE = q == 3 ? (br & 0xffu) : ((bc >> (8 * (q == 3 ? 3 : q + 1))) & 0xffu);
-            const unsigned kW = q == 0 ? (bl >> 24) : ((bc >> (8 * (q == 0 ? 0 : q - 1))) & 0xffu);
-            const unsigned kN = (bp >> (8 * q)) & 0xffu, kS = (bm >> (8 * q)) & 0xffu;
-            // the value the boundary kernel would have left in each stencil neighbour; at the domain's first / last column the
-            // clamped neighbour is the cell itself
-            const T vC = lazy_value(kC, a0, am1, a1, bm0, bp0);
-            const bool edgeE = lm.at_hi && q == 3, edgeW = lm.at_lo && q == 0;
-            const T pE = edgeE ? vC : lazy_value(kE, a1, a0, a2, bm1, bp1);
-            const T pW = edgeW ? vC : lazy_value(kW, am1, am2, a0, bmm1, bpm1);
-            const T pN = lazy_value(kN, bp0, bpm1, bp1, a0, cp);
-            const T pS = lazy_value(kS, bm0, bmm1, bm1, cm, a0);
-            o.a[q] = predict_from(pE, pW, pN, pS, S2.a[q], S3.a[q]);
-        }
+        const Q4<T> m = bc_row<T>(lm, P[0], P[1], P[2], bcmap_quad(g, bcmap, i0, j - 1)), c = bc_row<T>(lm, P[1], P[2], P[3], bcmap_quad(g, bcmap, i0, j)),
+                    n = bc_row<T>(lm, P[2], P[3], P[4], bcmap_quad(g, bcmap, i0, j + 1));
+        o = plain_row<T>(lm, m, c, n, S2, S3);
     }
     if (lm.owner && sel) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o.quad(), sel);
+}
+
+// Output row j of two sweeps, general case: raw rows j-4 .. j+4 of the input iterate -> K7 (bc_row) -> first sweep rows j-2 .. j+2 (cells it
+// does not compute take the intermediate buffer's wall content) -> K7 -> second sweep.  SW: see k_jacobi_pair.
+// A four-stage pipeline over the nine input rows with three rows alive per stage: written so, the kernel needs 88 VGPRs; with every row
+// of every stage in an array (all loads hoisted) it needed 120, and these few waves - dispatched first - must not set the occupancy of the
+// rest.  Its nine dependent trips to memory are the tail of the launch (23 vs 18 us on bc2 res 1600 without these rows).  Not kept:
+// scheduling barriers between the steps (same registers, same time); a compiler-visible prefetch pass (one register per touched row:
+// 117-123 VGPRs).
+//   t: raw row j-4+t  ->  K7 row j-5+t  ->  first-sweep row j-6+t  ->  K7 row j-7+t
+template <bool SW, typename T>
+__device__ __forceinline__ Q4<T> pair_general_row(const Grid &g, const LaneMap &lm, int i0, int j, const uint8_t *bcmap, const T *pn, const T *pc, const T *src)
+{
+    auto raw_row = [&](int row) {        // one row of the input iterate
+        row = clampy(g, row);
+        Q4<T> a(load_quad<1>(pc, g, 0, i0, row));
+        if (SW) {            // its wall cells live in the other buffer
+            const Q4<T> W(load_quad<1>(pn, g, 0, i0, row));
+            const unsigned s = sel_not_wall(mask_quad(g, i0, row));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.a[q] = (s >> q) & 1u ? a.a[q] : W.a[q];
+        }
+        return a;
+    };
+    // First touch every line the pipeline is going to read (one dword per lane and row, all in flight together, nothing else alive yet):
+    // its nine dependent steps then wait for L2 hits instead of nine trips to memory (these rows were the tail of the launch: +5 us).
+    Q4<T> a0, a1, a2, b0, b1, b2, s0, s1, s2, m, c, n;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t >= 2) a0 = a1;
+        if (t >= 1) a1 = a2;
+        a2 = raw_row(j - 4 + t);
+        if (t >= 2) {
+            if (t >= 4) b0 = b1;
+            if (t >= 3) b1 = b2;
+            b2 = bc_row<T>(lm, a0, a1, a2, bcmap_quad(g, bcmap, i0, j - 5 + t));
+        }
+        if (t >= 4) {
+            const int row = clampy(g, j - 6 + t);
+            const Q4<T> S2(load_quad<2>(src, g, 0, i0, row)), S3(load_quad<2>(src, g, 1, i0, row));
+            const Q4<T> H(load_quad<1>(SW ? pc : pn, g, 0, i0, row));      // the intermediate iterate's wall cells
+            const unsigned s = sel_not_wall(mask_quad(g, i0, row));
+            const Q4<T> v = plain_row<T>(lm, b0, b1, b2, S2, S3);
+            if (t >= 6) s0 = s1;
+            if (t >= 5) s1 = s2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s2.a[q] = (s >> q) & 1u ? v.a[q] : H.a[q];
+        }
+        if (t >= 6) {
+            if (t >= 8) m = c;
+            if (t >= 7) c = n;
+            n = bc_row<T>(lm, s0, s1, s2, bcmap_quad(g, bcmap, i0, j - 7 + t));
+        }
+    }
+    const Q4<T> S2(load_quad<2>(src, g, 0, i0, j)), S3(load_quad<2>(src, g, 1, i0, j));
+    return plain_row<T>(lm, m, c, n, S2, S3);
+}
+
+// list[k] = (wave column << 20) | row of every wave-tile row that k_jacobi_pair's general path must compute: a "hard" or "vertical" flag
+// (bits 2, 3) in one of rows r-2 .. r+2, and a not-wall owner cell in row r.  Built once per mask.
+static __global__ __launch_bounds__(256) void k_pair_list(Grid g, int nwx, uint8_t *flags, uint32_t *list, unsigned *count)
+{
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wx = wid % nwx, r = wid / nwx;
+    if (r >= g.rows) return;
+    const LaneMap lm = lane_map_wave(g, wx);
+    unsigned f = 0u;
+    for (int d = -2; d <= 2; ++d) f |= flags[(size_t)wx * g.rows + clampy(g, r + d)];
+    const bool computed = __any(lm.owner && sel_not_wall(mask_quad(g, lm.i0, r)) != 0u);
+    if (lane == 0 && (f & 12u)) {
+        flags[(size_t)wx * g.rows + r] |= 16u;          // bit 4: the general path owns this row (the other waves read bits 2, 3 of this byte only)
+        if (computed) list[atomicAdd(count, 1u)] = ((uint32_t)wx << 20) | (uint32_t)r;
+    }
+}
+
+// TWO sweeps in one pass ("temporal blocking"): the first sweep's rows j0-2 .. j0+RT+1 stay in registers (x-neighbours through the halo
+// lanes, whose 4 cells are exactly the reach of two lazily-bounded sweeps), the second sweep's RT rows are stored.  Half the launches and
+// half the bytes of two k_jacobi_lazy passes; every cell goes through the same two predict_p evaluations, so the bits are the same.
+// Per wave-tile row (flags, k_lazy_flags): bit 1 - a wall or a boundary-condition target within 2 columns of the wave's owner cells.  A tile
+// with no such row among j0-2 .. j0+RT+1 runs the plain two-sweep path; the others apply K7 row by row in registers, which is exact for
+// the targets that are 0 or copy their left / right neighbour (inflow / outflow columns, vertical wall faces).  Output rows with anything
+// else within 2 rows and 4 columns (bits 2, 3: targets with a source in another row - floors, ceilings, corners -, wall cells whose content
+// is history) are left out here and computed, one row per wave, by the workgroups of the first `zoff` z slices of the same launch from
+// `list` (k_pair_list): general, register-frugal and slow, dispatched first, a percent of the rows.
+// The two physical buffers differ in the wall cells NOTHING ever writes (no K7 assignment: e.g. the frame cells beside an inflow column),
+// and not-wall cells next to them read them.  The reference's rotation keeps every even iterate in one buffer and every odd one in the
+// other; a sequence of passes pc -> pn -> pc ... puts every second pass the other way round.  SW = false: the input iterate's wall cells
+// are pc's, the intermediate's are pn's.  SW = true: the input's are pn's, the intermediate's are pc's.
+template <int RT, bool SW, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_pair(Grid g, int nbx, int nby, int jb, int je, const uint8_t *bcmap, const uint8_t *flags,
+                                                     const uint32_t *list, int nlist, int zoff, T *pn, const T *pc, const T *src)
+{
+    if ((int)blockIdx.z < zoff) {        // the general rows
+        const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int k = (((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x) * 4 + w;
+        if (k >= nlist) return;
+        const uint32_t e = list[k];
+        const int wx = (int)(e >> 20), j = (int)(e & 0xfffffu);
+        if (j < jb || j >= je) return;
+        const LaneMap lm = lane_map_wave(g, wx);
+        const unsigned s_out = sel_not_wall(mask_quad(g, lm.i0, j));
+        const Q4<T> out = pair_general_row<SW, T>(g, lm, lm.i0, j, bcmap, pn, pc, src);
+        if (lm.owner && s_out) store_quad_sel<T>(pn + idx<1, T>(g, 0, lm.i0, j), out.quad(), s_out);
+        return;
+    }
+    int bx, by, cg;
+    if (!tile_coords<1>(g, nbx, nby, jb, je, RT, bx, by, cg, zoff)) return;   // bx: wave column, by: tile row
+    const LaneMap lm = lane_map_wave(g, bx);
+    const int i0 = lm.i0, j0 = jb + by * RT;
+    unsigned F[RT + 4], sel[RT], any = 0u, dirty = 0u;           // flags of rows j0-2 .. j0+RT+1
+#pragma unroll
+    for (int r = 0; r < RT + 4; ++r) { F[r] = flags[(size_t)bx * g.rows + clampy(g, j0 - 2 + r)]; dirty |= F[r]; }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        sel[r] = j0 + r < je && !(F[r + 2] & 16u) ? sel_not_wall(mask_quad(g, i0, j0 + r)) : 0u;      // bit 4: the general path's row
+        any |= sel[r];
+    }
+    if (!__any(any != 0u)) return;
+    Q4<T> S2[RT + 4], S3[RT + 4], o[RT];                         // source pair of rows j0-2 .. j0+RT+1 ([1 .. RT+2] are used)
+    if (!(dirty & 2u)) {
+        Q4<T> A[RT + 4], S1[RT + 2];                             // pc rows j0-2 .. j0+RT+1; first sweep rows j0-1 .. j0+RT
+#pragma unroll
+        for (int r = 0; r < RT + 4; ++r) A[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, clampy(g, j0 - 2 + r)));
+#pragma unroll
+        for (int r = 1; r < RT + 3; ++r) {
+            S2[r] = Q4<T>(load_quad<2>(src, g, 0, i0, clampy(g, j0 - 2 + r)));
+            S3[r] = Q4<T>(load_quad<2>(src, g, 1, i0, clampy(g, j0 - 2 + r)));
+        }
+#pragma unroll
+        for (int r = 0; r < RT + 2; ++r) S1[r] = plain_row<T>(lm, A[r], A[r + 1], A[r + 2], S2[r + 1], S3[r + 1]);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) o[r] = plain_row<T>(lm, S1[r], S1[r + 1], S1[r + 2], S2[r + 2], S3[r + 2]);
+    } else {
+        // K7 stays inside each row, and what the first sweep leaves in the wall cells it does not compute is never read: the footprint of
+        // the plain path plus one cheap pass per register row.  (Rows of this tile that the general path owns come out wrong here and
+        // are not stored; the rows that are stored depend on rows without bits 2, 3 only.)
+        Q4<T> A[RT + 4], S1[RT + 2];
+        uint32_t C[RT + 4];
+#pragma unroll
+        for (int r = 0; r < RT + 4; ++r) {
+            A[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, clampy(g, j0 - 2 + r)));
+            C[r] = bcmap_quad(g, bcmap, i0, j0 - 2 + r);
+        }
+#pragma unroll
+        for (int r = 1; r < RT + 3; ++r) {
+            S2[r] = Q4<T>(load_quad<2>(src, g, 0, i0, clampy(g, j0 - 2 + r)));
+            S3[r] = Q4<T>(load_quad<2>(src, g, 1, i0, clampy(g, j0 - 2 + r)));
+        }
+#pragma unroll
+        for (int r = 0; r < RT + 4; ++r) A[r] = bc_row_h<T>(lm, A[r], C[r]);
+#pragma unroll
+        for (int r = 0; r < RT + 2; ++r) S1[r] = bc_row_h<T>(lm, plain_row<T>(lm, A[r], A[r + 1], A[r + 2], S2[r + 1], S3[r + 1]), C[r + 1]);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) o[r] = plain_row<T>(lm, S1[r], S1[r + 1], S1[r + 2], S2[r + 2], S3[r + 2]);
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+        if (lm.owner && sel[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j0 + r), o[r].quad(), sel[r]);
 }
 
 

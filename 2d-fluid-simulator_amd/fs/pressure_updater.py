@@ -38,12 +38,20 @@ class JacobiPressureUpdater(PressureUpdater):
         # that admits it (fs_lazy_bc_ok) and a p that no user upload has put into an arbitrary state.
         self._lazy = (self._precompute and n_iter >= 6 and self._dev.lazy_bc_ok) if lazy_bc is None else \
             (bool(lazy_bc) and self._precompute and n_iter >= 3 and self._dev.lazy_bc_ok)
+        self._pairs = (self._lazy and os.environ.get("FS_JACOBI_PAIRS", "1") != "0"
+                       and (self._dev.nranks == 1 or 2 * max(2, 1 + self._dev.bc_radius_p) <= self._dev.halo))   # a pass reaches 4 rows
 
     def update(self, p, v_current):
         if self._precompute:
             self._dev.poisson_source(self.dt, self.dx, self._src, v_current)
         n_lazy = self._n_iter - 2 if self._lazy else 0
-        for _ in range(n_lazy):
+        # two sweeps per pass where possible; an even number of passes, so that every iterate lands in the physical buffer the
+        # reference's rotation puts it in (the buffers differ in the wall cells nothing ever writes)
+        n_pairs = (n_lazy // 4) * 2 if self._pairs else 0
+        for k in range(n_pairs):
+            self._dev.jacobi_pair_lazy(p.next, p.current, self._src, swapped=k & 1)
+            p.swap()
+        for _ in range(n_lazy - 2 * n_pairs):
             self._dev.jacobi_sweep_lazy(p.next, p.current, self._src)
             p.swap()
         for _ in range(self._n_iter - n_lazy):

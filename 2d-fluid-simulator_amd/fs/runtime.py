@@ -538,6 +538,12 @@ class DeviceBase:
         boundary kernel on this mask, were it larger)."""
         self._run("jacobi_sweep_lazy", (pn._h, pc._h, src._h), reads=[(pc, max(2, 1 + self.bc_radius_p)), (src, 0)], writes=[pn])
 
+    def jacobi_pair_lazy(self, pn, pc, src, swapped=False):
+        """Two such sweeps in one pass, pn <- sweep(sweep(pc)) (csrc/fs_march.h k_jacobi_pair).  `swapped`: this is the 2nd, 4th ... pass
+        of a pc -> pn -> pc sequence (include/fs_hip.h: which buffer's never-written wall cells belong to which iterate)."""
+        r = max(2, 1 + self.bc_radius_p)
+        self._run("jacobi_pair_lazy", (pn._h, pc._h, src._h, 1 if swapped else 0), reads=[(pc, 2 * r), (src, r), (pn, 2 * r)], writes=[pn])
+
     def rbsor_halfsweep_src(self, omega, parity, pn, pc, src):
         self._run("rbsor_halfsweep_src", (omega, parity, pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
 

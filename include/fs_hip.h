@@ -164,6 +164,12 @@ int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
  * (every K7 source a not-wall cell, no computed cell in the first / last row)?                                                */
 int fs_lazy_bc_ok(const fs_ctx *ctx, int *ok);
 int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end);
+/* TWO such sweeps in one pass: pn <- sweep(sweep(pc)), the first sweep's rows staying in registers.  The two buffers of the reference's
+ * rotation differ in the wall cells nothing ever writes, and not-wall cells beside them read them: swapped = 0 when pc is the physical
+ * buffer the reference holds this pass's input iterate in (the 1st, 3rd ... pass of a pc -> pn -> pc sequence; the intermediate iterate's
+ * wall cells are then pn's), 1 when it is the other way round (2nd, 4th ... pass).  Both buffers are read 4 rows beyond the written range,
+ * src 2 rows.                                                                                                                          */
+int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int swapped, int row_begin, int row_end);
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc,
                            const fs_field *src, int row_begin, int row_end);
 /* Residual diagnostic (new; the reference never measures convergence): sum over owned not-wall cells of
