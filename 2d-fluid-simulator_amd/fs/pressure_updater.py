@@ -38,8 +38,37 @@ class JacobiPressureUpdater(PressureUpdater):
         # that admits it (fs_lazy_bc_ok) and a p that no user upload has put into an arbitrary state.
         self._lazy = (self._precompute and n_iter >= 6 and self._dev.lazy_bc_ok) if lazy_bc is None else \
             (bool(lazy_bc) and self._precompute and n_iter >= 3 and self._dev.lazy_bc_ok)
-        self._pairs = (self._lazy and os.environ.get("FS_JACOBI_PAIRS", "1") != "0"
+        # Two sweeps per launch (fs_jacobi_pair_lazy) win where launches and latency dominate and few rows need its general path
+        # (bc2: +28 % at res 1600, +11 % at res 4096; bc1 res 2048: +27 %) and lose on masks full of small obstacles (bc3, bc5: -4 .. -9 %).
+        # Same bits either way, so a single-GPU run times both on this mask once (FS_JACOBI_PAIRS=0 / 1 decides instead).
+        want = os.environ.get("FS_JACOBI_PAIRS", "auto")
+        self._pairs = (self._lazy and want != "0" and n_iter >= 6
                        and (self._dev.nranks == 1 or 2 * max(2, 1 + self._dev.bc_radius_p) <= self._dev.halo))   # a pass reaches 4 rows
+        if self._pairs and want == "auto" and self._dev.nranks == 1 and hasattr(self._dev, "profile_report"):
+            self._pairs = self._pairs_are_faster()
+
+    def _pairs_are_faster(self):
+        dev = self._dev
+        if getattr(dev, "_pairs_verdict", None) is None:       # once per device (= per mask)
+            a, b, src = dev.alloc(1), dev.alloc(1), dev.alloc(2)
+
+            def run(n):
+                for _ in range(n):
+                    dev.jacobi_pair_lazy(b, a, src, swapped=False)
+                    dev.jacobi_pair_lazy(a, b, src, swapped=True)
+                for _ in range(2 * n):
+                    dev.jacobi_sweep_lazy(b, a, src)
+                    dev.jacobi_sweep_lazy(a, b, src)
+            run(1)
+            dev.profile_reset()
+            dev.profile(True)
+            run(3)
+            rep = dev.profile_report()
+            dev.profile(False)
+            dev.profile_reset()
+            (n2, ms2), (n1, ms1) = rep["jacobi_pair_lazy"], rep["jacobi_sweep_lazy"]
+            dev._pairs_verdict = ms2 / n2 < 2.0 * ms1 / n1
+        return dev._pairs_verdict
 
     def update(self, p, v_current):
         if self._precompute:

@@ -8,6 +8,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _force_pairs(monkeypatch):
+    """Two sweeps per launch wherever the updater may use them (by default it times both forms on the mask and keeps the faster)."""
+    monkeypatch.setenv("FS_JACOBI_PAIRS", "1")
+
+
 def _pair(const, mask, scheme, n_iter, res, dtype="f32", lazy=True, vc=5.0):
     import fs
     from fs.boundary_condition import BoundaryCondition
@@ -164,3 +170,16 @@ def test_pair_equals_two_sweeps(seed, rt, hip_lib, monkeypatch):
             assert np.array_equal(out[0][k], out[2][k]) and np.array_equal(out[1][k], out[2][k]), ("after 2 sweeps", "after 4 sweeps")[k]
     finally:
         dev.close()
+
+
+def test_autotune_keeps_the_bits(hip_lib, monkeypatch):
+    """FS_JACOBI_PAIRS unset: the updater times pairs against single sweeps on this mask and keeps the faster - either way the oracle's bits."""
+    from fs.boundary_condition import create_scene_arrays
+    monkeypatch.delenv("FS_JACOBI_PAIRS")
+    const, mask, _ = create_scene_arrays(2, 128)
+    solver, ref, pu = _pair(const, mask, "cip", 12, 128, lazy=None)
+    try:
+        assert pu._lazy and pu._pairs in (True, False) and solver._dev._pairs_verdict == pu._pairs
+        _run(solver, ref, 3, f"autotune pairs={pu._pairs}")
+    finally:
+        solver._dev.close()
