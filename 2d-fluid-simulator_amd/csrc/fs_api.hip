@@ -163,7 +163,7 @@ static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, in
     // the general rows ride in front: `zoff` leading z slices of the same launch, one wave per listed row
     const int per_slice = (int)(og.grid.x * og.grid.y), blocks = (ctx->n_pairlist + 3) / 4, zoff = (blocks + per_slice - 1) / per_slice;
     const dim3 grid(og.grid.x, og.grid.y, og.grid.z + zoff);
-    if (rt == 1) FS_PAIR(1); else if (rt == 4) FS_PAIR(4); else if (rt == 3) FS_PAIR(3); else FS_PAIR(2);
+    if (rt == 1) FS_PAIR(1); else if (rt == 4) FS_PAIR(4); else if (rt == 2) FS_PAIR(2); else FS_PAIR(3);
 }
 
 template <bool SRC, typename T>
@@ -1216,6 +1216,20 @@ int fs_lazy_bc_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
     *ok = ctx->mask_set && ctx->lazy_ok && ctx->use_march && ctx->use_lazy ? 1 : 0;
+    return FS_OK;
+}
+
+// diagnostic: the per wave-tile-row flags of the lazy / two-sweep kernels (fs_march.h k_lazy_flags, k_pair_list), [wave column][local row]
+int fs_lazy_flags(fs_ctx *ctx, uint8_t *out, int capacity, int *wave_columns, int *rows, int *general_rows)
+{
+    FS_REQUIRE(ctx && wave_columns && rows && general_rows, "null argument");
+    FS_REQUIRE(ctx->mask_set && ctx->d_lazyflags, "no mask uploaded");
+    *wave_columns = ctx->nwx; *rows = ctx->rows; *general_rows = ctx->n_pairlist;
+    if (out) {
+        FS_REQUIRE(capacity >= ctx->nwx * ctx->rows, "buffer too small");
+        FS_HIP(hipMemcpyAsync(out, ctx->d_lazyflags, (size_t)ctx->nwx * ctx->rows, hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return FS_OK;
 }
 

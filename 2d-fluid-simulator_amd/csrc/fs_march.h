@@ -1242,7 +1242,11 @@ static __global__ __launch_bounds__(256) void k_lazy_flags(Grid g, int nwx, cons
     // without a recipe that a not-wall cell reads (its content is history, and the two buffers' histories differ)
     const uint32_t mm = mask_quad(g, i0, clampy(g, r - 1)), mp = mask_quad(g, i0, clampy(g, r + 1));
     const uint32_t m_prev = lane_prev_u(m4), m_next = lane_next_u(m4);
-    const uint32_t ml = lm.at_lo ? (m4 << 24) : m_prev, mr = lm.at_hi ? (m4 >> 24) : m_next;
+    uint32_t ml = lm.at_lo ? (m4 << 24) : m_prev, mr = lm.at_hi ? (m4 >> 24) : m_next;
+    // the halo lanes have no outer neighbour in this wave: a wall, as far as this wave column is concerned (who reads the outermost halo
+    // cell from outside is 5 columns away from the owner cells - beyond the reach of two sweeps)
+    if (lane == 0 && !lm.at_lo) ml = 0x01000000u;
+    if (lane == 63 && !lm.at_hi) mr = 0x00000001u;
     uint32_t x4 = 0u, v4 = 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

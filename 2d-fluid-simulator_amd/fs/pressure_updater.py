@@ -38,9 +38,9 @@ class JacobiPressureUpdater(PressureUpdater):
         # that admits it (fs_lazy_bc_ok) and a p that no user upload has put into an arbitrary state.
         self._lazy = (self._precompute and n_iter >= 6 and self._dev.lazy_bc_ok) if lazy_bc is None else \
             (bool(lazy_bc) and self._precompute and n_iter >= 3 and self._dev.lazy_bc_ok)
-        # Two sweeps per launch (fs_jacobi_pair_lazy) win where launches and latency dominate and few rows need its general path
-        # (bc2: +28 % at res 1600, +11 % at res 4096; bc1 res 2048: +27 %) and lose on masks full of small obstacles (bc3, bc5: -4 .. -9 %).
-        # Same bits either way, so a single-GPU run times both on this mask once (FS_JACOBI_PAIRS=0 / 1 decides instead).
+        # Two sweeps per launch (fs_jacobi_pair_lazy): bc2 res 1600 +50 %, res 4096 +51 %, bc5 res 4096 +30 %, bc1 res 2048 +27 %; a mask
+        # full of small obstacles sends too many rows down its general path (bc3 res 1000: 31 % of the rows, -6 %).  Same bits either
+        # way, so a single-GPU run times both on this mask once (FS_JACOBI_PAIRS=0 / 1 decides instead).
         want = os.environ.get("FS_JACOBI_PAIRS", "auto")
         self._pairs = (self._lazy and want != "0" and n_iter >= 6
                        and (self._dev.nranks == 1 or 2 * max(2, 1 + self._dev.bc_radius_p) <= self._dev.halo))   # a pass reaches 4 rows

@@ -649,6 +649,14 @@ class Device(DeviceBase):
     def _p_kernel(self, name, *args):
         _lib.check(getattr(self._lib, "fs_" + name)(self._ctx, *args))
 
+    def lazy_flags(self):
+        """(flags[wave column, local row] uint8, number of rows the two-sweep kernel's general path owns) - diagnostic, include/fs_hip.h."""
+        nw, rows, ng = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.call("fs_lazy_flags", self._ctx, None, 0, ctypes.byref(nw), ctypes.byref(rows), ctypes.byref(ng))
+        out = np.empty((nw.value, rows.value), np.uint8)
+        _lib.call("fs_lazy_flags", self._ctx, out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(nw), ctypes.byref(rows), ctypes.byref(ng))
+        return out, ng.value
+
     def _p_lazy_bc_ok(self):
         ok = ctypes.c_int()
         _lib.call("fs_lazy_bc_ok", self._ctx, ctypes.byref(ok))

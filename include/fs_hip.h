@@ -164,6 +164,11 @@ int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
  * (every K7 source a not-wall cell, no computed cell in the first / last row)?                                                */
 int fs_lazy_bc_ok(const fs_ctx *ctx, int *ok);
 int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end);
+/* Diagnostic: the classification the two kernels above and below work from, one byte per (wave column of 248 cells, local row),
+ * [wave column][row]; bit 0: a computed cell of the row has a K7 target among its 4 neighbours, 1: a wall / target within 2 columns,
+ * 2, 3: targets that read another row / wall cells whose content is history within 4 columns, 4: the row goes through the general
+ * path of fs_jacobi_pair_lazy (general_rows = how many such rows hold computed cells).  out may be NULL to query the sizes.          */
+int fs_lazy_flags(fs_ctx *ctx, uint8_t *out, int capacity, int *wave_columns, int *rows, int *general_rows);
 /* TWO such sweeps in one pass: pn <- sweep(sweep(pc)), the first sweep's rows staying in registers.  The two buffers of the reference's
  * rotation differ in the wall cells nothing ever writes, and not-wall cells beside them read them: swapped = 0 when pc is the physical
  * buffer the reference holds this pass's input iterate in (the 1st, 3rd ... pass of a pc -> pn -> pc sequence; the intermediate iterate's

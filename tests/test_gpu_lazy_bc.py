@@ -183,3 +183,65 @@ def test_autotune_keeps_the_bits(hip_lib, monkeypatch):
         _run(solver, ref, 3, f"autotune pairs={pu._pairs}")
     finally:
         solver._dev.close()
+
+
+def _flags_numpy(mask):
+    """Restatement of k_lazy_flags / k_pair_list (csrc/fs_march.h) for a single-domain mask: bits 1-4 per (wave column of 248 cells, row)."""
+    X, Y = mask.shape
+    M = np.pad(mask, 1, constant_values=1).astype(np.int16)
+    W, E, S, N = M[:-2, 1:-1], M[2:, 1:-1], M[1:-1, :-2], M[1:-1, 2:]
+    wall = mask == 1
+    fW = (W == 0) & (S == 1) & (N == 1) & wall
+    fE = ~fW & (E == 0) & (S == 1) & (N == 1) & wall
+    fS = ~fW & ~fE & (S == 0) & (W == 1) & (E == 1) & wall
+    fN = ~fW & ~fE & ~fS & (N == 0) & (W == 1) & (E == 1) & wall
+    rest = wall & ~(fW | fE | fS | fN)
+    cWN = rest & (W == 0) & (N == 0)
+    cEN = rest & ~cWN & (E == 0) & (N == 0)
+    cWS = rest & ~cWN & ~cEN & (W == 0) & (S == 0)
+    cES = rest & ~cWN & ~cEN & ~cWS & (E == 0) & (S == 0)
+    inflow = mask == 2
+    inflow_self = np.zeros_like(inflow); inflow_self[-1, :] = inflow[-1, :]          # clamped onto itself: p[t] = p[t], no recipe
+    target = fW | fE | fS | fN | cWN | cEN | cWS | cES | (inflow & ~inflow_self) | (mask == 3)
+    # the vertical source (if any) and the cell on the other side of it; in-domain neighbours only (sample() clamps, rows 0 / Y-1 are walls)
+    src_below = fS | cWS | cES
+    src_above = fN | cWN | cEN
+    Mc = np.pad(mask, 1, mode="edge").astype(np.int16)                                # the kernel clamps rows / columns onto the edge
+    Wc, Ec, Sc, Nc = Mc[:-2, 1:-1], Mc[2:, 1:-1], Mc[1:-1, :-2], Mc[1:-1, 2:]
+    vert = src_below | src_above
+    hard = (src_below & (Nc != 1)) | (src_above & (Sc != 1)) | (wall & ~target & ((Wc != 1) | (Ec != 1) | (Sc != 1) | (Nc != 1)))
+    dirty = wall | target
+    nw = (X // 4 + 61) // 62
+    out = np.zeros((nw, Y), np.uint8)
+    for w in range(nw):
+        lo, hi = w * 248, min(X, w * 248 + 248)
+        out[w] |= np.where(dirty[max(lo - 2, 0):hi + 2].any(axis=0), 2, 0).astype(np.uint8)
+        out[w] |= np.where(hard[max(lo - 4, 0):hi + 4].any(axis=0), 4, 0).astype(np.uint8)
+        out[w] |= np.where(vert[max(lo - 4, 0):hi + 4].any(axis=0), 8, 0).astype(np.uint8)
+        g = (out[w] & 12) != 0
+        G = g.copy()
+        for d in (1, 2):
+            G[d:] |= g[:-d]; G[:-d] |= g[d:]
+        out[w] |= np.where(G, 16, 0).astype(np.uint8)
+    computed = np.stack([(~wall[w * 248:min(X, w * 248 + 248)]).any(axis=0) for w in range(nw)])
+    return out, int((((out & 16) != 0) & computed).sum())
+
+
+@pytest.mark.parametrize("n,res", [(1, 128), (2, 200), (3, 128), (4, 128), (5, 256), (2, 1600)])
+def test_tile_classification_matches_its_definition(n, res, hip_lib):
+    """The flags that route rows between the plain, the row-local and the general path of the two-sweep kernel (include/fs_hip.h
+    fs_lazy_flags) against a numpy restatement - a mask that sends most rows down the general path would still be bit-exact, only slow."""
+    import fs
+    from fs.boundary_condition import BoundaryCondition, create_scene_arrays
+    const, mask, _ = create_scene_arrays(n, res)
+    fs.runtime.init(gpu=0, dtype="f32")
+    bc = BoundaryCondition(const, mask)
+    try:
+        got, n_general = bc.device.lazy_flags()
+        want, want_general = _flags_numpy(mask)
+        for bit in (2, 4, 8, 16):
+            bad = np.argwhere((got & bit) != (want & bit))
+            assert len(bad) == 0, f"bit {bit}: {len(bad)} (wave column, row) entries differ, first {bad[:5].tolist()}, got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}"
+        assert n_general == want_general
+    finally:
+        bc.device.close()
