@@ -154,14 +154,15 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
     do { if constexpr (std::is_same<T, float>::value) { if (((dm) & 3) == 3) { CALL(3); break; } if ((dm) & 2) { CALL(2); break; } } \
          if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
 
-#define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end, \
-                               (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, (const uint32_t *)ctx->d_pairlist, ctx->n_pairlist, zoff, \
-                               (T *)pn->d, (const T *)pc->d, (const T *)src->d)
-template <bool SW, typename T>
+#define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, HV, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end, \
+                               (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, list, nlist, zoff, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
+template <bool SW, bool HV, typename T>
 static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, int row_end, fs_field *pn, const fs_field *pc, const fs_field *src)
 {
     // the general rows ride in front: `zoff` leading z slices of the same launch, one wave per listed row
-    const int per_slice = (int)(og.grid.x * og.grid.y), blocks = (ctx->n_pairlist + 3) / 4, zoff = (blocks + per_slice - 1) / per_slice;
+    const uint32_t *list = ctx->d_pairlist + (HV ? (size_t)ctx->nwx * ctx->rows : 0);
+    const int nlist = ctx->n_pairlist[HV ? 1 : 0];
+    const int per_slice = (int)(og.grid.x * og.grid.y), blocks = (nlist + 3) / 4, zoff = (blocks + per_slice - 1) / per_slice;
     const dim3 grid(og.grid.x, og.grid.y, og.grid.z + zoff);
     if (rt == 1) FS_PAIR(1); else if (rt == 4) FS_PAIR(4); else if (rt == 2) FS_PAIR(2); else FS_PAIR(3);
 }
@@ -657,7 +658,7 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     if (!ctx->d_bcmap) FS_HIP(hipMalloc(&ctx->d_bcmap, (size_t)ctx->rows * ctx->Pm));
     if (!ctx->d_lazyflags) FS_HIP(hipMalloc(&ctx->d_lazyflags, (size_t)std::max(ctx->nwx, 1) * ctx->rows));
     FS_HIP(hipMemsetAsync(ctx->d_bcmap, 0, (size_t)ctx->rows * ctx->Pm, ctx->stream));
-    FS_HIP(hipMemsetAsync(ctx->d_lazyflags, 31, (size_t)std::max(ctx->nwx, 1) * ctx->rows, ctx->stream));
+    FS_HIP(hipMemsetAsync(ctx->d_lazyflags, 63, (size_t)std::max(ctx->nwx, 1) * ctx->rows, ctx->stream));
     rc = upload_global(ctx, ctx->d_bcmap, 1, 1, ctx->h_bcmap.data(), ctx->Pm);
     std::vector<uint8_t>().swap(ctx->h_bcmap);
     if (rc) return rc;
@@ -666,16 +667,17 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
         hipLaunchKernelGGL(k_lazy_flags, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_bcmap, ctx->d_lazyflags);
         FS_HIP(hipGetLastError());
         // the rows the two-sweep kernel hands to its general path: list + count (read back once per mask)
-        if (!ctx->d_pairlist) FS_HIP(hipMalloc(&ctx->d_pairlist, ((size_t)ctx->nwx * ctx->rows + 1) * sizeof(uint32_t)));
-        unsigned *d_count = (unsigned *)(ctx->d_pairlist + (size_t)ctx->nwx * ctx->rows);
-        FS_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned), ctx->stream));
+        const size_t cap = (size_t)ctx->nwx * ctx->rows;
+        if (!ctx->d_pairlist) FS_HIP(hipMalloc(&ctx->d_pairlist, (2 * cap + 2) * sizeof(uint32_t)));
+        unsigned *d_count = (unsigned *)(ctx->d_pairlist + 2 * cap);
+        FS_HIP(hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned), ctx->stream));
         hipLaunchKernelGGL(k_pair_list, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, (uint8_t *)ctx->d_lazyflags,
-                           ctx->d_pairlist, d_count);
+                           ctx->d_pairlist, ctx->d_pairlist + cap, d_count);
         FS_HIP(hipGetLastError());
-        unsigned n = 0;
-        FS_HIP(hipMemcpyAsync(&n, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        unsigned n[2] = {0, 0};
+        FS_HIP(hipMemcpyAsync(n, d_count, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->n_pairlist = (int)n;
+        ctx->n_pairlist[0] = (int)n[0]; ctx->n_pairlist[1] = (int)n[1];
     }
     ctx->mask_set = true;
     return FS_OK;
@@ -1224,7 +1226,7 @@ int fs_lazy_flags(fs_ctx *ctx, uint8_t *out, int capacity, int *wave_columns, in
 {
     FS_REQUIRE(ctx && wave_columns && rows && general_rows, "null argument");
     FS_REQUIRE(ctx->mask_set && ctx->d_lazyflags, "no mask uploaded");
-    *wave_columns = ctx->nwx; *rows = ctx->rows; *general_rows = ctx->n_pairlist;
+    *wave_columns = ctx->nwx; *rows = ctx->rows; general_rows[0] = ctx->n_pairlist[0]; general_rows[1] = ctx->n_pairlist[1];
     if (out) {
         FS_REQUIRE(capacity >= ctx->nwx * ctx->rows, "buffer too small");
         FS_HIP(hipMemcpyAsync(out, ctx->d_lazyflags, (size_t)ctx->nwx * ctx->rows, hipMemcpyDeviceToHost, ctx->stream));
@@ -1251,19 +1253,24 @@ int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs
 
 // two lazily-bounded sweeps in one pass (fs_march.h k_jacobi_pair): pn <- sweep(sweep(pc)); pn's wall cells are read (the intermediate
 // buffer of the two-buffer rotation is pn itself)
-int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int swapped, int row_begin, int row_end)
+int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int mode, int row_begin, int row_end)
 {
     FS_REQUIRE(ctx, "ctx is null");
     FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
     FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
+    FS_REQUIRE(mode >= 0 && mode <= 3, "mode: bit 0 = swapped buffers, bit 1 = vertical recipes in the tile path");
     FS_ROWS();
     if (!(ctx->lazy_ok && ctx->use_march)) { set_error("this mask does not admit the lazy pressure boundary condition (fs_lazy_bc_ok)"); return FS_ERR_UNSUPPORTED; }
-    const int rt = ctx->pair_rt;
+    const int rt = (mode & 2) ? std::min(ctx->pair_rt, 2) : ctx->pair_rt;      // (the third tile path at 3 rows: 97 VGPRs, one wave per SIMD less)
     const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_JACOBI);
     FS_DISPATCH(ctx, {
         return launch(ctx, "jacobi_pair_lazy", [=] {
-            if (swapped) launch_pair<true, T>(ctx, og, rt, row_begin, row_end, pn, pc, src);
-            else launch_pair<false, T>(ctx, og, rt, row_begin, row_end, pn, pc, src);
+            switch (mode) {
+            case 0: launch_pair<false, false, T>(ctx, og, rt, row_begin, row_end, pn, pc, src); break;
+            case 1: launch_pair<true, false, T>(ctx, og, rt, row_begin, row_end, pn, pc, src); break;
+            case 2: launch_pair<false, true, T>(ctx, og, rt, row_begin, row_end, pn, pc, src); break;
+            default: launch_pair<true, true, T>(ctx, og, rt, row_begin, row_end, pn, pc, src); break;
+            }
         });
     })
 }

@@ -1404,8 +1404,8 @@ __device__ __forceinline__ Q4<T> pair_general_row(const Grid &g, const LaneMap &
 }
 
 // list[k] = (wave column << 20) | row of every wave-tile row that k_jacobi_pair's general path must compute: a "hard" or "vertical" flag
-// (bits 2, 3) in one of rows r-2 .. r+2, and a not-wall owner cell in row r.  Built once per mask.
-static __global__ __launch_bounds__(256) void k_pair_list(Grid g, int nwx, uint8_t *flags, uint32_t *list, unsigned *count)
+// (bits 2, 3; list_a) or a "hard" flag (list_b) in one of rows r-2 .. r+2, and a not-wall owner cell in row r.  Built once per mask.
+static __global__ __launch_bounds__(256) void k_pair_list(Grid g, int nwx, uint8_t *flags, uint32_t *list_a, uint32_t *list_b, unsigned *count)
 {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wx = wid % nwx, r = wid / nwx;
@@ -1415,8 +1415,13 @@ static __global__ __launch_bounds__(256) void k_pair_list(Grid g, int nwx, uint8
     for (int d = -2; d <= 2; ++d) f |= flags[(size_t)wx * g.rows + clampy(g, r + d)];
     const bool computed = __any(lm.owner && sel_not_wall(mask_quad(g, lm.i0, r)) != 0u);
     if (lane == 0 && (f & 12u)) {
-        flags[(size_t)wx * g.rows + r] |= 16u;          // bit 4: the general path owns this row (the other waves read bits 2, 3 of this byte only)
-        if (computed) list[atomicAdd(count, 1u)] = ((uint32_t)wx << 20) | (uint32_t)r;
+        // bit 4: the general path owns this row when the main tiles know horizontal recipes only (HV = false); bit 5: when they also handle
+        // the vertical ones (HV = true).  (The other waves read bits 2, 3 of this byte only.)
+        flags[(size_t)wx * g.rows + r] |= (f & 4u) ? 48u : 16u;
+        if (computed) {
+            list_a[atomicAdd(count, 1u)] = ((uint32_t)wx << 20) | (uint32_t)r;
+            if (f & 4u) list_b[atomicAdd(count + 1, 1u)] = ((uint32_t)wx << 20) | (uint32_t)r;
+        }
     }
 }
 
@@ -1428,12 +1433,15 @@ static __global__ __launch_bounds__(256) void k_pair_list(Grid g, int nwx, uint8
 // the targets that are 0 or copy their left / right neighbour (inflow / outflow columns, vertical wall faces).  Output rows with anything
 // else within 2 rows and 4 columns (bits 2, 3: targets with a source in another row - floors, ceilings, corners -, wall cells whose content
 // is history) are left out here and computed, one row per wave, by the workgroups of the first `zoff` z slices of the same launch from
-// `list` (k_pair_list): general, register-frugal and slow, dispatched first, a percent of the rows.
+// `list` (k_pair_list): general, register-frugal and slow, dispatched first.  HV = true adds a third tile path that also applies the
+// recipes with a source in the row below / above (walls thicker than one cell) inside the plain footprint, leaving only bit-2 rows to the
+// general path: for masks whose outlines are staircases (bc3's cylinders: 31 % -> 2 % general rows, +16 .. 28 %); on masks with few such
+// rows the extra code costs 6 % (bc2 res 1600), so the host picks per mask.
 // The two physical buffers differ in the wall cells NOTHING ever writes (no K7 assignment: e.g. the frame cells beside an inflow column),
 // and not-wall cells next to them read them.  The reference's rotation keeps every even iterate in one buffer and every odd one in the
 // other; a sequence of passes pc -> pn -> pc ... puts every second pass the other way round.  SW = false: the input iterate's wall cells
 // are pc's, the intermediate's are pn's.  SW = true: the input's are pn's, the intermediate's are pc's.
-template <int RT, bool SW, typename T>
+template <int RT, bool SW, bool HV, typename T>
 __global__ __launch_bounds__(256) void k_jacobi_pair(Grid g, int nbx, int nby, int jb, int je, const uint8_t *bcmap, const uint8_t *flags,
                                                      const uint32_t *list, int nlist, int zoff, T *pn, const T *pc, const T *src)
 {
@@ -1459,7 +1467,7 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(Grid g, int nbx, int nby, i
     for (int r = 0; r < RT + 4; ++r) { F[r] = flags[(size_t)bx * g.rows + clampy(g, j0 - 2 + r)]; dirty |= F[r]; }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-        sel[r] = j0 + r < je && !(F[r + 2] & 16u) ? sel_not_wall(mask_quad(g, i0, j0 + r)) : 0u;      // bit 4: the general path's row
+        sel[r] = j0 + r < je && !(F[r + 2] & (HV ? 32u : 16u)) ? sel_not_wall(mask_quad(g, i0, j0 + r)) : 0u;      // bit 4 / 5: the general path's row
         any |= sel[r];
     }
     if (!__any(any != 0u)) return;
@@ -1477,6 +1485,31 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(Grid g, int nbx, int nby, i
         for (int r = 0; r < RT + 2; ++r) S1[r] = plain_row<T>(lm, A[r], A[r + 1], A[r + 2], S2[r + 1], S3[r + 1]);
 #pragma unroll
         for (int r = 0; r < RT; ++r) o[r] = plain_row<T>(lm, S1[r], S1[r + 1], S1[r + 2], S2[r + 2], S3[r + 2]);
+    } else if (HV && (dirty & 8u)) {
+        // targets that copy from (or average with) the row below / above - floors, ceilings, corners - in walls thicker than one cell:
+        // whoever reads such a target sits on its source's side, so no row beyond the plain path's footprint is needed (a row missing at
+        // the edge of the window is stood in for by the row itself; what that produces is read by nobody, or only by rows within 2 of a
+        // bit-2 cell, which the general path owns)
+        Q4<T> A[RT + 4], B0[RT + 4], S1[RT + 2], B1[RT + 2];
+        uint32_t C[RT + 4];
+#pragma unroll
+        for (int r = 0; r < RT + 4; ++r) {
+            A[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, clampy(g, j0 - 2 + r)));
+            C[r] = bcmap_quad(g, bcmap, i0, j0 - 2 + r);
+        }
+#pragma unroll
+        for (int r = 1; r < RT + 3; ++r) {
+            S2[r] = Q4<T>(load_quad<2>(src, g, 0, i0, clampy(g, j0 - 2 + r)));
+            S3[r] = Q4<T>(load_quad<2>(src, g, 1, i0, clampy(g, j0 - 2 + r)));
+        }
+#pragma unroll
+        for (int r = 0; r < RT + 4; ++r) B0[r] = bc_row<T>(lm, A[r == 0 ? 0 : r - 1], A[r], A[r == RT + 3 ? r : r + 1], C[r]);
+#pragma unroll
+        for (int r = 0; r < RT + 2; ++r) S1[r] = plain_row<T>(lm, B0[r], B0[r + 1], B0[r + 2], S2[r + 1], S3[r + 1]);
+#pragma unroll
+        for (int r = 0; r < RT + 2; ++r) B1[r] = bc_row<T>(lm, S1[r == 0 ? 0 : r - 1], S1[r], S1[r == RT + 1 ? r : r + 1], C[r + 1]);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) o[r] = plain_row<T>(lm, B1[r], B1[r + 1], B1[r + 2], S2[r + 2], S3[r + 2]);
     } else {
         // K7 stays inside each row, and what the first sweep leaves in the wall cells it does not compute is never read: the footprint of
         // the plain path plus one cheap pass per register row.  (Rows of this tile that the general path owns come out wrong here and

@@ -40,34 +40,42 @@ class JacobiPressureUpdater(PressureUpdater):
             (bool(lazy_bc) and self._precompute and n_iter >= 3 and self._dev.lazy_bc_ok)
         # Two sweeps per launch (fs_jacobi_pair_lazy): bc2 res 1600 +50 %, res 4096 +51 %, bc5 res 4096 +30 %, bc1 res 2048 +27 %; a mask
         # full of small obstacles sends too many rows down its general path (bc3 res 1000: 31 % of the rows, -6 %).  Same bits either
-        # way, so a single-GPU run times both on this mask once (FS_JACOBI_PAIRS=0 / 1 decides instead).
+        # way, so a single-GPU run times the three forms on this mask once (FS_JACOBI_PAIRS=0 / 1 / 2 decides instead; 2 = vertical recipes in the tiles too).
         want = os.environ.get("FS_JACOBI_PAIRS", "auto")
         self._pairs = (self._lazy and want != "0" and n_iter >= 6
                        and (self._dev.nranks == 1 or 2 * max(2, 1 + self._dev.bc_radius_p) <= self._dev.halo))   # a pass reaches 4 rows
+        self._vertical = want == "2"
         if self._pairs and want == "auto" and self._dev.nranks == 1 and hasattr(self._dev, "profile_report"):
-            self._pairs = self._pairs_are_faster()
+            self._pairs, self._vertical = self._fastest_form()
 
-    def _pairs_are_faster(self):
+    def _fastest_form(self):
+        """(pairs?, vertical?) - single sweeps, two-sweep passes, or two-sweep passes whose tiles also apply the vertical recipes."""
         dev = self._dev
         if getattr(dev, "_pairs_verdict", None) is None:       # once per device (= per mask)
             a, b, src = dev.alloc(1), dev.alloc(1), dev.alloc(2)
 
-            def run(n):
+            def run(n, vertical):
                 for _ in range(n):
-                    dev.jacobi_pair_lazy(b, a, src, swapped=False)
-                    dev.jacobi_pair_lazy(a, b, src, swapped=True)
-                for _ in range(2 * n):
-                    dev.jacobi_sweep_lazy(b, a, src)
-                    dev.jacobi_sweep_lazy(a, b, src)
-            run(1)
+                    dev.jacobi_pair_lazy(b, a, src, swapped=False, vertical=vertical)
+                    dev.jacobi_pair_lazy(a, b, src, swapped=True, vertical=vertical)
+                if not vertical:
+                    for _ in range(2 * n):
+                        dev.jacobi_sweep_lazy(b, a, src)
+                        dev.jacobi_sweep_lazy(a, b, src)
+            run(1, False)
+            run(1, True)
+            reps = []
+            for vertical in (False, True):
+                dev.profile_reset()
+                dev.profile(True)
+                run(3, vertical)
+                reps.append(dev.profile_report())
+                dev.profile(False)
             dev.profile_reset()
-            dev.profile(True)
-            run(3)
-            rep = dev.profile_report()
-            dev.profile(False)
-            dev.profile_reset()
-            (n2, ms2), (n1, ms1) = rep["jacobi_pair_lazy"], rep["jacobi_sweep_lazy"]
-            dev._pairs_verdict = ms2 / n2 < 2.0 * ms1 / n1
+            avg = lambda rep, k: rep[k][1] / rep[k][0]
+            t = {(False, False): 2.0 * avg(reps[0], "jacobi_sweep_lazy"), (True, False): avg(reps[0], "jacobi_pair_lazy"),
+                 (True, True): avg(reps[1], "jacobi_pair_lazy")}
+            dev._pairs_verdict = min(t, key=t.get)
         return dev._pairs_verdict
 
     def update(self, p, v_current):
@@ -78,7 +86,7 @@ class JacobiPressureUpdater(PressureUpdater):
         # reference's rotation puts it in (the buffers differ in the wall cells nothing ever writes)
         n_pairs = (n_lazy // 4) * 2 if self._pairs else 0
         for k in range(n_pairs):
-            self._dev.jacobi_pair_lazy(p.next, p.current, self._src, swapped=k & 1)
+            self._dev.jacobi_pair_lazy(p.next, p.current, self._src, swapped=k & 1, vertical=self._vertical)
             p.swap()
         for _ in range(n_lazy - 2 * n_pairs):
             self._dev.jacobi_sweep_lazy(p.next, p.current, self._src)

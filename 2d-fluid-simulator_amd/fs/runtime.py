@@ -538,11 +538,13 @@ class DeviceBase:
         boundary kernel on this mask, were it larger)."""
         self._run("jacobi_sweep_lazy", (pn._h, pc._h, src._h), reads=[(pc, max(2, 1 + self.bc_radius_p)), (src, 0)], writes=[pn])
 
-    def jacobi_pair_lazy(self, pn, pc, src, swapped=False):
+    def jacobi_pair_lazy(self, pn, pc, src, swapped=False, vertical=False):
         """Two such sweeps in one pass, pn <- sweep(sweep(pc)) (csrc/fs_march.h k_jacobi_pair).  `swapped`: this is the 2nd, 4th ... pass
-        of a pc -> pn -> pc sequence (include/fs_hip.h: which buffer's never-written wall cells belong to which iterate)."""
+        of a pc -> pn -> pc sequence (include/fs_hip.h: which buffer's never-written wall cells belong to which iterate); `vertical`: the
+        kernel variant whose tiles also apply the recipes that read the row below / above."""
         r = max(2, 1 + self.bc_radius_p)
-        self._run("jacobi_pair_lazy", (pn._h, pc._h, src._h, 1 if swapped else 0), reads=[(pc, 2 * r), (src, r), (pn, 2 * r)], writes=[pn])
+        self._run("jacobi_pair_lazy", (pn._h, pc._h, src._h, (1 if swapped else 0) | (2 if vertical else 0)),
+                  reads=[(pc, 2 * r), (src, r), (pn, 2 * r)], writes=[pn])
 
     def rbsor_halfsweep_src(self, omega, parity, pn, pc, src):
         self._run("rbsor_halfsweep_src", (omega, parity, pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
@@ -650,12 +652,13 @@ class Device(DeviceBase):
         _lib.check(getattr(self._lib, "fs_" + name)(self._ctx, *args))
 
     def lazy_flags(self):
-        """(flags[wave column, local row] uint8, number of rows the two-sweep kernel's general path owns) - diagnostic, include/fs_hip.h."""
-        nw, rows, ng = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        _lib.call("fs_lazy_flags", self._ctx, None, 0, ctypes.byref(nw), ctypes.byref(rows), ctypes.byref(ng))
+        """(flags[wave column, local row] uint8, rows the two-sweep kernel's general path owns without / with its vertical tile path) -
+        diagnostic, include/fs_hip.h."""
+        nw, rows, ng = ctypes.c_int(), ctypes.c_int(), (ctypes.c_int * 2)()
+        _lib.call("fs_lazy_flags", self._ctx, None, 0, ctypes.byref(nw), ctypes.byref(rows), ng)
         out = np.empty((nw.value, rows.value), np.uint8)
-        _lib.call("fs_lazy_flags", self._ctx, out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(nw), ctypes.byref(rows), ctypes.byref(ng))
-        return out, ng.value
+        _lib.call("fs_lazy_flags", self._ctx, out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(nw), ctypes.byref(rows), ng)
+        return out, (ng[0], ng[1])
 
     def _p_lazy_bc_ok(self):
         ok = ctypes.c_int()

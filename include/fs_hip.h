@@ -166,15 +166,17 @@ int fs_lazy_bc_ok(const fs_ctx *ctx, int *ok);
 int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end);
 /* Diagnostic: the classification the two kernels above and below work from, one byte per (wave column of 248 cells, local row),
  * [wave column][row]; bit 0: a computed cell of the row has a K7 target among its 4 neighbours, 1: a wall / target within 2 columns,
- * 2, 3: targets that read another row / wall cells whose content is history within 4 columns, 4: the row goes through the general
- * path of fs_jacobi_pair_lazy (general_rows = how many such rows hold computed cells).  out may be NULL to query the sizes.          */
+ * 3: a target that reads another row within 4 columns, 2: such a target in a wall one cell thick, or a wall cell whose content is
+ * history, 4 / 5: the row goes through the general path of fs_jacobi_pair_lazy with mode bit 1 = 0 / 1 (general_rows[0 / 1] = how many
+ * such rows hold computed cells; an int[2]).  out may be NULL to query the sizes.                                                    */
 int fs_lazy_flags(fs_ctx *ctx, uint8_t *out, int capacity, int *wave_columns, int *rows, int *general_rows);
-/* TWO such sweeps in one pass: pn <- sweep(sweep(pc)), the first sweep's rows staying in registers.  The two buffers of the reference's
- * rotation differ in the wall cells nothing ever writes, and not-wall cells beside them read them: swapped = 0 when pc is the physical
- * buffer the reference holds this pass's input iterate in (the 1st, 3rd ... pass of a pc -> pn -> pc sequence; the intermediate iterate's
- * wall cells are then pn's), 1 when it is the other way round (2nd, 4th ... pass).  Both buffers are read 4 rows beyond the written range,
- * src 2 rows.                                                                                                                          */
-int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int swapped, int row_begin, int row_end);
+/* TWO such sweeps in one pass: pn <- sweep(sweep(pc)), the first sweep's rows staying in registers.  mode bit 0 ("swapped"): the two
+ * buffers of the reference's rotation differ in the wall cells nothing ever writes, and not-wall cells beside them read them - 0 when pc
+ * is the physical buffer the reference holds this pass's input iterate in (the 1st, 3rd ... pass of a pc -> pn -> pc sequence; the
+ * intermediate iterate's wall cells are then pn's), 1 when it is the other way round (2nd, 4th ... pass).  mode bit 1: the tile path also
+ * applies the recipes that read the row below / above (pays on masks with staircase outlines, costs a few percent elsewhere; same bits).
+ * Both buffers are read 4 rows beyond the written range, src 2 rows.                                                                  */
+int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int mode, int row_begin, int row_end);
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc,
                            const fs_field *src, int row_begin, int row_end);
 /* Residual diagnostic (new; the reference never measures convergence): sum over owned not-wall cells of

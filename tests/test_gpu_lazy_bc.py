@@ -8,10 +8,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _force_pairs(monkeypatch):
-    """Two sweeps per launch wherever the updater may use them (by default it times both forms on the mask and keeps the faster)."""
-    monkeypatch.setenv("FS_JACOBI_PAIRS", "1")
+@pytest.fixture(autouse=True, params=["1", "2"], ids=["pairs", "pairs+vertical"])
+def _force_pairs(request, monkeypatch):
+    """Two sweeps per launch wherever the updater may use them, in both kernel variants (by default it times the forms on the mask and
+    keeps the fastest)."""
+    monkeypatch.setenv("FS_JACOBI_PAIRS", request.param)
+    return request.param
 
 
 def _pair(const, mask, scheme, n_iter, res, dtype="f32", lazy=True, vc=5.0):
@@ -126,7 +128,7 @@ def test_inflow_next_to_a_wall_is_refused(hip_lib):
 
 @pytest.mark.parametrize("rt", [1, 2, 3, 4])
 @pytest.mark.parametrize("seed", [1, 3, 5, 6, 7])
-def test_pair_equals_two_sweeps(seed, rt, hip_lib, monkeypatch):
+def test_pair_equals_two_sweeps(seed, rt, hip_lib, monkeypatch, _force_pairs):
     """k_jacobi_pair (two sweeps per pass, every tile height) == two k_jacobi_lazy passes == two (K7, sweep) rounds, bit for bit, from random
     iterates - including a random INTERMEDIATE buffer, whose never-written wall cells the second sweep reads."""
     import fs
@@ -149,9 +151,9 @@ def test_pair_equals_two_sweeps(seed, rt, hip_lib, monkeypatch):
             a, b = dev.alloc(1), dev.alloc(1)
             a.from_numpy(a0); b.from_numpy(b0)
             if mode == "pair":                    # a -> b -> a: the second pass has the buffers the other way round
-                dev.jacobi_pair_lazy(b, a, src, swapped=False)
+                dev.jacobi_pair_lazy(b, a, src, swapped=False, vertical=_force_pairs == "2")
                 two = b.to_numpy()
-                dev.jacobi_pair_lazy(a, b, src, swapped=True)
+                dev.jacobi_pair_lazy(a, b, src, swapped=True, vertical=_force_pairs == "2")
             elif mode == "lazy":
                 for k in range(4):
                     dev.jacobi_sweep_lazy(b, a, src)
@@ -179,8 +181,8 @@ def test_autotune_keeps_the_bits(hip_lib, monkeypatch):
     const, mask, _ = create_scene_arrays(2, 128)
     solver, ref, pu = _pair(const, mask, "cip", 12, 128, lazy=None)
     try:
-        assert pu._lazy and pu._pairs in (True, False) and solver._dev._pairs_verdict == pu._pairs
-        _run(solver, ref, 3, f"autotune pairs={pu._pairs}")
+        assert pu._lazy and solver._dev._pairs_verdict == (pu._pairs, pu._vertical)
+        _run(solver, ref, 3, f"autotune pairs={pu._pairs} vertical={pu._vertical}")
     finally:
         solver._dev.close()
 
@@ -218,13 +220,14 @@ def _flags_numpy(mask):
         out[w] |= np.where(dirty[max(lo - 2, 0):hi + 2].any(axis=0), 2, 0).astype(np.uint8)
         out[w] |= np.where(hard[max(lo - 4, 0):hi + 4].any(axis=0), 4, 0).astype(np.uint8)
         out[w] |= np.where(vert[max(lo - 4, 0):hi + 4].any(axis=0), 8, 0).astype(np.uint8)
-        g = (out[w] & 12) != 0
-        G = g.copy()
-        for d in (1, 2):
-            G[d:] |= g[:-d]; G[:-d] |= g[d:]
-        out[w] |= np.where(G, 16, 0).astype(np.uint8)
+        for bits, flag in ((12, 16), (4, 32)):          # rows the general path owns without / with the vertical tile path
+            g = (out[w] & bits) != 0
+            G = g.copy()
+            for d in (1, 2):
+                G[d:] |= g[:-d]; G[:-d] |= g[d:]
+            out[w] |= np.where(G, flag, 0).astype(np.uint8)
     computed = np.stack([(~wall[w * 248:min(X, w * 248 + 248)]).any(axis=0) for w in range(nw)])
-    return out, int((((out & 16) != 0) & computed).sum())
+    return out, (int((((out & 16) != 0) & computed).sum()), int((((out & 32) != 0) & computed).sum()))
 
 
 @pytest.mark.parametrize("n,res", [(1, 128), (2, 200), (3, 128), (4, 128), (5, 256), (2, 1600)])
@@ -239,7 +242,7 @@ def test_tile_classification_matches_its_definition(n, res, hip_lib):
     try:
         got, n_general = bc.device.lazy_flags()
         want, want_general = _flags_numpy(mask)
-        for bit in (2, 4, 8, 16):
+        for bit in (2, 4, 8, 16, 32):
             bad = np.argwhere((got & bit) != (want & bit))
             assert len(bad) == 0, f"bit {bit}: {len(bad)} (wave column, row) entries differ, first {bad[:5].tolist()}, got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}"
         assert n_general == want_general
