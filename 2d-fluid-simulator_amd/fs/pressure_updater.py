@@ -29,8 +29,10 @@ class JacobiPressureUpdater(PressureUpdater):
     def __init__(self, boundary_condition, dt, dx, n_iter, precompute_source=None, lazy_bc=None):
         super().__init__(boundary_condition, dt, dx)
         self._n_iter = n_iter
-        # one extra pass per step (~112 us at res 4096) buys cheaper sweeps (74 vs 87 us): worth it from 9 sweeps on
-        self._precompute = (n_iter >= 9) if precompute_source is None else bool(precompute_source)
+        # one extra pass per step (~110 us at res 4096) buys cheaper sweeps (76 vs 87 us): worth it from 9 sweeps on - from 6 on where
+        # two-sweep passes are in use (decided below): 110 + 2 x 98 + 2 x 82 against 6 x 93 us
+        tentative = precompute_source is None and 6 <= n_iter < 9 and self._dev.lazy_bc_ok
+        self._precompute = (n_iter >= 9 or tentative) if precompute_source is None else bool(precompute_source)
         self._src = self._dev.alloc(2) if self._precompute else None
         # Long runs: all but the last two sweeps evaluate the pressure boundary condition on the fly from the raw output of the
         # previous sweep instead of launching the boundary kernel in between (same bits; the last two sweeps run the real kernel,
@@ -47,6 +49,8 @@ class JacobiPressureUpdater(PressureUpdater):
         self._vertical = want == "2"
         if self._pairs and want == "auto" and self._dev.nranks == 1 and hasattr(self._dev, "profile_report"):
             self._pairs, self._vertical = self._fastest_form()
+        if tentative and not self._pairs:
+            self._precompute, self._src, self._lazy = False, None, False
 
     def _fastest_form(self):
         """(pairs?, vertical?) - single sweeps, two-sweep passes, or two-sweep passes whose tiles also apply the vertical recipes."""
