@@ -541,7 +541,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
-    if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 ? 2 : (v >= 4 ? 4 : 0); }
+    if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 || v == 3 ? v : (v >= 4 ? 4 : 0); }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
@@ -1123,6 +1123,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
             rc = launch(ctx, "cip_grad_advect_rt", [=] {
                 if (RT == 2) { if (k.p2) FS_K34RT(2, true); else FS_K34RT(2, false); }
+                else if (RT == 3) { if (k.p2) FS_K34RT(3, true); else FS_K34RT(3, false); }
                 else { if (k.p2) FS_K34RT(4, true); else FS_K34RT(4, false); }
             });
         }
