@@ -540,6 +540,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_RCP")) c->use_rcp = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
+    if (const char *s = getenv("FS_RBSOR_RT")) { const int v = atoi(s); if (v >= 2 && v <= 4) c->rbsor_rt = v; }
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 || v == 3 ? v : (v >= 4 ? 4 : 0); }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
@@ -1306,13 +1307,20 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
         if (rc) return rc;
         return fs_rbsor_halfsweep(ctx, dt, dx, omega, 0, pn, pn, vc, row_begin, row_end);
     }
-    constexpr int RT = 2;
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 1, XCD_RBSOR);
+    const int rt = ctx->rbsor_rt;
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_RBSOR);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-#define FS_RBF(DM) hipLaunchKernelGGL((k_rbsor_fused<RT, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBF_RT(RT, DM) hipLaunchKernelGGL((k_rbsor_fused<RT, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
                                (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
-        return launch(ctx, "rbsor_iteration", [=] { FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF); });
+#define FS_RBF2(DM) FS_RBF_RT(2, DM)
+#define FS_RBF3(DM) FS_RBF_RT(3, DM)
+#define FS_RBF4(DM) FS_RBF_RT(4, DM)
+        return launch(ctx, "rbsor_iteration", [=] {
+            if (rt == 3) FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF3);
+            else if (rt == 4) FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF4);
+            else FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF2);
+        });
     })
 }
 
