@@ -540,6 +540,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_RCP")) c->use_rcp = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
+    if (const char *s = getenv("FS_VORT_RT")) { const int v = atoi(s); if (v >= 3 && v <= 6) c->vort_rt = v; }
     if (const char *s = getenv("FS_RBSOR_RT")) { const int v = atoi(s); if (v >= 2 && v <= 4) c->rbsor_rt = v; }
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 || v == 3 ? v : (v >= 4 ? 4 : 0); }
@@ -1173,18 +1174,20 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
         if (rc) return rc;
         return fs_vort_add(ctx, dt, dx, weight, vn, vc, vort, vort_abs, row_begin, row_end);
     }
-    constexpr int RT = 4;
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 1, XCD_VORT);
+    const int rt = ctx->vort_rt;
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_VORT);
     const dim3 grid = og.grid;
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
         const bool p2 = k.p2 != 0;
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
+#define FS_VORT(RT) do { \
+            if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot); \
+            else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot); \
+            else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot); \
+            else hipLaunchKernelGGL((k_vort_fused<RT, false, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot); } while (0)
         return launch(ctx, "vort_confine", [=] {
-            if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot);
-            else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot);
-            else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot);
-            else hipLaunchKernelGGL((k_vort_fused<RT, false, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot);
+            if (rt == 5) FS_VORT(5); else if (rt == 6) FS_VORT(6); else if (rt == 3) FS_VORT(3); else FS_VORT(4);
         });
     })
 }

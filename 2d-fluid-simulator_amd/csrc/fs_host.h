@@ -70,6 +70,7 @@ struct fs_ctx {
     bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
+    int vort_rt = 4;                         // rows per tile of the fused vorticity confinement (env FS_VORT_RT = 3 .. 6)
     int rbsor_rt = 3;                        // rows per tile of the fused red-black iteration (env FS_RBSOR_RT = 2, 3, 4)
     int pair_rt = 3;                         // rows per tile of the two-sweep kernel (env FS_PAIR_RT = 1 .. 4; 3: within 2 % of the best of 2 / 3 / 4 from res 1024 to 4096)
     uint8_t *d_rowact = nullptr;   // [nwx][rows] row-activity map of the row-streaming kernels (fs_march.h k_row_activity)
