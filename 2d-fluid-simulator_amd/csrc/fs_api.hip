@@ -1114,7 +1114,9 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
             });
         };
         // whole register tiles of RT rows in the interior (env FS_K34_RT = 0 / 2 / 4); what is left over, row by row
-        const int RT = sizeof(T) == 4 ? ctx->k34_rt : 0;      // f64: 256 VGPRs at one wave per SIMD - the one-row form stays
+        // f64: 256 VGPRs at one wave per SIMD - the one-row form stays.  f32: 3-row tiles on big grids (bc5 res 4096: 418 -> 400 us), 2-row
+        // tiles where the launch has few waves per SIMD slot (bc2 res 1600: 111 against 116 us)
+        const int RT = sizeof(T) != 4 ? 0 : (ctx->k34_rt >= 0 ? ctx->k34_rt : ((long long)ctx->nwx * ctx->rows >= 50000 ? 3 : 2));
         int tiled_end = in_lo;
         int rc = run(row_begin, in_lo, true);
         if (!rc && RT > 1 && in_hi - in_lo >= RT) {
