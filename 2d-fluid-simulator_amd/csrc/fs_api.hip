@@ -1137,6 +1137,34 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
     })
 }
 
+// K3 + K4 of the dye in one pass (fs_march.h k_cip_grad_advect_dye): d_out <- advect(fn with the gradients K3 derives from fc -> fn) by v
+int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, fs_field *gx_out, fs_field *gy_out,
+                           const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v,
+                           int clamp01, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(d_out, 3); FS_FIELD(gx_out, 3); FS_FIELD(gy_out, 3); FS_FIELD(fn, 3); FS_FIELD(fc, 3); FS_FIELD(gxc, 3); FS_FIELD(gyc, 3); FS_FIELD(v, 2);
+    FS_REQUIRE(d_out != fn && d_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
+    FS_REQUIRE(ctx->use_march, "the fused gradient+advection pass needs X % 4 == 0 (use the two-kernel form)");
+    FS_ROWS();
+    if (row_begin >= row_end) return FS_OK;
+    const Grid gg = ctx->grid();
+    FS_DISPATCH(ctx, {
+        if constexpr (sizeof(T) != 4) { set_error("the fused dye pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
+        else {
+            auto k = make_konst<T>(ctx, dt, dx, 1.0);
+            constexpr int RT = 2;
+            const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 3, XCD_ADVECT);
+#define FS_K34D(PP, CL) hipLaunchKernelGGL((k_cip_grad_advect_dye<RT, PP, CL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
+                (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
+            return launch(ctx, "cip_grad_advect_dye", [=] {
+                if (k.p2) { if (clamp01) FS_K34D(true, true); else FS_K34D(true, false); }
+                else { if (clamp01) FS_K34D(false, true); else FS_K34D(false, false); }
+            });
+        }
+    })
+}
+
 // ---- vorticity confinement -------------------------------------------------------------------------------
 int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, const fs_field *vc, int row_begin, int row_end)
 {

@@ -966,6 +966,147 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, 
     else cip_grad_advect_rt_body<1, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
 }
 
+// The same fusion for the dye (C = 3 channels advected by the final velocity of the flow step, fs/solver.py:378-401): K3 on the rows
+// j0-1 .. j0+RT and K4 on j0 .. j0+RT-1 of ONE channel per wave (blockIdx.y % 3; the three passes of a tile are adjacent in dispatch order
+// and share the velocity rows through the L2).  Every row is loaded clamped (sample() clamps coordinates, fs/differentiation.py:4-9), so the
+// rows next to the domain's first / last row need no separate launch: a register slot that stands for a row outside the domain takes the
+// K3 result of the edge row it clamps onto.  CLAMP: clamp_field(dye, 0, 1) (fs/solver.py:46-49) folded into the store of the advected value.
+template <int c, int RT, bool P2, bool CLAMP, typename T>
+__device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+                                                         T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                         const T *gxc, const T *gyc, const T *v)
+{
+    constexpr int DM = P2 ? DM_P2 : DM_IEEE;
+    DivGuard G;      // unused: exact multiplication or IEEE division only
+    int wx, ty, cg;
+    if (!tile_coords<3>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMap lm = lane_map_wave(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+
+    unsigned nw[RT + 2], fl[RT];                 // not-wall selectors of rows j0-1 .. j0+RT, fluid selectors of rows j0 .. j0+RT-1
+    bool any_fl = false;
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const uint32_t m4 = mask_quad(g, i0, clampy(g, j0 - 1 + s));
+        nw[s] = sel_not_wall(m4);
+        if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? sel_fluid(m4) : 0u; any_fl |= fl[s - 1] != 0u; }
+    }
+    if (!__any(any_fl)) {
+        // no fluid cell in this wave's tile: every output is a carried value (dout = fc everywhere, old gradients on inflow / outflow cells)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int j = j0 + t;
+            if (j >= je) break;
+            const typename Quad<T>::type f = load_quad<3>(fc, g, c, i0, j);
+            if (lm.owner) {
+                *reinterpret_cast<typename Quad<T>::type *>(dout + idx<3, T>(g, c, i0, j)) = f;
+                if (nw[t + 1]) {
+                    store_quad_sel<T>(gxo + idx<3, T>(g, c, i0, j), load_quad<3>(gxc, g, c, i0, j), nw[t + 1]);
+                    store_quad_sel<T>(gyo + idx<3, T>(g, c, i0, j), load_quad<3>(gyc, g, c, i0, j), nw[t + 1]);
+                }
+            }
+        }
+        return;
+    }
+
+    // slot u of N / Fc <-> row j0 - 2 + u;   slot s of GX / GY / VX / VY / NX / NY <-> row j0 - 1 + s   (rows clamped into the domain)
+    Q4<T> N[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], VX[RT + 2], VY[RT + 2];
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        N[u] = Q4<T>(load_quad<3>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
+        Fc[u] = Q4<T>(load_quad<3>(fc, g, c, i0, clampy(g, j0 - 2 + u)));
+    }
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const int row = clampy(g, j0 - 1 + s);
+        GX[s] = Q4<T>(load_quad<3>(gxc, g, c, i0, row));
+        GY[s] = Q4<T>(load_quad<3>(gyc, g, c, i0, row));
+        VX[s] = Q4<T>(load_quad<2>(v, g, 0, i0, row));
+        VY[s] = Q4<T>(load_quad<2>(v, g, 1, i0, row));
+    }
+    // ---- K3 on rows j0-1 .. j0+RT: wall cells keep the stored gradient ----
+    Q4<T> NX[RT + 2], NY[RT + 2];
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const Q4<T> &n1 = N[s + 1], &c1 = Fc[s + 1];
+        const T nl = quad_left<T>(lm, n1.quad()), nr = quad_right<T>(lm, n1.quad());
+        const T cl = quad_left<T>(lm, c1.quad()), cr = quad_right<T>(lm, c1.quad());
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T nE = q == 3 ? nr : n1.a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : n1.a[q == 0 ? 0 : q - 1];
+            const T cE = q == 3 ? cr : c1.a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : c1.a[q == 0 ? 0 : q - 1];
+            const T sx = ((nE - cE) - nW) + cW;
+            const T sy = ((N[s + 2].a[q] - Fc[s + 2].a[q]) - N[s].a[q]) + Fc[s].a[q];
+            const bool live = (nw[s] >> q) & 1u;
+            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, G) : GX[s].a[q];
+            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, G) : GY[s].a[q];
+        }
+    }
+    // slots that stand for rows outside the domain: the K3 result of the edge row they clamp onto (wave-uniform)
+    if (j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
+#pragma unroll
+    for (int s = 1; s < RT + 2; ++s)
+        if (j0 - 1 + s > g.jhi) { NX[s] = NX[s - 1]; NY[s] = NY[s - 1]; }
+    // ---- K4 on rows j0 .. j0+RT-1 ----
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        if (j >= je) break;
+        const Q4<T> &Nm = N[t + 1], &Nc = N[t + 2], &Np = N[t + 3];                                // value field rows j-1, j, j+1
+        const Q4<T> &VXm = VX[t], &VXr = VX[t + 1], &VXp = VX[t + 2], &VYm = VY[t], &VYr = VY[t + 1], &VYp = VY[t + 2];
+        const T vxl = quad_left<T>(lm, VXr.quad()), vxr = quad_right<T>(lm, VXr.quad());
+        const T vyl = quad_left<T>(lm, VYr.quad()), vyr = quad_right<T>(lm, VYr.quad());
+        const T fl0 = quad_left<T>(lm, Nm.quad()), fr0 = quad_right<T>(lm, Nm.quad());
+        const T fl1 = quad_left<T>(lm, Nc.quad()), fr1 = quad_right<T>(lm, Nc.quad());
+        const T fl2 = quad_left<T>(lm, Np.quad()), fr2 = quad_right<T>(lm, Np.quad());
+        const T fxl = quad_left<T>(lm, NX[t + 1].quad()), fxr = quad_right<T>(lm, NX[t + 1].quad());
+        const T fyl = quad_left<T>(lm, NY[t + 1].quad()), fyr = quad_right<T>(lm, NY[t + 1].quad());
+        Q4<T> OV = Fc[t + 2], OX = GX[t + 1], OY = GY[t + 1];       // carry values; fluid cells are replaced below
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T vx = VXr.a[q], vy = VYr.a[q];
+            const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
+            const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
+            const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
+            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, G);
+            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, G), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, G);
+            const T fE1 = q == 3 ? fr1 : Nc.a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
+            const T fE0 = q == 3 ? fr0 : Nm.a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
+            const T fE2 = q == 3 ? fr2 : Np.a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
+            const T fxE = q == 3 ? fxr : NX[t + 1].a[q == 3 ? 3 : q + 1], fxW = q == 0 ? fxl : NX[t + 1].a[q == 0 ? 0 : q - 1];
+            const T fyE = q == 3 ? fyr : NY[t + 1].a[q == 3 ? 3 : q + 1], fyW = q == 0 ? fyl : NY[t + 1].a[q == 0 ? 0 : q - 1];
+            const T f00 = Nc.a[q];
+            const T f0m = ny ? Np.a[q] : Nm.a[q];
+            const T fm0 = nx ? fE1 : fW1;
+            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
+            const T fx00 = NX[t + 1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[t + 2].a[q] : NX[t].a[q];
+            const T fy00 = NY[t + 1].a[q], fy0m = ny ? NY[t + 2].a[q] : NY[t].a[q], fym0 = nx ? fyE : fyW;
+            T of, ofx, ofy;
+            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy, G);
+            if (CLAMP) of = tmin(tmax(of, (T)0.0), (T)1.0);
+            if ((fl[t] >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
+        }
+        if (lm.owner) {
+            *reinterpret_cast<typename Quad<T>::type *>(dout + idx<3, T>(g, c, i0, j)) = OV.quad();   // every cell: result or carried value
+            if (nw[t + 1]) {
+                store_quad_sel<T>(gxo + idx<3, T>(g, c, i0, j), OX.quad(), nw[t + 1]);              // fluid: result, inflow/outflow: carried
+                store_quad_sel<T>(gyo + idx<3, T>(g, c, i0, j), OY.quad(), nw[t + 1]);
+            }
+        }
+    }
+}
+
+template <int RT, bool P2, bool CLAMP, typename T>
+__global__ __launch_bounds__(256) void k_cip_grad_advect_dye(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+                                                             T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                             const T *gxc, const T *gyc, const T *v)
+{
+    const int ly = (int)blockIdx.y / 3, ch = (int)blockIdx.y - 3 * ly;      // channel = blockIdx.y % 3 (the fallback grid: blockIdx.y itself)
+    if (ch == 0) cip_grad_advect_dye_body<0, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v);
+    else if (ch == 1) cip_grad_advect_dye_body<1, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v);
+    else cip_grad_advect_dye_body<2, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v);
+}
+
 // EDGE = false: rows at least two rows away from the domain's first / last row (static register slots, branch-free);
 // EDGE = true: the up to four remaining rows, launched separately (run-time slot selection - slow, but 4 rows of 4096).
 template <bool P2, bool EDGE, typename T>

@@ -48,6 +48,7 @@ _PROTOS = {
     "fs_cip_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
     "fs_cip_nonadv_fused": [_c_vp, _c_dbl, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
     "fs_cip_grad_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
+    "fs_cip_grad_advect_dye": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 8 + [_c_int] + _ROWS,
     "fs_vort_calc": [_c_vp, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_vort_add": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_vort_confine": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,

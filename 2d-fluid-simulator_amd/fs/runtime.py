@@ -502,6 +502,11 @@ class DeviceBase:
         self._run("cip_grad_advect", (dt, dx, v_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h),
                   reads=[(fn, 2), (fc, 2), (gxc, 1), (gyc, 1)], writes=[gx_out, gy_out], full_writes=[v_out])
 
+    def cip_grad_advect_dye(self, dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=False):
+        """K3 + K4 of the dye in one pass (csrc/fs_march.h k_cip_grad_advect_dye); clamp01 folds clamp_field(dye, 0, 1) into the store."""
+        self._run("cip_grad_advect_dye", (dt, dx, d_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, v._h, 1 if clamp01 else 0),
+                  reads=[(fn, 2), (fc, 2), (gxc, 1), (gyc, 1), (v, 1)], writes=[gx_out, gy_out], full_writes=[d_out])
+
     def vort_calc(self, dx, vort, vort_abs, vc):                # fs/vorticity_confinement.py:27-32
         self._run("vort_calc", (dx, vort._h, vort_abs._h, vc._h), reads=[(vc, 1)], writes=[vort, vort_abs])
 

@@ -5,6 +5,8 @@ DoubleBuffer swaps as the reference - that choreography is part of the algorithm
 The kernels themselves are HIP (csrc/fs_kernels.h); launches are asynchronous on the device stream.
 """
 import os
+
+import numpy as np
 from abc import ABCMeta, abstractmethod
 
 from .double_buffer import DoubleBuffer
@@ -199,6 +201,9 @@ class DyeCipMacSolver(CipMacSolver):
         # (advected) and inflow cells (rewritten by the dye BC) can leave [0, 1]; walls / outflow cells of this buffer are never
         # written.  Holds for device-initialised buffers; user-uploaded dye data falls back to the full-grid clamp.
         self._fused_clamp = self.resolution[0] % 4 == 0 and os.environ.get("FS_MARCH", "1") != "0"
+        # K3 + K4 of the dye in one pass as well (f32; a third dye buffer rotates like the velocity's): 355 + 459 us -> one launch
+        self._fused_dye = (self._fused_transport and self._dev.dtype == np.float32 and os.environ.get("FS_FUSE_DYE", "1") == "1")
+        self._dye_spare = self._dev.alloc(3) if self._fused_dye else None
 
     def update(self):
         self._flow_step()
@@ -218,6 +223,15 @@ class DyeCipMacSolver(CipMacSolver):
 
     def _update_dye(self, dye, dyex, dyey, v, clamp=False):
         self._non_advection_phase_dye(dye.next, dye.current)
+        if self._fused_dye and not any(f.user_data for f in (dyex.current, dyex.next, dyey.current, dyey.next)):
+            # one pass instead of K3 + swap + K4 + swap.  End state as in the reference: dye.current = advected dye with the previous
+            # values on non-fluid cells, dye.next = the dye after its non-advection phase, dyex / dyey.current = new gradients (.next: dead)
+            self._dev.cip_grad_advect_dye(self.dt, self.dx, self._dye_spare, dyex.next, dyey.next, dye.next, dye.current,
+                                          dyex.current, dyey.current, v.current, clamp01=clamp)
+            dye.current, self._dye_spare = self._dye_spare, dye.current
+            dyex.swap()
+            dyey.swap()
+            return
         self._non_advection_phase_grad(dyex.next, dyey.next, dyex.current, dyey.current, dye.current, dye.next)
         for buf in (dye, dyex, dyey):
             buf.swap()

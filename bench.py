@@ -70,6 +70,8 @@ def algorithmic_bytes(mask, esize=4):
         # fn on fluid cells; old gradients read and new gradients written on not-wall cells.  The intermediate gradients the
         # reference's two kernels exchange through HBM (16 B/cell written + read back 3x3) never leave the registers.
         "cip_grad_advect_rt": n * (1 + 2 * e + 2 * e) + fl * 2 * e + nw * (4 * e + 4 * e),
+        # the same fusion for the dye (k_cip_grad_advect_dye): 3 channels + the advecting velocity on fluid cells
+        "cip_grad_advect_dye": n * (1 + 3 * e + 3 * e) + fl * (3 * e + 2 * e) + nw * (6 * e + 6 * e),
         "vort_calc": n + fl * (2 * e + 2 * e),                           # v -> w, |w|
         "vort_add": n + fl * (2 * e + 2 * e + 2 * e),                    # w,|w|,v -> v'
         "rbsor_iteration": n + fl * (e + e + 2 * e + e),                 # fused odd+even: p.cur, p.next, v -> p.next

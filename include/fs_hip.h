@@ -125,6 +125,12 @@ int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *
 int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
                        const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc,
                        int row_begin, int row_end);
+/* The same for the dye (C = 3, advected by the velocity field v of the finished flow step; fs/solver.py:378-401 _update_dye without its
+ * first kernel): K3 (_non_advection_phase_grad, :242-261) + K4 (_cip_advect, :267-332), d_out = a third dye buffer the caller rotates.
+ * clamp01 != 0 folds clamp_field(dye, 0, 1) (:46-49) into the store of the advected cells.  f32 only.                                */
+int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, fs_field *gx_out, fs_field *gy_out,
+                           const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v,
+                           int clamp01, int row_begin, int row_end);
 
 /* ---- vorticity confinement -------------------------------------------------------------------- */
 /* VorticityConfinement._calc_vorticity    fs/vorticity_confinement.py:27-32                     */

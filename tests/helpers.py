@@ -53,4 +53,7 @@ def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=T
 def dead_buffers(solver):
     """Internal buffers whose content is unobservable in the run mode of `solver` and therefore not reproduced:
     with the fused gradient+advection pass the intermediate gradients (vx.next / vy.next) are never stored."""
-    return {"vx.next", "vy.next"} if getattr(solver, "_fused_transport", False) else set()
+    dead = {"vx.next", "vy.next"} if getattr(solver, "_fused_transport", False) else set()
+    if getattr(solver, "_fused_dye", False):
+        dead |= {"dyex.next", "dyey.next"}
+    return dead

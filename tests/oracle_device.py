@@ -139,6 +139,18 @@ class OracleSlabDevice(DeviceBase):
             nw = b.mask != 1
             gxo[nw] = tx[nw]; gyo[nw] = ty[nw]                     # not-wall cells: K4 result (fluid) or carried old gradient
             written = [vo, gxo, gyo]
+        elif name == "cip_grad_advect_dye":
+            dt, dx, do, gxo, gyo, fn, fc, gxc, gyc, v, clamp01 = A
+            O._call("oracle_cip_nonadv_grad", dt_, X, Y, dx, 3, b.mask, gxo, gyo, gxc, gyc, fc, fn)     # K3 into the output buffers
+            tx, ty = gxc.copy(), gyc.copy()                                                             # K4 targets: old gradient buffers
+            do[...] = fc
+            O._call("oracle_cip_advect", dt_, X, Y, dt, dx, 3, b.mask, do, tx, ty, fn, gxo, gyo, v)
+            if clamp01:
+                fl = b.mask == 0
+                do[fl] = np.fmin(np.fmax(do[fl], dt_.type(0)), dt_.type(1))
+            nw = b.mask != 1
+            gxo[nw] = tx[nw]; gyo[nw] = ty[nw]                     # not-wall cells: K4 result (fluid) or carried old gradient
+            written = [do, gxo, gyo]
         elif name == "vort_calc":
             dx, w, wa, vc = A
             O._call("oracle_vort_calc", dt_, X, Y, dx, b.mask, w, wa, vc); written = [w, wa]
