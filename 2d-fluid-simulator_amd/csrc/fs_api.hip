@@ -1113,24 +1113,24 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
                 else { if (edge) FS_K34(false, true); else FS_K34(false, false); }
             });
         };
-        // whole register tiles of RT rows in the interior (env FS_K34_RT = 0 / 2 / 4); what is left over, row by row
-        // f64: 256 VGPRs at one wave per SIMD - the one-row form stays.  f32: 3-row tiles on big grids (bc5 res 4096: 418 -> 400 us), 2-row
-        // tiles where the launch has few waves per SIMD slot (bc2 res 1600: 111 against 116 us)
-        const int RT = sizeof(T) != 4 ? 0 : (ctx->k34_rt >= 0 ? ctx->k34_rt : ((long long)ctx->nwx * ctx->rows >= 50000 ? 3 : 2));
-        int tiled_end = in_lo;
-        int rc = run(row_begin, in_lo, true);
-        if (!rc && RT > 1 && in_hi - in_lo >= RT) {
-            tiled_end = in_lo + (in_hi - in_lo) / (RT > 1 ? RT : 1) * RT;
-            const int jb = in_lo, je = tiled_end;
+        // f32: register tiles of RT rows (env FS_K34_RT = 0 / 2 / 3 / 4).  With every row loaded clamped the 2-row tile needs 116 VGPRs (4 waves
+        // per SIMD; it was 130 -> 3 waves when the rows next to the domain edge had their own launches and the tiles unclamped addresses), the
+        // 3-row tile 146 (3 waves): 394 against 417 us at bc5 res 4096, 111 against 115 at bc2 res 1600.  f64: 256 VGPRs - the one-row form stays.
+        const int RT = sizeof(T) != 4 ? 0 : (ctx->k34_rt >= 0 ? ctx->k34_rt : 2);
+        if (RT > 1) {       // one launch for every row: the tiles load their rows clamped and skip what lies beyond row_end
+            const int jb = row_begin, je = row_end;
+            if (jb >= je) return FS_OK;
             const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT);
 #define FS_K34RT(R, PP) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, PP, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
-            rc = launch(ctx, "cip_grad_advect_rt", [=] {
+            return launch(ctx, "cip_grad_advect_rt", [=] {
                 if (RT == 2) { if (k.p2) FS_K34RT(2, true); else FS_K34RT(2, false); }
                 else if (RT == 3) { if (k.p2) FS_K34RT(3, true); else FS_K34RT(3, false); }
                 else { if (k.p2) FS_K34RT(4, true); else FS_K34RT(4, false); }
             });
         }
+        int tiled_end = in_lo;
+        int rc = run(row_begin, in_lo, true);
         if (!rc) rc = run(tiled_end, in_hi, false);
         if (!rc) rc = run(in_hi, row_end, true);
         return rc;

@@ -110,7 +110,7 @@ struct fs_ctx {
     // slightly negative for the bandwidth-bound kernels (RB-SOR 136 -> 134, K2 116 -> 122, Jacobi 88 -> 91; K4 at a
     // non-power-of-two dx 78 -> 105 us: 244 VGPRs).  Default: the MAC update only.
     int use_rcp = 1;           // RCP_MAC
-    int k34_rt = -1;           // env FS_K34_RT: rows per register tile of the fused gradient-update + advection pass (0: one-row form; default: by grid size)
+    int k34_rt = -1;           // env FS_K34_RT: rows per register tile of the fused gradient-update + advection pass (0: one-row form; default 2)
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)

@@ -852,15 +852,16 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
     bool any_fl = false;
 #pragma unroll
     for (int s = 0; s < RT + 2; ++s) {
-        const uint32_t m4 = mask_quad(g, i0, j0 - 1 + s);
+        const uint32_t m4 = mask_quad(g, i0, clampy(g, j0 - 1 + s));
         nw[s] = sel_not_wall(m4);
-        if (s >= 1 && s <= RT) { fl[s - 1] = sel_fluid(m4); any_fl |= fl[s - 1] != 0u; }
+        if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? sel_fluid(m4) : 0u; any_fl |= fl[s - 1] != 0u; }
     }
     if (!__any(any_fl)) {
         // no fluid cell in this wave's tile: every output is a carried value (vo = fc everywhere, old gradients on inflow / outflow cells)
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const int j = j0 + t;
+            if (j >= je) break;
             const typename Quad<T>::type f = load_quad<2>(fc, g, c, i0, j);
             if (lm.owner) {
                 raise_hot(hot, hot1(f.x) || hot1(f.y) || hot1(f.z) || hot1(f.w));
@@ -878,14 +879,14 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
     Q4<T> N[RT + 4], Fc[RT + 4], NO[RT + 2], GX[RT + 2], GY[RT + 2];
 #pragma unroll
     for (int u = 0; u < RT + 4; ++u) {
-        N[u] = Q4<T>(load_quad<2>(fn, g, c, i0, j0 - 2 + u));
-        Fc[u] = Q4<T>(load_quad<2>(fc, g, c, i0, j0 - 2 + u));
+        N[u] = Q4<T>(load_quad<2>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
+        Fc[u] = Q4<T>(load_quad<2>(fc, g, c, i0, clampy(g, j0 - 2 + u)));
     }
 #pragma unroll
     for (int s = 0; s < RT + 2; ++s) {
-        NO[s] = Q4<T>(load_quad<2>(fn, g, o, i0, j0 - 1 + s));
-        GX[s] = Q4<T>(load_quad<2>(gxc, g, c, i0, j0 - 1 + s));
-        GY[s] = Q4<T>(load_quad<2>(gyc, g, c, i0, j0 - 1 + s));
+        NO[s] = Q4<T>(load_quad<2>(fn, g, o, i0, clampy(g, j0 - 1 + s)));
+        GX[s] = Q4<T>(load_quad<2>(gxc, g, c, i0, clampy(g, j0 - 1 + s)));
+        GY[s] = Q4<T>(load_quad<2>(gyc, g, c, i0, clampy(g, j0 - 1 + s)));
     }
     // ---- K3 on rows j0-1 .. j0+RT: wall cells keep the stored gradient ----
     Q4<T> NX[RT + 2], NY[RT + 2];
@@ -905,10 +906,17 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
             NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, G) : GY[s].a[q];
         }
     }
+    // every row is loaded clamped (sample() clamps coordinates), so the rows at the domain's first / last row need no launch of their own:
+    // a slot that stands for a row outside the domain takes the K3 result of the edge row it clamps onto (wave-uniform)
+    if (j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
+#pragma unroll
+    for (int s = 1; s < RT + 2; ++s)
+        if (j0 - 1 + s > g.jhi) { NX[s] = NX[s - 1]; NY[s] = NY[s - 1]; }
     // ---- K4 on rows j0 .. j0+RT-1 ----
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         const int j = j0 + t;
+        if (j >= je) break;
         const Q4<T> &Nm = N[t + 1], &Nc = N[t + 2], &Np = N[t + 3];                                // value field rows j-1, j, j+1
         const Q4<T> &VXr = c == 0 ? Nc : NO[t + 1], &VYr = c == 0 ? NO[t + 1] : Nc;                 // advecting velocity, row j
         const Q4<T> &VXm = c == 0 ? Nm : NO[t], &VXp = c == 0 ? Np : NO[t + 2];
