@@ -48,7 +48,10 @@ class JacobiPressureUpdater(PressureUpdater):
                        and (self._dev.nranks == 1 or 2 * max(2, 1 + self._dev.bc_radius_p) <= self._dev.halo))   # a pass reaches 4 rows
         self._vertical = want == "2"
         if self._pairs and want == "auto" and self._dev.nranks == 1 and hasattr(self._dev, "profile_report"):
-            self._pairs, self._vertical = self._fastest_form()
+            try:
+                self._pairs, self._vertical = self._fastest_form()
+            except Exception:       # a timing run that cannot be made is no reason to fail: the single sweeps need nothing from it
+                self._pairs, self._vertical = False, False
         if tentative and not self._pairs:
             self._precompute, self._src, self._lazy = False, None, False
 
