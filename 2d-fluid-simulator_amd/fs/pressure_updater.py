@@ -72,13 +72,16 @@ class JacobiPressureUpdater(PressureUpdater):
             run(1, False)
             run(1, True)
             reps = []
-            for vertical in (False, True):
-                dev.profile_reset()
-                dev.profile(True)
-                run(3, vertical)
-                reps.append(dev.profile_report())
+            try:
+                for vertical in (False, True):
+                    dev.profile_reset()
+                    dev.profile(True)
+                    run(3, vertical)
+                    reps.append(dev.profile_report())
+                    dev.profile(False)
+            finally:
                 dev.profile(False)
-            dev.profile_reset()
+                dev.profile_reset()
             avg = lambda rep, k: rep[k][1] / rep[k][0]
             t = {(False, False): 2.0 * avg(reps[0], "jacobi_sweep_lazy"), (True, False): avg(reps[0], "jacobi_pair_lazy"),
                  (True, True): avg(reps[1], "jacobi_pair_lazy")}
