@@ -172,3 +172,20 @@ def test_slabs_at_size_equal_single_domain(bc, res, scheme, vc, updater, world, 
         assert np.array_equal(full, ref[name]), name
     assert float(np.abs(ref["p"]).max()) > 0
     one._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("pairs", ["0", "1", "2"])
+@pytest.mark.parametrize("world,halo", [(2, 4), (3, 8)])
+def test_long_jacobi_runs_in_slabs(pairs, world, halo, hip_lib, monkeypatch):
+    """50 Jacobi sweeps per step cut into slabs, in the three forms the updater can issue (single lazily-bounded sweeps, two-sweep passes,
+    two-sweep passes with the vertical recipes in the tiles): the row windows, the general-row list and the 4-row reach of a pass all
+    act on slab-local rows here.  Bit-identical to the single-domain golden trajectory."""
+    monkeypatch.setenv("FS_JACOBI_PAIRS", pairs)
+    fname = "traj_bc2_cip_jacobi50_vc0.npz"
+    g = np.load(os.path.join(GOLDEN, fname))
+    cfg = traj_config(g)
+    results = _run_slabs(g, cfg, world, halo)
+    for step in cfg["snaps"]:
+        for k, name in enumerate(("v", "p")):
+            full = np.concatenate([results[r][0][step][k] for r in range(world)], axis=1)
+            assert np.array_equal(full, g[f"step{step}.{name}"]), f"{fname} step {step} {name} pairs={pairs}"
