@@ -119,7 +119,7 @@ class CipMacSolver(Solver):
         # Fused gradient-update + advection pass (same observable bits, 64 instead of 98 B/cell of HBM traffic; needs a third
         # velocity buffer because the reference's in-place result buffer is still an input of neighbouring tiles).  The first,
         # one-row form was issue-bound (544 us against 231 + 287 us for the two kernels at res 4096: three gradient rows
-        # recomputed per output row); on 2-row register tiles it takes 456 us -> ON by default since round 2
+        # recomputed per output row); on 2-row register tiles, every row in one launch, it takes 373-394 us -> ON by default since round 2
         # (fused_transport=False or FS_FUSE_TRANSPORT=0 gives the reference's two launches and its intermediate buffers).
         if fused_transport is None:
             fused_transport = os.environ.get("FS_FUSE_TRANSPORT", "1") == "1"
