@@ -162,7 +162,7 @@ static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, in
     // the general rows ride in front: `zoff` leading z slices of the same launch, one wave per listed row
     const uint32_t *list = ctx->d_pairlist + (HV ? (size_t)ctx->nwx * ctx->rows : 0);
     const int nlist = ctx->n_pairlist[HV ? 1 : 0];
-    const int per_slice = (int)(og.grid.x * og.grid.y), blocks = (nlist + 3) / 4, zoff = (blocks + per_slice - 1) / per_slice;
+    const int per_slice = (int)(og.grid.x * og.grid.y), blocks = nlist, zoff = (blocks + per_slice - 1) / per_slice;      // one listed row per workgroup
     const dim3 grid(og.grid.x, og.grid.y, og.grid.z + zoff);
     if (rt == 1) FS_PAIR(1); else if (rt == 4) FS_PAIR(4); else if (rt == 2) FS_PAIR(2); else FS_PAIR(3);
 }

@@ -1496,60 +1496,36 @@ __global__ __launch_bounds__(256) void k_jacobi_lazy(Grid g, int nbx, int nby, i
     if (lm.owner && sel) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o.quad(), sel);
 }
 
-// Output row j of two sweeps, general case: raw rows j-4 .. j+4 of the input iterate -> K7 (bc_row) -> first sweep rows j-2 .. j+2 (cells it
-// does not compute take the intermediate buffer's wall content) -> K7 -> second sweep.  SW: see k_jacobi_pair.
-// A four-stage pipeline over the nine input rows with three rows alive per stage: written so, the kernel needs 88 VGPRs; with every row
-// of every stage in an array (all loads hoisted) it needed 120, and these few waves - dispatched first - must not set the occupancy of the
-// rest.  Its nine dependent trips to memory are the tail of the launch (23 vs 18 us on bc2 res 1600 without these rows).  Not kept:
-// scheduling barriers between the steps (same registers, same time); a compiler-visible prefetch pass (one register per touched row:
-// 117-123 VGPRs).
-//   t: raw row j-4+t  ->  K7 row j-5+t  ->  first-sweep row j-6+t  ->  K7 row j-7+t
+// One row of the FIRST of two sweeps, general case: raw rows r-2 .. r+2 of the input iterate -> K7 on rows r-1 .. r+1 -> the plain stencil;
+// cells the sweep does not compute take the intermediate buffer's wall content.  (The workgroup form of the general path: a listed row is
+// computed by the four waves of a workgroup - its five first-sweep rows side by side, exchanged through LDS - instead of one wave walking
+// the nine-step pipeline above: one or two memory round trips instead of nine.  That pipeline was the tail of the launch.)
 template <bool SW, typename T>
-__device__ __forceinline__ Q4<T> pair_general_row(const Grid &g, const LaneMap &lm, int i0, int j, const uint8_t *bcmap, const T *pn, const T *pc, const T *src)
+__device__ __forceinline__ Q4<T> first_sweep_row(const Grid &g, const LaneMap &lm, int i0, int r, const uint8_t *bcmap, const T *pn, const T *pc, const T *src)
 {
-    auto raw_row = [&](int row) {        // one row of the input iterate
-        row = clampy(g, row);
-        Q4<T> a(load_quad<1>(pc, g, 0, i0, row));
-        if (SW) {            // its wall cells live in the other buffer
+    Q4<T> A[5], B0[3];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int row = clampy(g, r - 2 + u);
+        A[u] = Q4<T>(load_quad<1>(pc, g, 0, i0, row));
+        if (SW) {            // the input iterate's wall cells live in the other buffer
             const Q4<T> W(load_quad<1>(pn, g, 0, i0, row));
             const unsigned s = sel_not_wall(mask_quad(g, i0, row));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a.a[q] = (s >> q) & 1u ? a.a[q] : W.a[q];
-        }
-        return a;
-    };
-    // First touch every line the pipeline is going to read (one dword per lane and row, all in flight together, nothing else alive yet):
-    // its nine dependent steps then wait for L2 hits instead of nine trips to memory (these rows were the tail of the launch: +5 us).
-    Q4<T> a0, a1, a2, b0, b1, b2, s0, s1, s2, m, c, n;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        if (t >= 2) a0 = a1;
-        if (t >= 1) a1 = a2;
-        a2 = raw_row(j - 4 + t);
-        if (t >= 2) {
-            if (t >= 4) b0 = b1;
-            if (t >= 3) b1 = b2;
-            b2 = bc_row<T>(lm, a0, a1, a2, bcmap_quad(g, bcmap, i0, j - 5 + t));
-        }
-        if (t >= 4) {
-            const int row = clampy(g, j - 6 + t);
-            const Q4<T> S2(load_quad<2>(src, g, 0, i0, row)), S3(load_quad<2>(src, g, 1, i0, row));
-            const Q4<T> H(load_quad<1>(SW ? pc : pn, g, 0, i0, row));      // the intermediate iterate's wall cells
-            const unsigned s = sel_not_wall(mask_quad(g, i0, row));
-            const Q4<T> v = plain_row<T>(lm, b0, b1, b2, S2, S3);
-            if (t >= 6) s0 = s1;
-            if (t >= 5) s1 = s2;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s2.a[q] = (s >> q) & 1u ? v.a[q] : H.a[q];
-        }
-        if (t >= 6) {
-            if (t >= 8) m = c;
-            if (t >= 7) c = n;
-            n = bc_row<T>(lm, s0, s1, s2, bcmap_quad(g, bcmap, i0, j - 7 + t));
+            for (int q = 0; q < 4; ++q) A[u].a[q] = (s >> q) & 1u ? A[u].a[q] : W.a[q];
         }
     }
-    const Q4<T> S2(load_quad<2>(src, g, 0, i0, j)), S3(load_quad<2>(src, g, 1, i0, j));
-    return plain_row<T>(lm, m, c, n, S2, S3);
+    const int row = clampy(g, r);
+    const Q4<T> S2(load_quad<2>(src, g, 0, i0, row)), S3(load_quad<2>(src, g, 1, i0, row));
+    const Q4<T> H(load_quad<1>(SW ? pc : pn, g, 0, i0, row));          // the intermediate iterate's wall cells
+    const unsigned s = sel_not_wall(mask_quad(g, i0, row));
+#pragma unroll
+    for (int u = 0; u < 3; ++u) B0[u] = bc_row<T>(lm, A[u], A[u + 1], A[u + 2], bcmap_quad(g, bcmap, i0, r - 1 + u));
+    const Q4<T> v = plain_row<T>(lm, B0[0], B0[1], B0[2], S2, S3);
+    Q4<T> o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o.a[q] = (s >> q) & 1u ? v.a[q] : H.a[q];
+    return o;
 }
 
 // list[k] = (wave column << 20) | row of every wave-tile row that k_jacobi_pair's general path must compute: a "hard" or "vertical" flag
@@ -1581,8 +1557,8 @@ static __global__ __launch_bounds__(256) void k_pair_list(Grid g, int nwx, uint8
 // with no such row among j0-2 .. j0+RT+1 runs the plain two-sweep path; the others apply K7 row by row in registers, which is exact for
 // the targets that are 0 or copy their left / right neighbour (inflow / outflow columns, vertical wall faces).  Output rows with anything
 // else within 2 rows and 4 columns (bits 2, 3: targets with a source in another row - floors, ceilings, corners -, wall cells whose content
-// is history) are left out here and computed, one row per wave, by the workgroups of the first `zoff` z slices of the same launch from
-// `list` (k_pair_list): general, register-frugal and slow, dispatched first.  HV = true adds a third tile path that also applies the
+// is history) are left out here and computed, one row per workgroup, by the first `zoff` z slices of the same launch from
+// `list` (k_pair_list): general, register-frugal, dispatched first.  HV = true adds a third tile path that also applies the
 // recipes with a source in the row below / above (walls thicker than one cell) inside the plain footprint, leaving only bit-2 rows to the
 // general path: for masks whose outlines are staircases (bc3's cylinders: 31 % -> 2 % general rows, +16 .. 28 %); on masks with few such
 // rows the extra code costs 6 % (bc2 res 1600), so the host picks per mask.
@@ -1594,16 +1570,32 @@ template <int RT, bool SW, bool HV, typename T>
 __global__ __launch_bounds__(256) void k_jacobi_pair(Grid g, int nbx, int nby, int jb, int je, const uint8_t *bcmap, const uint8_t *flags,
                                                      const uint32_t *list, int nlist, int zoff, T *pn, const T *pc, const T *src)
 {
-    if ((int)blockIdx.z < zoff) {        // the general rows
-        const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const int k = (((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x) * 4 + w;
+    if ((int)blockIdx.z < zoff) {        // the general rows: one listed row per WORKGROUP
+        __shared__ __attribute__((aligned(16))) T s1[5][64][4];                  // first-sweep rows j-2 .. j+2 of the wave column
+        const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+        const int k = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (k >= nlist) return;
         const uint32_t e = list[k];
         const int wx = (int)(e >> 20), j = (int)(e & 0xfffffu);
-        if (j < jb || j >= je) return;
-        const LaneMap lm = lane_map_wave(g, wx);
+        if (j < jb || j >= je) return;                                           // (workgroup-uniform, like everything up to the barrier)
+        const LaneMap lm = lane_map_wave(g, wx);                                 // all four waves: the lanes of wave column wx
+        // wave 0: rows j-2 and j-1, waves 1 .. 3: rows j, j+1, j+2
+#pragma unroll 1
+        for (int t = 0; t < (w == 0 ? 2 : 1); ++t) {
+            const int sl = w == 0 ? t : w + 1;
+            const Q4<T> row = first_sweep_row<SW, T>(g, lm, lm.i0, j - 2 + sl, bcmap, pn, pc, src);
+            *reinterpret_cast<typename Quad<T>::type *>(&s1[sl][lane][0]) = row.quad();
+        }
+        __syncthreads();
+        if (w != 0) return;
+        Q4<T> S1[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) S1[u] = Q4<T>(*reinterpret_cast<const typename Quad<T>::type *>(&s1[u][lane][0]));
+        const Q4<T> m = bc_row<T>(lm, S1[0], S1[1], S1[2], bcmap_quad(g, bcmap, lm.i0, j - 1)), c = bc_row<T>(lm, S1[1], S1[2], S1[3], bcmap_quad(g, bcmap, lm.i0, j)),
+                    n = bc_row<T>(lm, S1[2], S1[3], S1[4], bcmap_quad(g, bcmap, lm.i0, j + 1));
+        const Q4<T> S2(load_quad<2>(src, g, 0, lm.i0, j)), S3(load_quad<2>(src, g, 1, lm.i0, j));
+        const Q4<T> out = plain_row<T>(lm, m, c, n, S2, S3);
         const unsigned s_out = sel_not_wall(mask_quad(g, lm.i0, j));
-        const Q4<T> out = pair_general_row<SW, T>(g, lm, lm.i0, j, bcmap, pn, pc, src);
         if (lm.owner && s_out) store_quad_sel<T>(pn + idx<1, T>(g, 0, lm.i0, j), out.quad(), s_out);
         return;
     }

@@ -253,7 +253,9 @@ class DeviceBase:
         """
         multi = self.nranks > 1
         off = self.y0 - self.halo
-        self._cur_writes = list(writes) + list(full_writes)
+        # (identities, not the fields: a reference kept here would postpone the release of a temporary field to the NEXT launch - which may
+        #  sit inside a hipGraph capture, where hipFree is illegal)
+        self._cur_writes = tuple(id(f._h) for f in list(writes) + list(full_writes))
         if pointwise or not multi:      # pointwise: all in-domain local rows, ghost rows included -> validity preserved
             lo, hi = (self.g_lo - off, self.g_hi - off) if pointwise else (self.halo, self.halo + self.nyl)
             self._kernel(name, args, lo, hi)
@@ -310,7 +312,7 @@ class DeviceBase:
     # ---- command tapes: a logged period of primitive operations, replayed without the bookkeeping above --------------------
     def _kernel(self, name, args, lo, hi):
         if self._oplog is not None:
-            self._oplog.append(("k", name, tuple(args) + (lo, hi), tuple(id(f._h) for f in self._cur_writes)))
+            self._oplog.append(("k", name, tuple(args) + (lo, hi), self._cur_writes))
         self._p_kernel(name, *args, lo, hi)
 
     def _state_signature(self):

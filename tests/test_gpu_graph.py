@@ -40,3 +40,27 @@ def test_graph_replay_equals_eager(bc, scheme, vc, dye, updater, hip_lib):
     finally:
         eager._solver._bc.device.close()
         dev.close()
+
+
+def test_capture_right_after_construction(hip_lib, monkeypatch):
+    """No eager step between building the solver and capturing: the pressure updater's timing run (two-sweep passes vs single sweeps, on
+    temporary fields) must leave nothing behind whose release would fall into the capture (hipFree inside a capture invalidates it)."""
+    import fs
+    monkeypatch.delenv("FS_JACOBI_PAIRS", raising=False)
+    res = 128
+    dt, dx, re = 0.05 / res, 1.0 / res, 1e6
+    fs.runtime.init(gpu=0, dtype="f32")
+    eager = fs.FluidSimulator.create(2, res, dt, dx, re, None, "cip", pressure_updater=("jacobi", 12))
+    graph = fs.FluidSimulator.create(2, res, dt, dx, re, None, "cip", pressure_updater=("jacobi", 12))
+    dev = graph._solver._bc.device
+    try:
+        gid = dev.capture(lambda: [graph._solver.update() for _ in range(6)])      # one period of the buffer rotation
+        dev.replay(gid, 2)
+        for _ in range(12):
+            eager.step()
+        a, b = eager.field_to_numpy(), graph.field_to_numpy()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    finally:
+        eager._solver._bc.device.close()
+        dev.close()
