@@ -569,6 +569,7 @@ int fs_destroy(fs_ctx *ctx)
     for (auto e : ctx->prof_pool) hipEventDestroy(e);
     free_ops(ctx->ops_vel); free_ops(ctx->ops_prs); free_ops(ctx->ops_dye);
     for (fs_field *f : ctx->fields) { if (f->d) hipFree(f->d); if (f->hot) hipFree(f->hot); delete f; }
+    for (fs_field *f : ctx->deferred_free) { if (f->d) hipFree(f->d); if (f->hot) hipFree(f->hot); delete f; }
     ctx->fields.clear();
     if (ctx->d_mask) hipFree(ctx->d_mask);
     if (ctx->d_bc_const) hipFree(ctx->d_bc_const);
@@ -728,15 +729,24 @@ int fs_field_alloc(fs_ctx *ctx, int nchan, fs_field **out)
     return FS_OK;
 }
 
-int fs_field_free(fs_field *f)
+static void field_release(fs_field *f)
 {
-    if (!f) return FS_OK;
-    hipSetDevice(f->ctx->device);
-    hipStreamSynchronize(f->ctx->stream);
-    f->ctx->fields.erase(f);
     if (f->d) hipFree(f->d);
     if (f->hot) hipFree(f->hot);
     delete f;
+}
+
+int fs_field_free(fs_field *f)
+{
+    if (!f) return FS_OK;
+    fs_ctx *ctx = f->ctx;
+    hipSetDevice(ctx->device);
+    ctx->fields.erase(f);
+    // inside a hipGraph capture neither the synchronisation nor hipFree is legal (either invalidates the capture): a field dropped by
+    // the host language's garbage collector at that moment is released when the capture ends
+    if (ctx->capturing) { ctx->deferred_free.push_back(f); return FS_OK; }
+    hipStreamSynchronize(ctx->stream);
+    field_release(f);
     return FS_OK;
 }
 
@@ -1518,7 +1528,10 @@ int fs_graph_end(fs_ctx *ctx, int *graph_id)
     FS_REQUIRE(ctx->capturing, "not capturing");
     hipGraph_t g = nullptr;
     ctx->capturing = false;
-    FS_HIP(hipStreamEndCapture(ctx->stream, &g));
+    const hipError_t ec = hipStreamEndCapture(ctx->stream, &g);
+    for (fs_field *f : ctx->deferred_free) field_release(f);          // fields dropped while the capture was open (fs_field_free)
+    ctx->deferred_free.clear();
+    if (ec != hipSuccess) return hip_fail(ec, "hipStreamEndCapture", __FILE__, __LINE__);
     hipGraphExec_t ex = nullptr;
     hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);

@@ -102,6 +102,7 @@ struct fs_ctx {
     // comm
     fs::Comm *comm = nullptr;
     std::set<fs_field *> fields;  // live fields, released with the context
+    std::vector<fs_field *> deferred_free;   // fs_field_free during a hipGraph capture: released when the capture ends
     // tuning knobs (env FS_MARCH=0: one-cell-per-lane kernels only)
     bool use_march = true;
     // Kernel families that use the reciprocal-FMA division for loop-invariant divisors (fs_device.h rdiv; env FS_RCP = bit mask).

@@ -64,3 +64,27 @@ def test_capture_right_after_construction(hip_lib, monkeypatch):
     finally:
         eager._solver._bc.device.close()
         dev.close()
+
+
+def test_fields_dropped_during_a_capture(hip_lib):
+    """A field released while a capture is open (the host's garbage collector can do that at any time) must not invalidate the capture:
+    fs_field_free defers the release to fs_graph_end."""
+    import fs
+    res = 64
+    dt, dx, re = 0.05 / res, 1.0 / res, 1e6
+    fs.runtime.init(gpu=0, dtype="f32")
+    eager = fs.FluidSimulator.create(1, res, dt, dx, re, 5.0, "cip")
+    graph = fs.FluidSimulator.create(1, res, dt, dx, re, 5.0, "cip")
+    dev = graph._solver._bc.device
+    try:
+        scratch = [dev.alloc(1) for _ in range(3)]          # dropped inside the captured sequence
+        gid = dev.capture(lambda: (scratch.clear(), [graph._solver.update() for _ in range(6)]))
+        dev.replay(gid, 1)
+        for _ in range(6):
+            eager.step()
+        a, b = eager.field_to_numpy(), graph.field_to_numpy()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    finally:
+        eager._solver._bc.device.close()
+        dev.close()
