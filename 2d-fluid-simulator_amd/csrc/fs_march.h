@@ -1571,7 +1571,7 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(Grid g, int nbx, int nby, i
                                                      const uint32_t *list, int nlist, int zoff, T *pn, const T *pc, const T *src)
 {
     if ((int)blockIdx.z < zoff) {        // the general rows: one listed row per WORKGROUP
-        __shared__ __attribute__((aligned(16))) T s1[5][64][4];                  // first-sweep rows j-2 .. j+2 of the wave column
+        __shared__ __attribute__((aligned(32))) T s1[5][64][4];                  // first-sweep rows j-2 .. j+2 of the wave column
         const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
         const int k = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (k >= nlist) return;
