@@ -144,6 +144,26 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
     return o;
 }
 
+template <int N>
+static OvGrid ov_grid_n(const fs_ctx *c, int jb, int je, int rt)
+{
+    // as ov_grid, for wave columns of 64 - 2 * (4 / N) owner lanes of N cells
+    constexpr int OW = 64 - 2 * (4 / N);
+    OvGrid o;
+    const int nu = c->X / N, waves = (nu + OW - 1) / OW, tiles = (je - jb + rt - 1) / rt;
+    const bool stacked = (c->stack_mask & XCD_RBSOR) != 0;
+    o.nbx = stacked ? waves : (waves + 3) / 4;
+    o.nby = stacked ? (tiles + 3) / 4 : tiles;
+    if (c->xcd_mask & XCD_RBSOR) {
+        const int group = stacked ? std::max(1, c->xcd_group / 4) : c->xcd_group;
+        const int groups = (o.nby + group - 1) / group;
+        o.grid = dim3(8 * o.nbx, group, (groups + 7) / 8);
+        o.nby |= (group - 1) << 24;
+    } else { o.grid = dim3(o.nbx * o.nby, 1, 1); o.nbx = -o.nbx; }
+    if (stacked) o.nby |= FS_STACKED;
+    return o;
+}
+
 // Division-mode dispatch (fs_device.h DM_*): CALL(DM) is expanded for the modes a kernel family distinguishes; the reciprocal-FMA
 // modes (2, 3) exist for f32 only.
 #define FS_DM2(dm, CALL)      /* modes 0 / 2 : no dx-derived divisor                */ \
@@ -484,7 +504,21 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
         }
         for (int i = 0; i < X && ok; ++i)                                  // no computed cell may sample a clamped y neighbour
             if (M(i, 0) != 1 || M(i, Y - 1) != 1) ok = false;
+        for (const HostOp &op : vel) map[op.t] |= 0x80;                     // bit 7: a cell the velocity boundary kernel writes (k_cip_grad_advect_rt)
         c->lazy_ok = ok && X % 4 == 0;
+        // Two red-black iterations per pass (fs_rbpair.h): additionally no recipe may read a source on the far side of its target as
+        // seen from a fluid cell (a wall one cell thick between two fluid regions) - the shrinking-window argument of that kernel
+        bool thin = false;
+        for (const HostOp &op : prs) {
+            if (op.kind == 2) continue;
+            const long long srcs[2] = {op.s1, op.kind == 1 ? op.s2 : -1};
+            for (long long s : srcs) {
+                if (s < 0 || s == op.t) continue;
+                const int oi = 2 * (int)(op.t / Y) - (int)(s / Y), oj = 2 * (int)(op.t % Y) - (int)(s % Y);
+                if (oi >= 0 && oi < X && oj >= 0 && oj < Y && M(oi, oj) == 0) thin = true;
+            }
+        }
+        c->rb_pair_ok = c->lazy_ok && !thin;
         c->h_bcmap.swap(map);            // uploaded by fs_upload_mask (same transpose path as the mask), then dropped
     }
     c->bc_incomplete = false;
@@ -543,6 +577,9 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_VORT_RT")) { const int v = atoi(s); if (v >= 3 && v <= 6) c->vort_rt = v; }
     if (const char *s = getenv("FS_RBSOR_RT")) { const int v = atoi(s); if (v >= 2 && v <= 4) c->rbsor_rt = v; }
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
+    if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
+    if (const char *s = getenv("FS_RBPAIR_N")) { const int v = atoi(s); if (v == 2 || v == 4) c->rbpair_n = v; }
+    if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s) != 0;
     if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 || v == 3 ? v : (v >= 4 ? 4 : 0); }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
@@ -1103,7 +1140,7 @@ int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *
 }
 
 int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
-                       const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, int row_begin, int row_end)
+                       const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end)
 {
     FS_REQUIRE(ctx, "ctx is null");
     FS_FIELD(v_out, 2); FS_FIELD(gx_out, 2); FS_FIELD(gy_out, 2); FS_FIELD(fn, 2); FS_FIELD(fc, 2); FS_FIELD(gxc, 2); FS_FIELD(gyc, 2);
@@ -1132,7 +1169,8 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
             if (jb >= je) return FS_OK;
             const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT);
 #define FS_K34RT(R, PP) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, PP, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
-                (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
+                (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, \
+                (const uint8_t *)ctx->d_bcmap, full)
             return launch(ctx, "cip_grad_advect_rt", [=] {
                 if (RT == 2) { if (k.p2) FS_K34RT(2, true); else FS_K34RT(2, false); }
                 else if (RT == 3) { if (k.p2) FS_K34RT(3, true); else FS_K34RT(3, false); }
@@ -1150,7 +1188,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
 // K3 + K4 of the dye in one pass (fs_march.h k_cip_grad_advect_dye): d_out <- advect(fn with the gradients K3 derives from fc -> fn) by v
 int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, fs_field *gx_out, fs_field *gy_out,
                            const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v,
-                           int clamp01, int row_begin, int row_end)
+                           int clamp01, int full, int row_begin, int row_end)
 {
     FS_REQUIRE(ctx, "ctx is null");
     FS_FIELD(d_out, 3); FS_FIELD(gx_out, 3); FS_FIELD(gy_out, 3); FS_FIELD(fn, 3); FS_FIELD(fc, 3); FS_FIELD(gxc, 3); FS_FIELD(gyc, 3); FS_FIELD(v, 2);
@@ -1166,7 +1204,7 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
             constexpr int RT = 2;
             const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 3, XCD_ADVECT);
 #define FS_K34D(PP, CL) hipLaunchKernelGGL((k_cip_grad_advect_dye<RT, PP, CL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
-                (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
+                (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, full)
             return launch(ctx, "cip_grad_advect_dye", [=] {
                 if (k.p2) { if (clamp01) FS_K34D(true, true); else FS_K34D(true, false); }
                 else { if (clamp01) FS_K34D(false, true); else FS_K34D(false, false); }
@@ -1365,6 +1403,50 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
             else FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF2);
         });
     })
+}
+
+int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok)
+{
+    FS_REQUIRE(ctx && ok, "null argument");
+    *ok = ctx->mask_set && ctx->rb_pair_ok && ctx->use_march && ctx->use_lazy && ctx->dtype == 0 ? 1 : 0;
+    return FS_OK;
+}
+
+// two red-black iterations + both pressure boundary passes in one pass (fs_rbpair.h): (pc_out, pn_out) <- the state two iterations of
+// fs/pressure_updater.py:86-96 leave in (p.current, p.next) when they start from (pc, pn)
+int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_out, fs_field *pn_out, const fs_field *pc, const fs_field *pn,
+                  const fs_field *vc, int full, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(pc_out, 1); FS_FIELD(pn_out, 1); FS_FIELD(pc, 1); FS_FIELD(pn, 1); FS_FIELD(vc, 2);
+    FS_REQUIRE(pc_out != pn_out && pc_out != pc && pc_out != pn && pn_out != pc && pn_out != pn && pc != pn, "the two-iteration pass needs four distinct pressure fields");
+    FS_ROWS();
+    if (!(ctx->rb_pair_ok && ctx->use_march && ctx->dtype == 0)) {
+        set_error("this mask / precision does not admit the two-iteration red-black pass (fs_rbsor_pair_ok)");
+        return FS_ERR_UNSUPPORTED;
+    }
+    using T = float;
+    const Grid gg = ctx->grid();
+    const int par0 = (gg.ybase + row_begin) & 1;
+    auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
+    const int dm = dm_const(ctx, k, RCP_RBPAIR);
+    // lanes of N cells, RT rows per tile; `split`: the tiles without / with a non-fluid cell within reach as two launches, each with
+    // its own register budget (fs_rbpair.h).  The carrying pass after an upload (full) is rare: one configuration.
+    const int n = full ? 2 : ctx->rbpair_n, rt = full ? 4 : ctx->rbpair_rt, split = full ? 0 : ctx->rbpair_split;
+    const OvGrid og = n == 4 ? ov_grid_n<4>(ctx, row_begin, row_end, rt) : ov_grid_n<2>(ctx, row_begin, row_end, rt);
+#define FS_RBP_K(N, RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<N, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
+                               (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
+#define FS_RBP_PAR(N, RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(N, RT, 1, DM, PATH, FULL); else FS_RBP_K(N, RT, 0, DM, PATH, FULL); } while (0)
+#define FS_RBP_DM(N, RT, PATH) do { if (dm & DM_RCP) FS_RBP_PAR(N, RT, 2, PATH, false); else FS_RBP_PAR(N, RT, 0, PATH, false); } while (0)
+#define FS_RBP_PATH(PATH) do { \
+        if (full) FS_RBP_PAR(2, 4, 0, 2, true); \
+        else if (n == 4) FS_RBP_PAR(4, 4, 0, PATH, false); \
+        else if (rt == 6) FS_RBP_DM(2, 6, PATH); \
+        else FS_RBP_DM(2, 4, PATH); } while (0)
+    if (!split) return launch(ctx, "rbsor_pair", [=] { FS_RBP_PATH(2); });
+    int rc = launch(ctx, "rbsor_pair", [=] { FS_RBP_PATH(0); });
+    if (rc) return rc;
+    return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_PATH(1); });
 }
 
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc, const fs_field *src,

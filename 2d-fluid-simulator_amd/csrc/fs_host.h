@@ -14,6 +14,7 @@
 #include "fs_device.h"
 #include "fs_kernels.h"
 #include "fs_march.h"
+#include "fs_rbpair.h"
 
 namespace fs {
 
@@ -68,6 +69,9 @@ struct fs_ctx {
     uint8_t *d_lazyflags = nullptr;   // [nwx][rows] tile needs the lazy evaluation
     std::vector<uint8_t> h_bcmap;  // host copy between build_bc_ops and the upload
     bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
+    bool rb_pair_ok = false;                 // mask admits the two-iteration red-black pass (fs_rbpair.h; decided in build_bc_ops)
+    int rbpair_rt = 4, rbpair_n = 2;         // rows per tile (env FS_RBPAIR_RT = 4, 6) and cells per lane (FS_RBPAIR_N = 2, 4) of that pass
+    bool rbpair_split = true;                // plain and boundary tiles as two launches (FS_RBPAIR_SPLIT)
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
     int vort_rt = 4;                         // rows per tile of the fused vorticity confinement (env FS_VORT_RT = 3 .. 6)
@@ -196,7 +200,7 @@ inline Konst<T> make_konst(fs_ctx *ctx, double dt, double dx, double re, double 
 }
 
 // division mode of a launch (fs_device.h): which kernels have which kinds of divisors decides how many modes they instantiate
-enum { RCP_MAC = 1, RCP_K2 = 2, RCP_K3 = 4, RCP_K4 = 8, RCP_RBSOR = 16, RCP_JACOBI = 32, RCP_DYE = 64 };
+enum { RCP_MAC = 1, RCP_K2 = 2, RCP_K3 = 4, RCP_K4 = 8, RCP_RBSOR = 16, RCP_JACOBI = 32, RCP_DYE = 64, RCP_RBPAIR = 128 };
 template <typename T> inline bool rcp_on(const fs_ctx *c, const Konst<T> &k, int family) { return k.rcp && (c->use_rcp & family); }
 template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k, int f) { return (k.p2 ? DM_P2 : 0) | (rcp_on(c, k, f) ? DM_RCP : 0); }      // dx-derived AND other divisors
 template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k, int f) { return k.p2 ? DM_P2 : (rcp_on(c, k, f) ? DM_RCP : DM_IEEE); }       // dx-derived divisors only

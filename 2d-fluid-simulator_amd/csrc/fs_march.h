@@ -79,6 +79,13 @@ __device__ __forceinline__ bool lane_needed(unsigned active) { return (active | 
 __device__ __forceinline__ uint32_t mask_quad(const Grid &g, int i0, int j)
 { return load_row_quad<uint32_t, uint8_t>(g.mask + (size_t)j * g.Pm, i0); }
 
+// recipe bytes of the boundary kernels, one per cell (fs_api.hip build_bc_ops): bits 0-6 the pressure recipe (k_jacobi_lazy below),
+// bit 7: the cell is a target of the velocity boundary kernel.  Rows are clamped into the domain.
+__device__ __forceinline__ uint32_t bcmap_quad(const Grid &g, const uint8_t *bcmap, int i0, int row)
+{ return load_row_quad<uint32_t, uint8_t>(bcmap + (size_t)clampy(g, row) * g.Pm, i0); }
+__device__ __forceinline__ unsigned sel_bit7(uint32_t c4)
+{ return ((c4 >> 7) & 1u) | ((c4 >> 14) & 2u) | ((c4 >> 21) & 4u) | ((c4 >> 28) & 8u); }
+
 // store the components of `v` whose mask byte satisfies the predicate encoded in `sel` (bit k = cell k)
 template <typename T>
 __device__ __forceinline__ void store_quad_sel(T *dst, const typename Quad<T>::type &v, unsigned sel)
@@ -838,7 +845,7 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
 template <int c, int RT, bool P2, typename T>
 __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                         T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                        const T *gxc, const T *gyc, unsigned *hot)
+                                                        const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
 {
     constexpr int DM = P2 ? DM_P2 : DM_IEEE;
     DivGuard G;      // unused: exact multiplication or IEEE division only
@@ -857,13 +864,18 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
         if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? sel_fluid(m4) : 0u; any_fl |= fl[s - 1] != 0u; }
     }
     if (!__any(any_fl)) {
-        // no fluid cell in this wave's tile: every output is a carried value (vo = fc everywhere, old gradients on inflow / outflow cells)
+        // no fluid cell in this wave's tile: every output is a carried value (vo = fc, old gradients on inflow / outflow cells) - and only
+        // cells that SOME kernel writes can differ between fc and vo: not-wall cells and the targets of the velocity boundary kernel
+        // (bit 7 of the recipe byte, fs_api.hip build_bc_ops).  Deep wall rows move nothing (a third of scene 5); `full`: after an
+        // upload the two buffers may differ anywhere - carry every cell once (fs/solver.py, Field.static_id).
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const int j = j0 + t;
             if (j >= je) break;
+            const unsigned touch = full ? 0xfu : (nw[t + 1] | sel_bit7(bcmap_quad(g, bcmap, i0, j)));
+            if (!__any(lm.owner && touch != 0u)) continue;
             const typename Quad<T>::type f = load_quad<2>(fc, g, c, i0, j);
-            if (lm.owner) {
+            if (lm.owner && touch) {
                 raise_hot(hot, hot1(f.x) || hot1(f.y) || hot1(f.z) || hot1(f.w));
                 *reinterpret_cast<typename Quad<T>::type *>(vo + idx<2, T>(g, c, i0, j)) = f;
                 if (nw[t + 1]) {
@@ -966,12 +978,12 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
 template <int RT, bool P2, typename T>
 __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                             T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                            const T *gxc, const T *gyc, unsigned *hot)
+                                                            const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
 {
     // blockIdx.y = (tile row in the XCD group) * 2 + component: the two component passes of a tile are adjacent in dispatch order on
     // the SAME XCD, so the second one finds the velocity rows both passes read in that XCD's L2 instead of fetching them again.
-    if ((blockIdx.y & 1) == 0) cip_grad_advect_rt_body<0, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
-    else cip_grad_advect_rt_body<1, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
+    if ((blockIdx.y & 1) == 0) cip_grad_advect_rt_body<0, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
+    else cip_grad_advect_rt_body<1, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
 }
 
 // The same fusion for the dye (C = 3 channels advected by the final velocity of the flow step, fs/solver.py:378-401): K3 on the rows
@@ -982,7 +994,7 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, 
 template <int c, int RT, bool P2, bool CLAMP, typename T>
 __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                          T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                         const T *gxc, const T *gyc, const T *v)
+                                                         const T *gxc, const T *gyc, const T *v, int full)
 {
     constexpr int DM = P2 ? DM_P2 : DM_IEEE;
     DivGuard G;      // unused: exact multiplication or IEEE division only
@@ -1000,13 +1012,16 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
         if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? sel_fluid(m4) : 0u; any_fl |= fl[s - 1] != 0u; }
     }
     if (!__any(any_fl)) {
-        // no fluid cell in this wave's tile: every output is a carried value (dout = fc everywhere, old gradients on inflow / outflow cells)
+        // no fluid cell in this wave's tile: every output is a carried value (dout = fc, old gradients on inflow / outflow cells); wall cells
+        // of the dye buffers are written by no kernel, so only quads with an inflow / outflow cell have anything to carry (`full`: see above)
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const int j = j0 + t;
             if (j >= je) break;
+            const unsigned touch = full ? 0xfu : nw[t + 1];
+            if (!__any(lm.owner && touch != 0u)) continue;
             const typename Quad<T>::type f = load_quad<3>(fc, g, c, i0, j);
-            if (lm.owner) {
+            if (lm.owner && touch) {
                 *reinterpret_cast<typename Quad<T>::type *>(dout + idx<3, T>(g, c, i0, j)) = f;
                 if (nw[t + 1]) {
                     store_quad_sel<T>(gxo + idx<3, T>(g, c, i0, j), load_quad<3>(gxc, g, c, i0, j), nw[t + 1]);
@@ -1107,12 +1122,12 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
 template <int RT, bool P2, bool CLAMP, typename T>
 __global__ __launch_bounds__(256) void k_cip_grad_advect_dye(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                              T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                             const T *gxc, const T *gyc, const T *v)
+                                                             const T *gxc, const T *gyc, const T *v, int full)
 {
     const int ly = (int)blockIdx.y / 3, ch = (int)blockIdx.y - 3 * ly;      // channel = blockIdx.y % 3 (the fallback grid: blockIdx.y itself)
-    if (ch == 0) cip_grad_advect_dye_body<0, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v);
-    else if (ch == 1) cip_grad_advect_dye_body<1, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v);
-    else cip_grad_advect_dye_body<2, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v);
+    if (ch == 0) cip_grad_advect_dye_body<0, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
+    else if (ch == 1) cip_grad_advect_dye_body<1, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
+    else cip_grad_advect_dye_body<2, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
 }
 
 // EDGE = false: rows at least two rows away from the domain's first / last row (static register slots, branch-free);
@@ -1355,9 +1370,6 @@ __device__ __forceinline__ T lazy_value(unsigned code, T raw, T sL, T sR, T sD, 
     const T b = d2 == 0u ? sL : (d2 == 1u ? sR : (d2 == 2u ? sD : sU));
     return kind == 0u ? a : (kind == 1u ? (a + b) / (T)2.0 : (T)0.0);
 }
-
-__device__ __forceinline__ uint32_t bcmap_quad(const Grid &g, const uint8_t *bcmap, int i0, int row)
-{ return load_row_quad<uint32_t, uint8_t>(bcmap + (size_t)clampy(g, row) * g.Pm, i0); }
 
 // flags[wx * rows + r]: bit 0 - a not-wall owner cell of wave column wx in row r has a boundary-condition target among its 4 neighbours;
 // (bit 4 is added by k_pair_list) bit 1 - a wall or a target lies in row r within 2 columns of the wave's owner cells; within 4 columns of them: bit 3 - a target with a

@@ -1,0 +1,298 @@
+// fs_rbpair.h - TWO red-black SOR iterations, and both pressure boundary passes between them, in one pass over HBM.
+//
+// Reference (fs/pressure_updater.py:86-114, n_iter = 2 is what fs/fluid_simulator.py:76-78 wires into every create()):
+//     K7(A)                                     A = p.current, B = p.next
+//     odd : B[odd fluid]  = (1-w) A + w predict_p(A)            even: B[even fluid] = (1-w) B + w predict_p(B)      swap
+//     K7(B)
+//     odd : A[odd fluid]  = (1-w) B + w predict_p(B)            even: A[even fluid] = (1-w) A + w predict_p(A)      swap
+// i.e. four dependent half sweeps of radius 1.  As four launches (two fused iterations + two boundary kernels) that is 2 x 21 B/cell
+// and 30 % of the headline step.  Here a lane holds rows j0-4 .. j0+RT+3 of its cells in registers, runs the four half sweeps on
+// shrinking row ranges (x-neighbours through the halo lanes, whose 4 cells are exactly the reach of four radius-1 stages) and stores
+// RT rows of both results: mask 1 + A 4 + B 4 + v 8 read, 8 written = 25 B per fluid cell for TWO iterations.  The Poisson source
+// (s2, s3 of predict_p) depends on v only: it is evaluated once per cell and serves both iterations.
+//
+// Lane width N (cells per lane): the window is RT + 8 rows of four planes - with quads (N = 4, one 16-byte load per row and plane, like
+// every other tile kernel) that is 240 VGPRs = 2 waves per SIMD, and a wave that computes cannot hide behind one that loads: measured
+// 252 us against 2 x (8.7 + 124) for the launches it replaces.  N = 2 (8-byte loads, 60 owner lanes + 2 x 2 halo lanes) halves the
+// registers per row.
+//
+// Out of place: other tiles read A and B in their halo rows while this one produces its rows, so the results go to a SECOND pair of
+// pressure buffers (C <- A after iteration 2, D <- B after iteration 1 + K7); the caller rotates (p.current, p.next) <-> spare pair.
+//
+// K7 (fs/boundary_condition.py:41-65) is evaluated where it is consumed, from the recipe bytes built at mask upload (fs_march.h
+// lazy_value: a boundary cell takes the value, or the mean of two values, of 4-neighbours; outflow 0; inflow its right neighbour):
+// "view(P)" below is buffer state P as K7 would leave it.  Cells no kernel ever writes (wall cells without a recipe) hold the same
+// value in all four buffers (zero, or - after an upload - whatever one FULL pass carries over), so only fluid cells and K7 targets
+// are stored.
+//
+// Validity of the shrinking-window argument (host-checked per mask, fs_api.hip build_bc_ops -> rb_pair_ok): a recipe never reads a
+// source that lies on the far side of its target as seen from a fluid reader (a wall one cell thick between two fluid regions) -
+// then whoever reads a boundary value finds the recipe's sources inside its own radius-1 neighbourhood, and the plain stencil's
+// footprint suffices; and the first / last domain row hold no fluid cell (no clamped y neighbour of a relaxed cell).  All of the
+// reference's scenes qualify at their usual resolutions; masks that do not keep the two-launch iterations.
+#pragma once
+#include "fs_march.h"
+
+namespace fs {
+
+// N consecutive cells of one row
+template <typename T, int N> struct LV { T a[N]; };
+template <typename T, int N> struct LVec;
+template <> struct LVec<float, 4> { using type = float4; };
+template <> struct LVec<float, 2> { using type = float2; };
+template <int N> struct LMaskWord;
+template <> struct LMaskWord<4> { using type = uint32_t; };
+template <> struct LMaskWord<2> { using type = uint16_t; };
+
+template <typename T, int N>
+__device__ __forceinline__ LV<T, N> lv_load(const T *row, int i0)
+{
+    const typename LVec<T, N>::type q = load_row_quad<typename LVec<T, N>::type, T>(row, i0);
+    LV<T, N> r;
+    if constexpr (N == 4) { r.a[0] = q.x; r.a[1] = q.y; r.a[2] = q.z; r.a[3] = q.w; }
+    else { r.a[0] = q.x; r.a[1] = q.y; }
+    return r;
+}
+template <int C, typename T, int N>
+__device__ __forceinline__ LV<T, N> lv_field(const T *f, const Grid &g, int c, int i0, int j)
+{ return lv_load<T, N>(f + ((size_t)j * C + c) * g.P, i0); }
+template <int N>
+__device__ __forceinline__ uint32_t lv_bytes(const uint8_t *plane, const Grid &g, int i0, int j)        // N mask / recipe bytes, byte k = cell k
+{ return (uint32_t)load_row_quad<typename LMaskWord<N>::type, uint8_t>(plane + (size_t)j * g.Pm, i0); }
+
+template <int N> __device__ __forceinline__ unsigned lv_sel_fluid(uint32_t m)
+{
+    unsigned s = 0u;
+#pragma unroll
+    for (int c = 0; c < N; ++c) s |= ((m >> (8 * c)) & 0xffu) == 0u ? (1u << c) : 0u;
+    return s;
+}
+template <int N> __device__ __forceinline__ unsigned lv_sel_target(uint32_t code)
+{
+    unsigned s = 0u;
+#pragma unroll
+    for (int c = 0; c < N; ++c) s |= ((code >> (8 * c)) & 1u) << c;
+    return s;
+}
+template <typename T, int N>
+__device__ __forceinline__ void lv_store_sel(T *dst, const LV<T, N> &v, unsigned sel)
+{
+    if (sel == (1u << N) - 1u) {
+        typename LVec<T, N>::type q;
+        if constexpr (N == 4) { q.x = v.a[0]; q.y = v.a[1]; q.z = v.a[2]; q.w = v.a[3]; }
+        else { q.x = v.a[0]; q.y = v.a[1]; }
+        *reinterpret_cast<typename LVec<T, N>::type *>(dst) = q;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+        if (sel & (1u << c)) dst[c] = v.a[c];
+}
+
+// overlapped-wave column mapping for lanes of N cells: 4 / N halo lanes on each side (4 cells: the reach of four radius-1 stages)
+template <int N> struct LaneMapN { int i0; bool owner, at_lo, at_hi; };
+template <int N>
+__device__ __forceinline__ LaneMapN<N> lane_map_n(const Grid &g, int wave)
+{
+    constexpr int HL = 4 / N, OW = 64 - 2 * HL;
+    const int lane = threadIdx.x & 63, nu = g.X / N;
+    int q = wave * OW - HL + lane;
+    LaneMapN<N> m;
+    m.owner = lane >= HL && lane < 64 - HL && q >= 0 && q < nu;
+    q = q < 0 ? 0 : (q > nu - 1 ? nu - 1 : q);
+    m.i0 = q * N;
+    m.at_lo = q == 0;
+    m.at_hi = q == nu - 1;
+    return m;
+}
+template <typename T, int N> __device__ __forceinline__ T lv_left(const LaneMapN<N> &m, const LV<T, N> &v)
+{ const T l = lane_prev(v.a[N - 1]); return m.at_lo ? v.a[0] : l; }
+template <typename T, int N> __device__ __forceinline__ T lv_right(const LaneMapN<N> &m, const LV<T, N> &v)
+{ const T r = lane_next(v.a[0]); return m.at_hi ? v.a[N - 1] : r; }
+
+template <int N>
+__device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y)
+{
+    constexpr int OW = 64 - 2 * (4 / N);
+    int bx, by, cg;
+    if (!band_coords<1>(nbx, nby_packed, bx, by, cg)) return false;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+    if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
+    else { wave_x = bx * nw + w; tile_y = by; }
+    return wave_x * OW < g.X / N && jb + tile_y * rt < je;
+}
+
+// one row of the buffer as K7 would leave it, from raw rows m / c / n = rows j-1 / j / j+1 and the recipe bytes of row j (whole wave)
+template <typename T, int N>
+__device__ __forceinline__ LV<T, N> lv_bc_row(const LaneMapN<N> &lm, const LV<T, N> &m, const LV<T, N> &c, const LV<T, N> &n, uint32_t code)
+{
+    if (!__any(lv_sel_target<N>(code) != 0u)) return c;            // wave-uniform: no target in this row of the wave
+    const T cl = lv_left<T, N>(lm, c), cr = lv_right<T, N>(lm, c);
+    LV<T, N> o;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const T sL = q == 0 ? cl : c.a[q == 0 ? 0 : q - 1], sR = q == N - 1 ? cr : c.a[q == N - 1 ? q : q + 1];
+        o.a[q] = lazy_value((code >> (8 * q)) & 0xffu, c.a[q], sL, sR, m.a[q], n.a[q]);
+    }
+    return o;
+}
+
+// one colour of one row from finished rows: cells c with ((c + PAR) & 1) == COLOR and a fluid bit are relaxed
+//   out[c] = (1-w) ctr[c] + w predict_p(neighbours of ctr; rows below / above: m / p)
+template <int PAR, int COLOR, typename T, int N>
+__device__ __forceinline__ void rbp_relax(const Konst<T> &k, const LaneMapN<N> &lm, unsigned fluid, const LV<T, N> &m, const LV<T, N> &ctr, const LV<T, N> &p,
+                                          const LV<T, N> &s2, const LV<T, N> &s3, LV<T, N> &out)
+{
+    const T pl = lv_left<T, N>(lm, ctr), pr = lv_right<T, N>(lm, ctr);
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        if (((c + PAR) & 1) != COLOR) continue;
+        const T pE = c == N - 1 ? pr : ctr.a[c == N - 1 ? c : c + 1], pW = c == 0 ? pl : ctr.a[c == 0 ? 0 : c - 1];
+        const T pred = predict_from(pE, pW, p.a[c], m.a[c], s2.a[c], s3.a[c]);
+        const T val = k.om1 * ctr.a[c] + k.om * pred;
+        out.a[c] = (fluid & (1u << c)) ? val : out.a[c];
+    }
+}
+
+// PAR0: parity of (g.ybase + j0 - 4), the first window row - a launch constant because RT is even and all tiles start at jb + k RT.
+// BND: the tile has non-fluid cells within reach (K7 views are evaluated); FULL: store every cell (carry pass after an upload).
+template <int N, int RT, int PAR0, int DM, bool BND, bool FULL, typename T>
+__device__ __forceinline__ bool rbsor_pair_tile(const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm, int i0, int j0, int je, const unsigned (&fl)[RT + 8],
+                                                const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
+{
+    constexpr int W = RT + 8;                  // window rows w = 0 .. W-1  <->  local rows j0-4 .. j0+RT+3 (clamped into the domain)
+    using R = LV<T, N>;
+    constexpr unsigned ALL = (1u << N) - 1u;
+    // fluid selector of window row w: in a tile without a single non-fluid cell within reach it is a constant (no registers, no selects)
+#define FS_FL(w) (BND ? fl[w] : ALL)
+    DivGuard G;
+    R PA[W], VX[W], VY[W], PB[W];              // PB[w] is loaded for w = 1 .. W-2
+    uint32_t code[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int j = clampy(g, j0 - 4 + w);
+        PA[w] = lv_field<1, T, N>(A, g, 0, i0, j);
+        VX[w] = lv_field<2, T, N>(v, g, 0, i0, j);
+        VY[w] = lv_field<2, T, N>(v, g, 1, i0, j);
+        if (w >= 1 && w <= W - 2) PB[w] = lv_field<1, T, N>(B, g, 0, i0, j);
+        code[w] = BND ? lv_bytes<N>(bcmap, g, i0, j) : 0u;
+    }
+    // Poisson source of rows 1 .. W-2, once per cell for both iterations
+    R S2[W], S3[W];
+#pragma unroll
+    for (int w = 1; w <= W - 2; ++w) {
+        const T xl = lv_left<T, N>(lm, VX[w]), xr = lv_right<T, N>(lm, VX[w]);
+        const T yl = lv_left<T, N>(lm, VY[w]), yr = lv_right<T, N>(lm, VY[w]);
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const T xE = c == N - 1 ? xr : VX[w].a[c == N - 1 ? c : c + 1], xW = c == 0 ? xl : VX[w].a[c == 0 ? 0 : c - 1];
+            const T yE = c == N - 1 ? yr : VY[w].a[c == N - 1 ? c : c + 1], yW = c == 0 ? yl : VY[w].a[c == 0 ? 0 : c - 1];
+            source_from<DM>(k, xE, xW, yE, yW, VX[w + 1].a[c], VX[w - 1].a[c], VY[w + 1].a[c], VY[w - 1].a[c], S2[w].a[c], S3[w].a[c], G);
+        }
+    }
+    // view(A): rows 0 .. W-1 (a row missing at the window's edge is stood in for by the row itself - see the header)
+    R VA[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) VA[w] = BND ? lv_bc_row<T, N>(lm, PA[w == 0 ? 0 : w - 1], PA[w], PA[w == W - 1 ? w : w + 1], code[w]) : PA[w];
+    // stage 1: odd pass of iteration 1 on rows 1 .. W-2:  B[odd] <- view(A)
+#pragma unroll
+    for (int w = 1; w <= W - 2; ++w) {
+        if ((PAR0 + w) & 1) rbp_relax<1, 1>(k, lm, FS_FL(w), VA[w - 1], VA[w], VA[w + 1], S2[w], S3[w], PB[w]);
+        else                rbp_relax<0, 1>(k, lm, FS_FL(w), VA[w - 1], VA[w], VA[w + 1], S2[w], S3[w], PB[w]);
+    }
+    // stage 2: even pass of iteration 1 on rows 2 .. W-3, in place on B (all rows from the stage-1 state: results go to P2)
+    R P2[W];
+#pragma unroll
+    for (int w = 2; w <= W - 3; ++w) {
+        P2[w] = PB[w];
+        if ((PAR0 + w) & 1) rbp_relax<1, 0>(k, lm, FS_FL(w), PB[w - 1], PB[w], PB[w + 1], S2[w], S3[w], P2[w]);
+        else                rbp_relax<0, 0>(k, lm, FS_FL(w), PB[w - 1], PB[w], PB[w + 1], S2[w], S3[w], P2[w]);
+    }
+    // view(B') on rows 2 .. W-3
+    R VB[W];
+#pragma unroll
+    for (int w = 2; w <= W - 3; ++w) VB[w] = BND ? lv_bc_row<T, N>(lm, P2[w == 2 ? 2 : w - 1], P2[w], P2[w == W - 3 ? w : w + 1], code[w]) : P2[w];
+    // stage 3: odd pass of iteration 2 on rows 3 .. W-4:  A[odd] <- view(B'),  the other cells of the row stay view(A)
+    R P3[W];
+#pragma unroll
+    for (int w = 3; w <= W - 4; ++w) {
+        P3[w] = VA[w];
+        if ((PAR0 + w) & 1) rbp_relax<1, 1>(k, lm, FS_FL(w), VB[w - 1], VB[w], VB[w + 1], S2[w], S3[w], P3[w]);
+        else                rbp_relax<0, 1>(k, lm, FS_FL(w), VB[w - 1], VB[w], VB[w + 1], S2[w], S3[w], P3[w]);
+    }
+    // stage 4: even pass of iteration 2 on the tile's own rows 4 .. W-5
+    R P4[W];
+#pragma unroll
+    for (int w = 4; w <= W - 5; ++w) {
+        P4[w] = P3[w];
+        if ((PAR0 + w) & 1) rbp_relax<1, 0>(k, lm, FS_FL(w), P3[w - 1], P3[w], P3[w + 1], S2[w], S3[w], P4[w]);
+        else                rbp_relax<0, 0>(k, lm, FS_FL(w), P3[w - 1], P3[w], P3[w + 1], S2[w], S3[w], P4[w]);
+    }
+    if (DM & DM_RCP) {
+#pragma unroll
+        for (int w = 4; w <= W - 5; ++w)
+#pragma unroll
+            for (int c = 0; c < N; ++c) { G.out(P4[w].a[c]); G.out(VB[w].a[c]); }
+        if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo with IEEE division
+    }
+#pragma unroll
+    for (int w = 4; w <= W - 5; ++w) {
+        const int j = j0 - 4 + w;
+        if (j >= je) break;
+        const unsigned sel = FULL ? ALL : (FS_FL(w) | (BND ? lv_sel_target<N>(code[w]) : 0u));
+        if (lm.owner && sel) {
+            lv_store_sel<T, N>(C + idx<1, T>(g, 0, i0, j), P4[w], sel);
+            lv_store_sel<T, N>(D + idx<1, T>(g, 0, i0, j), VB[w], sel);
+        }
+    }
+    return false;
+#undef FS_FL
+}
+
+// PATH: 0 - only the tiles without a non-fluid cell within reach, 1 - only the others, 2 - both.  Two launches (0, then 1) give each
+// path its own register budget: the plain path fits 4 waves per SIMD, the boundary path (recipe bytes, views) does not.
+template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
+__device__ __forceinline__ bool rbsor_pair_wave(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+                                                const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
+{
+    constexpr int W = RT + 8;
+    int wx, ty;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty)) return false;
+    const LaneMapN<N> lm = lane_map_n<N>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    unsigned fl[W];
+    bool own_fluid = false, all_fluid = true;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        fl[w] = lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 4 + w)));
+        all_fluid = all_fluid && fl[w] == (1u << N) - 1u;
+        if (w >= 4 && w <= W - 5 && j0 - 4 + w < je) own_fluid = own_fluid || (lm.owner && fl[w] != 0u);
+    }
+    if (!FULL && !__any(own_fluid)) {
+        // no fluid cell in the rows this tile stores: only K7 targets could change, and a tile without any has nothing to do
+        bool tgt = false;
+#pragma unroll
+        for (int w = 4; w <= W - 5; ++w)
+            if (j0 - 4 + w < je) tgt = tgt || (lm.owner && lv_sel_target<N>(lv_bytes<N>(bcmap, g, i0, clampy(g, j0 - 4 + w))) != 0u);
+        if (!__any(tgt)) return false;
+    }
+    if (__all(all_fluid)) {
+        if constexpr (PATH == 1) return false;
+        else return rbsor_pair_tile<N, RT, PAR0, DM, false, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
+    }
+    if constexpr (PATH == 0) return false;
+    else return rbsor_pair_tile<N, RT, PAR0, DM, true, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
+}
+
+template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
+__global__ __launch_bounds__(256) void k_rbsor_pair(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+                                                    const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
+{
+    static_assert(RT % 2 == 0, "the row parity of a tile is a launch constant only for even tile heights");
+    if (DM & DM_RCP) {
+        if (rbsor_pair_wave<N, RT, PAR0, DM, PATH, FULL, T>(g, k, nbx, nby, jb, je, bcmap, C, D, A, B, v))
+            rbsor_pair_wave<N, RT, PAR0, DM_IEEE, PATH, FULL, T>(g, k, nbx, nby, jb, je, opaque(bcmap), opaque(C), opaque(D), opaque(A), opaque(B), opaque(v));
+    } else rbsor_pair_wave<N, RT, PAR0, DM, PATH, FULL, T>(g, k, nbx, nby, jb, je, bcmap, C, D, A, B, v);
+}
+
+}  // namespace fs

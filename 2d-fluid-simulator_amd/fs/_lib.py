@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libfs_hip.so")     # FS_LIB: A/B builds (tools/)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -47,8 +47,8 @@ _PROTOS = {
     "fs_cip_nonadv_grad": [_c_vp, _c_dbl] + [_c_vp] * 6 + _ROWS,
     "fs_cip_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
     "fs_cip_nonadv_fused": [_c_vp, _c_dbl, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
-    "fs_cip_grad_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
-    "fs_cip_grad_advect_dye": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 8 + [_c_int] + _ROWS,
+    "fs_cip_grad_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + [_c_int] + _ROWS,
+    "fs_cip_grad_advect_dye": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 8 + [_c_int, _c_int] + _ROWS,
     "fs_vort_calc": [_c_vp, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_vort_add": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_vort_confine": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
@@ -61,6 +61,8 @@ _PROTOS = {
     "fs_jacobi_sweep_lazy": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_jacobi_pair_lazy": [_c_vp, _c_vp, _c_vp, _c_vp, _c_int] + _ROWS,
     "fs_lazy_flags": [_c_vp, _c_vp, _c_int, _P(_c_int), _P(_c_int), _P(_c_int)],
+    "fs_rbsor_pair_ok": [_c_vp, _P(_c_int)],
+    "fs_rbsor_pair": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int] + _ROWS,
     "fs_rbsor_halfsweep_src": [_c_vp, _c_dbl, _c_int, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_poisson_residual": [_c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _P(_c_dbl), _P(_c_dbl)],
     "fs_limit_field": [_c_vp, _c_dbl, _c_vp] + _ROWS,

@@ -48,8 +48,9 @@ class FluidSimulator:
         self._dev = solver._dev
         self.rgb_buf = self._dev.alloc(3)      # image buffer (fs/fluid_simulator.py:16), device resident
         self._wall_color = _WALL_COLOR
-        self._graph = None
-        self._tape = None
+        self._graph = None         # (signature, graph id, period) of the most recent capture
+        self._graphs = {}          # signature -> (graph id, period)
+        self._tapes = {}           # (signature, ghost-row bookkeeping state) -> tape
         self._steps = 0
 
     def step(self):
@@ -68,52 +69,71 @@ class FluidSimulator:
             db = getattr(s, name, None)
             if db is not None:
                 for f in (db.current, db.next):
-                    sig.append((id(f), f.user_data))
-        spare = getattr(s, "_v_spare", None)
-        sig.append(id(spare) if spare is not None else 0)
+                    # serial: a Field's identity for life (id() is recycled); static_id: which carry decisions the capture baked in
+                    sig.append((f.serial, f.user_data, f.static_id))
+        for spare in (getattr(s, "_v_spare", None), getattr(s, "_dye_spare", None)) + tuple(getattr(s.pressure_updater, "_spare", None) or ()):
+            sig.append((spare.serial, spare.static_id) if spare is not None else 0)
         return tuple(sig)
+
+    _MAX_CACHED = 8      # captured graphs / tapes kept per simulator (one per phase of the buffer rotation; the oldest is freed first)
 
     def run(self, nsteps, graph=True):
         """`nsteps` x step().  With graph=True (single GPU) the launches of a whole number of steps are captured once into a
         hipGraph and replayed, so no Python runs between kernels - for small grids (res 200: 8 kernels of ~3 us per step) that
-        is the difference between launch-bound and GPU-bound.  Results are identical to calling step() nsteps times."""
+        is the difference between launch-bound and GPU-bound.  Results are identical to calling step() nsteps times.
+
+        A graph is valid for one phase of the solver's buffer rotation (self._signature()).  A chunk that is not a multiple of the
+        period ends in another phase; graphs are therefore cached per phase (at most `period` of them exist) instead of being
+        re-captured - and leaked - chunk after chunk, and a capture is only started when the chunk is long enough to pay for it."""
         dev = self._dev
         if graph and dev.nranks > 1 and nsteps >= 24:
             # slab run: a hipGraph cannot carry the RCCL exchange; the period of the step (launches + exchanges) is logged
             # once and replayed from C++ instead (runtime.py tape_period / replay_tape)
-            if self._tape is None or self._tape[0] != (self._signature(), dev._state_signature()):
+            key = (self._signature(), dev._state_signature())
+            tape = self._tapes.get(key)
+            if tape is None:
                 before = self._steps
                 tape = dev.tape_period(self._counted_step, nsteps=2)
                 nsteps -= self._steps - before
-                self._tape = ((self._signature(), dev._state_signature()), tape) if tape is not None else None
-            if self._tape is not None:
-                per = self._tape[1]["nsteps"]
-                dev.replay_tape(self._tape[1], nsteps // per)
+                if tape is not None:
+                    self._remember(self._tapes, (self._signature(), dev._state_signature()), tape, lambda t: dev.free_tape(t))
+            if tape is not None:
+                per = tape["nsteps"]
+                dev.replay_tape(tape, nsteps // per)
                 self._steps += nsteps - nsteps % per
                 nsteps %= per
-        if not graph or dev.nranks > 1 or not hasattr(dev, "capture") or nsteps < 4:
+        if not graph or dev.nranks > 1 or not hasattr(dev, "capture"):
             for _ in range(nsteps):
                 self._counted_step()
             return
-        if self._graph is None or self._graph[0] != self._signature():
-            done = self.capture_period(budget=nsteps)
-            nsteps -= done
-        if self._graph is not None:
-            _, gid, period = self._graph
+        entry = self._graphs.get(self._signature())
+        if entry is None and nsteps >= 16:
+            nsteps -= self.capture_period(budget=nsteps)
+            entry = self._graphs.get(self._signature())
+        if entry is not None:
+            gid, period = entry
+            self._graph = (self._signature(), gid, period)
             dev.replay(gid, nsteps // period)
             nsteps %= period
         for _ in range(nsteps):
             self.step()
+
+    def _remember(self, cache, key, value, free):
+        if key in cache:
+            free(cache.pop(key))
+        while len(cache) >= self._MAX_CACHED:
+            free(cache.pop(next(iter(cache))))
+        cache[key] = value
 
     def capture_period(self, budget=24):
         """Capture the launches of one PERIOD of the step into a hipGraph -> number of steps this took (they are executed).
 
         A replayed graph re-issues kernels on fixed device buffers, so it must cover a whole period of the solver's buffer
         rotation: 2 steps when every DoubleBuffer just swaps (two swaps restore it), 6 steps for the CIP solver with its fused
-        gradient + advection pass and vorticity confinement (the velocity rotates through three buffers, the gradients through
-        two).  Periods are tried in increasing order; a capture whose steps do not bring every buffer back to its place is still
-        executed once (the host-side swaps have happened) and discarded.  Leaves self._graph = (signature, graph id, period) or
-        None if nothing within the budget repeats."""
+        gradient + advection pass and vorticity confinement (the velocity rotates through three buffers, the gradients and - with the
+        two-iteration red-black pass - the pressure pairs through two).  Periods are tried in increasing order; a capture whose steps
+        do not bring every buffer back to its place is still executed once (the host-side swaps have happened) and freed.  Leaves
+        self._graph = (signature, graph id, period) - also cached for run() - or None if nothing within the budget repeats."""
         dev, done = self._dev, 0
         self._graph = None
         for period in (1, 2, 3, 4, 6):
@@ -125,6 +145,7 @@ class FluidSimulator:
             dev.replay(gid, 1)                                                    # now the captured steps run once
             done += period
             if back:
+                self._remember(self._graphs, sig, (gid, period), lambda e: dev.free_graph(e[0]))
                 self._graph = (sig, gid, period)
                 break
             dev.free_graph(gid)

@@ -118,7 +118,7 @@ class RedBlackSorPressureUpdater(PressureUpdater):
     into p.next, then the even cells are relaxed IN PLACE on p.next (blending with that buffer's stale
     value), then the buffers swap.  Not a textbook single-buffer SOR - reproduced literally."""
 
-    def __init__(self, boundary_condition, dt, dx, relaxation_factor, n_iter, precompute_source=False, fused=True):
+    def __init__(self, boundary_condition, dt, dx, relaxation_factor, n_iter, precompute_source=False, fused=True, pair=None):
         super().__init__(boundary_condition, dt, dx)
         self._n_iter = n_iter
         self._relaxation_factor = relaxation_factor
@@ -127,11 +127,30 @@ class RedBlackSorPressureUpdater(PressureUpdater):
                        and os.environ.get("FS_MARCH", "1") != "0")
         self._precompute = bool(precompute_source)
         self._src = self._dev.alloc(2) if self._precompute else None
+        # pair: TWO iterations and the two boundary passes between them in one pass over HBM (csrc/fs_rbpair.h; same bits, 25 instead of
+        # 2 x 21 B per fluid cell and two launches less).  Out of place: the pressure rotates through a second pair of buffers.  Needs a
+        # mask that admits it (Device.rb_pair_ok: no one-cell-thin walls between fluid regions), f32, and on slabs a halo of 4 rows.
+        if pair is None:
+            pair = os.environ.get("FS_RBSOR_PAIR", "1") == "1"
+        self._pair = (bool(pair) and self._fused and n_iter >= 2 and getattr(self._dev, "rb_pair_ok", False)
+                      and (self._dev.nranks == 1 or self._dev.halo >= 4))
+        self._spare = (self._dev.alloc(1), self._dev.alloc(1)) if self._pair else None
 
     def update(self, p, v_current):
         if self._precompute:
             self._dev.poisson_source(self.dt, self.dx, self._src, v_current)
-        for _ in range(self._n_iter):
+        n = self._n_iter
+        while self._pair and n >= 2:
+            c_out, n_out = self._spare
+            # the pass stores fluid cells and boundary targets only: every other cell must already be equal in the buffer it reads and
+            # the one it writes (Field.static_id).  After an upload / fill into one of them the pass carries every cell once.
+            full = c_out.static_id != p.current.static_id or n_out.static_id != p.next.static_id
+            self._dev.rbsor_pair(self.dt, self.dx, self._relaxation_factor, c_out, n_out, p.current, p.next, v_current, full=full)
+            c_out.static_id, n_out.static_id = p.current.static_id, p.next.static_id
+            self._spare = (p.current, p.next)
+            p.current, p.next = c_out, n_out
+            n -= 2
+        for _ in range(n):
             self._bc.set_pressure_boundary_condition(p.current)
             self._update(p.next, p.current, v_current)
             p.swap()

@@ -14,6 +14,7 @@ With nranks == 1 all of this is a no-op and the launches are exactly the referen
 numpy/gloo stand-in to check the slab logic without a GPU); `Device` binds it to libfs_hip.so.
 """
 import ctypes
+import itertools
 import os
 import weakref
 
@@ -32,6 +33,7 @@ _config = {
     "device_cls": None,   # test hook: a DeviceBase subclass
 }
 _devices = []
+_serials = itertools.count(1)
 
 
 def init(gpu=0, dtype="f32", rank=0, nranks=1, halo=None, bcast=None, allgather=None, device_cls=None):
@@ -86,6 +88,11 @@ class Field:
         self._h = dev._p_alloc(nchan)
         self.valid = dev.halo          # ghost rows valid to this depth (zero-filled == consistent everywhere)
         self.user_data = False         # set once the user uploads / fills data (disables fusions that rely on invariants)
+        self.serial = next(_serials)   # unique for life (id() is recycled after garbage collection): identity in signatures and op keys
+        self.static_id = 0             # content class of the cells NO kernel ever writes (deep wall cells): 0 = still the zeros of the
+                                       # allocation, a fresh token after every upload / fill.  Passes that store only the cells that can
+                                       # change (fs_rbsor_pair, the fused gradient + advection pass) need source and target buffer in
+                                       # the same class, and run one carrying pass when they are not (which then copies the class).
 
     @property
     def shape(self):
@@ -97,6 +104,7 @@ class Field:
     def fill(self, value):
         self.dev._p_fill(self._h, float(value))
         self.valid = self.dev.halo
+        self.static_id = next(_serials)
         self.user_data = self.user_data or float(value) != 0.0
 
     def from_numpy(self, arr):
@@ -109,6 +117,7 @@ class Field:
         dev._p_upload(self._h, self.nchan, win, dev.g_lo - (dev.y0 - dev.halo), dev.g_hi - dev.g_lo)
         self.valid = dev.halo
         self.user_data = True
+        self.static_id = next(_serials)
 
     def to_numpy(self, local=False):
         """Global (X, Y[, C]) array (gathered over slabs) or, with local=True, this slab's owned rows."""
@@ -165,6 +174,7 @@ class DeviceBase:
         self.g_hi = min(self.ny, self.y0 + self.nyl + self.halo)
         self.bc_radius_v, self.bc_radius_p = 2, 1
         self.lazy_bc_ok = False
+        self.rb_pair_ok = False       # the mask admits the two-iteration red-black pass (rbsor_pair)
         self.n_exchanges = 0          # grouped send/recv launches issued
         self.n_exchanged_fields = 0   # fields refreshed by them
         self.n_exchanged_bytes = 0    # payload sent to ONE neighbour by them (an interior rank sends twice that)
@@ -231,6 +241,9 @@ class DeviceBase:
         pass
 
     def _p_lazy_bc_ok(self):        # backends without the lazy pressure boundary condition
+        return False
+
+    def _p_rb_pair_ok(self):        # backends without the two-iteration red-black pass
         return False
 
     def _p_max_over_ranks(self, values):
@@ -316,7 +329,7 @@ class DeviceBase:
         self._p_kernel(name, *args, lo, hi)
 
     def _state_signature(self):
-        return tuple(sorted((id(f), f.valid, f.user_data) for f in self._fields))
+        return tuple(sorted((f.serial, f.valid, f.user_data, f.static_id) for f in self._fields))
 
     @staticmethod
     def _op_key(op):
@@ -327,7 +340,7 @@ class DeviceBase:
             return ("begin", tuple((id(h), c, v) for h, c, v in op[1]), op[2])
         return (op[0],)
 
-    def tape_period(self, step_fn, nsteps=2, tries=10, hoist=True, max_blocks=3):
+    def tape_period(self, step_fn, nsteps=2, tries=14, hoist=True, max_blocks=6):
         """Log blocks of `nsteps` x step_fn() (executed normally) until the last P blocks (P = 1 .. max_blocks) repeat the P blocks
         before them - the same primitive operations from the same bookkeeping state - then compile those P blocks into a tape of
         P * nsteps steps (see replay_tape).  Returns None if nothing repeated within `tries` blocks (the caller keeps stepping
@@ -413,6 +426,9 @@ class DeviceBase:
     def _p_tape_build(self, ops):       # backends without a native tape: replay issues the operations one by one
         return None
 
+    def free_tape(self, tape):
+        pass
+
     def _p_tape_replay(self, tape, times):
         for _ in range(times):
             for op in tape["ops"]:
@@ -451,8 +467,9 @@ class DeviceBase:
         # every slab analysed its own rows of the mask: the reach of chained thin walls differs from slab to slab, but the
         # ranks must run the SAME validity bookkeeping (same exchanges, same message sizes) -> one global pair of radii
         # (and one answer to "may the pressure boundary condition be evaluated lazily?")
-        rv, rp, no_lazy = self._p_max_over_ranks([rv, rp, 0 if self._p_lazy_bc_ok() else 1])
+        rv, rp, no_lazy, no_pair = self._p_max_over_ranks([rv, rp, 0 if self._p_lazy_bc_ok() else 1, 0 if self._p_rb_pair_ok() else 1])
         self.lazy_bc_ok = not no_lazy
+        self.rb_pair_ok = not no_pair
         self.bc_radius_v, self.bc_radius_p = max(2, int(rv)), max(1, int(rp))
         if self.nranks > 1 and max(self.bc_radius_v, self.bc_radius_p) > self.halo:
             raise RuntimeError(
@@ -499,14 +516,15 @@ class DeviceBase:
         self._run("cip_nonadv_fused", (dt, dx, re, fn._h, gx_out._h, gy_out._h, fc._h, pc._h, gxc._h, gyc._h),
                   reads=[(fc, 2), (pc, 2), (fn, 1), (gxc, 0), (gyc, 0)], writes=[fn, gx_out, gy_out])
 
-    def cip_grad_advect(self, dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc):
-        """K3 + K4 of the velocity field in one pass (build-side fusion): see csrc/fs_march.h k_cip_grad_advect."""
-        self._run("cip_grad_advect", (dt, dx, v_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h),
+    def cip_grad_advect(self, dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, full=False):
+        """K3 + K4 of the velocity field in one pass (build-side fusion): see csrc/fs_march.h k_cip_grad_advect.  v_out receives every
+        cell that can differ from fc (full: every cell - the carrying pass after an upload, include/fs_hip.h)."""
+        self._run("cip_grad_advect", (dt, dx, v_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, 1 if full else 0),
                   reads=[(fn, 2), (fc, 2), (gxc, 1), (gyc, 1)], writes=[gx_out, gy_out], full_writes=[v_out])
 
-    def cip_grad_advect_dye(self, dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=False):
+    def cip_grad_advect_dye(self, dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=False, full=False):
         """K3 + K4 of the dye in one pass (csrc/fs_march.h k_cip_grad_advect_dye); clamp01 folds clamp_field(dye, 0, 1) into the store."""
-        self._run("cip_grad_advect_dye", (dt, dx, d_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, v._h, 1 if clamp01 else 0),
+        self._run("cip_grad_advect_dye", (dt, dx, d_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, v._h, 1 if clamp01 else 0, 1 if full else 0),
                   reads=[(fn, 2), (fc, 2), (gxc, 1), (gyc, 1), (v, 1)], writes=[gx_out, gy_out], full_writes=[d_out])
 
     def vort_calc(self, dx, vort, vort_abs, vc):                # fs/vorticity_confinement.py:27-32
@@ -532,6 +550,13 @@ class DeviceBase:
     def rbsor_iteration(self, dt, dx, omega, pn, pc, vc):
         """Odd pass (pc -> pn) + even pass (in place on pn) fused into one kernel; same bits as the two half-sweeps."""
         self._run("rbsor_iteration", (dt, dx, omega, pn._h, pc._h, vc._h), reads=[(pc, 2), (pn, 1), (vc, 2)], writes=[pn])
+
+    def rbsor_pair(self, dt, dx, omega, pc_out, pn_out, pc, pn, vc, full=False):
+        """Two red-black iterations and the pressure boundary passes between them in one pass (csrc/fs_rbpair.h): (pc_out, pn_out) <-
+        what fs/pressure_updater.py:86-96 with n_iter = 2 leaves in (p.current, p.next), starting from (pc, pn).  Every cell that can
+        differ between the buffers is stored (fluid cells and boundary targets; all cells with `full`), hence full_writes."""
+        self._run("rbsor_pair", (dt, dx, omega, pc_out._h, pn_out._h, pc._h, pn._h, vc._h, 1 if full else 0),
+                  reads=[(pc, 4), (pn, 3), (vc, 4)], full_writes=[pc_out, pn_out])
 
     def poisson_source(self, dt, dx, src, vc):                  # build-side: source of predict_p, once per step
         self._run("poisson_source", (dt, dx, src._h, vc._h), reads=[(vc, 1)], writes=[src])
@@ -672,6 +697,11 @@ class Device(DeviceBase):
         _lib.call("fs_lazy_bc_ok", self._ctx, ctypes.byref(ok))
         return bool(ok.value)
 
+    def _p_rb_pair_ok(self):
+        ok = ctypes.c_int()
+        _lib.call("fs_rbsor_pair_ok", self._ctx, ctypes.byref(ok))
+        return bool(ok.value)
+
     def _p_exchange(self, h, nchan, depth):
         _lib.call("fs_halo_exchange", self._ctx, h, depth)
 
@@ -764,6 +794,11 @@ class Device(DeviceBase):
         if tape["id"] is None:
             return DeviceBase._p_tape_replay(self, tape, times)
         _lib.call("fs_tape_replay", self._ctx, tape["id"], times)
+
+    def free_tape(self, tape):
+        if tape.get("id") is not None and self._ctx is not None:
+            _lib.call("fs_tape_free", self._ctx, tape["id"])
+            tape["id"] = None
 
     # -- per-kernel HIP-event timing ---------------------------------------------------------------------
     def profile(self, on=True):

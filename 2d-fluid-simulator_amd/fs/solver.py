@@ -165,7 +165,11 @@ class CipMacSolver(Solver):
         if fused34:
             # one pass instead of K3 + swap + K4 + swap.  End state as in the reference: v.current = advected velocity with the
             # pre-K2 values on non-fluid cells, v.next = post-K2 velocity, vx/vy.current = new gradients (their .next: dead data)
-            self._dev.cip_grad_advect(self.dt, self.dx, self._v_spare, vx.next, vy.next, v.next, v.current, vx.current, vy.current)
+            # (the pass carries only the cells some kernel writes; after an upload into v.current or the spare buffer - Field.static_id -
+            #  the two may differ anywhere: one pass then carries every cell)
+            full = self._v_spare.static_id != v.current.static_id
+            self._dev.cip_grad_advect(self.dt, self.dx, self._v_spare, vx.next, vy.next, v.next, v.current, vx.current, vy.current, full=full)
+            self._v_spare.static_id = v.current.static_id
             v.current, self._v_spare = self._v_spare, v.current
             vx.swap()
             vy.swap()
@@ -226,8 +230,10 @@ class DyeCipMacSolver(CipMacSolver):
         if self._fused_dye and not any(f.user_data for f in (dyex.current, dyex.next, dyey.current, dyey.next)):
             # one pass instead of K3 + swap + K4 + swap.  End state as in the reference: dye.current = advected dye with the previous
             # values on non-fluid cells, dye.next = the dye after its non-advection phase, dyex / dyey.current = new gradients (.next: dead)
+            full = self._dye_spare.static_id != dye.current.static_id
             self._dev.cip_grad_advect_dye(self.dt, self.dx, self._dye_spare, dyex.next, dyey.next, dye.next, dye.current,
-                                          dyex.current, dyey.current, v.current, clamp01=clamp)
+                                          dyex.current, dyey.current, v.current, clamp01=clamp, full=full)
+            self._dye_spare.static_id = dye.current.static_id
             dye.current, self._dye_spare = self._dye_spare, dye.current
             dyex.swap()
             dyey.swap()

@@ -75,6 +75,8 @@ def algorithmic_bytes(mask, esize=4):
         "vort_calc": n + fl * (2 * e + 2 * e),                           # v -> w, |w|
         "vort_add": n + fl * (2 * e + 2 * e + 2 * e),                    # w,|w|,v -> v'
         "rbsor_iteration": n + fl * (e + e + 2 * e + e),                 # fused odd+even: p.cur, p.next, v -> p.next
+        # two iterations + both boundary passes in one pass (csrc/fs_rbpair.h): mask; p.cur, p.next, v read and both results written on fluid cells
+        "rbsor_pair": n + fl * (e + e + 2 * e) + fl * (e + e),
         "vort_confine": n + fl * (2 * e + 2 * e),                        # fused K5+K6: v -> v'
         "rbsor_odd": n // 2 + fl * e + (fl // 2) * (2 * e) + (fl // 2) * e,   # p (both colours), v of the other colour, write half
         "rbsor_even": n // 2 + fl * e + (fl // 2) * (2 * e) + (fl // 2) * e,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 3
+#define FS_ABI_VERSION 4
 
 typedef struct fs_ctx fs_ctx;
 typedef struct fs_field fs_field;
@@ -119,18 +119,20 @@ int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *
                         int row_begin, int row_end);
 /* _non_advection_phase_grad + _advection_phase of the VELOCITY field fused into one pass (build-side optimisation, same
  * bits for everything observable): the intermediate gradients never go through HBM.  fn = velocity after
- * _non_advection_phase, fc = velocity before it, gxc/gyc = gradients before; outputs: v_out (EVERY cell: advected value on
- * fluid cells, fc carried elsewhere - what the reference's in-place update of fc's buffer leaves), gx_out / gy_out (not-wall
- * cells).  v_out must be a third buffer distinct from fn and fc; the caller rotates buffers (see fs/solver.py).          */
+ * _non_advection_phase, fc = velocity before it, gxc/gyc = gradients before; outputs: v_out (advected value on fluid cells, fc
+ * carried elsewhere - what the reference's in-place update of fc's buffer leaves), gx_out / gy_out (not-wall cells).  v_out must
+ * be a third buffer distinct from fn and fc; the caller rotates buffers (see fs/solver.py).  Tiles without a fluid cell carry only
+ * the cells some kernel writes (not-wall cells and the targets of the velocity boundary kernel): every other cell is equal in fc and
+ * v_out unless somebody uploaded into one of them - then ONE call with full != 0 carries every cell.                           */
 int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
                        const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc,
-                       int row_begin, int row_end);
+                       int full, int row_begin, int row_end);
 /* The same for the dye (C = 3, advected by the velocity field v of the finished flow step; fs/solver.py:378-401 _update_dye without its
  * first kernel): K3 (_non_advection_phase_grad, :242-261) + K4 (_cip_advect, :267-332), d_out = a third dye buffer the caller rotates.
- * clamp01 != 0 folds clamp_field(dye, 0, 1) (:46-49) into the store of the advected cells.  f32 only.                                */
+ * clamp01 != 0 folds clamp_field(dye, 0, 1) (:46-49) into the store of the advected cells; full as above.  f32 only.                   */
 int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, fs_field *gx_out, fs_field *gy_out,
                            const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v,
-                           int clamp01, int row_begin, int row_end);
+                           int clamp01, int full, int row_begin, int row_end);
 
 /* ---- vorticity confinement -------------------------------------------------------------------- */
 /* VorticityConfinement._calc_vorticity    fs/vorticity_confinement.py:27-32                     */
@@ -183,6 +185,17 @@ int fs_lazy_flags(fs_ctx *ctx, uint8_t *out, int capacity, int *wave_columns, in
  * applies the recipes that read the row below / above (pays on masks with staircase outlines, costs a few percent elsewhere; same bits).
  * Both buffers are read 4 rows beyond the written range, src 2 rows.                                                                  */
 int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int mode, int row_begin, int row_end);
+/* TWO red-black iterations - RedBlackSorPressureUpdater.update with n_iter = 2, fs/pressure_updater.py:86-96, which is what
+ * fs/fluid_simulator.py:76-78 wires into every create() - and the two set_pressure_boundary_condition passes between them
+ * (fs/boundary_condition.py:41-65) in ONE pass over HBM (build-side optimisation, same bits): (pc_out, pn_out) receive what the
+ * reference leaves in (p.current, p.next) after two iterations that start from (pc, pn).  Out of place: four distinct fields; the caller
+ * rotates the pairs.  Only fluid cells and boundary-condition targets are stored (every other cell holds the same value in all four
+ * buffers as long as nobody uploads into them); full != 0 stores every cell of the row range - the carry pass after an upload.  pc and
+ * vc are read 4 rows beyond the written range, pn 3.  fs_rbsor_pair_ok: f32, X % 4 == 0, and a mask without one-cell-thin walls between
+ * fluid regions and without fluid in the first / last row (csrc/fs_rbpair.h); otherwise FS_ERR_UNSUPPORTED - use fs_rbsor_iteration. */
+int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok);
+int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_out, fs_field *pn_out, const fs_field *pc,
+                  const fs_field *pn, const fs_field *vc, int full, int row_begin, int row_end);
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc,
                            const fs_field *src, int row_begin, int row_end);
 /* Residual diagnostic (new; the reference never measures convergence): sum over owned not-wall cells of

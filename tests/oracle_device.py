@@ -53,7 +53,26 @@ class OracleSlabDevice(DeviceBase):
     def _p_upload_scene(self, bc_mask, bc_const, bc_dye):
         sl = slice(self.g_lo, self.g_hi)
         self.obc = O.OracleBC(bc_const[:, sl], bc_mask[:, sl], None if bc_dye is None else bc_dye[:, sl], self.dtype)
+        # cells the pressure boundary kernel assigns (every cell gets a unique value; an assigned cell takes a neighbour's, a mean or 0)
+        probe = (np.arange(self.nx * self.nloc, dtype=np.float64).reshape(self.nx, self.nloc) + 1.0).astype(self.dtype)
+        after = probe.copy()
+        self.obc.set_pressure_boundary_condition(after)
+        self.p_targets = after != probe
+        probe2 = np.stack([probe + 0.25, -probe - 0.75], axis=2).astype(self.dtype)              # likewise for the velocity boundary kernel
+        after2 = probe2.copy()
+        self.obc.set_velocity_boundary_condition(after2)
+        self.v_touched = (after2 != probe2).any(axis=2) | (self.obc.mask != 1)
+        # the two-iteration red-black pass reads 4 rows beyond what it writes only on masks without one-cell-thin walls between fluid
+        # regions (csrc/fs_rbpair.h; the library decides per recipe - this is the conservative restatement on the global mask)
+        m = np.pad(np.asarray(bc_mask), 1, constant_values=1)
+        fl, solid = m == 0, m[1:-1, 1:-1] != 0
+        thin = solid & ((fl[:-2, 1:-1] & fl[2:, 1:-1]) | (fl[1:-1, :-2] & fl[1:-1, 2:]))
+        thin |= (m[1:-1, 1:-1] == 2) & fl[:-2, 1:-1]
+        self.pair_ok = not thin.any() and bool((bc_mask[:, 0] == 1).all() and (bc_mask[:, -1] == 1).all())
         return 2, 1
+
+    def _p_rb_pair_ok(self):
+        return self.pair_ok
 
     def _p_exchange(self, h, nchan, depth, v=0):
         """Ghost rows at depth offsets [v, depth) on each side (v = rows the tracker still trusts: they are NOT refreshed, so
@@ -131,19 +150,21 @@ class OracleSlabDevice(DeviceBase):
             O._call("oracle_cip_nonadv", dt_, X, Y, dt, dx, re, b.mask, fn, fc, pc)
             O._call("oracle_cip_nonadv_grad", dt_, X, Y, dx, 2, b.mask, gxo, gyo, gxc, gyc, fc, fn); written = [fn, gxo, gyo]
         elif name == "cip_grad_advect":
-            dt, dx, vo, gxo, gyo, fn, fc, gxc, gyc = A
+            dt, dx, vo, gxo, gyo, fn, fc, gxc, gyc, full = A
             O._call("oracle_cip_nonadv_grad", dt_, X, Y, dx, 2, b.mask, gxo, gyo, gxc, gyc, fc, fn)     # K3 into the output buffers
             tx, ty = gxc.copy(), gyc.copy()                                                             # K4 targets: old gradient buffers
-            vo[...] = fc
+            st = np.ones_like(self.v_touched) if full else self.v_touched       # what the kernel carries (include/fs_hip.h)
+            vo[st] = fc[st]
             O._call("oracle_cip_advect", dt_, X, Y, dt, dx, 2, b.mask, vo, tx, ty, fn, gxo, gyo, fn)
             nw = b.mask != 1
             gxo[nw] = tx[nw]; gyo[nw] = ty[nw]                     # not-wall cells: K4 result (fluid) or carried old gradient
             written = [vo, gxo, gyo]
         elif name == "cip_grad_advect_dye":
-            dt, dx, do, gxo, gyo, fn, fc, gxc, gyc, v, clamp01 = A
+            dt, dx, do, gxo, gyo, fn, fc, gxc, gyc, v, clamp01, full = A
             O._call("oracle_cip_nonadv_grad", dt_, X, Y, dx, 3, b.mask, gxo, gyo, gxc, gyc, fc, fn)     # K3 into the output buffers
             tx, ty = gxc.copy(), gyc.copy()                                                             # K4 targets: old gradient buffers
-            do[...] = fc
+            st = np.ones_like(self.v_touched) if full else (b.mask != 1)
+            do[st] = fc[st]
             O._call("oracle_cip_advect", dt_, X, Y, dt, dx, 3, b.mask, do, tx, ty, fn, gxo, gyo, v)
             if clamp01:
                 fl = b.mask == 0
@@ -176,6 +197,16 @@ class OracleSlabDevice(DeviceBase):
             par = self.g_lo & 1
             O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, 1 ^ par, b.mask, pn, pc, vc)
             O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, 0 ^ par, b.mask, pn, pn, vc); written = [pn]
+        elif name == "rbsor_pair":
+            dt, dx, omega, co, no, pc, pn, vc, full = A
+            par = self.g_lo & 1
+            a, n_ = pc.copy(), pn.copy()
+            for cur, nxt in ((a, n_), (n_, a)):
+                b.set_pressure_boundary_condition(cur)
+                O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, 1 ^ par, b.mask, nxt, cur, vc)
+                O._call("oracle_rbsor_half", dt_, X, Y, dt, dx, omega, 0 ^ par, b.mask, nxt, nxt, vc)
+            st = np.ones_like(self.p_targets) if full else ((b.mask == 0) | self.p_targets)      # what the kernel stores (include/fs_hip.h)
+            co[st] = a[st]; no[st] = n_[st]; written = [co, no]
         elif name == "cip_advect_dye_clamped":
             dt, dx, fn, fxn, fyn, fc, fxc, fyc, v = A
             O._call("oracle_cip_advect", dt_, X, Y, dt, dx, 3, b.mask, fn, fxn, fyn, fc, fxc, fyc, v)

@@ -88,3 +88,30 @@ def test_fields_dropped_during_a_capture(hip_lib):
     finally:
         eager._solver._bc.device.close()
         dev.close()
+
+
+def test_run_in_odd_chunks_keeps_one_graph_per_phase(hip_lib):
+    """run() used to drop (and leak) its graph whenever a chunk was not a multiple of the period and re-capture on the
+    next chunk.  Graphs are cached per phase of the buffer rotation now: a long sequence of odd chunks holds at most `period`
+    of them, and the results equal eager stepping."""
+    import fs
+    res = 64
+    dt, dx, re = 0.05 / res, 1.0 / res, 1e6
+    fs.runtime.init(gpu=0, dtype="f32")
+    eager = fs.FluidSimulator.create(5, res, dt, dx, re, 5.0, "cip")
+    graph = fs.FluidSimulator.create(5, res, dt, dx, re, 5.0, "cip")
+    try:
+        total = 0
+        for chunk in (40, 17, 5, 23, 16, 3, 19, 31, 18, 25, 16, 17, 41, 20):
+            graph.run(chunk)
+            total += chunk
+            assert len(graph._graphs) <= 6
+        for _ in range(total):
+            eager.step()
+        a, b = eager.field_to_numpy(), graph.field_to_numpy()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+        assert 1 <= len(graph._graphs) <= 6
+    finally:
+        eager._solver._bc.device.close()
+        graph._solver._bc.device.close()
