@@ -33,6 +33,30 @@ __global__ __launch_bounds__(256) static void k_verify_rcp(float d, float r, uns
     if (__float_as_uint(q) != __float_as_uint(t) || __float_as_uint(qn) != __float_as_uint(tn)) atomicOr(bad, 1u);
 }
 
+// ---- f64-multiply division (fs_device.h f64div): the identity checked ON THE DEVICE for one divisor -------------------------------
+// every significand of x in 9 binades (tiny, denormal quotients, huge), both signs, plus 2^24 arbitrary bit patterns (NaN compared as NaN)
+__global__ __launch_bounds__(256) static void k_verify_f64div(float d, double rd, unsigned *bad)
+{
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;          // 2^23 significands; blockIdx.y: the binade / the random sweep
+    float x;
+    if (blockIdx.y < 9) {
+        const int e[9] = {0, -60, -100, -126, 60, 100, -20, 20, 127};
+        x = __uint_as_float(0x3f800000u | m);
+        x = ldexpf(x, e[blockIdx.y]);
+        if (blockIdx.y == 3) x = __uint_as_float(m);             // the denormals themselves
+    } else {
+        unsigned h = (m + 0x9e3779b9u * (blockIdx.y - 8u)) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x = __uint_as_float(h);
+    }
+#pragma unroll
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        const float xs = sgn ? -x : x;
+        const float q = f64div(xs, rd), t = xs / d;
+        const bool same = __float_as_uint(q) == __float_as_uint(t) || (q != q && t != t);
+        if (!same) atomicAdd(bad, 1u);
+    }
+}
+
 bool rcp_verified(fs_ctx *ctx, float d, bool may_verify)
 {
     static std::mutex mu;
@@ -164,15 +188,18 @@ static OvGrid ov_grid_n(const fs_ctx *c, int jb, int je, int rt)
     return o;
 }
 
-// Division-mode dispatch (fs_device.h DM_*): CALL(DM) is expanded for the modes a kernel family distinguishes; the reciprocal-FMA
-// modes (2, 3) exist for f32 only.
-#define FS_DM2(dm, CALL)      /* modes 0 / 2 : no dx-derived divisor                */ \
-    do { if constexpr (std::is_same<T, float>::value) { if ((dm) & 2) { CALL(2); break; } } CALL(0); } while (0)
-#define FS_DM3(dm, CALL)      /* modes 0 / 1 / 2 : dx-derived divisors only         */ \
-    do { if ((dm) & 1) { CALL(1); break; } if constexpr (std::is_same<T, float>::value) { if ((dm) & 2) { CALL(2); break; } } CALL(0); } while (0)
-#define FS_DM4(dm, CALL)      /* modes 0 / 1 / 2 / 3 : both kinds                   */ \
-    do { if constexpr (std::is_same<T, float>::value) { if (((dm) & 3) == 3) { CALL(3); break; } if ((dm) & 2) { CALL(2); break; } } \
-         if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
+// Division-mode dispatch (fs_device.h DM_*): CALL(DM) is expanded for the modes a kernel family distinguishes.  f32 fields divide by their
+// loop-invariant divisors through the f64 multiplication (modes 4 / 5; FS_F64DIV=0: IEEE division, modes 0 / 1); power-of-two dx-derived
+// divisors by exact multiplication (bit 0).  The reciprocal-FMA modes (2, 3) survive for the MAC update only (FS_RCP=1, A/B).
+#define FS_F32_ONLY(dm, bits, CALL, MODE) if constexpr (std::is_same<T, float>::value) { if (((dm) & 7) == (bits)) { CALL(MODE); break; } }
+#define FS_DMC(dm, CALL)      /* modes 0 / 4 : no dx-derived divisor                */ \
+    do { FS_F32_ONLY(dm, 4, CALL, 4) CALL(0); } while (0)
+#define FS_DMX(dm, CALL)      /* modes 0 / 1 / 4 : dx-derived divisors only         */ \
+    do { if ((dm) & 1) { CALL(1); break; } FS_F32_ONLY(dm, 4, CALL, 4) CALL(0); } while (0)
+#define FS_DMA(dm, CALL)      /* modes 0 / 1 / 4 / 5 : both kinds                   */ \
+    do { FS_F32_ONLY(dm, 5, CALL, 5) FS_F32_ONLY(dm, 4, CALL, 4) if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
+#define FS_DMA_RCP(dm, CALL)  /* ... + the reciprocal-FMA modes 2 / 3               */ \
+    do { FS_F32_ONLY(dm, 3, CALL, 3) FS_F32_ONLY(dm, 2, CALL, 2) FS_F32_ONLY(dm, 5, CALL, 5) FS_F32_ONLY(dm, 4, CALL, 4) if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
 
 #define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, HV, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, list, nlist, zoff, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
@@ -220,7 +247,7 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
         else if (rt == 3) hipLaunchKernelGGL((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
         else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
         else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
-    return launch(ctx, name, [=] { FS_DM2(dm, FS_JAC); });
+    return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC); });
 }
 
 static int check_rows(const fs_ctx *c, int jb, int je)
@@ -572,6 +599,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_RCP")) c->use_rcp = atoi(s);
+    if (const char *s = getenv("FS_F64DIV")) c->use_f64div = atoi(s) != 0;
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
     if (const char *s = getenv("FS_VORT_RT")) { const int v = atoi(s); if (v >= 3 && v <= 6) c->vort_rt = v; }
@@ -934,7 +962,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
 #define FS_K2M_UP(DM) FS_K2M(0, DM)
 #define FS_K2M_KK(DM) FS_K2M(1, DM)
-                if (scheme == FS_UPWIND) FS_DM4(dm_all(ctx, k, RCP_MAC), FS_K2M_UP); else FS_DM4(dm_all(ctx, k, RCP_MAC), FS_K2M_KK);
+                if (scheme == FS_UPWIND) FS_DMA_RCP(dm_all(ctx, k, RCP_MAC), FS_K2M_UP); else FS_DMA_RCP(dm_all(ctx, k, RCP_MAC), FS_K2M_KK);
             });
         }
         if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_update_upwind", (k_mac_update<0, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot) }
@@ -984,7 +1012,7 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, "cip_nonadv", [=] {
 #define FS_K2Q(DM) hipLaunchKernelGGL((k_cip_nonadv_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
-                FS_DM4(dm_all(ctx, k, RCP_K2), FS_K2Q);
+                FS_DMA(dm_all(ctx, k, 0), FS_K2Q);
             });
         }
         if (k.p2) { FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<true, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot) }
@@ -1004,7 +1032,7 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, "cip_nonadv_dye", [=] {
 #define FS_K12Q(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
-                FS_DM4(dm_all(ctx, k, RCP_DYE), FS_K12Q);
+                FS_DMA(dm_all(ctx, k, 0), FS_K12Q);
             });
         }
         FS_LAUNCH_CELLS("cip_nonadv_dye", (k_cip_nonadv_dye<T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d)
@@ -1029,7 +1057,7 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
             return launch(ctx, C == 2 ? "cip_nonadv_grad" : "cip_nonadv_grad_c3", [=] {
 #define FS_K3Q_V(DM) FS_K3Q(2, 2, DM)
 #define FS_K3Q_D(DM) FS_K3Q(3, 1, DM)
-                if (C == 2) FS_DM3(dm_dx(ctx, k, RCP_K3), FS_K3Q_V); else FS_DM3(dm_dx(ctx, k, RCP_K3), FS_K3Q_D);
+                if (C == 2) FS_DMX(dm_dx(ctx, k, 0), FS_K3Q_V); else FS_DMX(dm_dx(ctx, k, 0), FS_K3Q_D);
             });
         }
         if (C == 2 && k.p2) FS_K3(2, true, "cip_nonadv_grad")
@@ -1063,9 +1091,9 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
             if (ctx->use_march) {
 #define FS_K4Q_SELF(DM) FS_K4Q(2, 2, true, DM)
 #define FS_K4Q_OTHER(DM) FS_K4Q(2, 1, false, DM)
-                if (C == 2 && self) FS_DM3(dm_dx(ctx, k, RCP_K4), FS_K4Q_SELF);
-                else if (C == 2) FS_DM3(dm_dx(ctx, k, RCP_K4), FS_K4Q_OTHER);
-                else FS_DM3(dm_dx(ctx, k, RCP_K4), FS_K4D);
+                if (C == 2 && self) FS_DMX(dm_dx(ctx, k, 0), FS_K4Q_SELF);
+                else if (C == 2) FS_DMX(dm_dx(ctx, k, 0), FS_K4Q_OTHER);
+                else FS_DMX(dm_dx(ctx, k, 0), FS_K4D);
             } else {
                 if (C == 2) { if (k.p2) FS_K4N(2, true); else FS_K4N(2, false); }
                 else { if (k.p2) FS_K4N(3, true); else FS_K4N(3, false); }
@@ -1090,7 +1118,7 @@ int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, f
         return launch(ctx, "cip_advect_c3_clamped", [=] {
 #define FS_K4DC(DM) hipLaunchKernelGGL((k_cip_advect_dye<DM, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
                                          (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-            FS_DM3(dm_dx(ctx, k, RCP_K4), FS_K4DC);
+            FS_DMX(dm_dx(ctx, k, 0), FS_K4DC);
         });
     })
 }
@@ -1168,13 +1196,15 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
             const int jb = row_begin, je = row_end;
             if (jb >= je) return FS_OK;
             const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT);
-#define FS_K34RT(R, PP) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, PP, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
+#define FS_K34RT(R, DM) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, DM, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, \
                 (const uint8_t *)ctx->d_bcmap, full)
+#define FS_K34RT2(DM) FS_K34RT(2, DM)
+#define FS_K34RT3(DM) FS_K34RT(3, DM)
+#define FS_K34RT4(DM) FS_K34RT(4, DM)
+            const int dm = dm_dx(ctx, k, 0);
             return launch(ctx, "cip_grad_advect_rt", [=] {
-                if (RT == 2) { if (k.p2) FS_K34RT(2, true); else FS_K34RT(2, false); }
-                else if (RT == 3) { if (k.p2) FS_K34RT(3, true); else FS_K34RT(3, false); }
-                else { if (k.p2) FS_K34RT(4, true); else FS_K34RT(4, false); }
+                if (RT == 2) FS_DMX(dm, FS_K34RT2); else if (RT == 3) FS_DMX(dm, FS_K34RT3); else FS_DMX(dm, FS_K34RT4);
             });
         }
         int tiled_end = in_lo;
@@ -1203,12 +1233,12 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
             auto k = make_konst<T>(ctx, dt, dx, 1.0);
             constexpr int RT = 2;
             const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 3, XCD_ADVECT);
-#define FS_K34D(PP, CL) hipLaunchKernelGGL((k_cip_grad_advect_dye<RT, PP, CL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K34D(DM, CL) hipLaunchKernelGGL((k_cip_grad_advect_dye<RT, DM, CL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
                 (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, full)
-            return launch(ctx, "cip_grad_advect_dye", [=] {
-                if (k.p2) { if (clamp01) FS_K34D(true, true); else FS_K34D(true, false); }
-                else { if (clamp01) FS_K34D(false, true); else FS_K34D(false, false); }
-            });
+#define FS_K34D_C(DM) FS_K34D(DM, true)
+#define FS_K34D_N(DM) FS_K34D(DM, false)
+            const int dm = dm_dx(ctx, k, 0);
+            return launch(ctx, "cip_grad_advect_dye", [=] { if (clamp01) FS_DMX(dm, FS_K34D_C); else FS_DMX(dm, FS_K34D_N); });
         }
     })
 }
@@ -1257,16 +1287,13 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
     const dim3 grid = og.grid;
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
-        const bool p2 = k.p2 != 0;
+        const int dm = dm_dx(ctx, k, 0);
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
-#define FS_VORT(RT) do { \
-            if (p2 && !vort) hipLaunchKernelGGL((k_vort_fused<RT, true, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot); \
-            else if (p2) hipLaunchKernelGGL((k_vort_fused<RT, true, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot); \
-            else if (!vort) hipLaunchKernelGGL((k_vort_fused<RT, false, false, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot); \
-            else hipLaunchKernelGGL((k_vort_fused<RT, false, true, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot); } while (0)
-        return launch(ctx, "vort_confine", [=] {
-            if (rt == 5) FS_VORT(5); else if (rt == 6) FS_VORT(6); else if (rt == 3) FS_VORT(3); else FS_VORT(4);
-        });
+#define FS_VORT(RT, DM, ST) hipLaunchKernelGGL((k_vort_fused<RT, DM, ST, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
+#define FS_VORT_RT(DM, ST) do { if (rt == 5) FS_VORT(5, DM, ST); else if (rt == 6) FS_VORT(6, DM, ST); else if (rt == 3) FS_VORT(3, DM, ST); else FS_VORT(4, DM, ST); } while (0)
+#define FS_VORT_S(DM) FS_VORT_RT(DM, true)
+#define FS_VORT_N(DM) FS_VORT_RT(DM, false)
+        return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORT_S); else FS_DMX(dm, FS_VORT_N); });
     })
 }
 
@@ -1398,11 +1425,33 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
 #define FS_RBF3(DM) FS_RBF_RT(3, DM)
 #define FS_RBF4(DM) FS_RBF_RT(4, DM)
         return launch(ctx, "rbsor_iteration", [=] {
-            if (rt == 3) FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF3);
-            else if (rt == 4) FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF4);
-            else FS_DM2(dm_const(ctx, k, RCP_RBSOR), FS_RBF2);
+            if (rt == 3) FS_DMC(dm_const(ctx, k, 0), FS_RBF3);
+            else if (rt == 4) FS_DMC(dm_const(ctx, k, 0), FS_RBF4);
+            else FS_DMC(dm_const(ctx, k, 0), FS_RBF2);
         });
     })
+}
+
+// diagnostic: how many of ~2^28 dividends (see k_verify_f64div) does the f64-multiply division of f32 values get wrong for this divisor?
+int fs_selftest_f64div(fs_ctx *ctx, double divisor, int *mismatches)
+{
+    FS_REQUIRE(ctx && mismatches, "null argument");
+    FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "self test during graph capture / tape recording");
+    const float d = (float)divisor;
+    FS_REQUIRE(d != 0.0f && d == d, "divisor must be a non-zero number");
+    FS_HIP(hipSetDevice(ctx->device));
+    unsigned *flag = nullptr, h = ~0u;
+    FS_HIP(hipMalloc(&flag, sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_verify_f64div, dim3(1u << 15, 9 + 2), dim3(256), 0, ctx->stream, d, 1.0 / (double)d, flag);
+        e = hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(flag);
+    if (e != hipSuccess) return hip_fail(e, "fs_selftest_f64div", __FILE__, __LINE__);
+    *mismatches = (int)std::min<unsigned>(h, 0x7fffffffu);
+    return FS_OK;
 }
 
 int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok)
@@ -1429,7 +1478,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     const Grid gg = ctx->grid();
     const int par0 = (gg.ybase + row_begin) & 1;
     auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-    const int dm = dm_const(ctx, k, RCP_RBPAIR);
+    const int dm = dm_const(ctx, k, 0);
     // lanes of N cells, RT rows per tile; `split`: the tiles without / with a non-fluid cell within reach as two launches, each with
     // its own register budget (fs_rbpair.h).  The carrying pass after an upload (full) is rare: one configuration.
     const int n = full ? 2 : ctx->rbpair_n, rt = full ? 4 : ctx->rbpair_rt, split = full ? 0 : ctx->rbpair_split;
@@ -1437,7 +1486,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
 #define FS_RBP_K(N, RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<N, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBP_PAR(N, RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(N, RT, 1, DM, PATH, FULL); else FS_RBP_K(N, RT, 0, DM, PATH, FULL); } while (0)
-#define FS_RBP_DM(N, RT, PATH) do { if (dm & DM_RCP) FS_RBP_PAR(N, RT, 2, PATH, false); else FS_RBP_PAR(N, RT, 0, PATH, false); } while (0)
+#define FS_RBP_DM(N, RT, PATH) do { if (dm & DM_F64) FS_RBP_PAR(N, RT, 4, PATH, false); else FS_RBP_PAR(N, RT, 0, PATH, false); } while (0)
 #define FS_RBP_PATH(PATH) do { \
         if (full) FS_RBP_PAR(2, 4, 0, 2, true); \
         else if (n == 4) FS_RBP_PAR(4, 4, 0, PATH, false); \

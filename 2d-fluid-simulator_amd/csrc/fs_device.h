@@ -45,6 +45,8 @@ struct Konst {
     // IEEE quotient x / d for all 2^23 significands of x (fs_api.hip rcp_verified; f32 only).  See rdiv() below.
     int rcp;
     T inv_six_dx, inv_eight_dt, inv_re;
+    // RN64(1 / d) of every loop-invariant divisor d (as rounded to T), for the f64-multiply division below (f32 fields only)
+    double r_dx, r_two_dx, r_dx_sq, r_dx2_fold, r_dx3_fold, r_six_dx, r_eight_dt, r_re;
 };
 
 // ---- division by loop-invariant divisors --------------------------------------------------------------------------------
@@ -59,7 +61,8 @@ struct Konst {
 // Mode bits of the kernels' DM template parameter:
 //   bit 0: the dx-derived divisors are powers of two  -> x * (1/d) is exact
 //   bit 1: reciprocal-FMA sequence for every other loop-invariant divisor (and for the dx-derived ones unless bit 0)
-constexpr int DM_IEEE = 0, DM_P2 = 1, DM_RCP = 2;
+//   bit 2: f64-multiply division for every loop-invariant divisor that is not covered by bit 0 (see f64div)
+constexpr int DM_IEEE = 0, DM_P2 = 1, DM_RCP = 2, DM_F64 = 4;
 struct DivGuard {
     int emin;          // smallest binary exponent (frexp) among the dividends seen; zero, inf and NaN report 0
     unsigned nonfin;   // an OUTPUT was inf / NaN (an inf dividend gives NaN here but inf in IEEE arithmetic; overflow of x * r likewise)
@@ -85,11 +88,23 @@ __device__ __forceinline__ float rdiv(float x, float d, float r, DivGuard &G)
     return __uint_as_float((__float_as_uint(q1) & 0x7fffffffu) | (__float_as_uint(q0) & 0x80000000u));
 }
 __device__ __forceinline__ double rdiv(double x, double d, double, DivGuard &) { return x / d; }   // f64: never selected (no exhaustive check)
+// The f32 quotient x / d through ONE f64 multiplication: with R = RN64(1 / d), RN32(RN64(x R)) == RN32(x / d) for EVERY f32 x (zeros
+// with their sign, denormals, infinities and NaN included) and every f32 d != 0: x R misses the real quotient by less than 2^-52
+// relative (R's rounding + the product's), while the quotient of two 24-bit numbers is either a 25-bit rounding boundary's exact value
+// or at least 2^-49 relative away from one - the argument that makes double rounding innocuous for division once the wide format has
+// 2 p + 2 bits (Figueroa) - and a boundary value x / d = m exactly means x = d m exactly, which the f64 product reproduces to within
+// half an f64 ulp of m, i.e. rounds to m.  3 instructions (v_cvt_f64_f32, v_mul_f64, v_cvt_f32_f64) against 11 of the IEEE division
+// sequence, no range guard, no redo path, no exhaustive per-divisor check (tests/test_f64div.py checks the identity anyway, against
+// numpy on all 2^23 significands of several binades and on random bit patterns for the divisors of several resolutions).
+__device__ __forceinline__ float f64div(float x, double rd) { return (float)((double)x * rd); }
+__device__ __forceinline__ double f64div(double x, double) { return x; }                    // f64 fields: never selected
 // x / d for a dx-derived divisor / for any other loop-invariant divisor
 template <int DM, typename T>
-__device__ __forceinline__ T xdiv(T x, T d, T inv_d, DivGuard &G) { return (DM & DM_P2) ? x * inv_d : ((DM & DM_RCP) ? rdiv(x, d, inv_d, G) : x / d); }
+__device__ __forceinline__ T xdiv(T x, T d, T inv_d, double rd, DivGuard &G)
+{ return (DM & DM_P2) ? x * inv_d : ((DM & DM_F64) ? f64div(x, rd) : ((DM & DM_RCP) ? rdiv(x, d, inv_d, G) : x / d)); }
 template <int DM, typename T>
-__device__ __forceinline__ T cdiv(T x, T d, T inv_d, DivGuard &G) { return (DM & DM_RCP) ? rdiv(x, d, inv_d, G) : x / d; }
+__device__ __forceinline__ T cdiv(T x, T d, T inv_d, double rd, DivGuard &G)
+{ return (DM & DM_F64) ? f64div(x, rd) : ((DM & DM_RCP) ? rdiv(x, d, inv_d, G) : x / d); }
 
 
 template <typename T> __device__ __forceinline__ T tmin(T a, T b);

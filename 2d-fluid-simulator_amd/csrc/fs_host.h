@@ -71,7 +71,7 @@ struct fs_ctx {
     bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
     bool rb_pair_ok = false;                 // mask admits the two-iteration red-black pass (fs_rbpair.h; decided in build_bc_ops)
     int rbpair_rt = 4, rbpair_n = 2;         // rows per tile (env FS_RBPAIR_RT = 4, 6) and cells per lane (FS_RBPAIR_N = 2, 4) of that pass
-    bool rbpair_split = true;                // plain and boundary tiles as two launches (FS_RBPAIR_SPLIT)
+    bool rbpair_split = false;               // plain and boundary tiles as two launches (FS_RBPAIR_SPLIT; measured slower: both classify every tile)
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
     int vort_rt = 4;                         // rows per tile of the fused vorticity confinement (env FS_VORT_RT = 3 .. 6)
@@ -114,7 +114,8 @@ struct fs_ctx {
     // kernel is issue-bound - Kawamura-Kuwahara MAC update 227 -> 207 us (8 divisions by 6dx / Re per cell) - and is neutral to
     // slightly negative for the bandwidth-bound kernels (RB-SOR 136 -> 134, K2 116 -> 122, Jacobi 88 -> 91; K4 at a
     // non-power-of-two dx 78 -> 105 us: 244 VGPRs).  Default: the MAC update only.
-    int use_rcp = 1;           // RCP_MAC
+    int use_rcp = 0;           // (round 3: off - the f64-multiply division below does the same without a guard; FS_RCP=1 for the A/B)
+    bool use_f64div = true;    // env FS_F64DIV=0: IEEE division for the loop-invariant divisors of f32 runs (A/B; the results are the same)
     int k34_rt = -1;           // env FS_K34_RT: rows per register tile of the fused gradient-update + advection pass (0: one-row form; default 2)
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
@@ -184,6 +185,8 @@ inline Konst<T> make_konst(fs_ctx *ctx, double dt, double dx, double re, double 
     k.inv_six_dx = (T)1 / k.six_dx;
     k.inv_eight_dt = (T)1 / k.eight_dt;
     k.inv_re = (T)1 / k.re;
+    k.r_dx = 1.0 / (double)k.dx; k.r_two_dx = 1.0 / (double)k.two_dx; k.r_dx_sq = 1.0 / (double)k.dx_sq; k.r_dx2_fold = 1.0 / (double)k.dx2_fold;
+    k.r_dx3_fold = 1.0 / (double)k.dx3_fold; k.r_six_dx = 1.0 / (double)k.six_dx; k.r_eight_dt = 1.0 / (double)k.eight_dt; k.r_re = 1.0 / (double)k.re;
     // reciprocal-FMA division (fs_device.h rdiv): every divisor of the set must be a normal number of moderate magnitude (the
     // range check of the dividends assumes 2^-66 <= |d| <= 2^66) and must have passed the exhaustive check on the device
     k.rcp = 0;
@@ -202,9 +205,10 @@ inline Konst<T> make_konst(fs_ctx *ctx, double dt, double dx, double re, double 
 // division mode of a launch (fs_device.h): which kernels have which kinds of divisors decides how many modes they instantiate
 enum { RCP_MAC = 1, RCP_K2 = 2, RCP_K3 = 4, RCP_K4 = 8, RCP_RBSOR = 16, RCP_JACOBI = 32, RCP_DYE = 64, RCP_RBPAIR = 128 };
 template <typename T> inline bool rcp_on(const fs_ctx *c, const Konst<T> &k, int family) { return k.rcp && (c->use_rcp & family); }
-template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k, int f) { return (k.p2 ? DM_P2 : 0) | (rcp_on(c, k, f) ? DM_RCP : 0); }      // dx-derived AND other divisors
-template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k, int f) { return k.p2 ? DM_P2 : (rcp_on(c, k, f) ? DM_RCP : DM_IEEE); }       // dx-derived divisors only
-template <typename T> inline int dm_const(const fs_ctx *c, const Konst<T> &k, int f) { return rcp_on(c, k, f) ? DM_RCP : DM_IEEE; }                     // no dx-derived divisor
+template <typename T> inline int f64_mode(const fs_ctx *c) { return sizeof(T) == 4 && c->use_f64div ? DM_F64 : DM_IEEE; }      // f32 fields: the f64-multiply division
+template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k, int f) { return (k.p2 ? DM_P2 : 0) | (rcp_on(c, k, f) ? DM_RCP : f64_mode<T>(c)); }   // dx-derived AND other divisors
+template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k, int) { return k.p2 ? DM_P2 : f64_mode<T>(c); }       // dx-derived divisors only
+template <typename T> inline int dm_const(const fs_ctx *c, const Konst<T> &, int) { return f64_mode<T>(c); }                    // no dx-derived divisor
 
 
 }  // namespace fs

@@ -165,17 +165,18 @@ __device__ __forceinline__ void cip_point(const Konst<T> &k, T vx, T vy, T dxx, 
     const T js = vy < (T)0.0 ? (T)-1 : (T)1;
     const T i_s_denom = is * k.dx3_fold, j_s_denom = js * k.dx3_fold, is_dx = is * k.dx;
     const T i_s_inv = is * k.inv_dx3_fold, j_s_inv = js * k.inv_dx3_fold, is_dx_inv = is * k.inv_dx;   // +-1 times the reciprocal: exact
+    const double i_s_r = (double)is * k.r_dx3_fold, j_s_r = (double)js * k.r_dx3_fold, is_dx_r = (double)is * k.r_dx;   // likewise (1 / (-d) = -(1 / d))
     const T Xd = (-vx) * k.dt, Yd = (-vy) * k.dt;
     const T tmp1 = ((f00 - f0m) - fm0) + fmm;
     const T tmp2 = fm0 - f00;
     const T tmp3 = f0m - f00;
-    const T a = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2), i_s_denom, i_s_inv, G);
-    const T b = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3), j_s_denom, j_s_inv, G);
-    const T cc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv, G);
-    const T d = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv, G);
-    const T e = xdiv<DM>((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, G);
-    const T f = xdiv<DM>((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, G);
-    const T gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, G);
+    const T a = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2), i_s_denom, i_s_inv, i_s_r, G);
+    const T b = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3), j_s_denom, j_s_inv, j_s_r, G);
+    const T cc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv, j_s_r, G);
+    const T d = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv, i_s_r, G);
+    const T e = xdiv<DM>((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold, G);
+    const T f = xdiv<DM>((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold, G);
+    const T gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, is_dx_r, G);
     out_f = (((((a * Xd + cc * Yd) + e) * Xd + gq * Yd) + fx00) * Xd + (((b * Yd + d * Xd) + f) * Yd + fy00) * Yd) + f00;
     const T Fx = ((((T)3.0 * a) * Xd + ((T)2.0 * cc) * Yd) + (T)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
     const T Fy = ((((T)3.0 * b) * Yd + ((T)2.0 * d) * Xd) + (T)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;

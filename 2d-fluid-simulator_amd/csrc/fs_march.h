@@ -119,7 +119,7 @@ __device__ __forceinline__ void source_from(const Konst<T> &k, T vxE, T vxW, T v
 {
     T sxx = vxE - vxW, sxy = vyE - vyW, syx = vxN - vxS, syy = vyN - vyS;
     s2 = ((sxx * sxx + syy * syy) + (syx * sxy)) / (T)8.0;
-    s3 = cdiv<DM>(k.dx * (sxx + syy), k.eight_dt, k.inv_eight_dt, G);
+    s3 = cdiv<DM>(k.dx * (sxx + syy), k.eight_dt, k.inv_eight_dt, k.r_eight_dt, G);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,8 +212,8 @@ __device__ __forceinline__ T quad_right(const LaneMap &m, const typename Quad<T>
 
 // x / dx for the central differences: a true IEEE division unless dx is a power of two, where the
 // (exact) multiplication by 1/dx gives the same bits for a fraction of the instructions.
-template <bool P2, typename T>
-__device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return P2 ? x * k.inv_dx : x / k.dx; }   // P2 only when k.p2
+template <int DM, typename T>
+__device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { DivGuard G; return xdiv<DM & (DM_P2 | DM_F64)>(x, k.dx, k.inv_dx, k.r_dx, G); }   // P2 only when k.p2
 
 // ------------------------------------------------------------------------------------------------
 // K5 + K6 fused: vorticity confinement in one pass (fs/vorticity_confinement.py:27-55).
@@ -224,7 +224,7 @@ __device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return P2 ? x * k.
 // lanes (DPP) and writes RT rows of vn.  w / |w| never touch HBM unless STORE_W (they are public attributes of
 // VorticityConfinement; the unfused pair of kernels remains available and is what parity tests compare with).
 // ------------------------------------------------------------------------------------------------
-template <int RT, bool P2, bool STORE_W, typename T>
+template <int RT, int DM, bool STORE_W, typename T>
 __global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot)
 {
     using V = typename Quad<T>::type;
@@ -260,10 +260,10 @@ __global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx,
         const V &yc = VY[r + 1], &xm = VX[r], &xp = VX[r + 2];
         const T yl = quad_left<T>(lm, yc), yr = quad_right<T>(lm, yc);
         V w;
-        w.x = div_dx<P2>((T)0.5 * (yc.y - yl), k) - div_dx<P2>((T)0.5 * (xp.x - xm.x), k);
-        w.y = div_dx<P2>((T)0.5 * (yc.z - yc.x), k) - div_dx<P2>((T)0.5 * (xp.y - xm.y), k);
-        w.z = div_dx<P2>((T)0.5 * (yc.w - yc.y), k) - div_dx<P2>((T)0.5 * (xp.z - xm.z), k);
-        w.w = div_dx<P2>((T)0.5 * (yr - yc.z), k) - div_dx<P2>((T)0.5 * (xp.w - xm.w), k);
+        w.x = div_dx<DM>((T)0.5 * (yc.y - yl), k) - div_dx<DM>((T)0.5 * (xp.x - xm.x), k);
+        w.y = div_dx<DM>((T)0.5 * (yc.z - yc.x), k) - div_dx<DM>((T)0.5 * (xp.y - xm.y), k);
+        w.z = div_dx<DM>((T)0.5 * (yc.w - yc.y), k) - div_dx<DM>((T)0.5 * (xp.z - xm.z), k);
+        w.w = div_dx<DM>((T)0.5 * (yr - yc.z), k) - div_dx<DM>((T)0.5 * (xp.w - xm.w), k);
         const unsigned f = fl[r];
         w.x = (f & 1u) ? w.x : (T)0; w.y = (f & 2u) ? w.y : (T)0; w.z = (f & 4u) ? w.z : (T)0; w.w = (f & 8u) ? w.w : (T)0;
         W[r] = w;
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx,
         const V &cx = VX[r + 2], &cy = VY[r + 2];
 #define FS_VC_CELL(comp, aE, aW)                                                              \
         {                                                                                     \
-            T gx = div_dx<P2>((T)0.5 * ((aE) - (aW)), k);                                     \
-            T gy = div_dx<P2>((T)0.5 * (tabs(wp.comp) - tabs(wm.comp)), k);                   \
+            T gx = div_dx<DM>((T)0.5 * ((aE) - (aW)), k);                                     \
+            T gy = div_dx<DM>((T)0.5 * (tabs(wp.comp) - tabs(wm.comp)), k);                   \
             T nrm = tsqrt(gx * gx + gy * gy);                                                 \
             gx = gx / nrm; gy = gy / nrm;                                                     \
             T f0 = gy * wc.comp, f1 = (-gx) * wc.comp;                                        \
@@ -499,8 +499,8 @@ __device__ __forceinline__ bool cip_advect_quad_tile(Grid g, Konst<T> k, int nbx
         const bool nx = vx < (T)0.0, ny = vy < (T)0.0;       // upwind cell is E / N when the velocity is negative
         const T vxE = q == 3 ? vxr : VX[1].a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VX[1].a[q == 0 ? 0 : q - 1];
         const T vyE = q == 3 ? vyr : VY[1].a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VY[1].a[q == 0 ? 0 : q - 1];
-        const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, G);
-        const T dyx = xdiv<DM>((T)0.5 * (VX[2].a[q] - VX[0].a[q]), k.dx, k.inv_dx, G), dyy = xdiv<DM>((T)0.5 * (VY[2].a[q] - VY[0].a[q]), k.dx, k.inv_dx, G);
+        const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx, G);
+        const T dyx = xdiv<DM>((T)0.5 * (VX[2].a[q] - VX[0].a[q]), k.dx, k.inv_dx, k.r_dx, G), dyy = xdiv<DM>((T)0.5 * (VY[2].a[q] - VY[0].a[q]), k.dx, k.inv_dx, k.r_dx, G);
         const int ru = ny ? 2 : 0;                             // row of the upwind cell
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -593,15 +593,15 @@ __device__ __forceinline__ bool cip_nonadv_quad_tile(Grid g, Konst<T> k, int nbx
         for (int q = 0; q < 4; ++q) {
             const T fE = q == 3 ? r : F[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : F[c][1].a[q == 0 ? 0 : q - 1];
             const T f0 = F[c][1].a[q];
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, G);
-            const T d2y = xdiv<DM>((F[c][2].a[q] - (T)2.0 * f0) + F[c][0].a[q], k.dx_sq, k.inv_dx_sq, G);
-            const T dif = cdiv<DM>(d2x + d2y, k.re, k.inv_re, G);
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
+            const T d2y = xdiv<DM>((F[c][2].a[q] - (T)2.0 * f0) + F[c][0].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
+            const T dif = cdiv<DM>(d2x + d2y, k.re, k.inv_re, k.r_re, G);
             T gp;
             if (c == 0) {
                 const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
-                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, G);
+                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx, G);
             } else {
-                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, G);
+                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, k.r_dx, G);
             }
             const T gg = (-gp) + dif;
             O[c].a[q] = f0 + gg * k.dt;
@@ -665,8 +665,8 @@ __device__ __forceinline__ bool cip_nonadv_grad_quad_tile(Grid g, Konst<T> k, in
             const T cE = q == 3 ? cr : Fc[c][1].a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : Fc[c][1].a[q == 0 ? 0 : q - 1];
             const T sx = ((nE - cE) - nW) + cW;
             const T sy = ((N[c][2].a[q] - Fc[c][2].a[q]) - N[c][0].a[q]) + Fc[c][0].a[q];
-            OX.a[q] = GX[c].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, G);
-            OY.a[q] = GY[c].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, G);
+            OX.a[q] = GX[c].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G);
+            OY.a[q] = GY[c].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G);
         }
         if (DM & DM_RCP) {
 #pragma unroll
@@ -788,8 +788,8 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
                 const T sx = ((nE - cE) - nW) + cW;
                 const T sy = ((nN.a[q] - cN.a[q]) - nS.a[q]) + cS.a[q];
                 const bool live = (nw[s] >> q) & 1u;
-                NX[s].a[q] = live ? GX[s].a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sx, k.two_dx, k.inv_two_dx, G) : GX[s].a[q];
-                NY[s].a[q] = live ? GY[s].a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sy, k.two_dx, k.inv_two_dx, G) : GY[s].a[q];
+                NX[s].a[q] = live ? GX[s].a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GX[s].a[q];
+                NY[s].a[q] = live ? GY[s].a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GY[s].a[q];
             }
         }
         // ---- K4 on row j ----
@@ -809,8 +809,8 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
             const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
             const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
             const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, G), dxy = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, G);
-            const T dyx = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, G), dyy = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, G);
+            const T dxx = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx, G), dxy = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx, G);
+            const T dyx = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx, G), dyy = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx, G);
             const T fE1 = q == 3 ? fr_[1] : N[2].a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl_[1] : N[2].a[q == 0 ? 0 : q - 1];
             const T fE0 = q == 3 ? fr_[0] : N[1].a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl_[0] : N[1].a[q == 0 ? 0 : q - 1];
             const T fE2 = q == 3 ? fr_[2] : N[3].a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl_[2] : N[3].a[q == 0 ? 0 : q - 1];
@@ -842,13 +842,12 @@ __device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<
 // recompute overhead that made the one-row form issue-bound drops from 3x to 1.5x - and the five input planes are requested up front
 // as 5 RT + 14 16-byte loads per lane.  Rows that do not fill a whole tile, and the rows next to the domain edge, take the one-row
 // kernels below.
-template <int c, int RT, bool P2, typename T>
+template <int c, int RT, int DM, typename T>
 __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                         T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
                                                         const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
 {
-    constexpr int DM = P2 ? DM_P2 : DM_IEEE;
-    DivGuard G;      // unused: exact multiplication or IEEE division only
+    DivGuard G;      // unused: exact multiplication, f64-multiply or IEEE division only
     int wx, ty, cg;
     if (!tile_coords<2>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
     const LaneMap lm = lane_map_wave(g, wx);
@@ -914,8 +913,8 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
             const T sx = ((nE - cE) - nW) + cW;
             const T sy = ((N[s + 2].a[q] - Fc[s + 2].a[q]) - N[s].a[q]) + Fc[s].a[q];
             const bool live = (nw[s] >> q) & 1u;
-            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, G) : GX[s].a[q];
-            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, G) : GY[s].a[q];
+            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GX[s].a[q];
+            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GY[s].a[q];
         }
     }
     // every row is loaded clamped (sample() clamps coordinates), so the rows at the domain's first / last row need no launch of their own:
@@ -947,8 +946,8 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
             const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
             const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
             const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, G);
-            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, G), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, G);
+            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx, G);
+            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx, G), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx, G);
             const T fE1 = q == 3 ? fr1 : Nc.a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
             const T fE0 = q == 3 ? fr0 : Nm.a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
             const T fE2 = q == 3 ? fr2 : Np.a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
@@ -975,15 +974,15 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
     }
 }
 
-template <int RT, bool P2, typename T>
+template <int RT, int DM, typename T>
 __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                             T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
                                                             const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
 {
     // blockIdx.y = (tile row in the XCD group) * 2 + component: the two component passes of a tile are adjacent in dispatch order on
     // the SAME XCD, so the second one finds the velocity rows both passes read in that XCD's L2 instead of fetching them again.
-    if ((blockIdx.y & 1) == 0) cip_grad_advect_rt_body<0, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
-    else cip_grad_advect_rt_body<1, RT, P2, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
+    if ((blockIdx.y & 1) == 0) cip_grad_advect_rt_body<0, RT, DM, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
+    else cip_grad_advect_rt_body<1, RT, DM, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
 }
 
 // The same fusion for the dye (C = 3 channels advected by the final velocity of the flow step, fs/solver.py:378-401): K3 on the rows
@@ -991,13 +990,12 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, 
 // and share the velocity rows through the L2).  Every row is loaded clamped (sample() clamps coordinates, fs/differentiation.py:4-9), so the
 // rows next to the domain's first / last row need no separate launch: a register slot that stands for a row outside the domain takes the
 // K3 result of the edge row it clamps onto.  CLAMP: clamp_field(dye, 0, 1) (fs/solver.py:46-49) folded into the store of the advected value.
-template <int c, int RT, bool P2, bool CLAMP, typename T>
+template <int c, int RT, int DM, bool CLAMP, typename T>
 __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                          T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
                                                          const T *gxc, const T *gyc, const T *v, int full)
 {
-    constexpr int DM = P2 ? DM_P2 : DM_IEEE;
-    DivGuard G;      // unused: exact multiplication or IEEE division only
+    DivGuard G;      // unused: exact multiplication, f64-multiply or IEEE division only
     int wx, ty, cg;
     if (!tile_coords<3>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
     const LaneMap lm = lane_map_wave(g, wx);
@@ -1061,8 +1059,8 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
             const T sx = ((nE - cE) - nW) + cW;
             const T sy = ((N[s + 2].a[q] - Fc[s + 2].a[q]) - N[s].a[q]) + Fc[s].a[q];
             const bool live = (nw[s] >> q) & 1u;
-            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, G) : GX[s].a[q];
-            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, G) : GY[s].a[q];
+            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GX[s].a[q];
+            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GY[s].a[q];
         }
     }
     // slots that stand for rows outside the domain: the K3 result of the edge row they clamp onto (wave-uniform)
@@ -1091,8 +1089,8 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
             const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
             const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
             const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, G);
-            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, G), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, G);
+            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx, G);
+            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx, G), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx, G);
             const T fE1 = q == 3 ? fr1 : Nc.a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
             const T fE0 = q == 3 ? fr0 : Nm.a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
             const T fE2 = q == 3 ? fr2 : Np.a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
@@ -1119,15 +1117,15 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
     }
 }
 
-template <int RT, bool P2, bool CLAMP, typename T>
+template <int RT, int DM, bool CLAMP, typename T>
 __global__ __launch_bounds__(256) void k_cip_grad_advect_dye(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                              T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
                                                              const T *gxc, const T *gyc, const T *v, int full)
 {
     const int ly = (int)blockIdx.y / 3, ch = (int)blockIdx.y - 3 * ly;      // channel = blockIdx.y % 3 (the fallback grid: blockIdx.y itself)
-    if (ch == 0) cip_grad_advect_dye_body<0, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
-    else if (ch == 1) cip_grad_advect_dye_body<1, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
-    else cip_grad_advect_dye_body<2, RT, P2, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
+    if (ch == 0) cip_grad_advect_dye_body<0, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
+    else if (ch == 1) cip_grad_advect_dye_body<1, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
+    else cip_grad_advect_dye_body<2, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
 }
 
 // EDGE = false: rows at least two rows away from the domain's first / last row (static register slots, branch-free);
@@ -1735,8 +1733,8 @@ __device__ __forceinline__ bool mac_update_quad_tile(Grid g, Konst<T> k, int nbx
             const T fN = V[c][R + 1].a[q], fS = V[c][R - 1].a[q];
             T adv;
             if (SCHEME == 0) {
-                const T ax = ux * xdiv<DM>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx, G);
-                const T ay = uy * xdiv<DM>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx, G);
+                const T ax = ux * xdiv<DM>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx, k.r_dx, G);
+                const T ay = uy * xdiv<DM>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx, k.r_dx, G);
                 adv = ax + ay;
             } else {
                 // cells i+2 / i-2 of the row: inside the quad, or one of the two DPP'd neighbours; at the domain edge sample() clamps
@@ -1747,24 +1745,24 @@ __device__ __forceinline__ bool mac_update_quad_tile(Grid g, Konst<T> k, int nbx
                 T w0 = nx ? (T)-2 : (T)1, w1 = nx ? (T)10 : (T)-2, w2 = nx ? (T)-9 : (T)9, w3 = nx ? (T)2 : (T)-10, w4 = nx ? (T)-1 : (T)2;
                 T acc = fEE * w0;
                 acc = acc + fE * w1; acc = acc + f0 * w2; acc = acc + fW * w3; acc = acc + fWW * w4;
-                const T a = cdiv<DM>(acc, k.six_dx, k.inv_six_dx, G);
+                const T a = cdiv<DM>(acc, k.six_dx, k.inv_six_dx, k.r_six_dx, G);
                 const bool ny = uy < (T)0;
                 w0 = ny ? (T)-2 : (T)1; w1 = ny ? (T)10 : (T)-2; w2 = ny ? (T)-9 : (T)9; w3 = ny ? (T)2 : (T)-10; w4 = ny ? (T)-1 : (T)2;
                 acc = V[c][R + 2 > NR - 1 ? NR - 1 : R + 2].a[q] * w0;
                 acc = acc + fN * w1; acc = acc + f0 * w2; acc = acc + fS * w3; acc = acc + V[c][R - 2 < 0 ? 0 : R - 2].a[q] * w4;
-                const T b = cdiv<DM>(acc, k.six_dx, k.inv_six_dx, G);
+                const T b = cdiv<DM>(acc, k.six_dx, k.inv_six_dx, k.r_six_dx, G);
                 adv = ux * a + uy * b;
             }
             T gp;
             if (c == 0) {
                 const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
-                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, G);
+                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx, G);
             } else {
-                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, G);
+                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, k.r_dx, G);
             }
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, G);
-            const T d2y = xdiv<DM>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq, G);
-            const T lap = cdiv<DM>(d2x + d2y, k.re, k.inv_re, G);
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
+            const T d2y = xdiv<DM>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
+            const T lap = cdiv<DM>(d2x + d2y, k.re, k.inv_re, k.r_re, G);
             O[c].a[q] = f0 + k.dt * (((-adv) - gp) + lap);
         }
     }
@@ -1852,15 +1850,15 @@ __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst
         for (int q = 0; q < 4; ++q) {
             const T f0 = row.a[q];
             const T fE = q == 3 ? r : row.a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : row.a[q == 0 ? 0 : q - 1];
-            const T d2x = xdiv<P2 ? DM_P2 : DM_IEEE>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, G);
-            const T d2y = xdiv<P2 ? DM_P2 : DM_IEEE>((fN.a[q] - (T)2.0 * f0) + fS.a[q], k.dx_sq, k.inv_dx_sq, G);
+            const T d2x = xdiv<P2 ? DM_P2 : DM_IEEE>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
+            const T d2y = xdiv<P2 ? DM_P2 : DM_IEEE>((fN.a[q] - (T)2.0 * f0) + fS.a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
             const T dif = (d2x + d2y) / k.re;
             T gp;
             if (c == 0) {
                 const T pE = q == 3 ? pr : P[s + 1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[s + 1].a[q == 0 ? 0 : q - 1];
-                gp = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (pE - pW), k.dx, k.inv_dx, G);
+                gp = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx, G);
             } else {
-                gp = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (pN.a[q] - pS.a[q]), k.dx, k.inv_dx, G);
+                gp = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (pN.a[q] - pS.a[q]), k.dx, k.inv_dx, k.r_dx, G);
             }
             const T gg = (-gp) + dif;
             const T val = f0 + gg * k.dt;
@@ -1877,8 +1875,8 @@ __device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst
         const T cE = q == 3 ? cr : F[2].a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : F[2].a[q == 0 ? 0 : q - 1];
         const T sx = ((nE - cE) - nW) + cW;
         const T sy = ((N[2].a[q] - F[3].a[q]) - N[0].a[q]) + F[1].a[q];
-        OX.a[q] = GX.a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sx, k.two_dx, k.inv_two_dx, G);
-        OY.a[q] = GY.a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sy, k.two_dx, k.inv_two_dx, G);
+        OX.a[q] = GX.a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G);
+        OY.a[q] = GY.a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G);
     }
     if (lm.owner && nw[1]) {
 #pragma unroll
@@ -1956,9 +1954,9 @@ __device__ __forceinline__ bool cip_nonadv_dye_quad_tile(Grid g, Konst<T> k, int
         for (int q = 0; q < 4; ++q) {
             const T f0 = D[c][1].a[q];
             const T fE = q == 3 ? r : D[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : D[c][1].a[q == 0 ? 0 : q - 1];
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, G);
-            const T d2y = xdiv<DM>((D[c][2].a[q] - (T)2.0 * f0) + D[c][0].a[q], k.dx_sq, k.inv_dx_sq, G);
-            const T dif = cdiv<DM>(d2x + d2y, k.re, k.inv_re, G);
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
+            const T d2y = xdiv<DM>((D[c][2].a[q] - (T)2.0 * f0) + D[c][0].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
+            const T dif = cdiv<DM>(d2x + d2y, k.re, k.inv_re, k.r_re, G);
             O.a[q] = f0 + dif * k.dt;
         }
         if (DM & DM_RCP) {
@@ -2033,8 +2031,8 @@ __device__ __forceinline__ bool cip_advect_dye_tile(Grid g, Konst<T> k, int nbx,
             vx[q] = X1.a[q]; vy[q] = Y1.a[q];
             const T xE = q == 3 ? xr : X1.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : X1.a[q == 0 ? 0 : q - 1];
             const T yE = q == 3 ? yr : Y1.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : Y1.a[q == 0 ? 0 : q - 1];
-            dxx[q] = xdiv<DM>((T)0.5 * (xE - xW), k.dx, k.inv_dx, G); dxy[q] = xdiv<DM>((T)0.5 * (yE - yW), k.dx, k.inv_dx, G);
-            dyx[q] = xdiv<DM>((T)0.5 * (X2.a[q] - X0.a[q]), k.dx, k.inv_dx, G); dyy[q] = xdiv<DM>((T)0.5 * (Y2.a[q] - Y0.a[q]), k.dx, k.inv_dx, G);
+            dxx[q] = xdiv<DM>((T)0.5 * (xE - xW), k.dx, k.inv_dx, k.r_dx, G); dxy[q] = xdiv<DM>((T)0.5 * (yE - yW), k.dx, k.inv_dx, k.r_dx, G);
+            dyx[q] = xdiv<DM>((T)0.5 * (X2.a[q] - X0.a[q]), k.dx, k.inv_dx, k.r_dx, G); dyy[q] = xdiv<DM>((T)0.5 * (Y2.a[q] - Y0.a[q]), k.dx, k.inv_dx, k.r_dx, G);
         }
     }
 #pragma unroll 1

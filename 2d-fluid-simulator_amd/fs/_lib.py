@@ -61,6 +61,7 @@ _PROTOS = {
     "fs_jacobi_sweep_lazy": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_jacobi_pair_lazy": [_c_vp, _c_vp, _c_vp, _c_vp, _c_int] + _ROWS,
     "fs_lazy_flags": [_c_vp, _c_vp, _c_int, _P(_c_int), _P(_c_int), _P(_c_int)],
+    "fs_selftest_f64div": [_c_vp, _c_dbl, _P(_c_int)],
     "fs_rbsor_pair_ok": [_c_vp, _P(_c_int)],
     "fs_rbsor_pair": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int] + _ROWS,
     "fs_rbsor_halfsweep_src": [_c_vp, _c_dbl, _c_int, _c_vp, _c_vp, _c_vp] + _ROWS,

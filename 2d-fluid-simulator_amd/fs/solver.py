@@ -140,6 +140,11 @@ class CipMacSolver(Solver):
             self.v.swap()
         self.pressure_updater.update(self.p, self.v.current)
         limit_field(self.v.current, VELOCITY_LIMIT)
+        if self._v_spare is not None and self._v_spare.static_id != 0:
+            # limit_field is the one kernel that rewrites wall cells nothing else touches (uploaded data above the limit).  The fused
+            # transport pass relies on those cells being EQUAL in v.current and the spare buffer it writes next (it carries only what
+            # some kernel writes): limit the spare's copy of them the same way.  Only in runs that uploaded a velocity field.
+            limit_field(self._v_spare, VELOCITY_LIMIT)
 
     def update(self):
         self._flow_step()
@@ -218,6 +223,8 @@ class DyeCipMacSolver(CipMacSolver):
             self._dev.clamp_inflow(0.0, 1.0, self.dye.current)
         else:
             clamp_field(self.dye.current, 0.0, 1.0)
+            if self._dye_spare is not None:      # (wall cells of an uploaded dye: clamped in both copies, see _flow_step)
+                clamp_field(self._dye_spare, 0.0, 1.0)
 
     def get_fields(self):
         return self.v.current, self.p.current, self.dye.current

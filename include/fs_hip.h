@@ -185,6 +185,12 @@ int fs_lazy_flags(fs_ctx *ctx, uint8_t *out, int capacity, int *wave_columns, in
  * applies the recipes that read the row below / above (pays on masks with staircase outlines, costs a few percent elsewhere; same bits).
  * Both buffers are read 4 rows beyond the written range, src 2 rows.                                                                  */
 int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int mode, int row_begin, int row_end);
+/* Diagnostic.  f32 runs divide by their loop-invariant divisors (dx, 2 dx, dx^2, dx^3, 6 dx, 8 dt, Re - the divisions of
+ * fs/differentiation.py:41-60, fs/solver.py:257-260, 304-313, fs/advection.py:46-58, fs/pressure_updater.py:37) as
+ * (float)((double)x * (1.0 / d)), which equals the IEEE quotient x / d for every f32 x (csrc/fs_device.h f64div).  This checks the
+ * identity on the device for one divisor: ~2^28 dividends (all significands of nine binades incl. the denormals, both signs, and
+ * arbitrary bit patterns); *mismatches must come back 0.                                                                        */
+int fs_selftest_f64div(fs_ctx *ctx, double divisor, int *mismatches);
 /* TWO red-black iterations - RedBlackSorPressureUpdater.update with n_iter = 2, fs/pressure_updater.py:86-96, which is what
  * fs/fluid_simulator.py:76-78 wires into every create() - and the two set_pressure_boundary_condition passes between them
  * (fs/boundary_condition.py:41-65) in ONE pass over HBM (build-side optimisation, same bits): (pc_out, pn_out) receive what the
