@@ -22,17 +22,6 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     return FS_ERR_HIP;
 }
 
-// ---- reciprocal-FMA division: exhaustive check of a divisor on the device (fs_device.h rdiv) -----------------------------------
-__global__ __launch_bounds__(256) static void k_verify_rcp(float d, float r, unsigned *bad)
-{
-    const unsigned m = blockIdx.x * 256u + threadIdx.x;          // all 2^23 significands of x in [1, 2): the sequence and the quotient
-    const float x = __uint_as_float(0x3f800000u | m);            // scale exactly with the exponent of x (range-checked in the kernels)
-    DivGuard G;
-    const float q = rdiv(x, d, r, G), t = x / d;
-    const float qn = rdiv(-x, d, r, G), tn = (-x) / d;
-    if (__float_as_uint(q) != __float_as_uint(t) || __float_as_uint(qn) != __float_as_uint(tn)) atomicOr(bad, 1u);
-}
-
 // ---- f64-multiply division (fs_device.h f64div): the identity checked ON THE DEVICE for one divisor -------------------------------
 // every significand of x in 9 binades (tiny, denormal quotients, huge), both signs, plus 2^24 arbitrary bit patterns (NaN compared as NaN)
 __global__ __launch_bounds__(256) static void k_verify_f64div(float d, double rd, unsigned *bad)
@@ -55,31 +44,6 @@ __global__ __launch_bounds__(256) static void k_verify_f64div(float d, double rd
         const bool same = __float_as_uint(q) == __float_as_uint(t) || (q != q && t != t);
         if (!same) atomicAdd(bad, 1u);
     }
-}
-
-bool rcp_verified(fs_ctx *ctx, float d, bool may_verify)
-{
-    static std::mutex mu;
-    static std::unordered_map<uint32_t, bool> cache;
-    uint32_t key;
-    memcpy(&key, &d, 4);
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    if (!may_verify) return false;
-    bool ok = false;
-    unsigned *flag = nullptr, h = 1u;
-    if (hipMalloc(&flag, sizeof(unsigned)) == hipSuccess) {
-        if (hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream) == hipSuccess) {
-            hipLaunchKernelGGL(k_verify_rcp, dim3(1u << 15), dim3(256), 0, ctx->stream, d, 1.0f / d, flag);
-            if (hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess)
-                ok = h == 0u;
-        }
-        hipFree(flag);
-    }
-    cache[key] = ok;
-    return ok;
 }
 
 // ---- launch helper: optional HIP-event pair around every launch (fs_prof_*) --------------------
@@ -190,7 +154,7 @@ static OvGrid ov_grid_n(const fs_ctx *c, int jb, int je, int rt)
 
 // Division-mode dispatch (fs_device.h DM_*): CALL(DM) is expanded for the modes a kernel family distinguishes.  f32 fields divide by their
 // loop-invariant divisors through the f64 multiplication (modes 4 / 5; FS_F64DIV=0: IEEE division, modes 0 / 1); power-of-two dx-derived
-// divisors by exact multiplication (bit 0).  The reciprocal-FMA modes (2, 3) survive for the MAC update only (FS_RCP=1, A/B).
+// divisors by exact multiplication (bit 0).
 #define FS_F32_ONLY(dm, bits, CALL, MODE) if constexpr (std::is_same<T, float>::value) { if (((dm) & 7) == (bits)) { CALL(MODE); break; } }
 #define FS_DMC(dm, CALL)      /* modes 0 / 4 : no dx-derived divisor                */ \
     do { FS_F32_ONLY(dm, 4, CALL, 4) CALL(0); } while (0)
@@ -198,8 +162,6 @@ static OvGrid ov_grid_n(const fs_ctx *c, int jb, int je, int rt)
     do { if ((dm) & 1) { CALL(1); break; } FS_F32_ONLY(dm, 4, CALL, 4) CALL(0); } while (0)
 #define FS_DMA(dm, CALL)      /* modes 0 / 1 / 4 / 5 : both kinds                   */ \
     do { FS_F32_ONLY(dm, 5, CALL, 5) FS_F32_ONLY(dm, 4, CALL, 4) if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
-#define FS_DMA_RCP(dm, CALL)  /* ... + the reciprocal-FMA modes 2 / 3               */ \
-    do { FS_F32_ONLY(dm, 3, CALL, 3) FS_F32_ONLY(dm, 2, CALL, 2) FS_F32_ONLY(dm, 5, CALL, 5) FS_F32_ONLY(dm, 4, CALL, 4) if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
 
 #define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, HV, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, list, nlist, zoff, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
@@ -217,31 +179,12 @@ static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, in
 template <bool SRC, typename T>
 static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
 {
-    // overlapped-wave register tiles of 1, 2 or 4 rows (FS_JACOBI=21/22/24), 30 = LDS halo tile.  Default (0): the source-pair
+    // overlapped-wave register tiles of 1 - 4 rows (FS_JACOBI=21 .. 24).  Default (0): the source-pair
     // form streams best with 1-row tiles at 8 waves/SIMD (76 vs 79 us), the v-reading form with 2-row tiles (89 vs 95 us)
     const int v = ctx->jacobi_variant ? ctx->jacobi_variant : (SRC ? 21 : 22);
-    if (v >= 100) {      // row-streaming form: FS_JACOBI = 100 * RING + rows per strip (e.g. 632 = ring of 6 slots, 32-row strips)
-        const int ring = v / 100, S = std::min(v % 100 ? v % 100 : 32, 62);
-        const int nwx = ctx->nwx, strips = (je - jb + S - 1) / S;       // S <= 62 (the activity masks are 64 bits)
-        const dim3 grid((nwx * strips + 3) / 4, 1, 1);
-        const uint8_t *act = ctx->d_rowact;
-        return launch(ctx, name, [=] {
-            if (ring == 4) hipLaunchKernelGGL((k_jacobi_stream<SRC, 4, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, nwx, S, jb, je, act, pn, pc, vs);
-            else if (ring == 5) hipLaunchKernelGGL((k_jacobi_stream<SRC, 5, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, nwx, S, jb, je, act, pn, pc, vs);
-            else if (ring == 8) hipLaunchKernelGGL((k_jacobi_stream<SRC, 8, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, nwx, S, jb, je, act, pn, pc, vs);
-            else hipLaunchKernelGGL((k_jacobi_stream<SRC, 6, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, nwx, S, jb, je, act, pn, pc, vs);
-        });
-    }
-    if (v == 30) {
-        constexpr int TY = 16;
-        const dim3 grid((ctx->X + 255) / 256, (je - jb + TY - 1) / TY, 1);
-        return launch(ctx, name, [=] {
-            hipLaunchKernelGGL((k_jacobi_lds<SRC, TY, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, jb, je, pn, pc, vs);
-        });
-    }
     const int rt = v == 24 ? 4 : (v == 21 ? 1 : (v == 23 ? 3 : 2));
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
-    const int dm = SRC ? 0 : dm_const(ctx, k, RCP_JACOBI);           // the source-pair form divides nothing
+    const int dm = SRC ? 0 : dm_const(ctx, k);           // the source-pair form divides nothing
 #define FS_JAC(DM) do { \
         if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
         else if (rt == 3) hipLaunchKernelGGL((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
@@ -594,11 +537,8 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e == hipSuccess) e = hipMemsetAsync(c->d_mask, 1, (size_t)c->rows * c->Pm, c->stream);   // never the null stream: see upload_ops
     if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
     c->nwx = (nx / 4 + 61) / 62;
-    if (e == hipSuccess) e = hipMalloc(&c->d_rowact, (size_t)std::max(c->nwx, 1) * c->rows);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_rowact, 0, (size_t)std::max(c->nwx, 1) * c->rows, c->stream);
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
-    if (const char *s = getenv("FS_RCP")) c->use_rcp = atoi(s);
     if (const char *s = getenv("FS_F64DIV")) c->use_f64div = atoi(s) != 0;
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
@@ -606,9 +546,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_RBSOR_RT")) { const int v = atoi(s); if (v >= 2 && v <= 4) c->rbsor_rt = v; }
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
-    if (const char *s = getenv("FS_RBPAIR_N")) { const int v = atoi(s); if (v == 2 || v == 4) c->rbpair_n = v; }
-    if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s) != 0;
-    if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); c->k34_rt = v == 2 || v == 3 ? v : (v >= 4 ? 4 : 0); }
+    if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); if (v >= 2) c->k34_rt = v == 2 || v == 3 ? v : 4; }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
@@ -641,7 +579,6 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_bc_dye) hipFree(ctx->d_bc_dye);
     if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->d_acc) hipFree(ctx->d_acc);
-    if (ctx->d_rowact) hipFree(ctx->d_rowact);
     if (ctx->d_bcmap) hipFree(ctx->d_bcmap);
     if (ctx->d_lazyflags) hipFree(ctx->d_lazyflags);
     if (ctx->d_pairlist) hipFree(ctx->d_pairlist);
@@ -730,8 +667,7 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     rc = upload_global(ctx, ctx->d_bcmap, 1, 1, ctx->h_bcmap.data(), ctx->Pm);
     std::vector<uint8_t>().swap(ctx->h_bcmap);
     if (rc) return rc;
-    if (ctx->X % 4 == 0) {      // row-activity map of the row-streaming kernels; per-tile flags of the lazy pressure BC
-        hipLaunchKernelGGL(k_row_activity, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_rowact);
+    if (ctx->X % 4 == 0) {      // per-tile flags of the lazy pressure BC
         hipLaunchKernelGGL(k_lazy_flags, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_bcmap, ctx->d_lazyflags);
         FS_HIP(hipGetLastError());
         // the rows the two-sweep kernel hands to its general path: list + count (read back once per mask)
@@ -962,7 +898,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
 #define FS_K2M_UP(DM) FS_K2M(0, DM)
 #define FS_K2M_KK(DM) FS_K2M(1, DM)
-                if (scheme == FS_UPWIND) FS_DMA_RCP(dm_all(ctx, k, RCP_MAC), FS_K2M_UP); else FS_DMA_RCP(dm_all(ctx, k, RCP_MAC), FS_K2M_KK);
+                if (scheme == FS_UPWIND) FS_DMA(dm_all(ctx, k), FS_K2M_UP); else FS_DMA(dm_all(ctx, k), FS_K2M_KK);
             });
         }
         if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_update_upwind", (k_mac_update<0, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot) }
@@ -1012,7 +948,7 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, "cip_nonadv", [=] {
 #define FS_K2Q(DM) hipLaunchKernelGGL((k_cip_nonadv_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
-                FS_DMA(dm_all(ctx, k, 0), FS_K2Q);
+                FS_DMA(dm_all(ctx, k), FS_K2Q);
             });
         }
         if (k.p2) { FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<true, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot) }
@@ -1032,7 +968,7 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, "cip_nonadv_dye", [=] {
 #define FS_K12Q(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
-                FS_DMA(dm_all(ctx, k, 0), FS_K12Q);
+                FS_DMA(dm_all(ctx, k), FS_K12Q);
             });
         }
         FS_LAUNCH_CELLS("cip_nonadv_dye", (k_cip_nonadv_dye<T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d)
@@ -1057,7 +993,7 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
             return launch(ctx, C == 2 ? "cip_nonadv_grad" : "cip_nonadv_grad_c3", [=] {
 #define FS_K3Q_V(DM) FS_K3Q(2, 2, DM)
 #define FS_K3Q_D(DM) FS_K3Q(3, 1, DM)
-                if (C == 2) FS_DMX(dm_dx(ctx, k, 0), FS_K3Q_V); else FS_DMX(dm_dx(ctx, k, 0), FS_K3Q_D);
+                if (C == 2) FS_DMX(dm_dx(ctx, k), FS_K3Q_V); else FS_DMX(dm_dx(ctx, k), FS_K3Q_D);
             });
         }
         if (C == 2 && k.p2) FS_K3(2, true, "cip_nonadv_grad")
@@ -1091,9 +1027,9 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
             if (ctx->use_march) {
 #define FS_K4Q_SELF(DM) FS_K4Q(2, 2, true, DM)
 #define FS_K4Q_OTHER(DM) FS_K4Q(2, 1, false, DM)
-                if (C == 2 && self) FS_DMX(dm_dx(ctx, k, 0), FS_K4Q_SELF);
-                else if (C == 2) FS_DMX(dm_dx(ctx, k, 0), FS_K4Q_OTHER);
-                else FS_DMX(dm_dx(ctx, k, 0), FS_K4D);
+                if (C == 2 && self) FS_DMX(dm_dx(ctx, k), FS_K4Q_SELF);
+                else if (C == 2) FS_DMX(dm_dx(ctx, k), FS_K4Q_OTHER);
+                else FS_DMX(dm_dx(ctx, k), FS_K4D);
             } else {
                 if (C == 2) { if (k.p2) FS_K4N(2, true); else FS_K4N(2, false); }
                 else { if (k.p2) FS_K4N(3, true); else FS_K4N(3, false); }
@@ -1102,8 +1038,6 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
     })
 }
 
-#define FS_K34(PP, EE) hipLaunchKernelGGL((k_cip_grad_advect<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
-                (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
 int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
                               const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
 {
@@ -1118,7 +1052,7 @@ int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, f
         return launch(ctx, "cip_advect_c3_clamped", [=] {
 #define FS_K4DC(DM) hipLaunchKernelGGL((k_cip_advect_dye<DM, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
                                          (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-            FS_DMX(dm_dx(ctx, k, 0), FS_K4DC);
+            FS_DMX(dm_dx(ctx, k), FS_K4DC);
         });
     })
 }
@@ -1138,35 +1072,6 @@ int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row
     })
 }
 
-#define FS_K23(PP, EE) hipLaunchKernelGGL((k_cip_nonadv_fused<PP, EE, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
-                (T *)fn->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, fn->hot)
-int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, fs_field *gx_out, fs_field *gy_out,
-                        const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(fn, 2); FS_FIELD(gx_out, 2); FS_FIELD(gy_out, 2); FS_FIELD(fc, 2); FS_FIELD(pc, 1); FS_FIELD(gxc, 2); FS_FIELD(gyc, 2);
-    FS_REQUIRE(fn != fc && gx_out != gxc && gy_out != gyc, "outputs must not alias inputs");
-    FS_REQUIRE(ctx->use_march, "the fused non-advection pass needs X % 4 == 0 (use the two-kernel form)");
-    FS_ROWS();
-    const Grid gg = ctx->grid();
-    const int in_lo = std::min(std::max(row_begin, gg.jlo + 2), row_end), in_hi = std::max(std::min(row_end, gg.jhi - 1), in_lo);
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, re);
-        auto run = [&](int jb, int je, bool edge) -> int {
-            if (jb >= je) return FS_OK;
-            const OvGrid og = ov_grid(ctx, jb, je, 1, 2, XCD_NONADV);
-            return launch(ctx, edge ? "cip_nonadv_fused_edge" : "cip_nonadv_fused", [=] {
-                if (k.p2) { if (edge) FS_K23(true, true); else FS_K23(true, false); }
-                else { if (edge) FS_K23(false, true); else FS_K23(false, false); }
-            });
-        };
-        int rc = run(row_begin, in_lo, true);
-        if (!rc) rc = run(in_lo, in_hi, false);
-        if (!rc) rc = run(in_hi, row_end, true);
-        return rc;
-    })
-}
-
 int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
                        const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end)
 {
@@ -1175,26 +1080,15 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
     FS_REQUIRE(v_out != fn && v_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
     FS_REQUIRE(ctx->use_march, "the fused gradient+advection pass needs X % 4 == 0 (use the two-kernel form)");
     FS_ROWS();
-    // rows within two rows of the domain's first / last row take the run-time-slot (EDGE) instantiation
     const Grid gg = ctx->grid();
-    const int in_lo = std::min(std::max(row_begin, gg.jlo + 2), row_end), in_hi = std::max(std::min(row_end, gg.jhi - 1), in_lo);
     FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        auto run = [&](int jb, int je, bool edge) -> int {
-            if (jb >= je) return FS_OK;
-            const OvGrid og = ov_grid(ctx, jb, je, 1, 2, XCD_ADVECT);
-            return launch(ctx, edge ? "cip_grad_advect_edge" : "cip_grad_advect", [=] {
-                if (k.p2) { if (edge) FS_K34(true, true); else FS_K34(true, false); }
-                else { if (edge) FS_K34(false, true); else FS_K34(false, false); }
-            });
-        };
-        // f32: register tiles of RT rows (env FS_K34_RT = 0 / 2 / 3 / 4).  With every row loaded clamped the 2-row tile needs 116 VGPRs (4 waves
-        // per SIMD; it was 130 -> 3 waves when the rows next to the domain edge had their own launches and the tiles unclamped addresses), the
-        // 3-row tile 146 (3 waves): 394 against 417 us at bc5 res 4096, 111 against 115 at bc2 res 1600.  f64: 256 VGPRs - the one-row form stays.
-        const int RT = sizeof(T) != 4 ? 0 : (ctx->k34_rt >= 0 ? ctx->k34_rt : 2);
-        if (RT > 1) {       // one launch for every row: the tiles load their rows clamped and skip what lies beyond row_end
+        if constexpr (sizeof(T) != 4) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
+        else {
+            auto k = make_konst<T>(ctx, dt, dx, 1.0);
+            // register tiles of RT rows (env FS_K34_RT = 2 / 3 / 4), one launch for every row: the tiles load their rows clamped and skip what
+            // lies beyond row_end.  2 rows: 116 VGPRs = 4 waves per SIMD; 3 rows: 146 (3 waves) - 394 against 417 us at bc5 res 4096.
+            const int RT = ctx->k34_rt >= 2 ? ctx->k34_rt : 2;
             const int jb = row_begin, je = row_end;
-            if (jb >= je) return FS_OK;
             const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT);
 #define FS_K34RT(R, DM) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, DM, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, \
@@ -1202,16 +1096,11 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
 #define FS_K34RT2(DM) FS_K34RT(2, DM)
 #define FS_K34RT3(DM) FS_K34RT(3, DM)
 #define FS_K34RT4(DM) FS_K34RT(4, DM)
-            const int dm = dm_dx(ctx, k, 0);
+            const int dm = dm_dx(ctx, k);
             return launch(ctx, "cip_grad_advect_rt", [=] {
                 if (RT == 2) FS_DMX(dm, FS_K34RT2); else if (RT == 3) FS_DMX(dm, FS_K34RT3); else FS_DMX(dm, FS_K34RT4);
             });
         }
-        int tiled_end = in_lo;
-        int rc = run(row_begin, in_lo, true);
-        if (!rc) rc = run(tiled_end, in_hi, false);
-        if (!rc) rc = run(in_hi, row_end, true);
-        return rc;
     })
 }
 
@@ -1237,7 +1126,7 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
                 (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, full)
 #define FS_K34D_C(DM) FS_K34D(DM, true)
 #define FS_K34D_N(DM) FS_K34D(DM, false)
-            const int dm = dm_dx(ctx, k, 0);
+            const int dm = dm_dx(ctx, k);
             return launch(ctx, "cip_grad_advect_dye", [=] { if (clamp01) FS_DMX(dm, FS_K34D_C); else FS_DMX(dm, FS_K34D_N); });
         }
     })
@@ -1287,7 +1176,7 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
     const dim3 grid = og.grid;
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
-        const int dm = dm_dx(ctx, k, 0);
+        const int dm = dm_dx(ctx, k);
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
 #define FS_VORT(RT, DM, ST) hipLaunchKernelGGL((k_vort_fused<RT, DM, ST, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
 #define FS_VORT_RT(DM, ST) do { if (rt == 5) FS_VORT(5, DM, ST); else if (rt == 6) FS_VORT(6, DM, ST); else if (rt == 3) FS_VORT(3, DM, ST); else FS_VORT(4, DM, ST); } while (0)
@@ -1425,9 +1314,9 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
 #define FS_RBF3(DM) FS_RBF_RT(3, DM)
 #define FS_RBF4(DM) FS_RBF_RT(4, DM)
         return launch(ctx, "rbsor_iteration", [=] {
-            if (rt == 3) FS_DMC(dm_const(ctx, k, 0), FS_RBF3);
-            else if (rt == 4) FS_DMC(dm_const(ctx, k, 0), FS_RBF4);
-            else FS_DMC(dm_const(ctx, k, 0), FS_RBF2);
+            if (rt == 3) FS_DMC(dm_const(ctx, k), FS_RBF3);
+            else if (rt == 4) FS_DMC(dm_const(ctx, k), FS_RBF4);
+            else FS_DMC(dm_const(ctx, k), FS_RBF2);
         });
     })
 }
@@ -1478,24 +1367,20 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     const Grid gg = ctx->grid();
     const int par0 = (gg.ybase + row_begin) & 1;
     auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-    const int dm = dm_const(ctx, k, 0);
-    // lanes of N cells, RT rows per tile; `split`: the tiles without / with a non-fluid cell within reach as two launches, each with
-    // its own register budget (fs_rbpair.h).  The carrying pass after an upload (full) is rare: one configuration.
-    const int n = full ? 2 : ctx->rbpair_n, rt = full ? 4 : ctx->rbpair_rt, split = full ? 0 : ctx->rbpair_split;
-    const OvGrid og = n == 4 ? ov_grid_n<4>(ctx, row_begin, row_end, rt) : ov_grid_n<2>(ctx, row_begin, row_end, rt);
-#define FS_RBP_K(N, RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<N, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
+    const int dm = dm_const(ctx, k);
+    // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 (FS_RBPAIR_RT=6: 6) rows per tile.  The carrying
+    // pass after an upload (full) is rare: one configuration.
+    const int rt = full ? 4 : ctx->rbpair_rt;
+    const OvGrid og = ov_grid_n<2>(ctx, row_begin, row_end, rt);
+#define FS_RBP_K(RT, PAR, DM, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, 2, FULL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
-#define FS_RBP_PAR(N, RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(N, RT, 1, DM, PATH, FULL); else FS_RBP_K(N, RT, 0, DM, PATH, FULL); } while (0)
-#define FS_RBP_DM(N, RT, PATH) do { if (dm & DM_F64) FS_RBP_PAR(N, RT, 4, PATH, false); else FS_RBP_PAR(N, RT, 0, PATH, false); } while (0)
-#define FS_RBP_PATH(PATH) do { \
-        if (full) FS_RBP_PAR(2, 4, 0, 2, true); \
-        else if (n == 4) FS_RBP_PAR(4, 4, 0, PATH, false); \
-        else if (rt == 6) FS_RBP_DM(2, 6, PATH); \
-        else FS_RBP_DM(2, 4, PATH); } while (0)
-    if (!split) return launch(ctx, "rbsor_pair", [=] { FS_RBP_PATH(2); });
-    int rc = launch(ctx, "rbsor_pair", [=] { FS_RBP_PATH(0); });
-    if (rc) return rc;
-    return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_PATH(1); });
+#define FS_RBP_PAR(RT, DM, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, FULL); else FS_RBP_K(RT, 0, DM, FULL); } while (0)
+#define FS_RBP_DM(RT) do { if (dm & DM_F64) FS_RBP_PAR(RT, 4, false); else FS_RBP_PAR(RT, 0, false); } while (0)
+    return launch(ctx, "rbsor_pair", [=] {
+        if (full) FS_RBP_PAR(4, 0, true);
+        else if (rt == 6) FS_RBP_DM(6);
+        else FS_RBP_DM(4);
+    });
 }
 
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc, const fs_field *src,

@@ -40,71 +40,35 @@ struct Konst {
     // x / d == x * (1/d) bit for bit (exact scaling); p2 switches those divisions to multiplications.
     int p2;
     T inv_dx, inv_two_dx, inv_dx_sq, inv_dx2_fold, inv_dx3_fold;
-    // Correctly rounded reciprocals RN(1/d) of the remaining loop-invariant divisors, and `rcp`: every divisor of this set (the
-    // dx-derived ones included) passed the exhaustive check that  q0 = x*r; e = fma(-q0, d, x); q = fma(e, r, q0)  equals the
-    // IEEE quotient x / d for all 2^23 significands of x (fs_api.hip rcp_verified; f32 only).  See rdiv() below.
-    int rcp;
-    T inv_six_dx, inv_eight_dt, inv_re;
     // RN64(1 / d) of every loop-invariant divisor d (as rounded to T), for the f64-multiply division below (f32 fields only)
     double r_dx, r_two_dx, r_dx_sq, r_dx2_fold, r_dx3_fold, r_six_dx, r_eight_dt, r_re;
 };
 
 // ---- division by loop-invariant divisors --------------------------------------------------------------------------------
-// HIP's IEEE f32 division expands to ~13 instructions (div_scale x2, rcp, 5 fma, div_fmas, div_fixup).  For a divisor d that
-// is constant over the launch three of them suffice: with r = RN(1/d), q0 = RN(x r), the remainder e = x - q0 d is exact in
-// an FMA and q = RN(q0 + e r) is the correctly rounded quotient (Markstein's division theorem; here additionally VERIFIED for
-// every significand of x on the device for each divisor actually used, fs_api.hip).  The identity needs x/d and e to be
-// normal numbers, so DivGuard tracks the smallest exponent among the dividends of a tile (zero is fine: the sign of a zero
-// quotient is taken from q0) and whether an output came out non-finite (inf / NaN dividends, overflow); a tile that saw
-// either is recomputed with the IEEE division before anything is stored - one wave-uniform branch per tile, never taken in
-// a healthy run.  Large finite dividends are exact as long as nothing overflows.
-// Mode bits of the kernels' DM template parameter:
-//   bit 0: the dx-derived divisors are powers of two  -> x * (1/d) is exact
-//   bit 1: reciprocal-FMA sequence for every other loop-invariant divisor (and for the dx-derived ones unless bit 0)
-//   bit 2: f64-multiply division for every loop-invariant divisor that is not covered by bit 0 (see f64div)
-constexpr int DM_IEEE = 0, DM_P2 = 1, DM_RCP = 2, DM_F64 = 4;
-struct DivGuard {
-    int emin;          // smallest binary exponent (frexp) among the dividends seen; zero, inf and NaN report 0
-    unsigned nonfin;   // an OUTPUT was inf / NaN (an inf dividend gives NaN here but inf in IEEE arithmetic; overflow of x * r likewise)
-    __device__ __forceinline__ DivGuard() : emin(0), nonfin(0u) {}
-    __device__ __forceinline__ void see(float x)
-    {
-        const int e = __builtin_amdgcn_frexp_expf(x);      // one instruction; 0 for +-0 (fine: the quotient is a zero of the right sign)
-        emin = e < emin ? e : emin;
-    }
-    __device__ __forceinline__ void out(float o) { nonfin |= (__float_as_uint(o) & 0x7f800000u) == 0x7f800000u ? 1u : 0u; }
-    __device__ __forceinline__ void see(double) {}
-    __device__ __forceinline__ void out(double) {}
-    // a dividend below 2^-60 in magnitude (denormals included): the remainder / the quotient may leave the normal range
-    __device__ __forceinline__ bool bad() const { return emin < -59 || nonfin != 0u; }
-};
-__device__ __forceinline__ float rdiv(float x, float d, float r, DivGuard &G)
-{
-    G.see(x);
-    const float q0 = x * r;
-    const float e = __builtin_fmaf(-q0, d, x);
-    const float q1 = __builtin_fmaf(e, r, q0);
-    // magnitude of q1, sign of q0 (x = -0 gives q1 = +0 but the quotient is -0): one v_bfi_b32
-    return __uint_as_float((__float_as_uint(q1) & 0x7fffffffu) | (__float_as_uint(q0) & 0x80000000u));
-}
-__device__ __forceinline__ double rdiv(double x, double d, double, DivGuard &) { return x / d; }   // f64: never selected (no exhaustive check)
+// HIP's IEEE f32 division expands to 11 instructions (div_scale x2, rcp, 5 fma, div_fmas, div_fixup); the kernels divide by a handful
+// of launch constants (dx, 2 dx, dx^2, dx^3, 6 dx, 8 dt, Re) up to 20 times per cell.  Two exact shortcuts, chosen per launch through
+// the kernels' DM template parameter:
+//   bit 0 (DM_P2):  the dx-derived divisors are powers of two (res 1024, 4096, 8192 ...) -> x * (1/d) is exact
+//   bit 2 (DM_F64): every other loop-invariant divisor through ONE f64 multiplication (f32 fields only), see f64div
+// DM_IEEE = neither: the plain division (f64 fields; FS_F64DIV=0 for the A/B).
+// (Round 2's reciprocal-FMA sequence with its range guard, redo path and exhaustive per-divisor check - bit 1 - is gone: the f64
+//  multiplication is shorter, needs no guard and measured faster everywhere, MAC update included: 176 against 208 / 194 us.)
+constexpr int DM_IEEE = 0, DM_P2 = 1, DM_F64 = 4;
 // The f32 quotient x / d through ONE f64 multiplication: with R = RN64(1 / d), RN32(RN64(x R)) == RN32(x / d) for EVERY f32 x (zeros
 // with their sign, denormals, infinities and NaN included) and every f32 d != 0: x R misses the real quotient by less than 2^-52
-// relative (R's rounding + the product's), while the quotient of two 24-bit numbers is either a 25-bit rounding boundary's exact value
-// or at least 2^-49 relative away from one - the argument that makes double rounding innocuous for division once the wide format has
-// 2 p + 2 bits (Figueroa) - and a boundary value x / d = m exactly means x = d m exactly, which the f64 product reproduces to within
-// half an f64 ulp of m, i.e. rounds to m.  3 instructions (v_cvt_f64_f32, v_mul_f64, v_cvt_f32_f64) against 11 of the IEEE division
-// sequence, no range guard, no redo path, no exhaustive per-divisor check (tests/test_f64div.py checks the identity anyway, against
-// numpy on all 2^23 significands of several binades and on random bit patterns for the divisors of several resolutions).
+// relative (R's rounding + the product's), while the quotient of two 24-bit numbers is either exactly a rounding boundary of the f32
+// grid or at least ~2^-49 relative away from one - the argument that makes double rounding innocuous for division once the wide format
+// has 2 p + 2 bits (Figueroa) - and a boundary value x / d = m exactly means x = d m exactly, which the f64 product reproduces to within
+// half an f64 ulp of m, i.e. rounds to m.  3 instructions (v_cvt_f64_f32, v_mul_f64, v_cvt_f32_f64) against 11, no range guard, no redo
+// path.  Checked anyway: tests/test_f64div.py (numpy: all 2^23 significands of several binades + random bit patterns, divisors of
+// several resolutions) and on the device (fs_selftest_f64div: ~2^28 dividends per divisor).
 __device__ __forceinline__ float f64div(float x, double rd) { return (float)((double)x * rd); }
 __device__ __forceinline__ double f64div(double x, double) { return x; }                    // f64 fields: never selected
 // x / d for a dx-derived divisor / for any other loop-invariant divisor
 template <int DM, typename T>
-__device__ __forceinline__ T xdiv(T x, T d, T inv_d, double rd, DivGuard &G)
-{ return (DM & DM_P2) ? x * inv_d : ((DM & DM_F64) ? f64div(x, rd) : ((DM & DM_RCP) ? rdiv(x, d, inv_d, G) : x / d)); }
+__device__ __forceinline__ T xdiv(T x, T d, T inv_d, double rd) { return (DM & DM_P2) ? x * inv_d : ((DM & DM_F64) ? f64div(x, rd) : x / d); }
 template <int DM, typename T>
-__device__ __forceinline__ T cdiv(T x, T d, T inv_d, double rd, DivGuard &G)
-{ return (DM & DM_F64) ? f64div(x, rd) : ((DM & DM_RCP) ? rdiv(x, d, inv_d, G) : x / d); }
+__device__ __forceinline__ T cdiv(T x, T d, double rd) { return (DM & DM_F64) ? f64div(x, rd) : x / d; }
 
 
 template <typename T> __device__ __forceinline__ T tmin(T a, T b);

@@ -70,14 +70,12 @@ struct fs_ctx {
     std::vector<uint8_t> h_bcmap;  // host copy between build_bc_ops and the upload
     bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
     bool rb_pair_ok = false;                 // mask admits the two-iteration red-black pass (fs_rbpair.h; decided in build_bc_ops)
-    int rbpair_rt = 4, rbpair_n = 2;         // rows per tile (env FS_RBPAIR_RT = 4, 6) and cells per lane (FS_RBPAIR_N = 2, 4) of that pass
-    bool rbpair_split = false;               // plain and boundary tiles as two launches (FS_RBPAIR_SPLIT; measured slower: both classify every tile)
+    int rbpair_rt = 4;                       // rows per tile of that pass (env FS_RBPAIR_RT = 4, 6)
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
     int vort_rt = 4;                         // rows per tile of the fused vorticity confinement (env FS_VORT_RT = 3 .. 6)
     int rbsor_rt = 3;                        // rows per tile of the fused red-black iteration (env FS_RBSOR_RT = 2, 3, 4)
     int pair_rt = 3;                         // rows per tile of the two-sweep kernel (env FS_PAIR_RT = 1 .. 4; 3: within 2 % of the best of 2 / 3 / 4 from res 1024 to 4096)
-    uint8_t *d_rowact = nullptr;   // [nwx][rows] row-activity map of the row-streaming kernels (fs_march.h k_row_activity)
     int nwx = 0;                   // wave columns of 62 quads across a row
     void *d_bc_const = nullptr, *d_bc_dye = nullptr;
     bool mask_set = false, bc_incomplete = false;
@@ -109,12 +107,6 @@ struct fs_ctx {
     std::vector<fs_field *> deferred_free;   // fs_field_free during a hipGraph capture: released when the capture ends
     // tuning knobs (env FS_MARCH=0: one-cell-per-lane kernels only)
     bool use_march = true;
-    // Kernel families that use the reciprocal-FMA division for loop-invariant divisors (fs_device.h rdiv; env FS_RCP = bit mask).
-    // HIP's IEEE f32 division is ~10 instructions here, the sequence + range guard 6: measured on MI355X it only pays where the
-    // kernel is issue-bound - Kawamura-Kuwahara MAC update 227 -> 207 us (8 divisions by 6dx / Re per cell) - and is neutral to
-    // slightly negative for the bandwidth-bound kernels (RB-SOR 136 -> 134, K2 116 -> 122, Jacobi 88 -> 91; K4 at a
-    // non-power-of-two dx 78 -> 105 us: 244 VGPRs).  Default: the MAC update only.
-    int use_rcp = 0;           // (round 3: off - the f64-multiply division below does the same without a guard; FS_RCP=1 for the A/B)
     bool use_f64div = true;    // env FS_F64DIV=0: IEEE division for the loop-invariant divisors of f32 runs (A/B; the results are the same)
     int k34_rt = -1;           // env FS_K34_RT: rows per register tile of the fused gradient-update + advection pass (0: one-row form; default 2)
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
@@ -122,7 +114,7 @@ struct fs_ctx {
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int stack_mask = 0;       // env FS_STACK: kernel families (XCD_* bits) launched with stacked workgroups
     bool pack_halo = true;    // env FS_PACK_HALO=0: one ncclSend/ncclRecv per field instead of one packed message per neighbour
-    int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default, 22 / 24 / 21 = overlapped-wave tiles of 2 / 4 / 1 rows, 30 = LDS tile
+    int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default, 21 / 22 / 23 / 24 = overlapped-wave tiles of 1 - 4 rows
 
     fs::Grid grid() const
     {
@@ -155,12 +147,6 @@ inline bool is_pow2(T x)
     return x > 0 && std::frexp(x, &e) == (T)0.5;
 }
 
-// f32: is  q0 = x*r; e = fma(-q0, d, x); q = fma(e, r, q0)  (r = RN(1/d)) bit-identical to x / d for EVERY significand of x on
-// this device?  Checked exhaustively by a kernel once per divisor value and cached (fs_api.hip).  `may_verify` = false (graph
-// capture in progress) answers from the cache only.
-bool rcp_verified(fs_ctx *ctx, float d, bool may_verify);
-inline bool rcp_verified(fs_ctx *, double, bool) { return false; }     // f64: 2^52 significands - keeps the IEEE division
-
 template <typename T>
 inline Konst<T> make_konst(fs_ctx *ctx, double dt, double dx, double re, double weight = 0.0, double omega = 0.0)
 {
@@ -182,33 +168,15 @@ inline Konst<T> make_konst(fs_ctx *ctx, double dt, double dx, double re, double 
     k.inv_dx_sq = (T)1 / k.dx_sq;
     k.inv_dx2_fold = (T)1 / k.dx2_fold;
     k.inv_dx3_fold = (T)1 / k.dx3_fold;
-    k.inv_six_dx = (T)1 / k.six_dx;
-    k.inv_eight_dt = (T)1 / k.eight_dt;
-    k.inv_re = (T)1 / k.re;
     k.r_dx = 1.0 / (double)k.dx; k.r_two_dx = 1.0 / (double)k.two_dx; k.r_dx_sq = 1.0 / (double)k.dx_sq; k.r_dx2_fold = 1.0 / (double)k.dx2_fold;
     k.r_dx3_fold = 1.0 / (double)k.dx3_fold; k.r_six_dx = 1.0 / (double)k.six_dx; k.r_eight_dt = 1.0 / (double)k.eight_dt; k.r_re = 1.0 / (double)k.re;
-    // reciprocal-FMA division (fs_device.h rdiv): every divisor of the set must be a normal number of moderate magnitude (the
-    // range check of the dividends assumes 2^-66 <= |d| <= 2^66) and must have passed the exhaustive check on the device
-    k.rcp = 0;
-    if (ctx && ctx->use_rcp != 0 && sizeof(T) == 4) {
-        const T ds[8] = {k.dx, k.two_dx, k.dx_sq, k.dx2_fold, k.dx3_fold, k.six_dx, k.eight_dt, k.re};
-        bool ok = true;
-        for (T d : ds) {
-            const double a = std::fabs((double)d);
-            ok = ok && a >= 0x1p-66 && a <= 0x1p66 && rcp_verified(ctx, d, !ctx->capturing);
-        }
-        k.rcp = ok ? 1 : 0;
-    }
     return k;
 }
 
-// division mode of a launch (fs_device.h): which kernels have which kinds of divisors decides how many modes they instantiate
-enum { RCP_MAC = 1, RCP_K2 = 2, RCP_K3 = 4, RCP_K4 = 8, RCP_RBSOR = 16, RCP_JACOBI = 32, RCP_DYE = 64, RCP_RBPAIR = 128 };
-template <typename T> inline bool rcp_on(const fs_ctx *c, const Konst<T> &k, int family) { return k.rcp && (c->use_rcp & family); }
+// division mode of a launch (fs_device.h DM_*): which kinds of divisors a kernel has decides how many modes it instantiates
 template <typename T> inline int f64_mode(const fs_ctx *c) { return sizeof(T) == 4 && c->use_f64div ? DM_F64 : DM_IEEE; }      // f32 fields: the f64-multiply division
-template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k, int f) { return (k.p2 ? DM_P2 : 0) | (rcp_on(c, k, f) ? DM_RCP : f64_mode<T>(c)); }   // dx-derived AND other divisors
-template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k, int) { return k.p2 ? DM_P2 : f64_mode<T>(c); }       // dx-derived divisors only
-template <typename T> inline int dm_const(const fs_ctx *c, const Konst<T> &, int) { return f64_mode<T>(c); }                    // no dx-derived divisor
-
+template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k) { return (k.p2 ? DM_P2 : 0) | f64_mode<T>(c); }   // dx-derived AND other divisors
+template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k) { return k.p2 ? DM_P2 : f64_mode<T>(c); }          // dx-derived divisors only
+template <typename T> inline int dm_const(const fs_ctx *c, const Konst<T> &) { return f64_mode<T>(c); }                      // no dx-derived divisor
 
 }  // namespace fs

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad(Grid g, Konst<T> k, int
 template <int DM, typename T>
 __device__ __forceinline__ void cip_point(const Konst<T> &k, T vx, T vy, T dxx, T dxy, T dyx, T dyy,
                                           T f00, T f0m, T fm0, T fmm, T fx00, T fxm0, T fx0m, T fy00, T fy0m, T fym0,
-                                          T &out_f, T &out_fx, T &out_fy, DivGuard &G)
+                                          T &out_f, T &out_fx, T &out_fy)
 {
     const T is = vx < (T)0.0 ? (T)-1 : (T)1;   // sign(0) = +1, fs/differentiation.py:12-14
     const T js = vy < (T)0.0 ? (T)-1 : (T)1;
@@ -170,13 +170,13 @@ __device__ __forceinline__ void cip_point(const Konst<T> &k, T vx, T vy, T dxx, 
     const T tmp1 = ((f00 - f0m) - fm0) + fmm;
     const T tmp2 = fm0 - f00;
     const T tmp3 = f0m - f00;
-    const T a = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2), i_s_denom, i_s_inv, i_s_r, G);
-    const T b = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3), j_s_denom, j_s_inv, j_s_r, G);
-    const T cc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv, j_s_r, G);
-    const T d = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv, i_s_r, G);
-    const T e = xdiv<DM>((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold, G);
-    const T f = xdiv<DM>((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold, G);
-    const T gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, is_dx_r, G);
+    const T a = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2), i_s_denom, i_s_inv, i_s_r);
+    const T b = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3), j_s_denom, j_s_inv, j_s_r);
+    const T cc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv, j_s_r);
+    const T d = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv, i_s_r);
+    const T e = xdiv<DM>((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold);
+    const T f = xdiv<DM>((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold);
+    const T gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, is_dx_r);
     out_f = (((((a * Xd + cc * Yd) + e) * Xd + gq * Yd) + fx00) * Xd + (((b * Yd + d * Xd) + f) * Yd + fy00) * Yd) + f00;
     const T Fx = ((((T)3.0 * a) * Xd + ((T)2.0 * cc) * Yd) + (T)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
     const T Fy = ((((T)3.0 * b) * Yd + ((T)2.0 * d) * Xd) + (T)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;
@@ -198,11 +198,10 @@ __global__ __launch_bounds__(256) void k_cip_advect(Grid g, Konst<T> k, int jb, 
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         T of, ofx, ofy;
-        DivGuard G;      // unused: the one-cell-per-lane kernels divide by IEEE division or exact multiplication only
         cip_point<P2 ? DM_P2 : DM_IEEE>(k, vx, vy, dxx, dxy, dyx, dyy,
                   at<C>(fc, g, c, i, j), smp<C>(fc, g, c, i, jm), smp<C>(fc, g, c, im, j), smp<C>(fc, g, c, im, jm),
                   at<C>(fxc, g, c, i, j), smp<C>(fxc, g, c, im, j), smp<C>(fxc, g, c, i, jm),
-                  at<C>(fyc, g, c, i, j), smp<C>(fyc, g, c, i, jm), smp<C>(fyc, g, c, im, j), of, ofx, ofy, G);
+                  at<C>(fyc, g, c, i, j), smp<C>(fyc, g, c, i, jm), smp<C>(fyc, g, c, im, j), of, ofx, ofy);
         fn[idx<C, T>(g, c, i, j)] = of;
         fxn[idx<C, T>(g, c, i, j)] = ofx;
         fyn[idx<C, T>(g, c, i, j)] = ofy;

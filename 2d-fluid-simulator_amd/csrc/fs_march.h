@@ -24,10 +24,6 @@ template <typename T> struct Quad;
 template <> struct Quad<float> { using type = float4; };
 template <> struct Quad<double> { using type = double4; };
 
-// an address the optimiser knows nothing about (same value): loads through it are not merged with earlier loads of the same data
-template <typename P>
-__device__ __forceinline__ P *opaque(P *p) { asm volatile("" : "+s"(p)); return p; }
-
 // value of the previous / next lane (undefined in lane 0 / lane 63: the caller patches those)
 __device__ __forceinline__ float lane_prev(float x)
 { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, false)); }   // wave_shr:1
@@ -115,11 +111,11 @@ __device__ __forceinline__ T predict_from(T pE, T pW, T pN, T pS, T s2, T s3)
 { return ((T)0.25 * (((pE + pW) + pN) + pS) + s2) - s3; }
 
 template <int DM, typename T>
-__device__ __forceinline__ void source_from(const Konst<T> &k, T vxE, T vxW, T vyE, T vyW, T vxN, T vxS, T vyN, T vyS, T &s2, T &s3, DivGuard &G)
+__device__ __forceinline__ void source_from(const Konst<T> &k, T vxE, T vxW, T vyE, T vyW, T vxN, T vxS, T vyN, T vyS, T &s2, T &s3)
 {
     T sxx = vxE - vxW, sxy = vyE - vyW, syx = vxN - vxS, syy = vyN - vyS;
     s2 = ((sxx * sxx + syy * syy) + (syx * sxy)) / (T)8.0;
-    s3 = cdiv<DM>(k.dx * (sxx + syy), k.eight_dt, k.inv_eight_dt, k.r_eight_dt, G);
+    s3 = cdiv<DM>(k.dx * (sxx + syy), k.eight_dt, k.r_eight_dt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -213,7 +209,7 @@ __device__ __forceinline__ T quad_right(const LaneMap &m, const typename Quad<T>
 // x / dx for the central differences: a true IEEE division unless dx is a power of two, where the
 // (exact) multiplication by 1/dx gives the same bits for a fraction of the instructions.
 template <int DM, typename T>
-__device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { DivGuard G; return xdiv<DM & (DM_P2 | DM_F64)>(x, k.dx, k.inv_dx, k.r_dx, G); }   // P2 only when k.p2
+__device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return xdiv<DM & (DM_P2 | DM_F64)>(x, k.dx, k.inv_dx, k.r_dx); }   // P2 only when k.p2
 
 // ------------------------------------------------------------------------------------------------
 // K5 + K6 fused: vorticity confinement in one pass (fs/vorticity_confinement.py:27-55).
@@ -335,7 +331,7 @@ struct Q4 {
 
 // one colour of one row: cells k with ((k + PAR) & 1) == COLOR ... relax from centre row C, neighbours M (j-1), P (j+1)
 template <int PAR, int COLOR, int DM, typename T>
-__device__ __forceinline__ void rb_relax_row(const Konst<T> &k, DivGuard &G, const LaneMap &lm, unsigned fluid,
+__device__ __forceinline__ void rb_relax_row(const Konst<T> &k, const LaneMap &lm, unsigned fluid,
                                              const Q4<T> &pm, const Q4<T> &pc, const Q4<T> &pp,     // pressure rows j-1, j, j+1
                                              const Q4<T> &xm, const Q4<T> &xc, const Q4<T> &xp,     // v.x rows
                                              const Q4<T> &ym, const Q4<T> &yc, const Q4<T> &yp,     // v.y rows
@@ -352,18 +348,17 @@ __device__ __forceinline__ void rb_relax_row(const Konst<T> &k, DivGuard &G, con
         const T xE = c == 3 ? xr : xc.a[c == 3 ? 3 : c + 1], xW = c == 0 ? xl : xc.a[c == 0 ? 0 : c - 1];
         const T yE = c == 3 ? yr : yc.a[c == 3 ? 3 : c + 1], yW = c == 0 ? yl : yc.a[c == 0 ? 0 : c - 1];
         T s2, s3;
-        source_from<DM>(k, xE, xW, yE, yW, xp.a[c], xm.a[c], yp.a[c], ym.a[c], s2, s3, G);
+        source_from<DM>(k, xE, xW, yE, yW, xp.a[c], xm.a[c], yp.a[c], ym.a[c], s2, s3);
         const T pred = predict_from(pE, pW, pp.a[c], pm.a[c], s2, s3);
         out.a[c] = k.om1 * pc.a[c] + k.om * pred;
     }
 }
 
 template <int RT, int DM, typename T>
-__device__ __forceinline__ bool rbsor_fused_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
+__device__ __forceinline__ void rbsor_fused_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
 {
-    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return false;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j0 = jb + by * RT;
@@ -375,7 +370,7 @@ __device__ __forceinline__ bool rbsor_fused_tile(Grid g, Konst<T> k, int nbx, in
         fl[r] = sel_fluid(mask_quad(g, i0, clampy(g, j0 - 1 + r)));
         if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
     }
-    if (!__any(any)) return false;
+    if (!__any(any)) return;
 
     Q4<T> PC[RT + 4], VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1 (clamped)
 #pragma unroll
@@ -395,8 +390,8 @@ __device__ __forceinline__ bool rbsor_fused_tile(Grid g, Konst<T> k, int nbx, in
         const int j = j0 - 1 + r;
         if (j < g.jlo || j > g.jhi) continue;    // virtual row outside the domain: never consumed
         const int par = (g.ybase + j) & 1;
-        if (par) rb_relax_row<1, 1, DM>(k, G, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
-        else     rb_relax_row<0, 1, DM>(k, G, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
+        if (par) rb_relax_row<1, 1, DM>(k, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
+        else     rb_relax_row<0, 1, DM>(k, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
     }
     // even pass on rows j0 .. j0+RT-1, in place on pnO; the clamped neighbour of the first / last domain row is the row itself.
     // All rows are relaxed BEFORE anything is stored: pn is input and output of this kernel, and a tile whose reciprocal divisions
@@ -411,35 +406,21 @@ __device__ __forceinline__ bool rbsor_fused_tile(Grid g, Konst<T> k, int nbx, in
         const Q4<T> ctr = PO[r];
         Q4<T> out = ctr;
         const int par = (g.ybase + j) & 1;
-        if (par) rb_relax_row<1, 0, DM>(k, G, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
-        else     rb_relax_row<0, 0, DM>(k, G, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
+        if (par) rb_relax_row<1, 0, DM>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
+        else     rb_relax_row<0, 0, DM>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
         OUT[r - 1] = out;
-        if (DM & DM_RCP) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) G.out(out.a[q]);
-        }
     }
-    if ((DM & DM_RCP) && __any(G.bad())) return true;
 #pragma unroll
     for (int r = 1; r <= RT; ++r) {
         const int j = j0 - 1 + r;
         if (j >= je) break;
         if (lm.owner && fl[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), OUT[r - 1].quad(), fl[r]);
     }
-    return false;
-}
-// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
-// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
-template <int RT, int DM, typename T>
-__device__ __forceinline__ void rbsor_fused_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
-{
-    rbsor_fused_tile<RT, DM_IEEE, T>(g, k, nbx, nby, jb, je, opaque(pn), opaque(pc), opaque(vc));
 }
 template <int RT, int DM, typename T>
 __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
 {
-    if (DM & DM_RCP) { if (rbsor_fused_tile<RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vc)) rbsor_fused_tile_redo<RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vc); }
-    else rbsor_fused_tile<RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vc);
+    rbsor_fused_tile<RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vc);
 }
 
 
@@ -452,18 +433,17 @@ __global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx
 // channel group (dye: 3 single-channel passes sharing the advecting velocity).
 // ------------------------------------------------------------------------------------------------
 template <int C, int NC, bool SELF, int DM, bool CLAMP01, typename T>
-__device__ __forceinline__ bool cip_advect_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+__device__ __forceinline__ void cip_advect_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
                                                          const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
 {
-    DivGuard G;
     int bx, by, cg;
-    if (!tile_coords<C / NC>(g, nbx, nby, jb, je, 1, bx, by, cg)) return false;   // bx: wave column, by: tile row, cg: channel group
+    if (!tile_coords<C / NC>(g, nbx, nby, jb, je, 1, bx, by, cg)) return;   // bx: wave column, by: tile row, cg: channel group
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j = jb + by;
     const int c0 = cg * NC;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
-    if (!__any(fl != 0u)) return false;
+    if (!__any(fl != 0u)) return;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
 
     Q4<T> F[NC][3], FX[NC][3], FY[NC][3];      // rows j-1, j, j+1
@@ -499,8 +479,8 @@ __device__ __forceinline__ bool cip_advect_quad_tile(Grid g, Konst<T> k, int nbx
         const bool nx = vx < (T)0.0, ny = vy < (T)0.0;       // upwind cell is E / N when the velocity is negative
         const T vxE = q == 3 ? vxr : VX[1].a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VX[1].a[q == 0 ? 0 : q - 1];
         const T vyE = q == 3 ? vyr : VY[1].a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VY[1].a[q == 0 ? 0 : q - 1];
-        const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx, G);
-        const T dyx = xdiv<DM>((T)0.5 * (VX[2].a[q] - VX[0].a[q]), k.dx, k.inv_dx, k.r_dx, G), dyy = xdiv<DM>((T)0.5 * (VY[2].a[q] - VY[0].a[q]), k.dx, k.inv_dx, k.r_dx, G);
+        const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx);
+        const T dyx = xdiv<DM>((T)0.5 * (VX[2].a[q] - VX[0].a[q]), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>((T)0.5 * (VY[2].a[q] - VY[0].a[q]), k.dx, k.inv_dx, k.r_dx);
         const int ru = ny ? 2 : 0;                             // row of the upwind cell
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -517,7 +497,7 @@ __device__ __forceinline__ bool cip_advect_quad_tile(Grid g, Konst<T> k, int nbx
             const T fy00 = FY[c][1].a[q], fy0m = ny ? FY[c][2].a[q] : FY[c][0].a[q], fym0 = nx ? fyE : fyW;
             (void)ru;
             cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
-                      OF[c].a[q], OFX[c].a[q], OFY[c].a[q], G);
+                      OF[c].a[q], OFX[c].a[q], OFY[c].a[q]);
         }
     }
     if (CLAMP01) {      // clamp_field(dye, 0, 1) (fs/solver.py:46-49) folded into the store of the advected value
@@ -525,13 +505,6 @@ __device__ __forceinline__ bool cip_advect_quad_tile(Grid g, Konst<T> k, int nbx
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) OF[c].a[q] = tmin(tmax(OF[c].a[q], (T)0.0), (T)1.0);
-    }
-    if (DM & DM_RCP) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { G.out(OF[c].a[q]); G.out(OFX[c].a[q]); G.out(OFY[c].a[q]); }
-        if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
     }
     if (lm.owner && fl) {
         if (C == 2) {       // the advected field is a velocity: keep its "hot" flag honest (per component when the pass holds one)
@@ -546,22 +519,12 @@ __device__ __forceinline__ bool cip_advect_quad_tile(Grid g, Konst<T> k, int nbx
             store_quad_sel<T>(fyn + idx<C, T>(g, c0 + c, i0, j), OFY[c].quad(), fl);
         }
     }
-    return false;
-}
-// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
-// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
-template <int C, int NC, bool SELF, int DM, bool CLAMP01, typename T>
-__device__ __forceinline__ void cip_advect_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
-                                                         const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
-{
-    cip_advect_quad_tile<C, NC, SELF, DM & DM_P2, CLAMP01, T>(g, k, nbx, nby, jb, je, opaque(fn), opaque(fxn), opaque(fyn), opaque(fc), opaque(fxc), opaque(fyc), opaque(v), hot);
 }
 template <int C, int NC, bool SELF, int DM, bool CLAMP01, typename T>
 __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
                                                          const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
 {
-    if (DM & DM_RCP) { if (cip_advect_quad_tile<C, NC, SELF, DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot)) cip_advect_quad_tile_redo<C, NC, SELF, DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot); }
-    else cip_advect_quad_tile<C, NC, SELF, DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot);
+    cip_advect_quad_tile<C, NC, SELF, DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot);
 }
 
 
@@ -570,15 +533,14 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
 // and p are requested up front; not-wall cells get  fn = fc + ((-grad p) + lap(fc)/re) * dt.
 // ------------------------------------------------------------------------------------------------
 template <int DM, typename T>
-__device__ __forceinline__ bool cip_nonadv_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
+__device__ __forceinline__ void cip_nonadv_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
 {
-    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
-    if (!__any(nw != 0u)) return false;
+    if (!__any(nw != 0u)) return;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> F[2][3], P[3];
 #pragma unroll
@@ -593,41 +555,31 @@ __device__ __forceinline__ bool cip_nonadv_quad_tile(Grid g, Konst<T> k, int nbx
         for (int q = 0; q < 4; ++q) {
             const T fE = q == 3 ? r : F[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : F[c][1].a[q == 0 ? 0 : q - 1];
             const T f0 = F[c][1].a[q];
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
-            const T d2y = xdiv<DM>((F[c][2].a[q] - (T)2.0 * f0) + F[c][0].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
-            const T dif = cdiv<DM>(d2x + d2y, k.re, k.inv_re, k.r_re, G);
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const T d2y = xdiv<DM>((F[c][2].a[q] - (T)2.0 * f0) + F[c][0].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const T dif = cdiv<DM>(d2x + d2y, k.re, k.r_re);
             T gp;
             if (c == 0) {
                 const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
-                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx, G);
+                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx);
             } else {
-                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, k.r_dx, G);
+                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, k.r_dx);
             }
             const T gg = (-gp) + dif;
             O[c].a[q] = f0 + gg * k.dt;
         }
     }
-    if ((DM & DM_RCP) && __any(G.bad())) return true;      // a dividend outside the range the reciprocal division is exact for: redo
     if (lm.owner && nw) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) raise_hot(hot, ((nw >> q) & 1u) && hot2(O[0].a[q], O[1].a[q]));
         store_quad_sel<T>(fn + idx<2, T>(g, 0, i0, j), O[0].quad(), nw);
         store_quad_sel<T>(fn + idx<2, T>(g, 1, i0, j), O[1].quad(), nw);
     }
-    return false;
-}
-// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
-// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
-template <int DM, typename T>
-__device__ __forceinline__ void cip_nonadv_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
-{
-    cip_nonadv_quad_tile<DM & DM_P2, T>(g, k, nbx, nby, jb, je, opaque(fn), opaque(fc), opaque(pc), hot);
 }
 template <int DM, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
 {
-    if (DM & DM_RCP) { if (cip_nonadv_quad_tile<DM, T>(g, k, nbx, nby, jb, je, fn, fc, pc, hot)) cip_nonadv_quad_tile_redo<DM, T>(g, k, nbx, nby, jb, je, fn, fc, pc, hot); }
-    else cip_nonadv_quad_tile<DM, T>(g, k, nbx, nby, jb, je, fn, fc, pc, hot);
+    cip_nonadv_quad_tile<DM, T>(g, k, nbx, nby, jb, je, fn, fc, pc, hot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -635,16 +587,15 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int
 // Out-of-range neighbours are clamped (SURVEY.md H2 policy), as in the one-cell-per-lane kernel.
 // ------------------------------------------------------------------------------------------------
 template <int C, int NC, int DM, typename T>
-__device__ __forceinline__ bool cip_nonadv_grad_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
+__device__ __forceinline__ void cip_nonadv_grad_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
                                                               const T *fxc, const T *fyc, const T *fc, const T *fn)
 {
-    DivGuard G;
     int bx, by, cg;
-    if (!tile_coords<C / NC>(g, nbx, nby, jb, je, 1, bx, by, cg)) return false;   // bx: wave column, by: tile row, cg: channel group
+    if (!tile_coords<C / NC>(g, nbx, nby, jb, je, 1, bx, by, cg)) return;   // bx: wave column, by: tile row, cg: channel group
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by, c0 = cg * NC;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
-    if (!__any(nw != 0u)) return false;
+    if (!__any(nw != 0u)) return;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> N[NC][3], Fc[NC][3], GX[NC], GY[NC];
 #pragma unroll
@@ -665,35 +616,20 @@ __device__ __forceinline__ bool cip_nonadv_grad_quad_tile(Grid g, Konst<T> k, in
             const T cE = q == 3 ? cr : Fc[c][1].a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : Fc[c][1].a[q == 0 ? 0 : q - 1];
             const T sx = ((nE - cE) - nW) + cW;
             const T sy = ((N[c][2].a[q] - Fc[c][2].a[q]) - N[c][0].a[q]) + Fc[c][0].a[q];
-            OX.a[q] = GX[c].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G);
-            OY.a[q] = GY[c].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G);
-        }
-        if (DM & DM_RCP) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { G.out(OX.a[q]); G.out(OY.a[q]); }
-            if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
+            OX.a[q] = GX[c].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx);
+            OY.a[q] = GY[c].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx);
         }
         if (lm.owner && nw) {
             store_quad_sel<T>(fxn + idx<C, T>(g, c0 + c, i0, j), OX.quad(), nw);
             store_quad_sel<T>(fyn + idx<C, T>(g, c0 + c, i0, j), OY.quad(), nw);
         }
     }
-    return false;
-}
-// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
-// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
-template <int C, int NC, int DM, typename T>
-__device__ __forceinline__ void cip_nonadv_grad_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
-                                                              const T *fxc, const T *fyc, const T *fc, const T *fn)
-{
-    cip_nonadv_grad_quad_tile<C, NC, DM & DM_P2, T>(g, k, nbx, nby, jb, je, opaque(fxn), opaque(fyn), opaque(fxc), opaque(fyc), opaque(fc), opaque(fn));
 }
 template <int C, int NC, int DM, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fxn, T *fyn,
                                                               const T *fxc, const T *fyc, const T *fc, const T *fn)
 {
-    if (DM & DM_RCP) { if (cip_nonadv_grad_quad_tile<C, NC, DM, T>(g, k, nbx, nby, jb, je, fxn, fyn, fxc, fyc, fc, fn)) cip_nonadv_grad_quad_tile_redo<C, NC, DM, T>(g, k, nbx, nby, jb, je, fxn, fyn, fxc, fyc, fc, fn); }
-    else cip_nonadv_grad_quad_tile<C, NC, DM, T>(g, k, nbx, nby, jb, je, fxn, fyn, fxc, fyc, fc, fn);
+    cip_nonadv_grad_quad_tile<C, NC, DM, T>(g, k, nbx, nby, jb, je, fxn, fyn, fxc, fyc, fc, fn);
 }
 
 
@@ -716,127 +652,6 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k
 // uploaded gradient data.  The caller rotates (v.cur, v.next, spare) and swaps vx / vy once.
 //   fn = velocity after K2 (v.next), fc = velocity before K2 (v.cur), gxc/gyc = gradients before K3.
 // ------------------------------------------------------------------------------------------------
-// A[u] for a wave-uniform runtime u, as selects over by-value copies (a runtime index or a reference to the array would
-// force the whole register array into scratch)
-template <typename T>
-__device__ __forceinline__ Q4<T> pick5(Q4<T> a0, Q4<T> a1, Q4<T> a2, Q4<T> a3, Q4<T> a4, int u)
-{
-    Q4<T> r;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        r.a[q] = u == 0 ? a0.a[q] : (u == 1 ? a1.a[q] : (u == 2 ? a2.a[q] : (u == 3 ? a3.a[q] : a4.a[q])));
-    return r;
-}
-
-template <int c, bool P2, bool EDGE, typename T>
-__device__ __forceinline__ void cip_grad_advect_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
-                                                     T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                     const T *gxc, const T *gyc, unsigned *hot)
-{
-    DivGuard G;      // unused here: exact multiplication or IEEE division only
-    int bx, by, cg;
-    if (!tile_coords<2>(g, nbx, nby, jb, je, 1, bx, by, cg)) return;   // bx: wave column, by: tile row (cg == c: the wrapper picked this instantiation)
-    const LaneMap lm = lane_map_wave(g, bx);
-    const int i0 = lm.i0, j = jb + by;
-    constexpr int o = 1 - c;                        // c: this pass's component (compile time: runtime selection among the
-                                                    // register arrays below would push them to scratch), o: the other one
-    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1), jmm = clampy(g, j - 2), jpp = clampy(g, j + 2);
-
-    const uint32_t m_m = mask_quad(g, i0, jm), m_c = mask_quad(g, i0, j), m_p = mask_quad(g, i0, jp);
-    const unsigned nw[3] = {sel_not_wall(m_m), sel_not_wall(m_c), sel_not_wall(m_p)};
-    const unsigned fl = sel_fluid(m_c);
-    const bool act = lane_needed(fl);              // some fluid cell here or next door: the full stencil is needed
-
-    // velocity rows: this component j-2..j+2 of fn and fc; the other component of fn for rows j-1..j+1 (advecting velocity)
-    Q4<T> N[5], Fc[5], NO[3], GX[3], GY[3];
-    const int rows5[5] = {jmm, jm, j, jp, jpp};
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        N[r] = Q4<T>(load_quad_if<2>(act, fn, g, c, i0, rows5[r]));
-        Fc[r] = Q4<T>(load_quad_if<2>(act || r == 2, fc, g, c, i0, rows5[r]));     // row j of fc is always needed (carry)
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        NO[r] = Q4<T>(load_quad_if<2>(act, fn, g, o, i0, rows5[r + 1]));
-        GX[r] = Q4<T>(load_quad_if<2>(act || (r == 1 && nw[1] != 0u), gxc, g, c, i0, rows5[r + 1]));
-        GY[r] = Q4<T>(load_quad_if<2>(act || (r == 1 && nw[1] != 0u), gyc, g, c, i0, rows5[r + 1]));
-    }
-
-    Q4<T> OV = Fc[2], OX = GX[1], OY = GY[1];       // carry values; fluid cells are replaced below
-    if (__any(act)) {
-        // ---- K3 on rows j-1, j, j+1 (slot s <-> velocity slot s+1); wall cells keep the stored gradient ----
-        Q4<T> NX[3], NY[3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const Q4<T> &n1 = N[s + 1], &c1 = Fc[s + 1];
-            const T nl = quad_left<T>(lm, n1.quad()), nr = quad_right<T>(lm, n1.quad());
-            const T cl = quad_left<T>(lm, c1.quad()), cr = quad_right<T>(lm, c1.quad());
-            // sample()'s row neighbours of the row held in slot s+1.  Slot u holds row clamp(j-2+u); away from the domain's first /
-            // last two rows that is simply slots s and s+2.  Near the edge (clamped duplicates) the slot of row t is t-(j-2).
-            Q4<T> nS, nN, cS, cN;
-            if (!EDGE) { nS = N[s]; nN = N[s + 2]; cS = Fc[s]; cN = Fc[s + 2]; }
-            else {
-                const int jr = rows5[s + 1];
-                const int uS = clampy(g, jr - 1) - (j - 2), uN = clampy(g, jr + 1) - (j - 2);
-                nS = pick5(N[0], N[1], N[2], N[3], N[4], uS); nN = pick5(N[0], N[1], N[2], N[3], N[4], uN);
-                cS = pick5(Fc[0], Fc[1], Fc[2], Fc[3], Fc[4], uS); cN = pick5(Fc[0], Fc[1], Fc[2], Fc[3], Fc[4], uN);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const T nE = q == 3 ? nr : n1.a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : n1.a[q == 0 ? 0 : q - 1];
-                const T cE = q == 3 ? cr : c1.a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : c1.a[q == 0 ? 0 : q - 1];
-                const T sx = ((nE - cE) - nW) + cW;
-                const T sy = ((nN.a[q] - cN.a[q]) - nS.a[q]) + cS.a[q];
-                const bool live = (nw[s] >> q) & 1u;
-                NX[s].a[q] = live ? GX[s].a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GX[s].a[q];
-                NY[s].a[q] = live ? GY[s].a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GY[s].a[q];
-            }
-        }
-        // ---- K4 on row j ----
-        const Q4<T> &VXr = c == 0 ? N[2] : NO[1], &VYr = c == 0 ? NO[1] : N[2];                 // advecting velocity, row j
-        const Q4<T> &VXm = c == 0 ? N[1] : NO[0], &VXp = c == 0 ? N[3] : NO[2];                 // v.x rows j-1 / j+1
-        const Q4<T> &VYm = c == 0 ? NO[0] : N[1], &VYp = c == 0 ? NO[2] : N[3];
-        const T vxl = quad_left<T>(lm, VXr.quad()), vxr = quad_right<T>(lm, VXr.quad());
-        const T vyl = quad_left<T>(lm, VYr.quad()), vyr = quad_right<T>(lm, VYr.quad());
-        T fl_[3], fr_[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { fl_[r] = quad_left<T>(lm, N[r + 1].quad()); fr_[r] = quad_right<T>(lm, N[r + 1].quad()); }
-        const T fxl = quad_left<T>(lm, NX[1].quad()), fxr = quad_right<T>(lm, NX[1].quad());
-        const T fyl = quad_left<T>(lm, NY[1].quad()), fyr = quad_right<T>(lm, NY[1].quad());
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T vx = VXr.a[q], vy = VYr.a[q];
-            const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
-            const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
-            const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx, G), dxy = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx, G);
-            const T dyx = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx, G), dyy = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx, G);
-            const T fE1 = q == 3 ? fr_[1] : N[2].a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl_[1] : N[2].a[q == 0 ? 0 : q - 1];
-            const T fE0 = q == 3 ? fr_[0] : N[1].a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl_[0] : N[1].a[q == 0 ? 0 : q - 1];
-            const T fE2 = q == 3 ? fr_[2] : N[3].a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl_[2] : N[3].a[q == 0 ? 0 : q - 1];
-            const T fxE = q == 3 ? fxr : NX[1].a[q == 3 ? 3 : q + 1], fxW = q == 0 ? fxl : NX[1].a[q == 0 ? 0 : q - 1];
-            const T fyE = q == 3 ? fyr : NY[1].a[q == 3 ? 3 : q + 1], fyW = q == 0 ? fyl : NY[1].a[q == 0 ? 0 : q - 1];
-            const T f00 = N[2].a[q];
-            const T f0m = ny ? N[3].a[q] : N[1].a[q];
-            const T fm0 = nx ? fE1 : fW1;
-            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
-            const T fx00 = NX[1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[2].a[q] : NX[0].a[q];
-            const T fy00 = NY[1].a[q], fy0m = ny ? NY[2].a[q] : NY[0].a[q], fym0 = nx ? fyE : fyW;
-            T of, ofx, ofy;
-            cip_point<P2 ? DM_P2 : DM_IEEE>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy, G);
-            if ((fl >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
-        }
-    }
-    if (lm.owner) {
-        raise_hot(hot, hot1(OV.a[0]) || hot1(OV.a[1]) || hot1(OV.a[2]) || hot1(OV.a[3]));     // one component per pass: conservative
-        *reinterpret_cast<typename Quad<T>::type *>(vo + idx<2, T>(g, c, i0, j)) = OV.quad();     // every cell: result or carried value
-        if (nw[1]) {
-            store_quad_sel<T>(gxo + idx<2, T>(g, c, i0, j), OX.quad(), nw[1]);                  // fluid: result, inflow/outflow: carried
-            store_quad_sel<T>(gyo + idx<2, T>(g, c, i0, j), OY.quad(), nw[1]);
-        }
-    }
-}
-
 // The same fused pass on a register tile of RT rows (interior rows only: every row j0 - 2 .. j0 + RT + 1 lies inside the domain, so
 // no clamped duplicates).  The gradient update is evaluated for RT + 2 rows per RT output rows instead of 3 per 1 - at RT = 4 the
 // recompute overhead that made the one-row form issue-bound drops from 3x to 1.5x - and the five input planes are requested up front
@@ -847,7 +662,6 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
                                                         T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
                                                         const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
 {
-    DivGuard G;      // unused: exact multiplication, f64-multiply or IEEE division only
     int wx, ty, cg;
     if (!tile_coords<2>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
     const LaneMap lm = lane_map_wave(g, wx);
@@ -913,8 +727,8 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
             const T sx = ((nE - cE) - nW) + cW;
             const T sy = ((N[s + 2].a[q] - Fc[s + 2].a[q]) - N[s].a[q]) + Fc[s].a[q];
             const bool live = (nw[s] >> q) & 1u;
-            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GX[s].a[q];
-            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GY[s].a[q];
+            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx) : GX[s].a[q];
+            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx) : GY[s].a[q];
         }
     }
     // every row is loaded clamped (sample() clamps coordinates), so the rows at the domain's first / last row need no launch of their own:
@@ -946,8 +760,8 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
             const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
             const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
             const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx, G);
-            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx, G), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx, G);
+            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx);
+            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx);
             const T fE1 = q == 3 ? fr1 : Nc.a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
             const T fE0 = q == 3 ? fr0 : Nm.a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
             const T fE2 = q == 3 ? fr2 : Np.a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
@@ -960,7 +774,7 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
             const T fx00 = NX[t + 1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[t + 2].a[q] : NX[t].a[q];
             const T fy00 = NY[t + 1].a[q], fy0m = ny ? NY[t + 2].a[q] : NY[t].a[q], fym0 = nx ? fyE : fyW;
             T of, ofx, ofy;
-            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy, G);
+            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
             if ((fl[t] >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
         }
         if (lm.owner) {
@@ -995,7 +809,6 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
                                                          T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
                                                          const T *gxc, const T *gyc, const T *v, int full)
 {
-    DivGuard G;      // unused: exact multiplication, f64-multiply or IEEE division only
     int wx, ty, cg;
     if (!tile_coords<3>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
     const LaneMap lm = lane_map_wave(g, wx);
@@ -1059,8 +872,8 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
             const T sx = ((nE - cE) - nW) + cW;
             const T sy = ((N[s + 2].a[q] - Fc[s + 2].a[q]) - N[s].a[q]) + Fc[s].a[q];
             const bool live = (nw[s] >> q) & 1u;
-            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GX[s].a[q];
-            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G) : GY[s].a[q];
+            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx) : GX[s].a[q];
+            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx) : GY[s].a[q];
         }
     }
     // slots that stand for rows outside the domain: the K3 result of the edge row they clamp onto (wave-uniform)
@@ -1089,8 +902,8 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
             const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
             const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
             const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx, G), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx, G);
-            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx, G), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx, G);
+            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx);
+            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx);
             const T fE1 = q == 3 ? fr1 : Nc.a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
             const T fE0 = q == 3 ? fr0 : Nm.a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
             const T fE2 = q == 3 ? fr2 : Np.a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
@@ -1103,7 +916,7 @@ __device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Ko
             const T fx00 = NX[t + 1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[t + 2].a[q] : NX[t].a[q];
             const T fy00 = NY[t + 1].a[q], fy0m = ny ? NY[t + 2].a[q] : NY[t].a[q], fym0 = nx ? fyE : fyW;
             T of, ofx, ofy;
-            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy, G);
+            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
             if (CLAMP) of = tmin(tmax(of, (T)0.0), (T)1.0);
             if ((fl[t] >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
         }
@@ -1128,28 +941,16 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_dye(Grid g, Konst<T> k,
     else cip_grad_advect_dye_body<2, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
 }
 
-// EDGE = false: rows at least two rows away from the domain's first / last row (static register slots, branch-free);
-// EDGE = true: the up to four remaining rows, launched separately (run-time slot selection - slow, but 4 rows of 4096).
-template <bool P2, bool EDGE, typename T>
-__global__ __launch_bounds__(256) void k_cip_grad_advect(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
-                                                         T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                         const T *gxc, const T *gyc, unsigned *hot)
-{
-    if ((blockIdx.y & 1) == 0) cip_grad_advect_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
-    else cip_grad_advect_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot);
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // K8J  JacobiPressureUpdater._update (fs/pressure_updater.py:62-66), overlapped-wave register tile: x-neighbours of the wave-edge quads come
 // from halo lanes (DPP) instead of per-row edge loads, and blocks are dealt to the XCDs in groups of tile rows.
 // ------------------------------------------------------------------------------------------------
 template <bool SRC, int RT, int DM, typename T>
-__device__ __forceinline__ bool jacobi_ov_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
+__device__ __forceinline__ void jacobi_ov_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
 {
-    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return false;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0;
     const int j0 = jb + by * RT;
@@ -1161,7 +962,7 @@ __device__ __forceinline__ bool jacobi_ov_tile(Grid g, Konst<T> k, int nbx, int 
         sel[r] = j0 + r < je ? sel_not_wall(mask_quad(g, i0, j0 + r)) : 0u;
         any |= sel[r];
     }
-    if (!__any(any != 0u)) return false;
+    if (!__any(any != 0u)) return;
 
     Q4<T> P[RT + 2], VX[RT + 2], VY[RT + 2], S2[RT], S3[RT];
 #pragma unroll
@@ -1198,146 +999,18 @@ __device__ __forceinline__ bool jacobi_ov_tile(Grid g, Konst<T> k, int nbx, int 
                 const Q4<T> &xc = VX[r + 1], &yc = VY[r + 1];
                 const T xE = q == 3 ? xr : xc.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : xc.a[q == 0 ? 0 : q - 1];
                 const T yE = q == 3 ? yr : yc.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : yc.a[q == 0 ? 0 : q - 1];
-                source_from<DM>(k, xE, xW, yE, yW, VX[r + 2].a[q], VX[r].a[q], VY[r + 2].a[q], VY[r].a[q], s2, s3, G);
+                source_from<DM>(k, xE, xW, yE, yW, VX[r + 2].a[q], VX[r].a[q], VY[r + 2].a[q], VY[r].a[q], s2, s3);
             }
             const T pE = q == 3 ? pr : c.a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : c.a[q == 0 ? 0 : q - 1];
             o.a[q] = predict_from(pE, pW, n.a[q], m.a[q], s2, s3);
         }
-        if (DM & DM_RCP) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) G.out(o.a[q]);
-        }
-        if ((DM & DM_RCP) && __any(G.bad())) return true;      // (pn is not an input: rows already stored are exact and get rewritten identically)
         if (lm.owner && sel[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o.quad(), sel[r]);
     }
-    return false;
-}
-// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
-// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
-template <bool SRC, int RT, int DM, typename T>
-__device__ __forceinline__ void jacobi_ov_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
-{
-    jacobi_ov_tile<SRC, RT, DM_IEEE, T>(g, k, nbx, nby, jb, je, opaque(pn), opaque(pc), opaque(vs));
 }
 template <bool SRC, int RT, int DM, typename T>
 __global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vs)
 {
-    if (DM & DM_RCP) { if (jacobi_ov_tile<SRC, RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vs)) jacobi_ov_tile_redo<SRC, RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vs); }
-    else jacobi_ov_tile<SRC, RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vs);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// K8J, row-STREAMING form.  A wave owns a column strip of 62 quads x S rows and walks down it; every input row is requested
-// exactly once per strip, RING - 2 rows ahead of the row being relaxed, into a ring of RING row slots held in registers (the
-// loop is unrolled RING times, so every slot index is a compile-time constant and the ring never leaves the register file).
-// Against the register-TILE form above (RT output rows from RT + 2 input rows per field): 3 instead of 6 16-byte loads per
-// output row of the v-reading sweep, no vertical halo re-reads except the two rows a strip shares with its neighbours
-// (S = 32: 6 %), at the price of a longer dependent loop per wave - hidden by the RING - 3 rows (x 3 KiB per wave) that are
-// always in flight.  The first attempt at row marching (round 1: three rolling rows, nothing in flight beyond the next row)
-// was latency-bound; the prefetch ring is what was missing.  Same arithmetic, same bits.
-// ------------------------------------------------------------------------------------------------
-// Row-activity map for the row-streaming kernels: act[wx * rows + r] = bit 0: the 62 owner quads of wave column wx hold a
-// not-wall cell in local row r, bit 1: ... a fluid cell.  Built once per mask upload (fs_upload_mask).  A streaming wave reads
-// the bytes of its strip with one load per lane and turns them into two 64-bit scalar masks (ballot): skipping all-wall rows -
-// their compute AND the HBM traffic of the rows only they would need - is then pure scalar work.
-static __global__ __launch_bounds__(256) void k_row_activity(Grid g, int nwx, uint8_t *act)
-{
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wx = wid % nwx, r = wid / nwx;
-    if (r >= g.rows) return;
-    const int q = wx * 62 + lane;                       // owner quads only (lanes 62, 63 idle)
-    uint32_t m4 = 0x01010101u;
-    if (lane < 62 && q < (g.X >> 2)) m4 = mask_quad(g, q << 2, r);
-    const bool nw = sel_not_wall(m4) != 0u, fl = sel_fluid(m4) != 0u;
-    const unsigned a = (__any(nw) ? 1u : 0u) | (__any(fl) ? 2u : 0u);
-    if (lane == 0) act[(size_t)wx * g.rows + r] = (uint8_t)a;
-}
-
-// 64-bit activity masks of the rows j0 - 1 .. j0 + 62 of wave column wx (bit t <-> local row j0 - 1 + t; rows outside the slab: 0)
-__device__ __forceinline__ void strip_activity(const Grid &g, const uint8_t *act, int wx, int j0, unsigned long long &not_wall, unsigned long long &fluid)
-{
-    const int lane = threadIdx.x & 63, r = j0 - 1 + lane;
-    unsigned a = 0u;
-    if (r >= 0 && r < g.rows) a = act[(size_t)wx * g.rows + r];
-    not_wall = __ballot(a & 1u);
-    fluid = __ballot(a & 2u);
-}
-
-template <bool SRC, typename T>
-struct JacRow {
-    Q4<T> p, a, b;      // p; v.x, v.y (reads v) or s2, s3 (precomputed source pair)
-    uint32_t m;
-};
-
-template <bool SRC, typename T>
-__device__ __forceinline__ JacRow<SRC, T> jac_load_row(const Grid &g, const T *pc, const T *vs, int i0, int j)
-{
-    JacRow<SRC, T> r;
-    const int jc = clampy(g, j);
-    r.p = Q4<T>(load_quad<1>(pc, g, 0, i0, jc));
-    r.a = Q4<T>(load_quad<2>(vs, g, 0, i0, jc));
-    r.b = Q4<T>(load_quad<2>(vs, g, 1, i0, jc));
-    r.m = mask_quad(g, i0, jc);
-    return r;
-}
-
-template <bool SRC, int RING, typename T>
-__global__ __launch_bounds__(256) void k_jacobi_stream(Grid g, Konst<T> k, int nwx, int S, int jb, int je, const uint8_t *act, T *pn, const T *pc, const T *vs)
-{
-    const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int wx = wid % nwx, sy = wid / nwx;
-    const int j0 = jb + sy * S;
-    if (j0 >= je) return;
-    const int j1 = j0 + S < je ? j0 + S : je;
-    unsigned long long nwbits, flbits;
-    strip_activity(g, act, wx, j0, nwbits, flbits);            // bit t <-> row j0 - 1 + t
-    if (((nwbits >> 1) & ((1ull << (j1 - j0)) - 1ull)) == 0ull) return;      // no not-wall cell in the whole strip
-    const LaneMap lm = lane_map_wave(g, wx);
-    const int i0 = lm.i0;
-    const int jdummy = clampy(g, j0);
-    // row r is read by the relaxation of rows r - 1, r, r + 1: fetch it only if one of them has work, otherwise re-read a row that
-    // is already in cache (the load is still ISSUED: a branch around it would make the compiler drain the prefetch ring at the join)
-    auto row_or_dummy = [&](int r) { const int t = r - (j0 - 1); return ((t > 0 ? nwbits >> (t - 1) : nwbits << 1) & 7ull) ? r : jdummy; };
-
-    DivGuard G;                  // unused (IEEE division)
-    JacRow<SRC, T> R[RING];      // R[(r + 1) % RING] holds row j0 + r of the strip (slot 0: row j0 - 1)
-#pragma unroll
-    for (int r = 0; r < RING; ++r) R[r] = jac_load_row<SRC, T>(g, pc, vs, i0, row_or_dummy(j0 - 1 + r));
-
-    for (int jj = j0; jj < j1; jj += RING) {
-#pragma unroll
-        for (int u = 0; u < RING; ++u) {
-            const int j = jj + u;
-            if (j >= j1) break;
-            const JacRow<SRC, T> &rm = R[u], &rc = R[(u + 1) % RING], &rp = R[(u + 2) % RING];
-            if ((nwbits >> (j - (j0 - 1))) & 1ull) {
-                const unsigned sel = sel_not_wall(rc.m);
-                const T pl = quad_left<T>(lm, rc.p.quad()), pr = quad_right<T>(lm, rc.p.quad());
-                T xl = 0, xr = 0, yl = 0, yr = 0;
-                if (!SRC) {
-                    xl = quad_left<T>(lm, rc.a.quad()); xr = quad_right<T>(lm, rc.a.quad());
-                    yl = quad_left<T>(lm, rc.b.quad()); yr = quad_right<T>(lm, rc.b.quad());
-                }
-                Q4<T> o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    T s2, s3;
-                    if (SRC) { s2 = rc.a.a[q]; s3 = rc.b.a[q]; }
-                    else {
-                        const T xE = q == 3 ? xr : rc.a.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : rc.a.a[q == 0 ? 0 : q - 1];
-                        const T yE = q == 3 ? yr : rc.b.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : rc.b.a[q == 0 ? 0 : q - 1];
-                        source_from<DM_IEEE>(k, xE, xW, yE, yW, rp.a.a[q], rm.a.a[q], rp.b.a[q], rm.b.a[q], s2, s3, G);
-                    }
-                    const T pE = q == 3 ? pr : rc.p.a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : rc.p.a[q == 0 ? 0 : q - 1];
-                    o.a[q] = predict_from(pE, pW, rp.p.a[q], rm.p.a[q], s2, s3);
-                }
-                if (lm.owner && sel) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), o.quad(), sel);
-            }
-            // row j - 1 is done with: its slot takes row j - 1 + RING (needed RING - 2 steps from now)
-            R[u] = jac_load_row<SRC, T>(g, pc, vs, i0, j - 1 + RING <= j1 ? row_or_dummy(j - 1 + RING) : jdummy);
-        }
-    }
+    jacobi_ov_tile<SRC, RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vs);
 }
 
 
@@ -1695,17 +1368,16 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(Grid g, int nbx, int nby, i
 // Kawamura-Kuwahara (fs/advection.py:27-60, +-2 stencil: two DPP hops give the cells i0-2 .. i0+5 of a row).
 // ------------------------------------------------------------------------------------------------
 template <int SCHEME, int DM, typename T>
-__device__ __forceinline__ bool mac_update_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
+__device__ __forceinline__ void mac_update_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
 {
-    DivGuard G;
     constexpr int R = SCHEME == 0 ? 1 : 2;          // stencil radius
     constexpr int NR = 2 * R + 1;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
-    if (!__any(fl != 0u)) return false;
+    if (!__any(fl != 0u)) return;
     Q4<T> V[2][NR], P[3];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -1733,8 +1405,8 @@ __device__ __forceinline__ bool mac_update_quad_tile(Grid g, Konst<T> k, int nbx
             const T fN = V[c][R + 1].a[q], fS = V[c][R - 1].a[q];
             T adv;
             if (SCHEME == 0) {
-                const T ax = ux * xdiv<DM>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx, k.r_dx, G);
-                const T ay = uy * xdiv<DM>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx, k.r_dx, G);
+                const T ax = ux * xdiv<DM>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx, k.r_dx);
+                const T ay = uy * xdiv<DM>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx, k.r_dx);
                 adv = ax + ay;
             } else {
                 // cells i+2 / i-2 of the row: inside the quad, or one of the two DPP'd neighbours; at the domain edge sample() clamps
@@ -1745,31 +1417,26 @@ __device__ __forceinline__ bool mac_update_quad_tile(Grid g, Konst<T> k, int nbx
                 T w0 = nx ? (T)-2 : (T)1, w1 = nx ? (T)10 : (T)-2, w2 = nx ? (T)-9 : (T)9, w3 = nx ? (T)2 : (T)-10, w4 = nx ? (T)-1 : (T)2;
                 T acc = fEE * w0;
                 acc = acc + fE * w1; acc = acc + f0 * w2; acc = acc + fW * w3; acc = acc + fWW * w4;
-                const T a = cdiv<DM>(acc, k.six_dx, k.inv_six_dx, k.r_six_dx, G);
+                const T a = cdiv<DM>(acc, k.six_dx, k.r_six_dx);
                 const bool ny = uy < (T)0;
                 w0 = ny ? (T)-2 : (T)1; w1 = ny ? (T)10 : (T)-2; w2 = ny ? (T)-9 : (T)9; w3 = ny ? (T)2 : (T)-10; w4 = ny ? (T)-1 : (T)2;
                 acc = V[c][R + 2 > NR - 1 ? NR - 1 : R + 2].a[q] * w0;
                 acc = acc + fN * w1; acc = acc + f0 * w2; acc = acc + fS * w3; acc = acc + V[c][R - 2 < 0 ? 0 : R - 2].a[q] * w4;
-                const T b = cdiv<DM>(acc, k.six_dx, k.inv_six_dx, k.r_six_dx, G);
+                const T b = cdiv<DM>(acc, k.six_dx, k.r_six_dx);
                 adv = ux * a + uy * b;
             }
             T gp;
             if (c == 0) {
                 const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
-                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx, G);
+                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx);
             } else {
-                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, k.r_dx, G);
+                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, k.r_dx);
             }
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
-            const T d2y = xdiv<DM>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
-            const T lap = cdiv<DM>(d2x + d2y, k.re, k.inv_re, k.r_re, G);
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const T d2y = xdiv<DM>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const T lap = cdiv<DM>(d2x + d2y, k.re, k.r_re);
             O[c].a[q] = f0 + k.dt * (((-adv) - gp) + lap);
         }
-    }
-    if (DM & DM_RCP) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { G.out(O[0].a[q]); G.out(O[1].a[q]); }
-        if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
     }
     if (lm.owner && fl) {
 #pragma unroll
@@ -1777,122 +1444,11 @@ __device__ __forceinline__ bool mac_update_quad_tile(Grid g, Konst<T> k, int nbx
         store_quad_sel<T>(vn + idx<2, T>(g, 0, i0, j), O[0].quad(), fl);
         store_quad_sel<T>(vn + idx<2, T>(g, 1, i0, j), O[1].quad(), fl);
     }
-    return false;
-}
-// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
-// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
-template <int SCHEME, int DM, typename T>
-__device__ __forceinline__ void mac_update_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
-{
-    mac_update_quad_tile<SCHEME, DM & DM_P2, T>(g, k, nbx, nby, jb, je, opaque(vn), opaque(vc), opaque(pc), hot);
 }
 template <int SCHEME, int DM, typename T>
 __global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
 {
-    if (DM & DM_RCP) { if (mac_update_quad_tile<SCHEME, DM, T>(g, k, nbx, nby, jb, je, vn, vc, pc, hot)) mac_update_quad_tile_redo<SCHEME, DM, T>(g, k, nbx, nby, jb, je, vn, vc, pc, hot); }
-    else mac_update_quad_tile<SCHEME, DM, T>(g, k, nbx, nby, jb, je, vn, vc, pc, hot);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// K2 + K3 fused for the velocity field: non-advection phase (fs/solver.py:229-240) and the gradient update that consumes its
-// result on a 5-point stencil (fs/solver.py:242-261) in one pass, one component per launch slice (blockIdx.y).
-//   fn(cell) = not-wall ? fc + ((-grad p) + lap(fc)/re) dt : <stored fn>      (K2 leaves wall cells of the fn buffer untouched
-//                                                                              and K3 reads them as they are, H5)
-// is evaluated for rows j-1, j, j+1 of the lane's quad (halo recompute, 3x the cheap K2 arithmetic), row j is stored, and the
-// gradients of row j are updated from fn / fc of the four neighbours.  Saves K3's re-read of fn and fc: 56 instead of 70 B/cell.
-// Wall cells of fn are read-only here and not-wall cells are only written, so concurrent tiles never conflict.
-// ------------------------------------------------------------------------------------------------
-template <int c, bool P2, bool EDGE, typename T>
-__device__ __forceinline__ void cip_nonadv_fused_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
-                                                      T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc, unsigned *hot)
-{
-    DivGuard G;      // unused here: exact multiplication or IEEE division only
-    int bx, by, cg;
-    if (!tile_coords<2>(g, nbx, nby, jb, je, 1, bx, by, cg)) return;   // bx: wave column, by: tile row (cg == c: the wrapper picked this instantiation)
-    const LaneMap lm = lane_map_wave(g, bx);
-    const int i0 = lm.i0, j = jb + by;
-    const int rows5[5] = {clampy(g, j - 2), clampy(g, j - 1), j, clampy(g, j + 1), clampy(g, j + 2)};
-    const uint32_t m4[3] = {mask_quad(g, i0, rows5[1]), mask_quad(g, i0, rows5[2]), mask_quad(g, i0, rows5[3])};
-    const unsigned nw[3] = {sel_not_wall(m4[0]), sel_not_wall(m4[1]), sel_not_wall(m4[2])};
-    if (!__any(nw[1] != 0u)) return;
-    const bool need = lane_needed(nw[1]);
-
-    Q4<T> F[5], P[5], GX, GY, FNold[3];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        F[r] = Q4<T>(load_quad<2>(fc, g, c, i0, rows5[r]));
-        if (c == 1 || (r >= 1 && r <= 3)) P[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, rows5[r]));
-    }
-    GX = Q4<T>(load_quad_if<2>(nw[1] != 0u, gxc, g, c, i0, j));
-    GY = Q4<T>(load_quad_if<2>(nw[1] != 0u, gyc, g, c, i0, j));
-#pragma unroll
-    for (int s = 0; s < 3; ++s)      // stored fn only where this lane's quad has a wall cell in that row
-        FNold[s] = Q4<T>(load_quad_if<2>(need && nw[s] != 0xfu, fn, g, c, i0, rows5[s + 1]));
-
-    // ---- K2 on rows j-1, j, j+1 (slot s <-> row slot s+1) ----
-    Q4<T> N[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const Q4<T> &row = F[s + 1];
-        Q4<T> fS, fN, pS, pN;
-        if (!EDGE) { fS = F[s]; fN = F[s + 2]; if (c == 1) { pS = P[s]; pN = P[s + 2]; } }
-        else {
-            const int jr = rows5[s + 1];
-            const int uS = clampy(g, jr - 1) - (j - 2), uN = clampy(g, jr + 1) - (j - 2);
-            fS = pick5(F[0], F[1], F[2], F[3], F[4], uS); fN = pick5(F[0], F[1], F[2], F[3], F[4], uN);
-            if (c == 1) { pS = pick5(P[0], P[1], P[2], P[3], P[4], uS); pN = pick5(P[0], P[1], P[2], P[3], P[4], uN); }
-        }
-        const T l = quad_left<T>(lm, row.quad()), r = quad_right<T>(lm, row.quad());
-        T pl = 0, pr = 0;
-        if (c == 0) { pl = quad_left<T>(lm, P[s + 1].quad()); pr = quad_right<T>(lm, P[s + 1].quad()); }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T f0 = row.a[q];
-            const T fE = q == 3 ? r : row.a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : row.a[q == 0 ? 0 : q - 1];
-            const T d2x = xdiv<P2 ? DM_P2 : DM_IEEE>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
-            const T d2y = xdiv<P2 ? DM_P2 : DM_IEEE>((fN.a[q] - (T)2.0 * f0) + fS.a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
-            const T dif = (d2x + d2y) / k.re;
-            T gp;
-            if (c == 0) {
-                const T pE = q == 3 ? pr : P[s + 1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[s + 1].a[q == 0 ? 0 : q - 1];
-                gp = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx, G);
-            } else {
-                gp = xdiv<P2 ? DM_P2 : DM_IEEE>((T)0.5 * (pN.a[q] - pS.a[q]), k.dx, k.inv_dx, k.r_dx, G);
-            }
-            const T gg = (-gp) + dif;
-            const T val = f0 + gg * k.dt;
-            N[s].a[q] = ((nw[s] >> q) & 1u) ? val : FNold[s].a[q];
-        }
-    }
-    // ---- K3 on row j ----
-    const T nl = quad_left<T>(lm, N[1].quad()), nr = quad_right<T>(lm, N[1].quad());
-    const T cl = quad_left<T>(lm, F[2].quad()), cr = quad_right<T>(lm, F[2].quad());
-    Q4<T> OX, OY;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const T nE = q == 3 ? nr : N[1].a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : N[1].a[q == 0 ? 0 : q - 1];
-        const T cE = q == 3 ? cr : F[2].a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : F[2].a[q == 0 ? 0 : q - 1];
-        const T sx = ((nE - cE) - nW) + cW;
-        const T sy = ((N[2].a[q] - F[3].a[q]) - N[0].a[q]) + F[1].a[q];
-        OX.a[q] = GX.a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx, G);
-        OY.a[q] = GY.a[q] + xdiv<P2 ? DM_P2 : DM_IEEE>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx, G);
-    }
-    if (lm.owner && nw[1]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) raise_hot(hot, ((nw[1] >> q) & 1u) && hot1(N[1].a[q]));
-        store_quad_sel<T>(fn + idx<2, T>(g, c, i0, j), N[1].quad(), nw[1]);
-        store_quad_sel<T>(gxn + idx<2, T>(g, c, i0, j), OX.quad(), nw[1]);
-        store_quad_sel<T>(gyn + idx<2, T>(g, c, i0, j), OY.quad(), nw[1]);
-    }
-}
-
-template <bool P2, bool EDGE, typename T>
-__global__ __launch_bounds__(256) void k_cip_nonadv_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
-                                                          T *fn, T *gxn, T *gyn, const T *fc, const T *pc, const T *gxc, const T *gyc, unsigned *hot)
-{
-    if ((blockIdx.y & 1) == 0) cip_nonadv_fused_body<0, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc, hot);
-    else cip_nonadv_fused_body<1, P2, EDGE, T>(g, k, nbx, nby, jb, je, fn, gxn, gyn, fc, pc, gxc, gyc, hot);
+    mac_update_quad_tile<SCHEME, DM, T>(g, k, nbx, nby, jb, je, vn, vc, pc, hot);
 }
 
 
@@ -1929,15 +1485,14 @@ __global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, int je, T li
 // K12  DyeCipMacSolver._non_advection_phase_dye (fs/solver.py:378-383), quad form: dn = dc + (lap(dc)/re) dt on not-wall cells.
 // ------------------------------------------------------------------------------------------------
 template <int DM, typename T>
-__device__ __forceinline__ bool cip_nonadv_dye_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
+__device__ __forceinline__ void cip_nonadv_dye_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
 {
-    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
-    if (!__any(nw != 0u)) return false;
+    if (!__any(nw != 0u)) return;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
     Q4<T> D[3][3];
 #pragma unroll
@@ -1954,32 +1509,18 @@ __device__ __forceinline__ bool cip_nonadv_dye_quad_tile(Grid g, Konst<T> k, int
         for (int q = 0; q < 4; ++q) {
             const T f0 = D[c][1].a[q];
             const T fE = q == 3 ? r : D[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : D[c][1].a[q == 0 ? 0 : q - 1];
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
-            const T d2y = xdiv<DM>((D[c][2].a[q] - (T)2.0 * f0) + D[c][0].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq, G);
-            const T dif = cdiv<DM>(d2x + d2y, k.re, k.inv_re, k.r_re, G);
+            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const T d2y = xdiv<DM>((D[c][2].a[q] - (T)2.0 * f0) + D[c][0].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const T dif = cdiv<DM>(d2x + d2y, k.re, k.r_re);
             O.a[q] = f0 + dif * k.dt;
-        }
-        if (DM & DM_RCP) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) G.out(O.a[q]);
-            if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
         }
         if (lm.owner && nw) store_quad_sel<T>(dn + idx<3, T>(g, c, i0, j), O.quad(), nw);
     }
-    return false;
-}
-// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
-// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
-template <int DM, typename T>
-__device__ __forceinline__ void cip_nonadv_dye_quad_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
-{
-    cip_nonadv_dye_quad_tile<DM & DM_P2, T>(g, k, nbx, nby, jb, je, opaque(dn), opaque(dc));
 }
 template <int DM, typename T>
 __global__ __launch_bounds__(256) void k_cip_nonadv_dye_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
 {
-    if (DM & DM_RCP) { if (cip_nonadv_dye_quad_tile<DM, T>(g, k, nbx, nby, jb, je, dn, dc)) cip_nonadv_dye_quad_tile_redo<DM, T>(g, k, nbx, nby, jb, je, dn, dc); }
-    else cip_nonadv_dye_quad_tile<DM, T>(g, k, nbx, nby, jb, je, dn, dc);
+    cip_nonadv_dye_quad_tile<DM, T>(g, k, nbx, nby, jb, je, dn, dc);
 }
 
 // clamp_field restricted to the inflow cells (op list of the dye boundary kernel): with the clamp folded into the advection
@@ -2008,16 +1549,15 @@ __global__ __launch_bounds__(256) void k_clamp_inflow(Grid g, BcOps ops, int jb,
 // registers.  Replaces three single-channel launches slices that each re-read the velocity.
 // ------------------------------------------------------------------------------------------------
 template <int DM, bool CLAMP01, typename T>
-__device__ __forceinline__ bool cip_advect_dye_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
+__device__ __forceinline__ void cip_advect_dye_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
                                                         const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
 {
-    DivGuard G;
     int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return false;   // bx: wave column, by: tile row
+    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
     const LaneMap lm = lane_map_wave(g, bx);
     const int i0 = lm.i0, j = jb + by;
     const unsigned fl = sel_fluid(mask_quad(g, i0, j));
-    if (!__any(fl != 0u)) return false;
+    if (!__any(fl != 0u)) return;
     const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
 
     T vx[4], vy[4], dxx[4], dxy[4], dyx[4], dyy[4];
@@ -2031,8 +1571,8 @@ __device__ __forceinline__ bool cip_advect_dye_tile(Grid g, Konst<T> k, int nbx,
             vx[q] = X1.a[q]; vy[q] = Y1.a[q];
             const T xE = q == 3 ? xr : X1.a[q == 3 ? 3 : q + 1], xW = q == 0 ? xl : X1.a[q == 0 ? 0 : q - 1];
             const T yE = q == 3 ? yr : Y1.a[q == 3 ? 3 : q + 1], yW = q == 0 ? yl : Y1.a[q == 0 ? 0 : q - 1];
-            dxx[q] = xdiv<DM>((T)0.5 * (xE - xW), k.dx, k.inv_dx, k.r_dx, G); dxy[q] = xdiv<DM>((T)0.5 * (yE - yW), k.dx, k.inv_dx, k.r_dx, G);
-            dyx[q] = xdiv<DM>((T)0.5 * (X2.a[q] - X0.a[q]), k.dx, k.inv_dx, k.r_dx, G); dyy[q] = xdiv<DM>((T)0.5 * (Y2.a[q] - Y0.a[q]), k.dx, k.inv_dx, k.r_dx, G);
+            dxx[q] = xdiv<DM>((T)0.5 * (xE - xW), k.dx, k.inv_dx, k.r_dx); dxy[q] = xdiv<DM>((T)0.5 * (yE - yW), k.dx, k.inv_dx, k.r_dx);
+            dyx[q] = xdiv<DM>((T)0.5 * (X2.a[q] - X0.a[q]), k.dx, k.inv_dx, k.r_dx); dyy[q] = xdiv<DM>((T)0.5 * (Y2.a[q] - Y0.a[q]), k.dx, k.inv_dx, k.r_dx);
         }
     }
 #pragma unroll 1
@@ -2060,13 +1600,8 @@ __device__ __forceinline__ bool cip_advect_dye_tile(Grid g, Konst<T> k, int nbx,
             const T fx00 = FX[1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? FX[2].a[q] : FX[0].a[q];
             const T fy00 = FY[1].a[q], fy0m = ny ? FY[2].a[q] : FY[0].a[q], fym0 = nx ? fyE : fyW;
             cip_point<DM>(k, vx[q], vy[q], dxx[q], dxy[q], dyx[q], dyy[q], f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0,
-                          OF.a[q], OFX.a[q], OFY.a[q], G);
+                          OF.a[q], OFX.a[q], OFY.a[q]);
             if (CLAMP01) OF.a[q] = tmin(tmax(OF.a[q], (T)0.0), (T)1.0);     // clamp_field(dye, 0, 1), fs/solver.py:46-49
-        }
-        if (DM & DM_RCP) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { G.out(OF.a[q]); G.out(OFX.a[q]); G.out(OFY.a[q]); }
-            if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo
         }
         if (lm.owner && fl) {
             store_quad_sel<T>(fn + idx<3, T>(g, c, i0, j), OF.quad(), fl);
@@ -2074,98 +1609,13 @@ __device__ __forceinline__ bool cip_advect_dye_tile(Grid g, Konst<T> k, int nbx,
             store_quad_sel<T>(fyn + idx<3, T>(g, c, i0, j), OFY.quad(), fl);
         }
     }
-    return false;
-}
-// the IEEE-division redo of a tile.  The pointers pass through an empty asm so that the compiler cannot keep the fast path's loads
-// alive for it (K4 went from 152 to 244 VGPRs when it did); an out-of-line call is worse still (caller + callee registers).
-template <int DM, bool CLAMP01, typename T>
-__device__ __forceinline__ void cip_advect_dye_tile_redo(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
-                                                        const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
-{
-    cip_advect_dye_tile<DM & DM_P2, CLAMP01, T>(g, k, nbx, nby, jb, je, opaque(fn), opaque(fxn), opaque(fyn), opaque(fc), opaque(fxc), opaque(fyc), opaque(v), hot);
 }
 template <int DM, bool CLAMP01, typename T>
 __global__ __launch_bounds__(256) void k_cip_advect_dye(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, T *fxn, T *fyn,
                                                         const T *fc, const T *fxc, const T *fyc, const T *v, unsigned *hot)
 {
-    if (DM & DM_RCP) { if (cip_advect_dye_tile<DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot)) cip_advect_dye_tile_redo<DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot); }
-    else cip_advect_dye_tile<DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot);
+    cip_advect_dye_tile<DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot);
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// K8J with an LDS halo tile - the textbook GPU stencil form, kept as a measured ALTERNATIVE (env FS_JACOBI=30), not the
-// default: a 256-thread workgroup stages a (256+2) x (TY+2) tile of p (and of v.x, v.y when it reads v) in LDS with 16-byte
-// global loads, barriers, and every lane then relaxes a quad x TY/4 rows from LDS (ds_read_b128 for the rows above / below,
-// two ds_read_b32 for the side cells).  Same arithmetic, same bits.  On MI355X the LDS round trip + barrier cost more than
-// the DPP/register form (see DESIGN.md for the numbers); the 5-point stencil simply has too little reuse to pay for LDS.
-// ------------------------------------------------------------------------------------------------
-template <bool SRC, int TY, typename T>
-__global__ __launch_bounds__(256) void k_jacobi_lds(Grid g, Konst<T> k, int jb, int je, T *pn, const T *pc, const T *vs)
-{
-    using V = typename Quad<T>::type;
-    constexpr int NP = SRC ? 1 : 3;                 // planes staged: p [, v.x, v.y]
-    constexpr int W = 256 + 8;                      // tile row: 4 pad + 256 cells + 4 pad (keeps 16-byte alignment; halo cells at [3], [260])
-    __shared__ __attribute__((aligned(16))) T tile[NP][TY + 2][W];
-    DivGuard G;                                     // unused (IEEE division)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * 256;                // first cell of the tile
-    const int j0 = jb + blockIdx.y * TY;
-    const int i0 = x0 + lane * 4;                   // this lane's quad (every wave covers the full 256-cell width)
-    const bool inx = i0 < g.X;
-
-    // ---- stage rows j0-1 .. j0+TY (clamped) : wave w takes rows w, w+4, ... ----
-    for (int r = wave; r < TY + 2; r += 4) {
-        const int jr = clampy(g, j0 - 1 + r);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            const T *src = pl == 0 ? pc : vs;
-            const int C = pl == 0 ? 1 : 2, c = pl == 0 ? 0 : pl - 1;
-            const size_t row = ((size_t)jr * C + c) * g.P;
-            if (inx) *reinterpret_cast<V *>(&tile[pl][r][4 + lane * 4]) = *reinterpret_cast<const V *>(src + row + i0);
-            if (lane == 0) tile[pl][r][3] = src[row + (x0 > 0 ? x0 - 1 : 0)];                                   // left halo cell (clamped)
-            if (lane == 63) { const int xr = x0 + 256 < g.X ? x0 + 256 : g.X - 1; tile[pl][r][260] = src[row + xr]; }   // right halo cell
-        }
-    }
-    __syncthreads();
-    if (!inx) return;
-    // right edge of the domain inside this tile: the clamped right neighbour of cell X-1 is cell X-1 itself
-    // ---- relax: wave w handles tile rows w*(TY/4) .. ----
-#pragma unroll
-    for (int rr = 0; rr < TY / 4; ++rr) {
-        const int r = wave * (TY / 4) + rr;         // tile row index 0..TY-1  <->  LDS row r+1
-        const int j = j0 + r;
-        if (j >= je) break;
-        const unsigned sel = sel_not_wall(mask_quad(g, i0, j));
-        if (sel == 0u) continue;
-        const int o = 4 + lane * 4;
-        const V c = *reinterpret_cast<const V *>(&tile[0][r + 1][o]);
-        const V n = *reinterpret_cast<const V *>(&tile[0][r + 2][o]);
-        const V m = *reinterpret_cast<const V *>(&tile[0][r][o]);
-        T pl_ = tile[0][r + 1][o - 1], pr_ = tile[0][r + 1][o + 4];
-        if (i0 + 4 >= g.X) pr_ = c.w;
-        V s2, s3;
-        if (SRC) {
-            s2 = load_quad<2>(vs, g, 0, i0, j);
-            s3 = load_quad<2>(vs, g, 1, i0, j);
-        } else {
-            const V xc = *reinterpret_cast<const V *>(&tile[1][r + 1][o]), yc = *reinterpret_cast<const V *>(&tile[2][r + 1][o]);
-            const V xn = *reinterpret_cast<const V *>(&tile[1][r + 2][o]), xm = *reinterpret_cast<const V *>(&tile[1][r][o]);
-            const V yn = *reinterpret_cast<const V *>(&tile[2][r + 2][o]), ym = *reinterpret_cast<const V *>(&tile[2][r][o]);
-            T xl = tile[1][r + 1][o - 1], xr = tile[1][r + 1][o + 4], yl = tile[2][r + 1][o - 1], yr = tile[2][r + 1][o + 4];
-            if (i0 + 4 >= g.X) { xr = xc.w; yr = yc.w; }
-            source_from<DM_IEEE>(k, xc.y, xl, yc.y, yl, xn.x, xm.x, yn.x, ym.x, s2.x, s3.x, G);
-            source_from<DM_IEEE>(k, xc.z, xc.x, yc.z, yc.x, xn.y, xm.y, yn.y, ym.y, s2.y, s3.y, G);
-            source_from<DM_IEEE>(k, xc.w, xc.y, yc.w, yc.y, xn.z, xm.z, yn.z, ym.z, s2.z, s3.z, G);
-            source_from<DM_IEEE>(k, xr, xc.z, yr, yc.z, xn.w, xm.w, yn.w, ym.w, s2.w, s3.w, G);
-        }
-        V out;
-        out.x = predict_from(c.y, pl_, n.x, m.x, s2.x, s3.x);
-        out.y = predict_from(c.z, c.x, n.y, m.y, s2.y, s3.y);
-        out.z = predict_from(c.w, c.y, n.z, m.z, s2.z, s3.z);
-        out.w = predict_from(pr_, c.z, n.w, m.w, s2.w, s3.w);
-        store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), out, sel);
-    }
-}
 
 }  // namespace fs

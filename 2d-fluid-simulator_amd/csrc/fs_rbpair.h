@@ -157,7 +157,7 @@ __device__ __forceinline__ void rbp_relax(const Konst<T> &k, const LaneMapN<N> &
 // PAR0: parity of (g.ybase + j0 - 4), the first window row - a launch constant because RT is even and all tiles start at jb + k RT.
 // BND: the tile has non-fluid cells within reach (K7 views are evaluated); FULL: store every cell (carry pass after an upload).
 template <int N, int RT, int PAR0, int DM, bool BND, bool FULL, typename T>
-__device__ __forceinline__ bool rbsor_pair_tile(const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm, int i0, int j0, int je, const unsigned (&fl)[RT + 8],
+__device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm, int i0, int j0, int je, const unsigned (&fl)[RT + 8],
                                                 const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
 {
     constexpr int W = RT + 8;                  // window rows w = 0 .. W-1  <->  local rows j0-4 .. j0+RT+3 (clamped into the domain)
@@ -165,7 +165,6 @@ __device__ __forceinline__ bool rbsor_pair_tile(const Grid &g, const Konst<T> &k
     constexpr unsigned ALL = (1u << N) - 1u;
     // fluid selector of window row w: in a tile without a single non-fluid cell within reach it is a constant (no registers, no selects)
 #define FS_FL(w) (BND ? fl[w] : ALL)
-    DivGuard G;
     R PA[W], VX[W], VY[W], PB[W];              // PB[w] is loaded for w = 1 .. W-2
     uint32_t code[W];
 #pragma unroll
@@ -187,7 +186,7 @@ __device__ __forceinline__ bool rbsor_pair_tile(const Grid &g, const Konst<T> &k
         for (int c = 0; c < N; ++c) {
             const T xE = c == N - 1 ? xr : VX[w].a[c == N - 1 ? c : c + 1], xW = c == 0 ? xl : VX[w].a[c == 0 ? 0 : c - 1];
             const T yE = c == N - 1 ? yr : VY[w].a[c == N - 1 ? c : c + 1], yW = c == 0 ? yl : VY[w].a[c == 0 ? 0 : c - 1];
-            source_from<DM>(k, xE, xW, yE, yW, VX[w + 1].a[c], VX[w - 1].a[c], VY[w + 1].a[c], VY[w - 1].a[c], S2[w].a[c], S3[w].a[c], G);
+            source_from<DM>(k, xE, xW, yE, yW, VX[w + 1].a[c], VX[w - 1].a[c], VY[w + 1].a[c], VY[w - 1].a[c], S2[w].a[c], S3[w].a[c]);
         }
     }
     // view(A): rows 0 .. W-1 (a row missing at the window's edge is stood in for by the row itself - see the header)
@@ -228,13 +227,6 @@ __device__ __forceinline__ bool rbsor_pair_tile(const Grid &g, const Konst<T> &k
         if ((PAR0 + w) & 1) rbp_relax<1, 0>(k, lm, FS_FL(w), P3[w - 1], P3[w], P3[w + 1], S2[w], S3[w], P4[w]);
         else                rbp_relax<0, 0>(k, lm, FS_FL(w), P3[w - 1], P3[w], P3[w + 1], S2[w], S3[w], P4[w]);
     }
-    if (DM & DM_RCP) {
-#pragma unroll
-        for (int w = 4; w <= W - 5; ++w)
-#pragma unroll
-            for (int c = 0; c < N; ++c) { G.out(P4[w].a[c]); G.out(VB[w].a[c]); }
-        if (__any(G.bad())) return true;      // a dividend outside the exact range of the reciprocal division: redo with IEEE division
-    }
 #pragma unroll
     for (int w = 4; w <= W - 5; ++w) {
         const int j = j0 - 4 + w;
@@ -245,19 +237,18 @@ __device__ __forceinline__ bool rbsor_pair_tile(const Grid &g, const Konst<T> &k
             lv_store_sel<T, N>(D + idx<1, T>(g, 0, i0, j), VB[w], sel);
         }
     }
-    return false;
 #undef FS_FL
 }
 
 // PATH: 0 - only the tiles without a non-fluid cell within reach, 1 - only the others, 2 - both.  Two launches (0, then 1) give each
 // path its own register budget: the plain path fits 4 waves per SIMD, the boundary path (recipe bytes, views) does not.
 template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
-__device__ __forceinline__ bool rbsor_pair_wave(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+__device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                 const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
 {
     constexpr int W = RT + 8;
     int wx, ty;
-    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty)) return false;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty)) return;
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned fl[W];
@@ -274,14 +265,13 @@ __device__ __forceinline__ bool rbsor_pair_wave(const Grid &g, const Konst<T> &k
 #pragma unroll
         for (int w = 4; w <= W - 5; ++w)
             if (j0 - 4 + w < je) tgt = tgt || (lm.owner && lv_sel_target<N>(lv_bytes<N>(bcmap, g, i0, clampy(g, j0 - 4 + w))) != 0u);
-        if (!__any(tgt)) return false;
+        if (!__any(tgt)) return;
     }
     if (__all(all_fluid)) {
-        if constexpr (PATH == 1) return false;
-        else return rbsor_pair_tile<N, RT, PAR0, DM, false, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
+        if constexpr (PATH != 1) rbsor_pair_tile<N, RT, PAR0, DM, false, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
+        return;
     }
-    if constexpr (PATH == 0) return false;
-    else return rbsor_pair_tile<N, RT, PAR0, DM, true, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
+    if constexpr (PATH != 0) rbsor_pair_tile<N, RT, PAR0, DM, true, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
 }
 
 template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
@@ -289,10 +279,7 @@ __global__ __launch_bounds__(256) void k_rbsor_pair(Grid g, Konst<T> k, int nbx,
                                                     const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
 {
     static_assert(RT % 2 == 0, "the row parity of a tile is a launch constant only for even tile heights");
-    if (DM & DM_RCP) {
-        if (rbsor_pair_wave<N, RT, PAR0, DM, PATH, FULL, T>(g, k, nbx, nby, jb, je, bcmap, C, D, A, B, v))
-            rbsor_pair_wave<N, RT, PAR0, DM_IEEE, PATH, FULL, T>(g, k, nbx, nby, jb, je, opaque(bcmap), opaque(C), opaque(D), opaque(A), opaque(B), opaque(v));
-    } else rbsor_pair_wave<N, RT, PAR0, DM, PATH, FULL, T>(g, k, nbx, nby, jb, je, bcmap, C, D, A, B, v);
+    rbsor_pair_wave<N, RT, PAR0, DM, PATH, FULL, T>(g, k, nbx, nby, jb, je, bcmap, C, D, A, B, v);
 }
 
 }  // namespace fs

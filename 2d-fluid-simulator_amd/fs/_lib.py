@@ -46,7 +46,6 @@ _PROTOS = {
     "fs_cip_nonadv_dye": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp] + _ROWS,
     "fs_cip_nonadv_grad": [_c_vp, _c_dbl] + [_c_vp] * 6 + _ROWS,
     "fs_cip_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
-    "fs_cip_nonadv_fused": [_c_vp, _c_dbl, _c_dbl, _c_dbl] + [_c_vp] * 7 + _ROWS,
     "fs_cip_grad_advect": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 7 + [_c_int] + _ROWS,
     "fs_cip_grad_advect_dye": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 8 + [_c_int, _c_int] + _ROWS,
     "fs_vort_calc": [_c_vp, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,

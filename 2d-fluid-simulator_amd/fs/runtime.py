@@ -511,11 +511,6 @@ class DeviceBase:
         self._run("cip_advect", (dt, dx, fn._h, fxn._h, fyn._h, fc._h, fxc._h, fyc._h, v._h),
                   reads=[(fc, 1), (fxc, 1), (fyc, 1), (v, 1)], writes=[fn, fxn, fyn])
 
-    def cip_nonadv_fused(self, dt, dx, re, fn, gx_out, gy_out, fc, pc, gxc, gyc):
-        """K2 + K3 of the velocity field in one pass (build-side fusion, same bits): see csrc/fs_march.h k_cip_nonadv_fused."""
-        self._run("cip_nonadv_fused", (dt, dx, re, fn._h, gx_out._h, gy_out._h, fc._h, pc._h, gxc._h, gyc._h),
-                  reads=[(fc, 2), (pc, 2), (fn, 1), (gxc, 0), (gyc, 0)], writes=[fn, gx_out, gy_out])
-
     def cip_grad_advect(self, dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, full=False):
         """K3 + K4 of the velocity field in one pass (build-side fusion): see csrc/fs_march.h k_cip_grad_advect.  v_out receives every
         cell that can differ from fc (full: every cell - the carrying pass after an upload, include/fs_hip.h)."""

@@ -123,14 +123,9 @@ class CipMacSolver(Solver):
         # (fused_transport=False or FS_FUSE_TRANSPORT=0 gives the reference's two launches and its intermediate buffers).
         if fused_transport is None:
             fused_transport = os.environ.get("FS_FUSE_TRANSPORT", "1") == "1"
-        self._fused_transport = (bool(fused_transport) and self.resolution[0] % 4 == 0
-                                 and os.environ.get("FS_MARCH", "1") != "0")
+        self._fused_transport = (bool(fused_transport) and self.resolution[0] % 4 == 0 and self._dev.dtype == np.float32
+                                 and os.environ.get("FS_MARCH", "1") != "0")      # (f64: 256 VGPRs per tile - the two-kernel form)
         self._v_spare = self._dev.alloc(2) if self._fused_transport else None
-        # Optional K2 + K3 in one pass (same bits, K3 no longer re-reads fn / fc: 56 instead of 70 B/cell).  Measured 373 us
-        # against 120 + 235 us for the two kernels at res 4096 (the 3x recompute of K2 in the halo rows and the second pass over
-        # p cost more than the saved bytes), so it is OFF by default; FS_FUSE_NONADV=1 enables it.
-        self._fused_nonadv = (self.resolution[0] % 4 == 0 and os.environ.get("FS_MARCH", "1") != "0"
-                              and os.environ.get("FS_FUSE_NONADV", "0") == "1")
 
     def _flow_step(self):
         self._bc.set_velocity_boundary_condition(self.v.current)
@@ -158,14 +153,6 @@ class CipMacSolver(Solver):
     def _update_velocities(self, v, vx, vy, p):
         grads = (vx.current, vx.next, vy.current, vy.next)
         fused34 = self._fused_transport and not any(f.user_data for f in grads)
-        if self._fused_nonadv and not fused34:
-            self._dev.cip_nonadv_fused(self.dt, self.dx, self.re, v.next, vx.next, vy.next, v.current, p.current, vx.current, vy.current)
-            for buf in (v, vx, vy):
-                buf.swap()
-            self._advection_phase(v.next, vx.next, vy.next, v.current, vx.current, vy.current, v.current)
-            for buf in (v, vx, vy):
-                buf.swap()
-            return
         self._non_advection_phase(v.next, v.current, p.current)
         if fused34:
             # one pass instead of K3 + swap + K4 + swap.  End state as in the reference: v.current = advected velocity with the

@@ -112,11 +112,6 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
                   const fs_field *fc, const fs_field *fxc, const fs_field *fyc, const fs_field *v,
                   int row_begin, int row_end);
 
-/* _non_advection_phase + _non_advection_phase_grad of the VELOCITY field fused into one pass (build-side optimisation, same
- * bits): fn (not-wall cells) and the updated gradients are produced together; fn's wall cells are read as stored.        */
-int fs_cip_nonadv_fused(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, fs_field *gx_out, fs_field *gy_out,
-                        const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc,
-                        int row_begin, int row_end);
 /* _non_advection_phase_grad + _advection_phase of the VELOCITY field fused into one pass (build-side optimisation, same
  * bits for everything observable): the intermediate gradients never go through HBM.  fn = velocity after
  * _non_advection_phase, fc = velocity before it, gxc/gyc = gradients before; outputs: v_out (advected value on fluid cells, fc

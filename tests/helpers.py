@@ -23,7 +23,7 @@ def make_oracle(g, cfg=None):
     return sim
 
 
-def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=True, fused_transport=None, fused_nonadv=None, fused_clamp=None):
+def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=True, fused_transport=None, fused_clamp=None, rb_pair=None):
     """Compose the product classes by hand from the scene arrays stored in the fixture (constructor-level API)."""
     import fs
     from fs.boundary_condition import BoundaryCondition, DyeBoundaryCondition
@@ -33,12 +33,10 @@ def make_product(g, cfg=None, precompute_source=None, vc_kwargs=None, rb_fused=T
           else BoundaryCondition(g["bc_const"], g["bc_mask"]))
     vc = fs.VorticityConfinement(bc, dt, dx, cfg["vor_eps"], **(vc_kwargs or {})) if cfg["vor_eps"] is not None else None
     u = cfg["updater"]
-    pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, u[1], u[2], precompute_source=bool(precompute_source), fused=rb_fused) if u[0] == "rbsor"
+    pu = (fs.RedBlackSorPressureUpdater(bc, dt, dx, u[1], u[2], precompute_source=bool(precompute_source), fused=rb_fused, pair=rb_pair) if u[0] == "rbsor"
           else fs.JacobiPressureUpdater(bc, dt, dx, u[1], precompute_source=precompute_source))
     if cfg["scheme"] == "cip":
         solver = (fs.DyeCipMacSolver if cfg["dye"] else fs.CipMacSolver)(bc, pu, dt, dx, re, vc, fused_transport=fused_transport)
-        if fused_nonadv is not None:
-            solver._fused_nonadv = bool(fused_nonadv) and solver.resolution[0] % 4 == 0
         if fused_clamp is not None and cfg["dye"]:
             solver._fused_clamp = bool(fused_clamp) and solver.resolution[0] % 4 == 0
     else:

@@ -145,10 +145,6 @@ class OracleSlabDevice(DeviceBase):
         elif name == "cip_advect":
             dt, dx, fn, fxn, fyn, fc, fxc, fyc, v = A
             O._call("oracle_cip_advect", dt_, X, Y, dt, dx, fc.shape[2], b.mask, fn, fxn, fyn, fc, fxc, fyc, v); written = [fn, fxn, fyn]
-        elif name == "cip_nonadv_fused":
-            dt, dx, re, fn, gxo, gyo, fc, pc, gxc, gyc = A
-            O._call("oracle_cip_nonadv", dt_, X, Y, dt, dx, re, b.mask, fn, fc, pc)
-            O._call("oracle_cip_nonadv_grad", dt_, X, Y, dx, 2, b.mask, gxo, gyo, gxc, gyc, fc, fn); written = [fn, gxo, gyo]
         elif name == "cip_grad_advect":
             dt, dx, vo, gxo, gyo, fn, fc, gxc, gyc, full = A
             O._call("oracle_cip_nonadv_grad", dt_, X, Y, dx, 2, b.mask, gxo, gyo, gxc, gyc, fc, fn)     # K3 into the output buffers

@@ -16,7 +16,7 @@ def test_random_configurations_match_the_oracle(hip_lib, monkeypatch):
     import fuzz_parity
     from oracle import oracle as O
     O.set_threads(8)
-    for k in ("FS_MARCH", "FS_FUSE_TRANSPORT", "FS_FUSE_NONADV"):
+    for k in ("FS_MARCH", "FS_FUSE_TRANSPORT", "FS_RBSOR_PAIR"):
         monkeypatch.delenv(k, raising=False)
     failures = []
     try:
@@ -25,7 +25,7 @@ def test_random_configurations_match_the_oracle(hip_lib, monkeypatch):
             if r:
                 failures.append(r)
     finally:
-        for k in ("FS_FUSE_TRANSPORT", "FS_FUSE_NONADV"):
+        for k in ("FS_FUSE_TRANSPORT", "FS_RBSOR_PAIR"):
             os.environ.pop(k, None)
     assert not failures, "\n".join(failures[:10])
 

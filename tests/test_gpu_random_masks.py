@@ -36,10 +36,7 @@ def test_random_mask_trajectory(seed, scheme, vc, updater, hip_lib, monkeypatch)
     dt, dx, re = 0.05 / res, 1.0 / res, 1000.0
     with_dye = seed % 3 == 0
     if seed % 2 == 1:
-        monkeypatch.setenv("FS_FUSE_TRANSPORT", "1")        # also exercise the opt-in fused passes incl. their EDGE rows
-        monkeypatch.setenv("FS_FUSE_NONADV", "0")
-    elif seed == 4:
-        monkeypatch.setenv("FS_FUSE_NONADV", "1")
+        monkeypatch.setenv("FS_FUSE_TRANSPORT", "0")        # the reference's two launches for K3 / K4 on the odd seeds
     fs.runtime.init(gpu=0, dtype="f32")
     bc = DyeBoundaryCondition(const, dye, mask) if with_dye else BoundaryCondition(const, mask)
     vcobj = fs.VorticityConfinement(bc, dt, dx, vc) if vc is not None else None

@@ -19,7 +19,7 @@ REL_L2_TOL = 1e-4   # north_star tolerance (f32); the tests below assert the str
 FILES = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
 
 
-@pytest.mark.parametrize("mode", ["fast", "literal", "fused-transport", "fused-nonadv"])
+@pytest.mark.parametrize("mode", ["fast", "literal", "fused-transport", "no-pair"])
 @pytest.mark.parametrize("fname", FILES)
 def test_trajectory_bitwise(fname, mode, hip_lib):
     """fast: every build-side fusion on (defaults).  literal: the reference's kernel-by-kernel sequence (all fusions off),
@@ -28,16 +28,18 @@ def test_trajectory_bitwise(fname, mode, hip_lib):
     g = np.load(os.path.join(GOLDEN, fname))
     cfg = traj_config(g)
     fs.runtime.init(gpu=0, dtype="f64" if cfg["fp64"] else "f32")
-    if mode in ("fused-transport", "fused-nonadv") and cfg["scheme"] != "cip":
+    if mode == "fused-transport" and cfg["scheme"] != "cip":
         pytest.skip("the fused gradient+advection pass is a CIP kernel")
+    if mode == "no-pair" and cfg["updater"][0] != "rbsor":
+        pytest.skip("the two-iteration pass is a red-black SOR kernel")
     if mode == "fast":
         sim = make_product(g, cfg, vc_kwargs={"store_fields": True})   # fused K5+K6 pass that also writes w, |w|
     elif mode == "fused-transport":
         sim = make_product(g, cfg, vc_kwargs={"store_fields": True}, fused_transport=True)
-    elif mode == "fused-nonadv":
-        sim = make_product(g, cfg, vc_kwargs={"store_fields": True}, fused_nonadv=True)
+    elif mode == "no-pair":         # one fused red-black iteration per launch + the real pressure boundary kernel (round 2's default)
+        sim = make_product(g, cfg, vc_kwargs={"store_fields": True}, rb_pair=False)
     else:
-        sim = make_product(g, cfg, vc_kwargs={"fused": False}, rb_fused=False, fused_transport=False, fused_nonadv=False, fused_clamp=False, precompute_source=False)
+        sim = make_product(g, cfg, vc_kwargs={"fused": False}, rb_fused=False, fused_transport=False, fused_clamp=False, precompute_source=False)
     try:
         for step in range(1, max(cfg["snaps"]) + 1):
             sim.step()

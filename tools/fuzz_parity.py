@@ -68,9 +68,9 @@ def one_case(seed, max_cells, debug=False):
     dt = float(rng.choice([0.05 / res, 0.2 / res, 1e-4]))
     re = float(rng.choice([1.0, 100.0, 1e6, 1e8]))
     os.environ["FS_FUSE_TRANSPORT"] = "1" if rng.random() < 0.2 else "0"
-    os.environ["FS_FUSE_NONADV"] = "1" if rng.random() < 0.2 else "0"
+    os.environ["FS_RBSOR_PAIR"] = "0" if rng.random() < 0.3 else "1"
     desc = (f"seed {seed}: {X}x{Y} {np.dtype(dtype).name} {scheme} vc={vc} {updater} dye={with_dye} res={res:g} dt={dt:g} re={re:g} "
-            f"fuse={os.environ['FS_FUSE_TRANSPORT']}{os.environ['FS_FUSE_NONADV']}")
+            f"fuse={os.environ['FS_FUSE_TRANSPORT']} pair={os.environ['FS_RBSOR_PAIR']}")
     fs.runtime.init(gpu=0, dtype="f64" if f64 else "f32")
     bc = (DyeBoundaryCondition(const.astype(dtype), dye.astype(dtype), mask) if with_dye else BoundaryCondition(const.astype(dtype), mask))
     try:
@@ -89,7 +89,7 @@ def one_case(seed, max_cells, debug=False):
         p0 = rng.uniform(-1, 1, (X, Y)).astype(dtype)
         solver.v.current.from_numpy(v0); ref.v.current[...] = v0
         solver.p.current.from_numpy(p0); ref.p.current[...] = p0
-        if os.environ["FS_FUSE_TRANSPORT"] == "0" and os.environ["FS_FUSE_NONADV"] == "0" and rng.random() < 0.15:
+        if os.environ["FS_FUSE_TRANSPORT"] == "0" and rng.random() < 0.15:
             # hipGraph mode (what bench.py times): a captured pair of steps replayed twice = 4 steps, compared at the end
             dev = bc.device
             gid = dev.capture(lambda: (solver.update(), solver.update()))
