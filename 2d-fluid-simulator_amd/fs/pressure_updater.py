@@ -46,47 +46,21 @@ class JacobiPressureUpdater(PressureUpdater):
         want = os.environ.get("FS_JACOBI_PAIRS", "auto")
         self._pairs = (self._lazy and want != "0" and n_iter >= 6
                        and (self._dev.nranks == 1 or 2 * max(2, 1 + self._dev.bc_radius_p) <= self._dev.halo))   # a pass reaches 4 rows
+        # The tiles of the two-sweep pass hand rows with floors / ceilings / corners nearby to a general path (one row per workgroup); the
+        # variant whose tiles also apply the vertical recipes keeps only thin walls there but costs 6 % where it is not needed.  Decided from
+        # the mask, not from a timing run (round 2 timed three forms inside this constructor: the launch sequence then differed from run to
+        # run): vertical when more than 5 % of the wave-tile rows would take the general path otherwise (bc3's cylinders: 31 %; bc2 / bc5: < 1 %).
         self._vertical = want == "2"
-        if self._pairs and want == "auto" and self._dev.nranks == 1 and hasattr(self._dev, "profile_report"):
-            try:
-                self._pairs, self._vertical = self._fastest_form()
-            except Exception:       # a timing run that cannot be made is no reason to fail: the single sweeps need nothing from it
-                self._pairs, self._vertical = False, False
+        self.form = "single sweeps"
+        if self._pairs:
+            if want == "auto" and hasattr(self._dev, "lazy_flags"):
+                flags, (general, general_v) = self._dev.lazy_flags()
+                self._vertical = general > 0.05 * max(flags.size, 1) and general_v < general
+            self.form = "two sweeps per pass" + (", vertical recipes in the tiles" if self._vertical else "")
+        elif self._lazy:
+            self.form = "single sweeps, boundary condition in the sweep"
         if tentative and not self._pairs:
             self._precompute, self._src, self._lazy = False, None, False
-
-    def _fastest_form(self):
-        """(pairs?, vertical?) - single sweeps, two-sweep passes, or two-sweep passes whose tiles also apply the vertical recipes."""
-        dev = self._dev
-        if getattr(dev, "_pairs_verdict", None) is None:       # once per device (= per mask)
-            a, b, src = dev.alloc(1), dev.alloc(1), dev.alloc(2)
-
-            def run(n, vertical):
-                for _ in range(n):
-                    dev.jacobi_pair_lazy(b, a, src, swapped=False, vertical=vertical)
-                    dev.jacobi_pair_lazy(a, b, src, swapped=True, vertical=vertical)
-                if not vertical:
-                    for _ in range(2 * n):
-                        dev.jacobi_sweep_lazy(b, a, src)
-                        dev.jacobi_sweep_lazy(a, b, src)
-            run(1, False)
-            run(1, True)
-            reps = []
-            try:
-                for vertical in (False, True):
-                    dev.profile_reset()
-                    dev.profile(True)
-                    run(3, vertical)
-                    reps.append(dev.profile_report())
-                    dev.profile(False)
-            finally:
-                dev.profile(False)
-                dev.profile_reset()
-            avg = lambda rep, k: rep[k][1] / rep[k][0]
-            t = {(False, False): 2.0 * avg(reps[0], "jacobi_sweep_lazy"), (True, False): avg(reps[0], "jacobi_pair_lazy"),
-                 (True, True): avg(reps[1], "jacobi_pair_lazy")}
-            dev._pairs_verdict = min(t, key=t.get)
-        return dev._pairs_verdict
 
     def update(self, p, v_current):
         if self._precompute:
@@ -130,8 +104,11 @@ class RedBlackSorPressureUpdater(PressureUpdater):
         # pair: TWO iterations and the two boundary passes between them in one pass over HBM (csrc/fs_rbpair.h; same bits, 25 instead of
         # 2 x 21 B per fluid cell and two launches less).  Out of place: the pressure rotates through a second pair of buffers.  Needs a
         # mask that admits it (Device.rb_pair_ok: no one-cell-thin walls between fluid regions), f32, and on slabs a halo of 4 rows.
+        # Slab runs keep the single iterations by default: the pass wants v and p.current 4 rows deep at the END of the step, where the
+        # ghost rows are at their shallowest - at halo 16 the tracker then exchanges 1.5 times per step instead of once every step with an
+        # 11-step pattern no tape can hold (tools/slab_period.py), which costs more than the pass saves on an eighth of the grid.
         if pair is None:
-            pair = os.environ.get("FS_RBSOR_PAIR", "1") == "1"
+            pair = os.environ.get("FS_RBSOR_PAIR", "1" if self._dev.nranks == 1 else "0") == "1"
         self._pair = (bool(pair) and self._fused and n_iter >= 2 and getattr(self._dev, "rb_pair_ok", False)
                       and (self._dev.nranks == 1 or self._dev.halo >= 4))
         self._spare = (self._dev.alloc(1), self._dev.alloc(1)) if self._pair else None
