@@ -125,8 +125,10 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
         // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords)
         const int group = stacked ? std::max(1, c->xcd_group / 4) : c->xcd_group;     // the same number of field rows per XCD group
         const int groups = (o.nby + group - 1) / group;
-        o.grid = dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
+        const bool inner = zgroups > 1 && (c->cg_inner_mask & family) != 0;
+        o.grid = inner ? dim3(8 * o.nbx * zgroups, group, (groups + 7) / 8) : dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
         o.nby |= (group - 1) << 24;
+        if (inner) o.nby |= FS_CG_INNER;
     } else { o.grid = dim3(o.nbx * o.nby, zgroups, 1); o.nbx = -o.nbx; }   // negative nbx = row-major decode
     if (stacked) o.nby |= FS_STACKED;
     return o;
@@ -553,6 +555,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);
     c->stack_mask = XCD_RBSOR | XCD_ADVECT | XCD_GRAD;      // measured per family: K4 313 -> 301 us, K3 246 -> 243, RB-SOR 129 -> 127.5; the others lose 1 %
     if (const char *s = getenv("FS_STACK")) c->stack_mask = atoi(s);
+    if (const char *s = getenv("FS_CG_INNER")) c->cg_inner_mask = atoi(s);
     if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
     if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows
     *out = c;

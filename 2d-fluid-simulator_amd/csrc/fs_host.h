@@ -113,6 +113,7 @@ struct fs_ctx {
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int stack_mask = 0;       // env FS_STACK: kernel families (XCD_* bits) launched with stacked workgroups
+    int cg_inner_mask = 0;    // env FS_CG_INNER: kernel families whose channel-group passes over one tile are consecutive workgroups of one XCD
     bool pack_halo = true;    // env FS_PACK_HALO=0: one ncclSend/ncclRecv per field instead of one packed message per neighbour
     int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default, 21 / 22 / 23 / 24 = overlapped-wave tiles of 1 - 4 rows
 

@@ -144,10 +144,11 @@ struct LaneMap {
 //   blockIdx.z = lg                the lg-th group of this XCD:  by = (lg * 8 + xcd) * G + ly
 // No integer division in the decode (the first version, a 1-D grid decoded with two divisions per wave, spent ~70 of the ~700
 // instructions of a one-row K2 tile on them).
+constexpr int FS_CG_INNER = 1 << 22;
 template <int ZG = 1>
 __device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by, int &cg, int zoff = 0)
 {
-    const int nby = nby_packed & 0x7fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked
+    const int nby = nby_packed & 0x3fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked, bit 22 = channel groups innermost
     if (nbx < 0) {   // plain row-major decode (FS_XCD=0: rows of one tile row spread over the XCDs): grid = (nbx * nby, ZG)
         nbx = -nbx;
         by = blockIdx.x / nbx;
@@ -156,9 +157,19 @@ __device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, in
         return by < nby;
     }
     const int xcd = blockIdx.x & 7;
-    bx = blockIdx.x >> 3;
-    const int ly = ZG == 1 ? (int)blockIdx.y : (int)blockIdx.y / ZG;        // division by a compile-time 2 or 3
-    cg = ZG == 1 ? 0 : (int)blockIdx.y - ly * ZG;
+    int ly;
+    if (ZG > 1 && (nby_packed & FS_CG_INNER)) {
+        // channel groups innermost: blockIdx.x = (bx * ZG + cg) * 8 + xcd - the ZG passes over one tile are consecutive workgroups of ONE XCD
+        // (they share most of their input rows: the second finds them in that XCD's L2 while they are hot)
+        const int t = (int)blockIdx.x >> 3;
+        bx = t / ZG;                                                        // division by a compile-time 2 or 3
+        cg = t - bx * ZG;
+        ly = (int)blockIdx.y;
+    } else {
+        bx = blockIdx.x >> 3;
+        ly = ZG == 1 ? (int)blockIdx.y : (int)blockIdx.y / ZG;
+        cg = ZG == 1 ? 0 : (int)blockIdx.y - ly * ZG;
+    }
     by = (((int)blockIdx.z - zoff) * 8 + xcd) * FS_XCD_GROUP + ly;       // zoff: leading z slices that belong to someone else
     return by < nby;
 }
@@ -795,7 +806,8 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, 
 {
     // blockIdx.y = (tile row in the XCD group) * 2 + component: the two component passes of a tile are adjacent in dispatch order on
     // the SAME XCD, so the second one finds the velocity rows both passes read in that XCD's L2 instead of fetching them again.
-    if ((blockIdx.y & 1) == 0) cip_grad_advect_rt_body<0, RT, DM, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
+    const int comp = (nbx >= 0 && (nby & FS_CG_INNER)) ? (((int)blockIdx.x >> 3) & 1) : ((int)blockIdx.y & 1);
+    if (comp == 0) cip_grad_advect_rt_body<0, RT, DM, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
     else cip_grad_advect_rt_body<1, RT, DM, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
 }
 
@@ -935,7 +947,8 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_dye(Grid g, Konst<T> k,
                                                              T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
                                                              const T *gxc, const T *gyc, const T *v, int full)
 {
-    const int ly = (int)blockIdx.y / 3, ch = (int)blockIdx.y - 3 * ly;      // channel = blockIdx.y % 3 (the fallback grid: blockIdx.y itself)
+    const int yy = (nbx >= 0 && (nby & FS_CG_INNER)) ? ((int)blockIdx.x >> 3) : (int)blockIdx.y;
+    const int ly = yy / 3, ch = yy - 3 * ly;      // channel = (blockIdx.y or the block column index) % 3 (the fallback grid: blockIdx.y itself)
     if (ch == 0) cip_grad_advect_dye_body<0, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
     else if (ch == 1) cip_grad_advect_dye_body<1, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
     else cip_grad_advect_dye_body<2, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);

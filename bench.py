@@ -123,6 +123,7 @@ def cpu_baseline(args, scene, sim, dt, abytes_step):
     import numpy as np
     # team size: the cores this process may really use, at most one thread per 8 grid columns (the oracle's loops are parallel over x),
     # threads pinned and passive at barriers; set before libgomp starts
+    logical = len(os.sched_getaffinity(0))
     cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or max(1, min(usable_cores(), scene[1].shape[0] // 8))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
@@ -152,7 +153,7 @@ def cpu_baseline(args, scene, sim, dt, abytes_step):
         sim.step()
     out = sim.field_to_numpy()
     same = all(np.array_equal(out[k], e, equal_nan=True) for k, e in ref.fields().items())
-    return {"value": n / el, "unit": "steps/s", "cores": cores, "kind": "port", "host_logical_cpus": len(os.sched_getaffinity(0)),
+    return {"value": n / el, "unit": "steps/s", "cores": cores, "kind": "port", "host_logical_cpus": logical,
             "GBps": round(abytes_step * n / el / 1e9, 1),
             "sample": f"{n} steps of the same workload (bc{args.bc} res{res} {args.scheme}{' +dye' if args.dye else ''}) continuing from the "
                       f"GPU's state after the timed run, {el:.1f} s, OpenMP C oracle (boundary kernels serial over the boundary cells)",
@@ -250,30 +251,40 @@ def main():
     elapsed = max(dev.allgather_scalars(time.perf_counter() - t0))      # max over ranks
     steps_per_s = args.steps / elapsed
 
-    # Short timed regions (the driver's --steps 20 is 16 ms of work) say little about the spread: the same K-step block is repeated until
-    # ~0.25 s have been measured, and min / median / max per step are reported NEXT TO the contract's numbers (which stay the first block's).
-    def timed_block():
+    # Short timed regions (the driver's --steps 20 is 16 ms of work) say little about the spread: for K < 120 another 120 steps follow in
+    # blocks of the whole replay periods of K, each timed like the first, and min / median / max per step are reported NEXT TO the
+    # contract's numbers (which stay the first block's).  The number of extra steps depends on K alone, so every mode and every N ends
+    # after the same number of steps (state_checksum stays comparable).
+    period = gperiod if graph is not None else (tape["nsteps"] if tape is not None else 1)
+
+    def timed_block(nsteps):
         dev.barrier()
         t = time.perf_counter()
         if graph is not None:
-            dev.replay(graph, args.steps // gperiod)
-            for _ in range(args.steps % gperiod):
-                sim.step()
-        elif tape is not None and args.steps % tape["nsteps"] == 0:
-            dev.replay_tape(tape, args.steps // tape["nsteps"])
+            dev.replay(graph, nsteps // period)
+        elif tape is not None:
+            dev.replay_tape(tape, nsteps // period)
         else:
-            for _ in range(args.steps):
+            for _ in range(nsteps):
                 sim.step()
         dev.barrier()
         return max(dev.allgather_scalars(time.perf_counter() - t))
-    blocks = [elapsed]
-    extra = 0 if elapsed >= 0.25 else min(int(0.25 / max(elapsed, 1e-6)), 40)
-    if (graph is not None and args.steps % gperiod) or (tape is not None and args.steps % tape["nsteps"]):
-        extra = 0         # a block that ends in another phase of the buffer rotation cannot be replayed again
-    for _ in range(extra):
-        blocks.append(timed_block())
-    extra_steps = extra * args.steps
-    spread = sorted(1e3 * b / args.steps for b in blocks)
+    spread = [1e3 * elapsed / args.steps]
+    extra_steps = 0 if args.steps >= 120 else 120
+    used = (period - args.steps % period) % period          # finish the period the K steps ended in (eager, untimed)
+    bsteps = max((args.steps // period) * period, period)
+    if used <= extra_steps:
+        for _ in range(used):
+            sim.step()
+        while used + bsteps <= extra_steps:
+            spread.append(1e3 * timed_block(bsteps) / bsteps)
+            used += bsteps
+    else:
+        used = 0
+    for _ in range(extra_steps - used):
+        sim.step()
+    spread.sort()
+    blocks = spread
     for _ in range(later):
         sim.step()
 

@@ -174,17 +174,19 @@ def test_pair_equals_two_sweeps(seed, rt, hip_lib, monkeypatch, _force_pairs):
         dev.close()
 
 
-def test_autotune_keeps_the_bits(hip_lib, monkeypatch):
-    """FS_JACOBI_PAIRS unset: the updater times pairs against single sweeps on this mask and keeps the faster - either way the oracle's bits."""
+def test_form_is_decided_from_the_mask(hip_lib, monkeypatch):
+    """FS_JACOBI_PAIRS unset: two sweeps per pass; the variant with vertical recipes in the tiles only where the plain one would send more
+    than 5 % of the rows down its general path (scene 3's cylinders) - decided from the mask, the same on every run; the oracle's bits."""
     from fs.boundary_condition import create_scene_arrays
     monkeypatch.delenv("FS_JACOBI_PAIRS")
-    const, mask, _ = create_scene_arrays(2, 128)
-    solver, ref, pu = _pair(const, mask, "cip", 12, 128, lazy=None)
-    try:
-        assert pu._lazy and solver._dev._pairs_verdict == (pu._pairs, pu._vertical)
-        _run(solver, ref, 3, f"autotune pairs={pu._pairs} vertical={pu._vertical}")
-    finally:
-        solver._dev.close()
+    for bc, res, vertical in ((2, 512, False), (3, 256, None)):
+        const, mask, _ = create_scene_arrays(bc, res)
+        solver, ref, pu = _pair(const, mask, "cip", 12, res, lazy=None)
+        try:
+            assert pu._lazy and pu._pairs and vertical in (None, pu._vertical) and pu.form.startswith("two sweeps per pass"), (bc, pu.form)
+            _run(solver, ref, 3, f"bc{bc}: {pu.form}")
+        finally:
+            solver._dev.close()
 
 
 def _flags_numpy(mask):

@@ -7,9 +7,10 @@ OUT=gpurun_out/pmc_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 ARGS=${BENCH_ARGS:---steps 6 --warmup 6 --no-cpu --no-graph --sweeps 0}
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/sq -o p -- python3 bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- python3 bench.py $ARGS > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/write -o p -- python3 bench.py $ARGS > /dev/null 2> $OUT/write.err
+timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/sq -o p -- python3 bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
+timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- python3 bench.py $ARGS > /dev/null 2> $OUT/fetch.err
+timeout 240 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/write -o p -- python3 bench.py $ARGS > /dev/null 2> $OUT/write.err
+if [ -n "${EXTRA_PMC:-}" ]; then timeout 240 rocprofv3 --pmc $EXTRA_PMC --kernel-trace --output-format csv -d $OUT/extra -o p -- python3 bench.py $ARGS > /dev/null 2> $OUT/extra.err; fi
 python3 - "$OUT" <<'PY' | tee $OUT/summary.txt
 import csv, glob, collections, sys, re
 out = sys.argv[1]
@@ -30,5 +31,6 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0))[
     rd = 2 * d.get('FETCH_SIZE', 0) * 1024 / 1e6 / max(n[(k, 'FETCH_SIZE')], 1); wr = d.get('WRITE_SIZE', 0) * 1024 / 1e6 / max(n[(k, 'WRITE_SIZE')], 1)
     hit, miss = d.get('TCC_HIT_sum', 0), d.get('TCC_MISS_sum', 0)
     print(f"{k:56s} {nl:4d} {us:8.1f} {d.get('SQ_WAIT_ANY',0)/wc:5.2f} {d.get('SQ_WAIT_INST_ANY',0)/wc:5.2f} {d.get('SQ_ACTIVE_INST_ANY',0)/wc:5.2f} {d.get('SQ_ACTIVE_INST_VALU',0)/wc:5.2f} "
-          f"{wc/w:8.0f} {d.get('SQ_INSTS_VALU',0)/w:7.0f} {d.get('SQ_INSTS_SALU',0)/w:7.0f} {rd:7.1f} {wr:7.1f} {hit/max(hit+miss,1):6.2f} {(rd+wr)/max(us,1e-9)/1e6*1e6/1e6:5.2f}")
+          f"{wc/w:8.0f} {d.get('SQ_INSTS_VALU',0)/w:7.0f} {d.get('SQ_INSTS_SALU',0)/w:7.0f} {rd:7.1f} {wr:7.1f} {hit/max(hit+miss,1):6.2f} {(rd+wr)/max(us,1e-9):5.2f}"
+          + "  " + " ".join(f"{c}={v/w:.0f}/w" for c, v in sorted(d.items()) if c not in ('SQ_WAVE_CYCLES','SQ_WAIT_ANY','SQ_WAIT_INST_ANY','SQ_ACTIVE_INST_ANY','SQ_ACTIVE_INST_VALU','SQ_WAVES','SQ_INSTS_VALU','SQ_INSTS_SALU','FETCH_SIZE','WRITE_SIZE','TCC_HIT_sum','TCC_MISS_sum')))
 PY
