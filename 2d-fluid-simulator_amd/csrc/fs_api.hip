@@ -491,6 +491,24 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
             }
         }
         c->rb_pair_ok = c->lazy_ok && !thin;
+        // Four Jacobi sweeps per pass (fs_jquad.h): the same condition with every cell whose RAW value is live as a reader - fluid cells and
+        // the sources of recipes (an inflow cell of column 1 is computed by the sweep and read, raw, by the recipe of column 0)
+        {
+            std::vector<uint8_t> live((size_t)X * Y);
+            for (size_t q = 0; q < live.size(); ++q) live[q] = mask[q] == 0;
+            for (const HostOp &op : prs) { if (op.s1 >= 0) live[op.s1] = 1; if (op.kind == 1 && op.s2 >= 0) live[op.s2] = 1; }
+            bool thin_live = false;
+            for (const HostOp &op : prs) {
+                if (op.kind == 2) continue;
+                const long long srcs[2] = {op.s1, op.kind == 1 ? op.s2 : -1};
+                for (long long s : srcs) {
+                    if (s < 0 || s == op.t) continue;
+                    const int oi = 2 * (int)(op.t / Y) - (int)(s / Y), oj = 2 * (int)(op.t % Y) - (int)(s % Y);
+                    if (oi >= 0 && oi < X && oj >= 0 && oj < Y && live[(size_t)oi * Y + oj]) thin_live = true;
+                }
+            }
+            c->jq_ok = c->lazy_ok && !thin_live;
+        }
         c->h_bcmap.swap(map);            // uploaded by fs_upload_mask (same transpose path as the mask), then dropped
     }
     c->bc_incomplete = false;
@@ -547,6 +565,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_VORT_RT")) { const int v = atoi(s); if (v >= 3 && v <= 6) c->vort_rt = v; }
     if (const char *s = getenv("FS_RBSOR_RT")) { const int v = atoi(s); if (v >= 2 && v <= 4) c->rbsor_rt = v; }
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
+    if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
     if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); if (v >= 2) c->k34_rt = v == 2 || v == 3 ? v : 4; }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
@@ -1344,6 +1363,33 @@ int fs_selftest_f64div(fs_ctx *ctx, double divisor, int *mismatches)
     if (e != hipSuccess) return hip_fail(e, "fs_selftest_f64div", __FILE__, __LINE__);
     *mismatches = (int)std::min<unsigned>(h, 0x7fffffffu);
     return FS_OK;
+}
+
+// four lazily-bounded Jacobi sweeps in one pass (fs_jquad.h): pn[not wall] <- sweep^4(pc); both buffers hold raw sweep output
+int fs_jacobi_quad_ok(const fs_ctx *ctx, int *ok)
+{
+    FS_REQUIRE(ctx && ok, "null argument");
+    *ok = ctx->mask_set && ctx->jq_ok && ctx->use_march && ctx->use_lazy && ctx->dtype == 0 ? 1 : 0;
+    return FS_OK;
+}
+
+int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
+    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
+    FS_ROWS();
+    if (!(ctx->jq_ok && ctx->use_march && ctx->dtype == 0)) { set_error("this mask / precision does not admit the four-sweep Jacobi pass (fs_jacobi_quad_ok)"); return FS_ERR_UNSUPPORTED; }
+    using T = float;
+    const Grid gg = ctx->grid();
+    // lanes of 2 cells (116 VGPRs = 4 waves per SIMD at 4 rows; quads: 182 = 2 waves, 44.9 against 34.3 us per pass at bc2 res 1600)
+    const int rt = ctx->jquad_rt;
+    const OvGrid og = ov_grid_n<2>(ctx, row_begin, row_end, rt);
+#define FS_JQ(RT) hipLaunchKernelGGL((k_jacobi_quad<2, RT, T>), og.grid, dim3(256), 0, ctx->stream, gg, og.nbx, og.nby, row_begin, row_end, \
+                               (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
+    return launch(ctx, "jacobi_quad_lazy", [=] {
+        if (rt == 2) FS_JQ(2); else if (rt == 6) FS_JQ(6); else if (rt == 8) FS_JQ(8); else FS_JQ(4);
+    });
 }
 
 int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok)

@@ -15,6 +15,7 @@
 #include "fs_kernels.h"
 #include "fs_march.h"
 #include "fs_rbpair.h"
+#include "fs_jquad.h"
 
 namespace fs {
 
@@ -70,6 +71,8 @@ struct fs_ctx {
     std::vector<uint8_t> h_bcmap;  // host copy between build_bc_ops and the upload
     bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
     bool rb_pair_ok = false;                 // mask admits the two-iteration red-black pass (fs_rbpair.h; decided in build_bc_ops)
+    bool jq_ok = false;                      // mask admits the four-sweep Jacobi pass (fs_jquad.h)
+    int jquad_rt = 4;                        // its tile height (env FS_JQUAD_RT = 2, 4, 6, 8)
     int rbpair_rt = 4;                       // rows per tile of that pass (env FS_RBPAIR_RT = 4, 6)
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters

@@ -1,0 +1,110 @@
+// fs_jquad.h - FOUR Jacobi sweeps, and the pressure boundary passes in front of each, in one pass over the grid.
+//
+// Reference (fs/pressure_updater.py:56-66): n x { K7(p.current); p.next[not wall] = predict_p(p.current); swap }.  Long runs (BASELINE
+// configs[1]: 50 sweeps per step on a 3200 x 1600 grid whose 80 MB never leave the Infinity Cache) are bound by launches and
+// latency, not by HBM: round 2's two-sweep pass (k_jacobi_pair) takes 21.6 us per pass = 66 % of that step.  Here a lane holds rows
+// j0-4 .. j0+RT+3 of the iterate and rows j0-3 .. j0+RT+2 of the precomputed source pair in registers and runs four sweeps on
+// shrinking row ranges (x-neighbours through the halo lanes, whose 4 cells are exactly the reach of four radius-1 stages), with K7
+// evaluated as a view in front of every sweep from the recipe bytes (fs_march.h lazy_value; lv_bc_row in fs_rbpair.h).
+//
+// The buffers hold RAW sweep output during such a run (the host issues the last two sweeps with the real boundary kernel, which leaves
+// both physical buffers as the reference does).  A pass writes the not-wall cells of `pn` and nothing else: wall cells with a recipe are
+// recomputed by whoever reads them, wall cells without one hold the same value in both buffers - the host checks that (Field.static_id:
+// equal unless somebody uploaded into one of them) and otherwise keeps the two-sweep passes, which tell the two buffers' histories apart.
+//
+// Validity (host-checked per mask, fs_api.hip build_bc_ops -> jq_ok): no recipe reads a source on the far side of its target as seen
+// from a cell whose raw value is live (a fluid cell, or the source of some recipe) - then the plain stencil's footprint suffices, as in
+// fs_rbpair.h; and the first / last domain row hold no not-wall cell.
+#pragma once
+#include "fs_rbpair.h"
+
+namespace fs {
+
+template <int N> __device__ __forceinline__ unsigned lv_sel_not_wall(uint32_t m)
+{
+    unsigned s = 0u;
+#pragma unroll
+    for (int c = 0; c < N; ++c) s |= ((m >> (8 * c)) & 0xffu) != 1u ? (1u << c) : 0u;
+    return s;
+}
+
+// one sweep of one row from finished rows: out[c] = computed ? predict_p(neighbours) : ctr[c]
+template <typename T, int N>
+__device__ __forceinline__ LV<T, N> jq_row(const LaneMapN<N> &lm, unsigned computed, const LV<T, N> &m, const LV<T, N> &ctr, const LV<T, N> &p,
+                                           const LV<T, N> &s2, const LV<T, N> &s3)
+{
+    const T pl = lv_left<T, N>(lm, ctr), pr = lv_right<T, N>(lm, ctr);
+    LV<T, N> o;
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        const T pE = c == N - 1 ? pr : ctr.a[c == N - 1 ? c : c + 1], pW = c == 0 ? pl : ctr.a[c == 0 ? 0 : c - 1];
+        const T val = predict_from(pE, pW, p.a[c], m.a[c], s2.a[c], s3.a[c]);
+        o.a[c] = (computed & (1u << c)) ? val : ctr.a[c];
+    }
+    return o;
+}
+
+template <int N, int RT, bool BND, typename T>
+__device__ __forceinline__ void jacobi_quad_tile(const Grid &g, const LaneMapN<N> &lm, int i0, int j0, int je, const unsigned (&nw)[RT + 8],
+                                                 const uint8_t *bcmap, T *pn, const T *pc, const T *src)
+{
+    constexpr int W = RT + 8;                  // window rows w = 0 .. W-1  <->  local rows j0-4 .. j0+RT+3 (clamped into the domain)
+    using R = LV<T, N>;
+    constexpr unsigned ALL = (1u << N) - 1u;
+#define FS_NW(w) (BND ? nw[w] : ALL)
+    R P[W], S2[W], S3[W];
+    uint32_t code[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int j = clampy(g, j0 - 4 + w);
+        P[w] = lv_field<1, T, N>(pc, g, 0, i0, j);
+        if (w >= 1 && w <= W - 2) {
+            S2[w] = lv_field<2, T, N>(src, g, 0, i0, j);
+            S3[w] = lv_field<2, T, N>(src, g, 1, i0, j);
+        }
+        code[w] = BND ? lv_bytes<N>(bcmap, g, i0, j) : 0u;
+    }
+    // sweep s = 1 .. 4 on rows s .. W-1-s from the view of the rows s-1 .. W-s of the previous iterate (a row missing at the edge of the
+    // window is stood in for by the row itself: what that produces is only read where the validity argument of the header excludes it)
+#pragma unroll
+    for (int s = 1; s <= 4; ++s) {
+        R V[W];
+#pragma unroll
+        for (int w = s - 1; w <= W - s; ++w)
+            V[w] = BND ? lv_bc_row<T, N>(lm, P[w == s - 1 ? w : w - 1], P[w], P[w == W - s ? w : w + 1], code[w]) : P[w];
+#pragma unroll
+        for (int w = s; w <= W - 1 - s; ++w) P[w] = jq_row<T, N>(lm, FS_NW(w), V[w - 1], V[w], V[w + 1], S2[w], S3[w]);
+    }
+#pragma unroll
+    for (int w = 4; w <= W - 5; ++w) {
+        const int j = j0 - 4 + w;
+        if (j >= je) break;
+        const unsigned sel = FS_NW(w);
+        if (lm.owner && sel) lv_store_sel<T, N>(pn + idx<1, T>(g, 0, i0, j), P[w], sel);
+    }
+#undef FS_NW
+}
+
+template <int N, int RT, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_quad(Grid g, int nbx, int nby, int jb, int je, const uint8_t *bcmap, T *pn, const T *pc, const T *src)
+{
+    constexpr int W = RT + 8;
+    int wx, ty;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty)) return;
+    const LaneMapN<N> lm = lane_map_n<N>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    unsigned nw[W];
+    bool own = false, all_fluid = true;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 4 + w));
+        nw[w] = lv_sel_not_wall<N>(m);
+        all_fluid = all_fluid && m == 0u;
+        if (w >= 4 && w <= W - 5 && j0 - 4 + w < je) own = own || (lm.owner && nw[w] != 0u);
+    }
+    if (!__any(own)) return;                   // no not-wall cell in the rows this tile stores
+    if (__all(all_fluid)) jacobi_quad_tile<N, RT, false, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
+    else jacobi_quad_tile<N, RT, true, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
+}
+
+}  // namespace fs

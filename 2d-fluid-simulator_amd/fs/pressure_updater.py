@@ -59,6 +59,11 @@ class JacobiPressureUpdater(PressureUpdater):
             self.form = "two sweeps per pass" + (", vertical recipes in the tiles" if self._vertical else "")
         elif self._lazy:
             self.form = "single sweeps, boundary condition in the sweep"
+        # Four sweeps per pass (fs_jacobi_quad_lazy) where the mask admits it: the passes of a long run are launch- and latency-bound
+        # (BASELINE configs[1]: 24 two-sweep passes of 21.6 us = 78 % of the step)
+        self._quads = (self._pairs and n_iter >= 10 and os.environ.get("FS_JACOBI_QUADS", "1") == "1" and getattr(self._dev, "jacobi_quad_ok", False))
+        if self._quads:
+            self.form = "four sweeps per pass"
         if tentative and not self._pairs:
             self._precompute, self._src, self._lazy = False, None, False
 
@@ -66,16 +71,26 @@ class JacobiPressureUpdater(PressureUpdater):
         if self._precompute:
             self._dev.poisson_source(self.dt, self.dx, self._src, v_current)
         n_lazy = self._n_iter - 2 if self._lazy else 0
-        # two sweeps per pass where possible; an even number of passes, so that every iterate lands in the physical buffer the
-        # reference's rotation puts it in (the buffers differ in the wall cells nothing ever writes)
-        n_pairs = (n_lazy // 4) * 2 if self._pairs else 0
+        n_real = self._n_iter - n_lazy
+        if self._quads and p.current.static_id == p.next.static_id:
+            # four sweeps per pass (the pass writes not-wall cells only: the wall cells nothing writes must be equal in the two buffers,
+            # Field.static_id); what does not fill a pass runs as single lazily-bounded sweeps
+            for _ in range(n_lazy // 4):
+                self._dev.jacobi_quad_lazy(p.next, p.current, self._src)
+                p.swap()
+            n_lazy %= 4
+            n_pairs = n_lazy // 2        # (equal wall histories: a single two-sweep pass is as good as an even number of them)
+        else:
+            # two sweeps per pass where possible; an even number of passes, so that every iterate lands in the physical buffer the
+            # reference's rotation puts it in (the buffers differ in the wall cells nothing ever writes)
+            n_pairs = (n_lazy // 4) * 2 if self._pairs else 0
         for k in range(n_pairs):
-            self._dev.jacobi_pair_lazy(p.next, p.current, self._src, swapped=k & 1, vertical=self._vertical)
+            self._dev.jacobi_pair_lazy(p.next, p.current, self._src, swapped=bool(k & 1), vertical=self._vertical)
             p.swap()
         for _ in range(n_lazy - 2 * n_pairs):
             self._dev.jacobi_sweep_lazy(p.next, p.current, self._src)
             p.swap()
-        for _ in range(self._n_iter - n_lazy):
+        for _ in range(n_real):
             self._bc.set_pressure_boundary_condition(p.current)
             self._update(p.next, p.current, v_current)
             p.swap()

@@ -573,6 +573,10 @@ class DeviceBase:
         self._run("jacobi_pair_lazy", (pn._h, pc._h, src._h, (1 if swapped else 0) | (2 if vertical else 0)),
                   reads=[(pc, 2 * r), (src, r), (pn, 2 * r)], writes=[pn])
 
+    def jacobi_quad_lazy(self, pn, pc, src):
+        """Four lazily-bounded sweeps in one pass, pn[not wall] <- sweep^4(pc) (csrc/fs_jquad.h)."""
+        self._run("jacobi_quad_lazy", (pn._h, pc._h, src._h), reads=[(pc, 4), (src, 3)], writes=[pn])
+
     def rbsor_halfsweep_src(self, omega, parity, pn, pc, src):
         self._run("rbsor_halfsweep_src", (omega, parity, pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
 
@@ -696,6 +700,13 @@ class Device(DeviceBase):
         ok = ctypes.c_int()
         _lib.call("fs_rbsor_pair_ok", self._ctx, ctypes.byref(ok))
         return bool(ok.value)
+
+    @property
+    def jacobi_quad_ok(self):
+        """The mask admits the four-sweep Jacobi pass (single GPU)."""
+        ok = ctypes.c_int()
+        _lib.call("fs_jacobi_quad_ok", self._ctx, ctypes.byref(ok))
+        return bool(ok.value) and self.nranks == 1
 
     def _p_exchange(self, h, nchan, depth):
         _lib.call("fs_halo_exchange", self._ctx, h, depth)

@@ -197,6 +197,13 @@ int fs_selftest_f64div(fs_ctx *ctx, double divisor, int *mismatches);
 int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok);
 int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_out, fs_field *pn_out, const fs_field *pc,
                   const fs_field *pn, const fs_field *vc, int full, int row_begin, int row_end);
+/* FOUR such sweeps in one pass (csrc/fs_jquad.h): pn[not wall] <- sweep(sweep(sweep(sweep(pc)))), the boundary condition evaluated in
+ * front of each; for long Jacobi runs whose data stay cache resident and whose cost is launches and latency.  Writes the not-wall cells
+ * of pn only: the caller guarantees that the wall cells no kernel writes are equal in pn and pc (nobody uploaded into one of them).
+ * pc is read 4 rows beyond the written range, src 3.  fs_jacobi_quad_ok: f32, fs_lazy_bc_ok, and no recipe that reads the far side of
+ * its target as seen from a cell whose value is used; otherwise FS_ERR_UNSUPPORTED - use fs_jacobi_pair_lazy / fs_jacobi_sweep_lazy.  */
+int fs_jacobi_quad_ok(const fs_ctx *ctx, int *ok);
+int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end);
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc,
                            const fs_field *src, int row_begin, int row_end);
 /* Residual diagnostic (new; the reference never measures convergence): sum over owned not-wall cells of

@@ -175,10 +175,11 @@ def test_pair_equals_two_sweeps(seed, rt, hip_lib, monkeypatch, _force_pairs):
 
 
 def test_form_is_decided_from_the_mask(hip_lib, monkeypatch):
-    """FS_JACOBI_PAIRS unset: two sweeps per pass; the variant with vertical recipes in the tiles only where the plain one would send more
+    """FS_JACOBI_PAIRS unset (four-sweep passes off - tests/test_gpu_jquad.py covers them): two sweeps per pass; the variant with vertical recipes in the tiles only where the plain one would send more
     than 5 % of the rows down its general path (scene 3's cylinders) - decided from the mask, the same on every run; the oracle's bits."""
     from fs.boundary_condition import create_scene_arrays
     monkeypatch.delenv("FS_JACOBI_PAIRS")
+    monkeypatch.setenv("FS_JACOBI_QUADS", "0")
     for bc, res, vertical in ((2, 512, False), (3, 256, None)):
         const, mask, _ = create_scene_arrays(bc, res)
         solver, ref, pu = _pair(const, mask, "cip", 12, res, lazy=None)
