@@ -112,12 +112,68 @@ static int prof_drain(fs_ctx *c)
 static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
 
 // overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
-struct OvGrid { int nbx, nby; dim3 grid; };
+struct OvGrid { int nbx, nby; dim3 grid; Grid g; };
 enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16, XCD_JACOBI = 32 };
-static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroups, int family)
+// Compact list of the workgroups of a dense XCD-band launch that have anything to do (Grid::tiles), built once per geometry from the
+// host-side activity maps of the scene.  lanes = cells per lane (4: wave columns of 248 cells, 2: of 120), rt = rows per tile.
+static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby)
+{
+    if (c->halo != 0 || c->h_act4.empty() || nbx > 0xfff || nby > 0xfffff) return nullptr;
+    const uint32_t key = (uint32_t)lanes | ((uint32_t)rt << 4) | ((uint32_t)stacked << 12) | ((uint32_t)group << 16);
+    auto it = c->tile_lists.find(key);
+    if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
+    if (c->capturing || c->tape_rec) return nullptr;      // (building one synchronises the stream: not inside a capture - the dense grid then)
+    const std::vector<uint8_t> &act = lanes == 4 ? c->h_act4 : c->h_act2;
+    const int ow = lanes == 4 ? 62 : 60, waves = (c->X / lanes + ow - 1) / ow, Y = c->Y;
+    std::vector<uint32_t> per[8];
+    const int groups = (nby + group - 1) / group;
+    for (int xcd = 0; xcd < 8; ++xcd)
+        for (int lg = 0; lg * 8 + xcd < groups; ++lg)
+            for (int ly = 0; ly < group; ++ly) {
+                const int by = (lg * 8 + xcd) * group + ly;
+                if (by >= nby) continue;
+                for (int bx = 0; bx < nbx; ++bx) {
+                    // wave columns / rows of this workgroup (4 waves: side by side, or stacked = 4 tile rows of one column)
+                    const int wx0 = stacked ? bx : bx * 4, wx1 = std::min(waves, stacked ? bx + 1 : bx * 4 + 4);
+                    const int j0 = (stacked ? by * 4 : by) * rt, j1 = std::min(Y, (stacked ? by * 4 + 4 : by + 1) * rt);
+                    bool any = false;
+                    for (int wx = wx0; wx < wx1 && !any; ++wx)
+                        for (int j = j0; j < j1; ++j)
+                            if (act[(size_t)wx * Y + j]) { any = true; break; }
+                    if (any) per[xcd].push_back(((uint32_t)by << 12) | (uint32_t)bx);
+                }
+            }
+    size_t K = 0, total = 0;
+    for (auto &v : per) { K = std::max(K, v.size()); total += v.size(); }
+    fs_ctx::TileList tl;
+    if (K > 0 && total < (size_t)nbx * nby) {        // (nothing to skip: the dense grid needs no list)
+        std::vector<uint32_t> h(K * 8, 0xffffffffu);
+        for (int xcd = 0; xcd < 8; ++xcd)
+            for (size_t k = 0; k < per[xcd].size(); ++k) h[k * 8 + xcd] = per[xcd][k];
+        if (hipMalloc(&tl.d, h.size() * sizeof(uint32_t)) == hipSuccess &&
+            hipMemcpyAsync(tl.d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+            hipStreamSynchronize(c->stream) == hipSuccess)
+            tl.per_xcd = (int)K;
+        else { if (tl.d) hipFree(tl.d); tl.d = nullptr; }
+    }
+    auto &slot = c->tile_lists[key] = tl;
+    return slot.d ? &slot : nullptr;
+}
+
+static void tile_lists_free(fs_ctx *c)
+{
+    for (auto &kv : c->tile_lists) if (kv.second.d) hipFree(kv.second.d);
+    c->tile_lists.clear();
+}
+
+// XCD-band launch geometry of a tile kernel family (fs_march.h band_coords); `lanes`: cells per lane.  When the launch covers the whole
+// single-GPU grid, the workgroups without anything to do are left out (compact list, Grid::tiles).
+static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true)
 {
     OvGrid o;
-    const int nq = c->X / 4, waves = (nq + 61) / 62, tiles = (je - jb + rt - 1) / rt;
+    o.g = c->grid();
+    const int ow = lanes == 4 ? 62 : 60;
+    const int nu = c->X / lanes, waves = (nu + ow - 1) / ow, tiles = (je - jb + rt - 1) / rt;
     const bool stacked = (c->stack_mask & family) != 0;    // the 4 waves of a workgroup: 4 tile rows of one wave column
     o.nbx = stacked ? waves : (waves + 3) / 4;
     o.nby = stacked ? (tiles + 3) / 4 : tiles;
@@ -125,34 +181,20 @@ static inline OvGrid ov_grid(const fs_ctx *c, int jb, int je, int rt, int zgroup
         // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords)
         const int group = stacked ? std::max(1, c->xcd_group / 4) : c->xcd_group;     // the same number of field rows per XCD group
         const int groups = (o.nby + group - 1) / group;
-        const bool inner = zgroups > 1 && (c->cg_inner_mask & family) != 0;
-        o.grid = inner ? dim3(8 * o.nbx * zgroups, group, (groups + 7) / 8) : dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
+        const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && jb == 0 && je == c->rows ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby) : nullptr;
+        const bool inner = zgroups > 1 && (tl || (c->cg_inner_mask & family) != 0);
+        if (tl) { o.grid = dim3(8 * tl->per_xcd * zgroups, 1, 1); o.g.tiles = tl->d; }
+        else o.grid = inner ? dim3(8 * o.nbx * zgroups, group, (groups + 7) / 8) : dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
         o.nby |= (group - 1) << 24;
         if (inner) o.nby |= FS_CG_INNER;
     } else { o.grid = dim3(o.nbx * o.nby, zgroups, 1); o.nbx = -o.nbx; }   // negative nbx = row-major decode
     if (stacked) o.nby |= FS_STACKED;
     return o;
 }
-
+static inline OvGrid ov_grid(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, bool allow_list = true)
+{ return ov_grid_lanes(c, jb, je, rt, zgroups, family, 4, allow_list); }
 template <int N>
-static OvGrid ov_grid_n(const fs_ctx *c, int jb, int je, int rt)
-{
-    // as ov_grid, for wave columns of 64 - 2 * (4 / N) owner lanes of N cells
-    constexpr int OW = 64 - 2 * (4 / N);
-    OvGrid o;
-    const int nu = c->X / N, waves = (nu + OW - 1) / OW, tiles = (je - jb + rt - 1) / rt;
-    const bool stacked = (c->stack_mask & XCD_RBSOR) != 0;
-    o.nbx = stacked ? waves : (waves + 3) / 4;
-    o.nby = stacked ? (tiles + 3) / 4 : tiles;
-    if (c->xcd_mask & XCD_RBSOR) {
-        const int group = stacked ? std::max(1, c->xcd_group / 4) : c->xcd_group;
-        const int groups = (o.nby + group - 1) / group;
-        o.grid = dim3(8 * o.nbx, group, (groups + 7) / 8);
-        o.nby |= (group - 1) << 24;
-    } else { o.grid = dim3(o.nbx * o.nby, 1, 1); o.nbx = -o.nbx; }
-    if (stacked) o.nby |= FS_STACKED;
-    return o;
-}
+static OvGrid ov_grid_n(fs_ctx *c, int jb, int je, int rt) { return ov_grid_lanes(c, jb, je, rt, 1, XCD_RBSOR, N); }
 
 // Division-mode dispatch (fs_device.h DM_*): CALL(DM) is expanded for the modes a kernel family distinguishes.  f32 fields divide by their
 // loop-invariant divisors through the f64 multiplication (modes 4 / 5; FS_F64DIV=0: IEEE division, modes 0 / 1); power-of-two dx-derived
@@ -165,7 +207,7 @@ static OvGrid ov_grid_n(const fs_ctx *c, int jb, int je, int rt)
 #define FS_DMA(dm, CALL)      /* modes 0 / 1 / 4 / 5 : both kinds                   */ \
     do { FS_F32_ONLY(dm, 5, CALL, 5) FS_F32_ONLY(dm, 4, CALL, 4) if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
 
-#define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, HV, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end, \
+#define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, HV, T>), grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, list, nlist, zoff, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
 template <bool SW, bool HV, typename T>
 static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, int row_end, fs_field *pn, const fs_field *pc, const fs_field *src)
@@ -188,10 +230,10 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
     const int dm = SRC ? 0 : dm_const(ctx, k);           // the source-pair form divides nothing
 #define FS_JAC(DM) do { \
-        if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else if (rt == 3) hipLaunchKernelGGL((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
+        if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else if (rt == 3) hipLaunchKernelGGL((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
     return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC); });
 }
 
@@ -560,6 +602,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_F64DIV")) c->use_f64div = atoi(s) != 0;
+    if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
     if (const char *s = getenv("FS_VORT_RT")) { const int v = atoi(s); if (v >= 3 && v <= 6) c->vort_rt = v; }
@@ -593,6 +636,7 @@ int fs_destroy(fs_ctx *ctx)
     for (auto &r : ctx->prof_recs) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
     for (auto e : ctx->prof_pool) hipEventDestroy(e);
     free_ops(ctx->ops_vel); free_ops(ctx->ops_prs); free_ops(ctx->ops_dye);
+    tile_lists_free(ctx);
     for (fs_field *f : ctx->fields) { if (f->d) hipFree(f->d); if (f->hot) hipFree(f->hot); delete f; }
     for (fs_field *f : ctx->deferred_free) { if (f->d) hipFree(f->d); if (f->hot) hipFree(f->hot); delete f; }
     ctx->fields.clear();
@@ -687,6 +731,20 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     FS_HIP(hipMemsetAsync(ctx->d_bcmap, 0, (size_t)ctx->rows * ctx->Pm, ctx->stream));
     FS_HIP(hipMemsetAsync(ctx->d_lazyflags, 63, (size_t)std::max(ctx->nwx, 1) * ctx->rows, ctx->stream));
     rc = upload_global(ctx, ctx->d_bcmap, 1, 1, ctx->h_bcmap.data(), ctx->Pm);
+    // activity of the scene per (wave column, row) for the compact launches: a cell is "deep wall" when it is a wall cell that no
+    // boundary kernel writes - workgroups made of such cells only have nothing to do in any kernel
+    tile_lists_free(ctx);
+    ctx->h_act4.clear(); ctx->h_act2.clear();
+    if (ctx->halo == 0 && ctx->X % 4 == 0 && ctx->tile_list_mask) {
+        const int X = ctx->X, Y = ctx->Y, w4 = 248, w2 = 120;
+        ctx->h_act4.assign((size_t)((X + w4 - 1) / w4) * Y, 0);
+        ctx->h_act2.assign((size_t)((X + w2 - 1) / w2) * Y, 0);
+        for (int i = 0; i < X; ++i) {
+            const uint8_t *m = mask_xy + (size_t)i * Y, *b = ctx->h_bcmap.data() + (size_t)i * Y;
+            uint8_t *a4 = ctx->h_act4.data() + (size_t)(i / w4) * Y, *a2 = ctx->h_act2.data() + (size_t)(i / w2) * Y;
+            for (int j = 0; j < Y; ++j) { const uint8_t a = (m[j] != 1) | (b[j] != 0); a4[j] |= a; a2[j] |= a; }
+        }
+    }
     std::vector<uint8_t>().swap(ctx->h_bcmap);
     if (rc) return rc;
     if (ctx->X % 4 == 0) {      // per-tile flags of the lazy pressure BC
@@ -903,7 +961,7 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
         hipLaunchKernelGGL(kern, cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, __VA_ARGS__); \
     });
 
-#define FS_K2M(SS, PP) hipLaunchKernelGGL((k_mac_update_quad<SS, PP, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K2M(SS, PP) hipLaunchKernelGGL((k_mac_update_quad<SS, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
             (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot)
 int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_field *vn, const fs_field *vc,
                   const fs_field *pc, int row_begin, int row_end)
@@ -969,7 +1027,7 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, "cip_nonadv", [=] {
-#define FS_K2Q(DM) hipLaunchKernelGGL((k_cip_nonadv_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
+#define FS_K2Q(DM) hipLaunchKernelGGL((k_cip_nonadv_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
                 FS_DMA(dm_all(ctx, k), FS_K2Q);
             });
         }
@@ -989,7 +1047,7 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
         if (ctx->use_march) {
             const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
             return launch(ctx, "cip_nonadv_dye", [=] {
-#define FS_K12Q(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
+#define FS_K12Q(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
                 FS_DMA(dm_all(ctx, k), FS_K12Q);
             });
         }
@@ -997,7 +1055,7 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
     })
 }
 
-#define FS_K3Q(CC, NC, PP) hipLaunchKernelGGL((k_cip_nonadv_grad_quad<CC, NC, PP, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K3Q(CC, NC, PP) hipLaunchKernelGGL((k_cip_nonadv_grad_quad<CC, NC, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
             (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d)
 #define FS_K3(CC, PP, NAME) { FS_LAUNCH_CELLS(NAME, (k_cip_nonadv_grad<CC, PP, T>), ctx->grid(), k, row_begin, (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d) }
 int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, const fs_field *fxc, const fs_field *fyc,
@@ -1025,9 +1083,9 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
     })
 }
 
-#define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, false, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, false, T>), qgrid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-#define FS_K4D(PP) hipLaunchKernelGGL((k_cip_advect_dye<PP, false, T>), qgrid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K4D(PP) hipLaunchKernelGGL((k_cip_advect_dye<PP, false, T>), qgrid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
 #define FS_K4N(CC, PP) hipLaunchKernelGGL((k_cip_advect<CC, PP, T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
@@ -1072,7 +1130,7 @@ int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, f
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
         return launch(ctx, "cip_advect_c3_clamped", [=] {
-#define FS_K4DC(DM) hipLaunchKernelGGL((k_cip_advect_dye<DM, true, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K4DC(DM) hipLaunchKernelGGL((k_cip_advect_dye<DM, true, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                          (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
             FS_DMX(dm_dx(ctx, k), FS_K4DC);
         });
@@ -1111,8 +1169,8 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
             // lies beyond row_end.  2 rows: 116 VGPRs = 4 waves per SIMD; 3 rows: 146 (3 waves) - 394 against 417 us at bc5 res 4096.
             const int RT = ctx->k34_rt >= 2 ? ctx->k34_rt : 2;
             const int jb = row_begin, je = row_end;
-            const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT);
-#define FS_K34RT(R, DM) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, DM, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, jb, je, \
+            const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT, !full);      // (the carrying pass visits every tile)
+#define FS_K34RT(R, DM) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, \
                 (const uint8_t *)ctx->d_bcmap, full)
 #define FS_K34RT2(DM) FS_K34RT(2, DM)
@@ -1143,8 +1201,8 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
         else {
             auto k = make_konst<T>(ctx, dt, dx, 1.0);
             constexpr int RT = 2;
-            const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 3, XCD_ADVECT);
-#define FS_K34D(DM, CL) hipLaunchKernelGGL((k_cip_grad_advect_dye<RT, DM, CL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
+            const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, !full);
+#define FS_K34D(DM, CL) hipLaunchKernelGGL((k_cip_grad_advect_dye<RT, DM, CL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                 (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, full)
 #define FS_K34D_C(DM) FS_K34D(DM, true)
 #define FS_K34D_N(DM) FS_K34D(DM, false)
@@ -1200,7 +1258,7 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
         auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
         const int dm = dm_dx(ctx, k);
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
-#define FS_VORT(RT, DM, ST) hipLaunchKernelGGL((k_vort_fused<RT, DM, ST, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
+#define FS_VORT(RT, DM, ST) hipLaunchKernelGGL((k_vort_fused<RT, DM, ST, T>), grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
 #define FS_VORT_RT(DM, ST) do { if (rt == 5) FS_VORT(5, DM, ST); else if (rt == 6) FS_VORT(6, DM, ST); else if (rt == 3) FS_VORT(3, DM, ST); else FS_VORT(4, DM, ST); } while (0)
 #define FS_VORT_S(DM) FS_VORT_RT(DM, true)
 #define FS_VORT_N(DM) FS_VORT_RT(DM, false)
@@ -1266,7 +1324,7 @@ int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs
     const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_JACOBI);
     FS_DISPATCH(ctx, {
         return launch(ctx, "jacobi_sweep_lazy", [=] {
-            hipLaunchKernelGGL((k_jacobi_lazy<T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), og.nbx, og.nby, row_begin, row_end,
+            hipLaunchKernelGGL((k_jacobi_lazy<T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
                                (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
         });
     })
@@ -1283,7 +1341,7 @@ int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     FS_ROWS();
     if (!(ctx->lazy_ok && ctx->use_march)) { set_error("this mask does not admit the lazy pressure boundary condition (fs_lazy_bc_ok)"); return FS_ERR_UNSUPPORTED; }
     const int rt = (mode & 2) ? std::min(ctx->pair_rt, 2) : ctx->pair_rt;      // (the third tile path at 3 rows: 97 VGPRs, one wave per SIMD less)
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_JACOBI);
+    const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_JACOBI, false);      // (dense: its general rows ride in leading z slices)
     FS_DISPATCH(ctx, {
         return launch(ctx, "jacobi_pair_lazy", [=] {
             switch (mode) {
@@ -1330,7 +1388,7 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
     const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_RBSOR);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-#define FS_RBF_RT(RT, DM) hipLaunchKernelGGL((k_rbsor_fused<RT, DM, T>), og.grid, dim3(256), 0, ctx->stream, ctx->grid(), k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBF_RT(RT, DM) hipLaunchKernelGGL((k_rbsor_fused<RT, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
 #define FS_RBF2(DM) FS_RBF_RT(2, DM)
 #define FS_RBF3(DM) FS_RBF_RT(3, DM)
@@ -1385,7 +1443,7 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     // lanes of 2 cells (116 VGPRs = 4 waves per SIMD at 4 rows; quads: 182 = 2 waves, 44.9 against 34.3 us per pass at bc2 res 1600)
     const int rt = ctx->jquad_rt;
     const OvGrid og = ov_grid_n<2>(ctx, row_begin, row_end, rt);
-#define FS_JQ(RT) hipLaunchKernelGGL((k_jacobi_quad<2, RT, T>), og.grid, dim3(256), 0, ctx->stream, gg, og.nbx, og.nby, row_begin, row_end, \
+#define FS_JQ(RT) hipLaunchKernelGGL((k_jacobi_quad<2, RT, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
     return launch(ctx, "jacobi_quad_lazy", [=] {
         if (rt == 2) FS_JQ(2); else if (rt == 6) FS_JQ(6); else if (rt == 8) FS_JQ(8); else FS_JQ(4);
@@ -1420,8 +1478,8 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 (FS_RBPAIR_RT=6: 6) rows per tile.  The carrying
     // pass after an upload (full) is rare: one configuration.
     const int rt = full ? 4 : ctx->rbpair_rt;
-    const OvGrid og = ov_grid_n<2>(ctx, row_begin, row_end, rt);
-#define FS_RBP_K(RT, PAR, DM, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, 2, FULL, T>), og.grid, dim3(256), 0, ctx->stream, gg, k, og.nbx, og.nby, row_begin, row_end, \
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, !full);
+#define FS_RBP_K(RT, PAR, DM, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, 2, FULL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBP_PAR(RT, DM, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, FULL); else FS_RBP_K(RT, 0, DM, FULL); } while (0)
 #define FS_RBP_DM(RT) do { if (dm & DM_F64) FS_RBP_PAR(RT, 4, false); else FS_RBP_PAR(RT, 0, false); } while (0)

@@ -22,6 +22,10 @@ struct Grid {
     int jlo, jhi; // local rows of global y = 0 and y = Y-1 (clamp range of sample())
     int ybase;    // global y of local row 0 (red-black parity)
     const uint8_t *mask;  // [rows][Pm]; rows outside the global domain hold 1 (wall)
+    // Compact launch (set per launch by the host, nullptr = the dense grid): the workgroups that have anything to do, as
+    // (tile-row block << 12 | column block) of the dense decode, listed per XCD and interleaved - entry k * 8 + x is the k-th
+    // active workgroup of XCD x (0xffffffff: padding).  A third of scene 5 is solid wall: those workgroups are never launched.
+    const uint32_t *tiles;
 };
 
 // Kernel constants with Taichi's typing rules; filled on the host by make_konst().

@@ -120,9 +120,19 @@ struct fs_ctx {
     bool pack_halo = true;    // env FS_PACK_HALO=0: one ncclSend/ncclRecv per field instead of one packed message per neighbour
     int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default, 21 / 22 / 23 / 24 = overlapped-wave tiles of 1 - 4 rows
 
+    // compact launches (fs_device.h Grid::tiles): per-cell activity of the scene on the host (bit 0: some cell of wave column wx - 248
+    // cells - in row j is not deep wall, bit 1: the same for the 120-cell wave columns of the 2-cell-lane kernels), and the lists built from
+    // it per launch geometry (key: lane width, rows per tile, stacked, group size)
+    int tile_list_mask = 1 | 4;              // env FS_TILE_LIST: kernel families (XCD_* bits) launched compactly.  Measured at bc5 res 4096:
+                                             // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement unchanged, K2 111 -> 117
+    std::vector<uint8_t> h_act4, h_act2;     // [wave column][global row]
+    struct TileList { uint32_t *d = nullptr; int per_xcd = 0; };
+    std::map<uint32_t, TileList> tile_lists;
+
     fs::Grid grid() const
     {
         fs::Grid g;
+        g.tiles = nullptr;
         g.X = X; g.P = P; g.Pm = Pm; g.rows = rows;
         int jlo = halo - y0, jhi = halo - y0 + (Y - 1);
         g.jlo = jlo < 0 ? 0 : jlo;

@@ -146,8 +146,19 @@ struct LaneMap {
 // instructions of a one-row K2 tile on them).
 constexpr int FS_CG_INNER = 1 << 22;
 template <int ZG = 1>
-__device__ __forceinline__ bool band_coords(int nbx, int nby_packed, int &bx, int &by, int &cg, int zoff = 0)
+__device__ __forceinline__ bool band_coords(const Grid &g, int nbx, int nby_packed, int &bx, int &by, int &cg, int zoff = 0)
 {
+    if (g.tiles) {
+        // compact launch: blockIdx.x = (k * ZG + cg) * 8 + xcd  ->  the k-th listed workgroup of that XCD, channel group cg (the passes
+        // over one tile are consecutive workgroups of one XCD)
+        const int t = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+        const int k = ZG == 1 ? t : t / ZG;
+        cg = ZG == 1 ? 0 : t - k * ZG;
+        const uint32_t e = g.tiles[k * 8 + xcd];
+        bx = (int)(e & 0xfffu);
+        by = (int)(e >> 12);
+        return e != 0xffffffffu;
+    }
     const int nby = nby_packed & 0x3fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked, bit 22 = channel groups innermost
     if (nbx < 0) {   // plain row-major decode (FS_XCD=0: rows of one tile row spread over the XCDs): grid = (nbx * nby, ZG)
         nbx = -nbx;
@@ -184,7 +195,7 @@ template <int ZG = 1>
 __device__ __forceinline__ bool tile_coords(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg, int zoff = 0)
 {
     int bx, by;
-    if (!band_coords<ZG>(nbx, nby_packed, bx, by, cg, zoff)) return false;
+    if (!band_coords<ZG>(g, nbx, nby_packed, bx, by, cg, zoff)) return false;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }

@@ -115,7 +115,7 @@ __device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_pa
 {
     constexpr int OW = 64 - 2 * (4 / N);
     int bx, by, cg;
-    if (!band_coords<1>(nbx, nby_packed, bx, by, cg)) return false;
+    if (!band_coords<1>(g, nbx, nby_packed, bx, by, cg)) return false;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }
