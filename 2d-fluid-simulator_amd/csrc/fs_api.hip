@@ -116,10 +116,12 @@ struct OvGrid { int nbx, nby; dim3 grid; Grid g; };
 enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16, XCD_JACOBI = 32 };
 // Compact list of the workgroups of a dense XCD-band launch that have anything to do (Grid::tiles), built once per geometry from the
 // host-side activity maps of the scene.  lanes = cells per lane (4: wave columns of 248 cells, 2: of 120), rt = rows per tile.
-static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby)
+// cls: 0 = every workgroup with work; 1 / 2 = those whose tiles see nothing but fluid within `reach` rows and the halo lanes ("plain":
+// no mask loads, no boundary views - their own kernel and register budget) / the others
+static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls = 0, int reach = 0)
 {
     if (c->halo != 0 || c->h_act4.empty() || nbx > 0xfff || nby > 0xfffff) return nullptr;
-    const uint32_t key = (uint32_t)lanes | ((uint32_t)rt << 4) | ((uint32_t)stacked << 12) | ((uint32_t)group << 16);
+    const uint32_t key = (uint32_t)lanes | ((uint32_t)rt << 4) | ((uint32_t)stacked << 12) | ((uint32_t)group << 16) | ((uint32_t)cls << 24) | ((uint32_t)reach << 26);
     auto it = c->tile_lists.find(key);
     if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
     if (c->capturing || c->tape_rec) return nullptr;      // (building one synchronises the stream: not inside a capture - the dense grid then)
@@ -139,14 +141,21 @@ static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stac
                     bool any = false;
                     for (int wx = wx0; wx < wx1 && !any; ++wx)
                         for (int j = j0; j < j1; ++j)
-                            if (act[(size_t)wx * Y + j]) { any = true; break; }
+                            if (act[(size_t)wx * Y + j] & 1) { any = true; break; }
+                    if (any && cls) {
+                        bool plain = true;        // bit 1 of the activity byte: a non-fluid cell within the wave column's lanes (halo lanes included)
+                        for (int wx = wx0; wx < wx1 && plain; ++wx)
+                            for (int j = std::max(0, j0 - reach); j < std::min(Y, j1 + reach); ++j)
+                                if (act[(size_t)wx * Y + j] & 2) { plain = false; break; }
+                        any = plain == (cls == 1);
+                    }
                     if (any) per[xcd].push_back(((uint32_t)by << 12) | (uint32_t)bx);
                 }
             }
     size_t K = 0, total = 0;
     for (auto &v : per) { K = std::max(K, v.size()); total += v.size(); }
     fs_ctx::TileList tl;
-    if (K > 0 && total < (size_t)nbx * nby) {        // (nothing to skip: the dense grid needs no list)
+    if (K > 0 && (cls || total < (size_t)nbx * nby)) {        // (nothing to skip: the dense grid needs no list)
         std::vector<uint32_t> h(K * 8, 0xffffffffu);
         for (int xcd = 0; xcd < 8; ++xcd)
             for (size_t k = 0; k < per[xcd].size(); ++k) h[k * 8 + xcd] = per[xcd][k];
@@ -168,7 +177,7 @@ static void tile_lists_free(fs_ctx *c)
 
 // XCD-band launch geometry of a tile kernel family (fs_march.h band_coords); `lanes`: cells per lane.  When the launch covers the whole
 // single-GPU grid, the workgroups without anything to do are left out (compact list, Grid::tiles).
-static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true)
+static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true, int cls = 0, int reach = 0)
 {
     OvGrid o;
     o.g = c->grid();
@@ -179,9 +188,11 @@ static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroup
     o.nby = stacked ? (tiles + 3) / 4 : tiles;
     if (c->xcd_mask & family) {
         // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords)
-        const int group = stacked ? std::max(1, c->xcd_group / 4) : c->xcd_group;     // the same number of field rows per XCD group
+        int xg = c->xcd_group;
+        for (int f = 0; f < 6; ++f) if ((family >> f) & 1) xg = c->xcd_group_fam[f] > 0 ? c->xcd_group_fam[f] : xg;
+        const int group = stacked ? std::max(1, xg / 4) : xg;     // the same number of field rows per XCD group
         const int groups = (o.nby + group - 1) / group;
-        const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && jb == 0 && je == c->rows ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby) : nullptr;
+        const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && jb == 0 && je == c->rows ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach) : nullptr;
         const bool inner = zgroups > 1 && (tl || (c->cg_inner_mask & family) != 0);
         if (tl) { o.grid = dim3(8 * tl->per_xcd * zgroups, 1, 1); o.g.tiles = tl->d; }
         else o.grid = inner ? dim3(8 * o.nbx * zgroups, group, (groups + 7) / 8) : dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
@@ -609,6 +620,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_RBSOR_RT")) { const int v = atoi(s); if (v >= 2 && v <= 4) c->rbsor_rt = v; }
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
+    if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
     if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); if (v >= 2) c->k34_rt = v == 2 || v == 3 ? v : 4; }
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
@@ -619,6 +631,10 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_STACK")) c->stack_mask = atoi(s);
     if (const char *s = getenv("FS_CG_INNER")) c->cg_inner_mask = atoi(s);
     if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
+    if (const char *s = getenv("FS_XCD_GROUP_FAM")) {      // "bit:rows,bit:rows": tile rows per XCD group of single kernel families (XCD_* bit numbers 0 .. 5)
+        int f, v, n = 0;
+        while (sscanf(s, "%d:%d%n", &f, &v, &n) == 2) { if (f >= 0 && f < 6 && v >= 1 && v <= 128) c->xcd_group_fam[f] = v; s += n; if (*s == ',') ++s; else break; }
+    }
     if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows
     *out = c;
     return FS_OK;
@@ -739,10 +755,20 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
         const int X = ctx->X, Y = ctx->Y, w4 = 248, w2 = 120;
         ctx->h_act4.assign((size_t)((X + w4 - 1) / w4) * Y, 0);
         ctx->h_act2.assign((size_t)((X + w2 - 1) / w2) * Y, 0);
+        const int n4 = (X + w4 - 1) / w4, n2 = (X + w2 - 1) / w2;
         for (int i = 0; i < X; ++i) {
             const uint8_t *m = mask_xy + (size_t)i * Y, *b = ctx->h_bcmap.data() + (size_t)i * Y;
             uint8_t *a4 = ctx->h_act4.data() + (size_t)(i / w4) * Y, *a2 = ctx->h_act2.data() + (size_t)(i / w2) * Y;
-            for (int j = 0; j < Y; ++j) { const uint8_t a = (m[j] != 1) | (b[j] != 0); a4[j] |= a; a2[j] |= a; }
+            // the neighbouring wave column whose halo lanes (4 cells) cover column i, if any
+            const int r4 = i % w4, r2 = i % w2;
+            uint8_t *h4 = r4 < 4 && i / w4 > 0 ? a4 - Y : (r4 >= w4 - 4 && i / w4 + 1 < n4 ? a4 + Y : nullptr);
+            uint8_t *h2 = r2 < 4 && i / w2 > 0 ? a2 - Y : (r2 >= w2 - 4 && i / w2 + 1 < n2 ? a2 + Y : nullptr);
+            for (int j = 0; j < Y; ++j) {
+                const uint8_t a = (uint8_t)((m[j] != 1) | (b[j] != 0)), nf = m[j] != 0 ? 2 : 0;
+                a4[j] |= a | nf; a2[j] |= a | nf;
+                if (h4) h4[j] |= nf;
+                if (h2) h2[j] |= nf;
+            }
         }
     }
     std::vector<uint8_t>().swap(ctx->h_bcmap);
@@ -1442,11 +1468,22 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     const Grid gg = ctx->grid();
     // lanes of 2 cells (116 VGPRs = 4 waves per SIMD at 4 rows; quads: 182 = 2 waves, 44.9 against 34.3 us per pass at bc2 res 1600)
     const int rt = ctx->jquad_rt;
-    const OvGrid og = ov_grid_n<2>(ctx, row_begin, row_end, rt);
-#define FS_JQ(RT) hipLaunchKernelGGL((k_jacobi_quad<2, RT, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
+#define FS_JQ(RT, PATH) hipLaunchKernelGGL((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
+    // plain and boundary workgroups as two compact launches (as fs_rbsor_pair) - on large grids: a second launch costs ~5 us, which a
+    // cache-resident grid does not earn back (bc2 res 1600: 18.1 + 21.3 against 34.6 us; bc5 res 4096: 81.4 + 49.8 against 137.5)
+    if ((ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4);
+        if (og.g.tiles && ogb.g.tiles) {
+            int rc = launch(ctx, "jacobi_quad_lazy", [=] { FS_JQ(4, 3); });
+            if (rc) return rc;
+            { const OvGrid og = ogb; return launch(ctx, "jacobi_quad_lazy_bnd", [=] { FS_JQ(4, 2); }); }
+        }
+    }
+    const OvGrid og = ov_grid_n<2>(ctx, row_begin, row_end, rt);
     return launch(ctx, "jacobi_quad_lazy", [=] {
-        if (rt == 2) FS_JQ(2); else if (rt == 6) FS_JQ(6); else if (rt == 8) FS_JQ(8); else FS_JQ(4);
+        if (rt == 2) FS_JQ(2, 2); else if (rt == 6) FS_JQ(6, 2); else if (rt == 8) FS_JQ(8, 2); else FS_JQ(4, 2);
     });
 }
 
@@ -1478,15 +1515,26 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 (FS_RBPAIR_RT=6: 6) rows per tile.  The carrying
     // pass after an upload (full) is rare: one configuration.
     const int rt = full ? 4 : ctx->rbpair_rt;
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, !full);
-#define FS_RBP_K(RT, PAR, DM, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, 2, FULL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBP_K(RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
-#define FS_RBP_PAR(RT, DM, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, FULL); else FS_RBP_K(RT, 0, DM, FULL); } while (0)
-#define FS_RBP_DM(RT) do { if (dm & DM_F64) FS_RBP_PAR(RT, 4, false); else FS_RBP_PAR(RT, 0, false); } while (0)
+#define FS_RBP_PAR(RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, PATH, FULL); else FS_RBP_K(RT, 0, DM, PATH, FULL); } while (0)
+#define FS_RBP_DM(RT, PATH) do { if (dm & DM_F64) FS_RBP_PAR(RT, 4, PATH, false); else FS_RBP_PAR(RT, 0, PATH, false); } while (0)
+    // Compact launch in two parts where the lists exist (single GPU, whole grid): the workgroups that see nothing but fluid within reach run
+    // the plain path as its own kernel (PATH 3: no mask loads, 126 VGPRs = 4 waves per SIMD), the others the kernel with both paths.
+    if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4);
+        if (og.g.tiles && ogb.g.tiles) {
+            int rc = launch(ctx, "rbsor_pair", [=] { FS_RBP_DM(4, 3); });
+            if (rc) return rc;
+            { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_DM(4, 2); }); }
+        }
+    }
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, !full);
     return launch(ctx, "rbsor_pair", [=] {
-        if (full) FS_RBP_PAR(4, 0, true);
-        else if (rt == 6) FS_RBP_DM(6);
-        else FS_RBP_DM(4);
+        if (full) FS_RBP_PAR(4, 0, 2, true);
+        else if (rt == 6) FS_RBP_DM(6, 2);
+        else FS_RBP_DM(4, 2);
     });
 }
 

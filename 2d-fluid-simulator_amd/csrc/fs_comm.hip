@@ -23,6 +23,12 @@
 #include <cstring>
 #include <vector>
 
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+
 #include "fs_host.h"
 
 namespace fs {
@@ -159,7 +165,35 @@ int fs_comm_init(fs_ctx *ctx, int rank, int nranks, const void *unique_id_128_by
     memcpy(&id, unique_id_128_bytes, sizeof id);
     Comm *cm = new Comm();
     cm->rank = rank; cm->nranks = nranks;
-    ncclResult_t r = g_rccl.CommInitRank(&cm->comm, nranks, id, rank);
+    // ncclCommInitRank blocks until every rank has arrived.  If one never does (a rank that died while importing, a stale unique id) the
+    // others would hang for ever: it runs in a helper thread and the caller gives up after FS_COMM_TIMEOUT seconds (default 180) with a
+    // clear error.  (The helper stays blocked and is abandoned; the process is expected to exit on this error.)
+    struct InitState { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto st = std::make_shared<InitState>();
+    const int device = ctx->device;
+    std::thread([st, nranks, id, rank, device] {
+        (void)hipSetDevice(device);
+        ncclComm_t c = nullptr;
+        const ncclResult_t r = g_rccl.CommInitRank(&c, nranks, id, rank);
+        std::lock_guard<std::mutex> lock(st->mu);
+        st->r = r; st->comm = c; st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    double limit = 180.0;
+    if (const char *s = getenv("FS_COMM_TIMEOUT")) limit = atof(s);
+    {
+        std::unique_lock<std::mutex> lock(st->mu);
+        if (!st->cv.wait_for(lock, std::chrono::duration<double>(limit), [&] { return st->done; })) {
+            delete cm;
+            char buf[256];
+            snprintf(buf, sizeof buf, "ncclCommInitRank: rank %d of %d still waiting for its peers after %.0f s (FS_COMM_TIMEOUT) - "
+                     "a rank is missing or the unique id is stale", rank, nranks, limit);
+            set_error(buf);
+            return FS_ERR_COMM;
+        }
+    }
+    cm->comm = st->comm;
+    const ncclResult_t r = st->r;
     if (r != ncclSuccess) { delete cm; return nccl_fail(r, "ncclCommInitRank"); }
     hipError_t e = hipMalloc(&cm->d_red, 16 * sizeof(double));
     if (e == hipSuccess) {      // highest priority: the short pack / RCCL / unpack kernels must not queue behind the interior rows they overlap with

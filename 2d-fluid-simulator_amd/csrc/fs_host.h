@@ -73,6 +73,8 @@ struct fs_ctx {
     bool rb_pair_ok = false;                 // mask admits the two-iteration red-black pass (fs_rbpair.h; decided in build_bc_ops)
     bool jq_ok = false;                      // mask admits the four-sweep Jacobi pass (fs_jquad.h)
     int jquad_rt = 4;                        // its tile height (env FS_JQUAD_RT = 2, 4, 6, 8)
+    int rbpair_split = 1;                    // plain and boundary workgroups of that pass (and of the four-sweep Jacobi pass) as two compact
+                                             // launches: env FS_RBPAIR_SPLIT = 0 never, 1 on grids of 8 M cells or more, 2 always
     int rbpair_rt = 4;                       // rows per tile of that pass (env FS_RBPAIR_RT = 4, 6)
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
@@ -114,6 +116,7 @@ struct fs_ctx {
     int k34_rt = -1;           // env FS_K34_RT: rows per register tile of the fused gradient-update + advection pass (0: one-row form; default 2)
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
+    int xcd_group_fam[6] = {0, 0, 0, 0, 0, 0};   // ... of single kernel families (env FS_XCD_GROUP_FAM; 0: xcd_group)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int stack_mask = 0;       // env FS_STACK: kernel families (XCD_* bits) launched with stacked workgroups
     int cg_inner_mask = 0;    // env FS_CG_INNER: kernel families whose channel-group passes over one tile are consecutive workgroups of one XCD

@@ -85,7 +85,9 @@ __device__ __forceinline__ void jacobi_quad_tile(const Grid &g, const LaneMapN<N
 #undef FS_NW
 }
 
-template <int N, int RT, typename T>
+// PATH 2: classify the tile here (mask loads); 3: the host listed this workgroup as plain - nothing but fluid within reach (fs_api.hip
+// tile_list): the plain path without looking, as its own kernel with its own (small) register budget
+template <int N, int RT, int PATH, typename T>
 __global__ __launch_bounds__(256) void k_jacobi_quad(Grid g, int nbx, int nby, int jb, int je, const uint8_t *bcmap, T *pn, const T *pc, const T *src)
 {
     constexpr int W = RT + 8;
@@ -94,6 +96,10 @@ __global__ __launch_bounds__(256) void k_jacobi_quad(Grid g, int nbx, int nby, i
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[W];
+    if constexpr (PATH == 3) {
+        jacobi_quad_tile<N, RT, false, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
+        return;
+    }
     bool own = false, all_fluid = true;
 #pragma unroll
     for (int w = 0; w < W; ++w) {

@@ -240,8 +240,9 @@ __device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k
 #undef FS_FL
 }
 
-// PATH: 0 - only the tiles without a non-fluid cell within reach, 1 - only the others, 2 - both.  Two launches (0, then 1) give each
-// path its own register budget: the plain path fits 4 waves per SIMD, the boundary path (recipe bytes, views) does not.
+// PATH: 2 - classify the tile here (mask loads) and take the plain or the boundary path; 3 - the plain path without looking (compact launch
+// of the workgroups the host found to be plain: its own kernel, so its own register budget - 126 VGPRs = 4 waves per SIMD, where the
+// boundary path with its recipe bytes and views needs 156); 0 / 1 - classify and run only the plain / only the boundary tiles (A/B).
 template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
 __device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                 const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
@@ -252,6 +253,10 @@ __device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned fl[W];
+    if constexpr (PATH == 3) {      // the host listed this workgroup as plain: nothing but fluid within reach (fs_api.hip tile_list)
+        rbsor_pair_tile<N, RT, PAR0, DM, false, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
+        return;
+    }
     bool own_fluid = false, all_fluid = true;
 #pragma unroll
     for (int w = 0; w < W; ++w) {

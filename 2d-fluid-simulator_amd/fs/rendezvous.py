@@ -15,13 +15,12 @@ def _private_dir():
     """A directory only this user can write: $FS_RDZV_DIR, else /tmp/fs_rdzv_<uid> (mode 0700, owned by us, not a symlink) -
     nobody else can pre-create or redirect the rendezvous files."""
     d = os.environ.get("FS_RDZV_DIR")
-    if d:
-        return d
-    d = os.path.join("/tmp", f"fs_rdzv_{os.getuid()}")
-    try:
-        os.mkdir(d, 0o700)
-    except FileExistsError:
-        pass
+    if not d:
+        d = os.path.join("/tmp", f"fs_rdzv_{os.getuid()}")
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
     st = os.lstat(d)
     if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
         raise RuntimeError(f"rendezvous directory {d} is not a private directory of this user")
@@ -49,6 +48,15 @@ class FileRendezvous:
                             str(os.getppid()), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")])
         self.base = os.path.join(_private_dir(), f"fs_rdzv_{key}")
         self.calls = 0
+        if rank == 0:
+            # leftovers of a crashed earlier job whose key repeats (a long-lived parent launching several jobs on the same MASTER_PORT):
+            # rank 0 removes them before it writes anything - a reader can then only ever see this job's files or none
+            import glob
+            for old in glob.glob(self.base + "_*"):
+                try:
+                    os.remove(old)
+                except OSError:
+                    pass
         t_launch = _launcher_start_time()
         # files written before this job's launcher existed are stale; without /proc fall back to "not much older than me"
         # (rank 0 may be well ahead of a rank whose first import is still paging in)

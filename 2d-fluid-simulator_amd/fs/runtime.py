@@ -86,9 +86,10 @@ class Field:
         self.dev = dev
         self.nchan = nchan
         self._h = dev._p_alloc(nchan)
+        self.serial = next(_serials)   # unique for life (id() is recycled after garbage collection): identity in signatures and op keys
+        dev._handle_serial[id(self._h)] = self.serial
         self.valid = dev.halo          # ghost rows valid to this depth (zero-filled == consistent everywhere)
         self.user_data = False         # set once the user uploads / fills data (disables fusions that rely on invariants)
-        self.serial = next(_serials)   # unique for life (id() is recycled after garbage collection): identity in signatures and op keys
         self.static_id = 0             # content class of the cells NO kernel ever writes (deep wall cells): 0 = still the zeros of the
                                        # allocation, a fresh token after every upload / fill.  Passes that store only the cells that can
                                        # change (fs_rbsor_pair, the fused gradient + advection pass) need source and target buffer in
@@ -137,6 +138,7 @@ class Field:
 
     def __del__(self):
         try:
+            self.dev._handle_serial.pop(id(self._h), None)
             self.dev._p_free(self._h)
         except Exception:
             pass
@@ -182,10 +184,13 @@ class DeviceBase:
         self._oplog = None            # list of primitive operations while a period is being logged (see tape_period)
         self._cur_writes = ()
         self._fields = weakref.WeakSet()
+        self._handle_serial = {}      # id(handle) -> serial of the Field that owns it (dropped with the Field)
         # exchange behind the interior rows of the kernel that needs it (communication stream + events + two extra strip
         # launches): measured neutral in loop-back (181 vs 187 us per slab step), while running the exchange in line on the
         # compute stream saves the stream hand-offs -> off by default; FS_OVERLAP=1 turns it (and the communication stream) on
         self.overlap = nranks > 1 and os.environ.get("FS_OVERLAP", "0") == "1"
+        self.overlap_stream = self.overlap      # the exchanges run on a communication stream of their own (tape_period switches `overlap`
+                                                # off while it logs - this remembers what the context was created with)
         self.partial = os.environ.get("FS_PARTIAL_HALO", "1") != "0"     # send only the ghost rows beyond a field's validity
 
     # ---- ghost-row bookkeeping --------------------------------------------------------------------
@@ -251,6 +256,14 @@ class DeviceBase:
         if self.nranks == 1:
             return list(values)
         raise NotImplementedError("this backend needs _p_max_over_ranks for slab runs")
+
+    def _p_min_max_over_ranks(self, value):
+        """(min, max) of one small non-negative integer over all ranks (collective; built on _p_max_over_ranks)."""
+        if self.nranks == 1:
+            return value, value
+        big = 1 << 20
+        hi, neg_lo = self._p_max_over_ranks([value, big - value])
+        return big - int(neg_lo), int(hi)
 
     def _run(self, name, args, reads=(), writes=(), pointwise=False, full_writes=(), split=True):
         """Launch one kernel on this slab.
@@ -331,13 +344,14 @@ class DeviceBase:
     def _state_signature(self):
         return tuple(sorted((f.serial, f.valid, f.user_data, f.static_id) for f in self._fields))
 
-    @staticmethod
-    def _op_key(op):
-        """Hashable identity of a logged operation (handles by object identity: a Field keeps its handle for life)."""
+    def _op_key(self, op):
+        """Hashable identity of a logged operation.  Handles are named by the serial number of the Field that owns them (a Field keeps
+        its handle for life; id() alone would be recycled after a garbage collection and let a stale tape match a new Field)."""
+        name = lambda h: self._handle_serial.get(id(h), ("anon", id(h)))
         if op[0] == "k":
-            return ("k", op[1], tuple(a if isinstance(a, (int, float, type(None))) else id(a) for a in op[2]))
+            return ("k", op[1], tuple(a if isinstance(a, (int, float, type(None))) else name(a) for a in op[2]))
         if op[0] == "begin":
-            return ("begin", tuple((id(h), c, v) for h, c, v in op[1]), op[2])
+            return ("begin", tuple((name(h), c, v) for h, c, v in op[1]), op[2])
         return (op[0],)
 
     def tape_period(self, step_fn, nsteps=2, tries=14, hoist=True, max_blocks=6):
@@ -359,14 +373,28 @@ class DeviceBase:
                 log, self._oplog = self._oplog, None
                 c1 = (self.n_exchanges, self.n_exchanged_fields, self.n_exchanged_bytes)
                 blocks.append((sig0, [self._op_key(op) for op in log], log, tuple(b - a for a, b in zip(c0, c1))))
+                found = 0
                 for P in range(1, max_blocks + 1):
                     if len(blocks) < 2 * P:
                         break
                     a, b = blocks[-2 * P:-P], blocks[-P:]
                     if (all(x[0] == y[0] and x[1] == y[1] for x, y in zip(a, b)) and self._state_signature() == b[0][0]):
-                        log = [op for blk in b for op in blk[2]]
-                        per_period = tuple(sum(blk[3][k] for blk in b) for k in range(3))
-                        return self._compile_tape(log, P * nsteps, per_period, hoist)
+                        found = P
+                        break
+                # every rank runs the same tracker and should take the same decision - but a rank that found the period one block later
+                # (or not at all) would issue a different number of exchanges from here on, and the unpaired send / recv would hang:
+                # agree on it (one small collective per block on slab runs), and carry on logging unless ALL ranks found the same period
+                lo, hi = self._p_min_max_over_ranks(found)
+                if lo == hi and found:
+                    b = blocks[-found:]
+                    log = [op for blk in b for op in blk[2]]
+                    per_period = tuple(sum(blk[3][k] for blk in b) for k in range(3))
+                    tape = self._compile_tape(log, found * nsteps, per_period, hoist)
+                    np_lo, np_hi = self._p_min_max_over_ranks(len(tape["prologue"]) * 1000 + len(tape["ops"]))
+                    if np_lo != np_hi:
+                        self.free_tape(tape)
+                        return None
+                    return tape
             return None
         finally:
             self._oplog = None
@@ -409,9 +437,15 @@ class DeviceBase:
         return ops, prologue
 
     def _compile_tape(self, log, nsteps, per_period, hoist):
+        # Moving a begin up only pays when the exchange runs on its own stream (FS_OVERLAP=1), and it is only safe with partial-depth
+        # exchanges: a full-depth exchange rewrites ghost rows that are still valid while the kernels it was moved across read them.
+        hoist = hoist and self.hoist_ok()
         ops, prologue = self.hoist_exchanges(log) if hoist else (list(log), [])
         return {"ops": ops, "prologue": prologue, "nsteps": nsteps, "per_period": per_period, "id": self._p_tape_build(ops),
                 "sig": self._state_signature()}      # the bookkeeping state the period starts (and ends) in
+
+    def hoist_ok(self):
+        return bool(self.partial and self.overlap_stream)
 
     def _issue(self, op):
         if op[0] == "k":

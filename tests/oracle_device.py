@@ -28,6 +28,7 @@ class OracleSlabDevice(DeviceBase):
         self.r_off = self.g_lo - (self.y0 - self.halo)     # local row of the first in-domain row
         self.nloc = self.g_hi - self.g_lo                  # rows actually stored (in-domain only)
         self.poison = nranks > 1
+        self.overlap_stream = True     # (stands for a context whose exchanges run on their own stream: the tape compiler may hoist begins)
 
     # ---- primitives -------------------------------------------------------------------------------
     def _shape(self, nchan):

@@ -34,7 +34,9 @@ def compare(solver, ref, steps, tag):
 
 @pytest.mark.parametrize("X,Y", [(64, 24), (248, 20), (252, 37), (500, 18), (1000, 12), (128, 64)])
 @pytest.mark.parametrize("n_iter", [10, 11, 12, 13, 22])
-def test_quad_pass_against_the_oracle(X, Y, n_iter, hip_lib):
+def test_quad_pass_against_the_oracle(X, Y, n_iter, hip_lib, monkeypatch):
+    if (X + n_iter) % 2 == 0:
+        monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")      # plain / boundary workgroups as two compact launches (large grids do that by themselves)
     rng = np.random.default_rng(X * 7 + Y + n_iter)
     const, mask = thick_scene(rng, X, Y, outflow=(X + n_iter) % 2 == 0)
     solver, ref, pu = build(const, mask, n_iter, scheme=["cip", "upwind", "kk"][n_iter % 3])
@@ -49,8 +51,10 @@ def test_quad_pass_against_the_oracle(X, Y, n_iter, hip_lib):
 
 
 @pytest.mark.parametrize("bc,res", [(1, 64), (2, 64), (2, 200), (4, 100), (5, 128), (5, 256), (1, 256)])
-def test_reference_scenes(bc, res, hip_lib):
+def test_reference_scenes(bc, res, hip_lib, monkeypatch):
     from fs.boundary_condition import create_scene_arrays
+    if res >= 200:
+        monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")
     const, mask, _ = create_scene_arrays(bc, res)
     solver, ref, pu = build(const, mask, 14, res=res)
     try:

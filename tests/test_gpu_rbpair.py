@@ -48,7 +48,9 @@ def same_pressure(a, b, what):
 
 @pytest.mark.parametrize("X,Y", [(64, 16), (64, 37), (248, 24), (252, 41), (500, 18), (1000, 12), (32, 8)])
 @pytest.mark.parametrize("n_iter", [2, 3, 4, 5])
-def test_pair_pass_equals_single_iterations(X, Y, n_iter, hip_lib):
+def test_pair_pass_equals_single_iterations(X, Y, n_iter, hip_lib, monkeypatch):
+    if (X + n_iter) % 3 == 0:
+        monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")      # plain / boundary workgroups as two compact launches (large grids do that by themselves)
     rng = np.random.default_rng(X * 100 + Y + n_iter)
     const, mask = thick_scene(rng, X, Y, outflow=(X + n_iter) % 2 == 0)
     a, b = build(const, mask, n_iter, True), build(const, mask, n_iter, False)
@@ -99,8 +101,10 @@ def test_uploads_are_carried(seed, hip_lib):
 
 @pytest.mark.parametrize("bc", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("res", [64, 100, 256])
-def test_reference_scenes_admit_the_pair_pass(bc, res, hip_lib):
+def test_reference_scenes_admit_the_pair_pass(bc, res, hip_lib, monkeypatch):
     import fs
+    if res == 256:
+        monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")
     sims = []
     try:
         for pair in ("1", "0"):
