@@ -52,8 +52,9 @@ def main():
     res, world, rank = 4096, 8, 3
     const, mask, _ = create_scene_arrays(5, res)
     dt, dx = 0.05 / res, 1.0 / res
+    modes = os.environ.get("OB_MODES", "none,blocking-commstream,blocking,overlap,tape").split(",")
     for halo in [int(a) for a in sys.argv[1:]] or [4, 8, 16]:
-        for mode in ("none", "blocking-commstream", "blocking", "overlap", "tape"):
+        for mode in modes:
             dev = LoopbackSlab(mask.shape[0], mask.shape[1], rank, world, halo, mode)
             bc = BoundaryCondition(const, mask, device=dev)
             solver = fs.CipMacSolver(bc, fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2), dt, dx, 1e6, fs.VorticityConfinement(bc, dt, dx, 5.0))
@@ -69,7 +70,7 @@ def main():
                     solver.update()
             dev.sync()
             el = time.perf_counter() - t0
-            print(f"halo {halo:2d} {mode:9s}: {el / steps * 1e6:7.1f} us/step   {(dev.n_exchanges - n0) / steps:.2f} exchanges/step, "
+            print(f"halo {halo:2d} {mode:9s} all={int(dev.exchange_all)} pair={int(getattr(solver.pressure_updater, '_pair', False))}: {el / steps * 1e6:7.1f} us/step   {(dev.n_exchanges - n0) / steps:.2f} exchanges/step, "
                   f"{dev.n_overlapped / max(dev.n_exchanges, 1) * 100:.0f} % overlapped", flush=True)
             dev.close()
 

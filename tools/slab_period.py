@@ -18,8 +18,8 @@ class Null(DeviceBase):
     def _p_max_over_ranks(self, v): return list(v)
     dtype_=np.float32
 for PAIR in (True, False):
-  for halo in (2, 4, 8, 16):
-    res=256
+  for halo in (8, 12, 16, 20, 24, 32):
+    res=512
     const, mask, _ = create_scene_arrays(5, res)
     dev = Null(mask.shape[0], mask.shape[1], np.float32, rank=1, nranks=4, halo=halo)
     dt, dx = 0.05/res, 1.0/res
@@ -30,8 +30,9 @@ for PAIR in (True, False):
     ex=[]
     for step in range(60):
         n0=dev.n_exchanges; solver.update(); ex.append(dev.n_exchanges-n0)
+        if step == 19: b0 = dev.n_exchanged_bytes
     # find period of the exchange-count sequence in the tail
     tail=ex[20:]
     per=next((P for P in range(1,21) if all(tail[i]==tail[i+P] for i in range(len(tail)-P))), None)
     t = dev.tape_period(solver.update, nsteps=2)
-    print('pair',PAIR,'halo',halo,'exch/step', ''.join(map(str,ex[:40])), 'period',per, 'tape', None if t is None else t['nsteps'], 'avg', sum(tail)/len(tail))
+    print('pair',PAIR,'halo',halo,'exch/step', ''.join(map(str,ex[:40])), 'period',per, 'tape', None if t is None else t['nsteps'], 'avg', sum(tail)/len(tail), 'KB/step/neighbour at X=8192: %.0f' % ((dev.n_exchanged_bytes - b0) / 40 / 1024 * 8192 / dev.nx))

@@ -2,9 +2,9 @@
 # Run ON THE GPU BOX (gpurun -- 'bash tools/sq_counters.sh <tag>'): per-kernel SQ wave-cycle split of the headline workload -
 # parked on s_waitcnt (memory) / issue-stalled / issuing - from one rocprofv3 PMC pass.  Output: gpurun_out/sq_<tag>/summary.txt
 set -u
-TAG=${1:-r2}; OUT=gpurun_out/sq_$TAG; mkdir -p $OUT
+TAG=${1:-r3}; OUT=gpurun_out/sq_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT -o p -- \
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT -o p -- \
     python3 bench.py --steps 6 --warmup 6 --no-cpu --no-graph --sweeps 10 > $OUT/bench.json 2> $OUT/err.txt
 python3 - "$OUT" <<'PY' | tee $OUT/summary.txt
 import csv, glob, collections, sys
