@@ -1195,14 +1195,26 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
             // lies beyond row_end.  2 rows: 116 VGPRs = 4 waves per SIMD; 3 rows: 146 (3 waves) - 394 against 417 us at bc5 res 4096.
             const int RT = ctx->k34_rt >= 2 ? ctx->k34_rt : 2;
             const int jb = row_begin, je = row_end;
-            const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT, !full);      // (the carrying pass visits every tile)
-#define FS_K34RT(R, DM) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
+            const int dm = dm_dx(ctx, k);
+#define FS_K34RT(R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, DM, PL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
                 (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, \
                 (const uint8_t *)ctx->d_bcmap, full)
-#define FS_K34RT2(DM) FS_K34RT(2, DM)
-#define FS_K34RT3(DM) FS_K34RT(3, DM)
-#define FS_K34RT4(DM) FS_K34RT(4, DM)
-            const int dm = dm_dx(ctx, k);
+#define FS_K34RT2(DM) FS_K34RT(2, DM, false)
+#define FS_K34RT2P(DM) FS_K34RT(2, DM, true)
+#define FS_K34RT3(DM) FS_K34RT(3, DM, false)
+#define FS_K34RT4(DM) FS_K34RT(4, DM, false)
+            // Compact launch in two parts on large single-GPU grids (as fs_rbsor_pair): the workgroups that see nothing but fluid within
+            // reach run without mask loads, selects and conditional stores (PLAIN), the others the general tile
+            if (!full && RT == 2 && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
+                const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, 2, XCD_ADVECT, 4, true, 1, 2);
+                const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, 2, XCD_ADVECT, 4, true, 2, 2);
+                if (og.g.tiles && ogb.g.tiles) {
+                    int rc = launch(ctx, "cip_grad_advect_rt", [=] { FS_DMX(dm, FS_K34RT2P); });
+                    if (rc) return rc;
+                    { const OvGrid og = ogb; return launch(ctx, "cip_grad_advect_rt_bnd", [=] { FS_DMX(dm, FS_K34RT2); }); }
+                }
+            }
+            const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT, !full);      // (the carrying pass visits every tile)
             return launch(ctx, "cip_grad_advect_rt", [=] {
                 if (RT == 2) FS_DMX(dm, FS_K34RT2); else if (RT == 3) FS_DMX(dm, FS_K34RT3); else FS_DMX(dm, FS_K34RT4);
             });

@@ -679,7 +679,9 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k
 // recompute overhead that made the one-row form issue-bound drops from 3x to 1.5x - and the five input planes are requested up front
 // as 5 RT + 14 16-byte loads per lane.  Rows that do not fill a whole tile, and the rows next to the domain edge, take the one-row
 // kernels below.
-template <int c, int RT, int DM, typename T>
+// PLAIN: the host listed this workgroup as seeing nothing but fluid within its reach (fs_api.hip tile_list, compact launch): no mask loads,
+// constant selectors, unconditional stores - as its own kernel.
+template <int c, int RT, int DM, bool PLAIN, typename T>
 __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                         T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
                                                         const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
@@ -691,14 +693,15 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
     constexpr int o = 1 - c;
 
     unsigned nw[RT + 2], fl[RT];                 // not-wall selectors of rows j0-1 .. j0+RT, fluid selectors of rows j0 .. j0+RT-1
-    bool any_fl = false;
+    bool any_fl = PLAIN;
 #pragma unroll
     for (int s = 0; s < RT + 2; ++s) {
+        if (PLAIN) { nw[s] = 0xfu; if (s >= 1 && s <= RT) fl[s - 1] = j0 + s - 1 < je ? 0xfu : 0u; continue; }
         const uint32_t m4 = mask_quad(g, i0, clampy(g, j0 - 1 + s));
         nw[s] = sel_not_wall(m4);
         if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? sel_fluid(m4) : 0u; any_fl |= fl[s - 1] != 0u; }
     }
-    if (!__any(any_fl)) {
+    if (!PLAIN && !__any(any_fl)) {
         // no fluid cell in this wave's tile: every output is a carried value (vo = fc, old gradients on inflow / outflow cells) - and only
         // cells that SOME kernel writes can differ between fc and vo: not-wall cells and the targets of the velocity boundary kernel
         // (bit 7 of the recipe byte, fs_api.hip build_bc_ops).  Deep wall rows move nothing (a third of scene 5); `full`: after an
@@ -810,7 +813,7 @@ __device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Kon
     }
 }
 
-template <int RT, int DM, typename T>
+template <int RT, int DM, bool PLAIN, typename T>
 __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                             T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
                                                             const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
@@ -818,8 +821,8 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, 
     // blockIdx.y = (tile row in the XCD group) * 2 + component: the two component passes of a tile are adjacent in dispatch order on
     // the SAME XCD, so the second one finds the velocity rows both passes read in that XCD's L2 instead of fetching them again.
     const int comp = (nbx >= 0 && (nby & FS_CG_INNER)) ? (((int)blockIdx.x >> 3) & 1) : ((int)blockIdx.y & 1);
-    if (comp == 0) cip_grad_advect_rt_body<0, RT, DM, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
-    else cip_grad_advect_rt_body<1, RT, DM, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
+    if (comp == 0) cip_grad_advect_rt_body<0, RT, DM, PLAIN, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
+    else cip_grad_advect_rt_body<1, RT, DM, PLAIN, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
 }
 
 // The same fusion for the dye (C = 3 channels advected by the final velocity of the flow step, fs/solver.py:378-401): K3 on the rows
