@@ -14,10 +14,14 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
         s = stats.setdefault(k, [0, 0.0])
         s[0] += int(r["Calls"]); s[1] += float(r["TotalDurationNs"])
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+full = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))     # short -> instantiation -> counter -> values
 for sub in ("pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            full[short(r["Kernel_Name"])][r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# kernels launched in two compact parts per logical launch (workgroups that see nothing but fluid / the others: two instantiations)
+SPLIT = {"k_cip_grad_advect_rt", "k_rbsor_pair", "k_jacobi_quad"}
 import json
 traffic = {}
 NAMES = {"k_rbsor_pair": "rbsor_pair", "k_jacobi_quad": "jacobi_quad_lazy", "k_cip_grad_advect_dye": "cip_grad_advect_dye", "k_mac_update_quad": "mac_update_kk",
@@ -30,6 +34,11 @@ for k, (calls, tot) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     c = pmc.get(k, {})
     mean = lambda name: (sum(c[name]) / len(c[name])) if c.get(name) else None
     fe, wr, hit, miss = mean("FETCH_SIZE"), mean("WRITE_SIZE"), mean("TCC_HIT_sum"), mean("TCC_MISS_sum")
+    parts = len(full.get(k, {})) if k in SPLIT else 1
+    if parts > 1:       # per LOGICAL launch: the sum over the parts (each part's mean), time likewise
+        tot = lambda name: sum(sum(v[name]) / len(v[name]) for v in full[k].values() if v.get(name)) if any(v.get(name) for v in full[k].values()) else None
+        fe, wr = tot("FETCH_SIZE"), tot("WRITE_SIZE")
+        avg, calls = avg * parts, calls // parts
     fe_mb = None if fe is None else 2 * fe * 1024 / 1e6
     wr_mb = None if wr is None else wr * 1024 / 1e6
     hr = None if hit is None or miss is None or hit + miss == 0 else 100 * hit / (hit + miss)
