@@ -314,8 +314,10 @@ class DeviceBase:
                 # One grouped exchange costs ~26 us of latency whatever it carries: when one is due anyway, refresh EVERY field of the
                 # step's working set that is below full depth - the next exchange is then as far away as the halo allows (halo 16, CIP
                 # + VC + red-black SOR: one exchange every two steps instead of one per step, at the same number of rows moved)
-                need = unique(need + [f for f in self._fields if getattr(f, "ghost_read", False) and f.valid < H
-                                      and not any(f is w for w in full_writes)])
+                # (in creation order - the same on every rank; the WeakSet's own order is by address and differs between processes,
+                # and both sides of a slab boundary must pack the same fields in the same order)
+                need = unique(need + [f for f in sorted(self._fields, key=lambda f: f.serial)
+                                      if getattr(f, "ghost_read", False) and f.valid < H and not any(f is w for w in full_writes)])
         elif e_reads >= 2:
             need = unique([f for f in writes if f.valid < e_reads])     # lift the outputs so that the extension is not wasted
         pending = False

@@ -102,6 +102,18 @@ class OracleSlabDevice(DeviceBase):
             a[:, s] = t.numpy()
 
     def _p_exchange_many(self, handles, depth):
+        # both sides of a slab boundary must name the same fields in the same order (the packed RCCL message has no labels): compare
+        # the list with each neighbour before any row moves
+        mine = torch.tensor([[self._handle_serial.get(id(h), -1), nchan, v] for h, nchan, v in handles] + [[-7, len(handles), depth]],
+                            dtype=torch.int64)
+        for nb in (self.rank - 1, self.rank + 1):
+            if 0 <= nb < self.nranks:
+                theirs = torch.full((64, 3), -99, dtype=torch.int64)
+                pad = torch.full((64, 3), -99, dtype=torch.int64)
+                pad[:len(mine)] = mine
+                for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, pad, nb), dist.P2POp(dist.irecv, theirs, nb)]):
+                    r.wait()
+                assert torch.equal(pad, theirs), f"rank {self.rank} and {nb} disagree on the exchanged fields:\n{pad[:len(mine)]}\n{theirs[:len(mine) + 2]}"
         for h, nchan, v in handles:
             self._p_exchange(h, nchan, depth, v)
 

@@ -26,6 +26,9 @@ def run(rank, world, port, fname, halo, out_dir, tape=False):
 
     g = np.load(os.path.join(here, "golden", fname))
     cfg = traj_config(g)
+    # the ranks of a real job do not share an address-space layout: shift this rank's heap so that anything ordered by object address
+    # (sets of fields, id()-keyed dicts) comes out differently on every rank
+    run._ballast = [type("Ballast", (), {"__slots__": ()})() for _ in range(rank * 1237)] + [{"k": i} for i in range(rank * 311)]
     fs.runtime.init(dtype="f64" if cfg["fp64"] else "f32", rank=rank, nranks=world, halo=halo, allgather=allgather,
                     device_cls=OracleSlabDevice)
     sim = make_product(g, cfg)
