@@ -118,6 +118,10 @@ enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 1
 // host-side activity maps of the scene.  lanes = cells per lane (4: wave columns of 248 cells, 2: of 120), rt = rows per tile.
 // cls: 0 = every workgroup with work; 1 / 2 = those whose tiles see nothing but fluid within `reach` rows and the halo lanes ("plain":
 // no mask loads, no boundary views - their own kernel and register budget) / the others
+// `lanes` names the wave geometry: 4 = quads, 62 owner lanes (248 cells, 4 halo cells per side); 2 = pairs, 60 owner lanes (120 cells, 4 halo
+// cells); 3 = pairs, 62 owner lanes (124 cells, 2 halo cells)
+static inline int geo_cells(int lanes) { return lanes == 4 ? 4 : 2; }
+static inline int geo_owners(int lanes) { return lanes == 2 ? 60 : 62; }
 static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls = 0, int reach = 0)
 {
     if (c->halo != 0 || c->h_act4.empty() || nbx > 0xfff || nby > 0xfffff) return nullptr;
@@ -125,8 +129,8 @@ static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stac
     auto it = c->tile_lists.find(key);
     if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
     if (c->capturing || c->tape_rec) return nullptr;      // (building one synchronises the stream: not inside a capture - the dense grid then)
-    const std::vector<uint8_t> &act = lanes == 4 ? c->h_act4 : c->h_act2;
-    const int ow = lanes == 4 ? 62 : 60, waves = (c->X / lanes + ow - 1) / ow, Y = c->Y;
+    const std::vector<uint8_t> &act = lanes == 4 ? c->h_act4 : (lanes == 2 ? c->h_act2 : c->h_act2w);
+    const int ow = geo_owners(lanes), waves = (c->X / geo_cells(lanes) + ow - 1) / ow, Y = c->Y;
     std::vector<uint32_t> per[8];
     const int groups = (nby + group - 1) / group;
     for (int xcd = 0; xcd < 8; ++xcd)
@@ -181,8 +185,8 @@ static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroup
 {
     OvGrid o;
     o.g = c->grid();
-    const int ow = lanes == 4 ? 62 : 60;
-    const int nu = c->X / lanes, waves = (nu + ow - 1) / ow, tiles = (je - jb + rt - 1) / rt;
+    const int ow = geo_owners(lanes);
+    const int nu = c->X / geo_cells(lanes), waves = (nu + ow - 1) / ow, tiles = (je - jb + rt - 1) / rt;
     const bool stacked = (c->stack_mask & family) != 0;    // the 4 waves of a workgroup: 4 tile rows of one wave column
     o.nbx = stacked ? waves : (waves + 3) / 4;
     o.nby = stacked ? (tiles + 3) / 4 : tiles;
@@ -529,7 +533,7 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
         }
         for (int i = 0; i < X && ok; ++i)                                  // no computed cell may sample a clamped y neighbour
             if (M(i, 0) != 1 || M(i, Y - 1) != 1) ok = false;
-        for (const HostOp &op : vel) map[op.t] |= 0x80;                     // bit 7: a cell the velocity boundary kernel writes (k_cip_grad_advect_rt)
+        for (const HostOp &op : vel) map[op.t] |= 0x80;                     // bit 7: a cell the velocity boundary kernel writes (fs_k34n.h)
         c->lazy_ok = ok && X % 4 == 0;
         // Two red-black iterations per pass (fs_rbpair.h): additionally no recipe may read a source on the far side of its target as
         // seen from a fluid cell (a wall one cell thick between two fluid regions) - the shrinking-window argument of that kernel
@@ -578,6 +582,41 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
 
 using namespace fs;
 
+// K3 + K4 in one pass (fs_k34n.h), velocity (C = 2, v = nullptr) and dye (C = 3): lane width / tile rows from FS_K34_N / FS_K34_RT
+// (default: 2 cells per lane, 4 rows; 4 cells per lane: 2 rows), compact two-part launch on large single-GPU grids
+template <int C, bool CLAMP>
+static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, double dt, double dx, fs_field *f_out, fs_field *gx_out, fs_field *gy_out,
+                      const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v, int full, int jb, int je)
+{
+    using T = float;
+    auto k = make_konst<T>(ctx, dt, dx, 1.0);
+    const int dm = dm_dx(ctx, k);
+    const int N = ctx->k34_n, RT = N == 2 ? (ctx->k34_rt == 2 ? 2 : 4) : 2, geo = N == 2 ? 3 : 4;
+#define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
+        (T *)f_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v ? (const T *)v->d : (const T *)nullptr, \
+        f_out->hot, (const uint8_t *)ctx->d_bcmap, full)
+#define FS_K34_24(DM) FS_K34(2, 4, DM, false)
+#define FS_K34_24P(DM) FS_K34(2, 4, DM, true)
+#define FS_K34_22(DM) FS_K34(2, 2, DM, false)
+#define FS_K34_22P(DM) FS_K34(2, 2, DM, true)
+#define FS_K34_42(DM) FS_K34(4, 2, DM, false)
+#define FS_K34_42P(DM) FS_K34(4, 2, DM, true)
+#define FS_K34_ANY(SUF) do { if (N == 4) FS_DMX(dm, FS_K34_42##SUF); else if (RT == 4) FS_DMX(dm, FS_K34_24##SUF); else FS_DMX(dm, FS_K34_22##SUF); } while (0)
+    // Compact launch in two parts on large single-GPU grids (as fs_rbsor_pair): the workgroups that see nothing but fluid within
+    // reach run without mask loads, selects and conditional stores (PLAIN), the others the general tile
+    if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
+        const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 1, 2);
+        const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 2, 2);
+        if (og.g.tiles && ogb.g.tiles) {
+            int rc = launch(ctx, name, [=] { FS_K34_ANY(P); });
+            if (rc) return rc;
+            { const OvGrid og = ogb; return launch(ctx, name_bnd, [=] { FS_K34_ANY(); }); }
+        }
+    }
+    const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, !full);      // (the carrying pass visits every tile)
+    return launch(ctx, name, [=] { FS_K34_ANY(); });
+}
+
 extern "C" {
 
 int fs_abi_version(void) { return FS_ABI_VERSION; }
@@ -622,7 +661,8 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
-    if (const char *s = getenv("FS_K34_RT")) { int v = atoi(s); if (v >= 2) c->k34_rt = v == 2 || v == 3 ? v : 4; }
+    if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : 4;
+    if (const char *s = getenv("FS_K34_N")) c->k34_n = atoi(s) == 4 ? 4 : 2;
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
@@ -750,24 +790,24 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     // activity of the scene per (wave column, row) for the compact launches: a cell is "deep wall" when it is a wall cell that no
     // boundary kernel writes - workgroups made of such cells only have nothing to do in any kernel
     tile_lists_free(ctx);
-    ctx->h_act4.clear(); ctx->h_act2.clear();
+    ctx->h_act4.clear(); ctx->h_act2.clear(); ctx->h_act2w.clear();
     if (ctx->halo == 0 && ctx->X % 4 == 0 && ctx->tile_list_mask) {
-        const int X = ctx->X, Y = ctx->Y, w4 = 248, w2 = 120;
-        ctx->h_act4.assign((size_t)((X + w4 - 1) / w4) * Y, 0);
-        ctx->h_act2.assign((size_t)((X + w2 - 1) / w2) * Y, 0);
-        const int n4 = (X + w4 - 1) / w4, n2 = (X + w2 - 1) / w2;
-        for (int i = 0; i < X; ++i) {
-            const uint8_t *m = mask_xy + (size_t)i * Y, *b = ctx->h_bcmap.data() + (size_t)i * Y;
-            uint8_t *a4 = ctx->h_act4.data() + (size_t)(i / w4) * Y, *a2 = ctx->h_act2.data() + (size_t)(i / w2) * Y;
-            // the neighbouring wave column whose halo lanes (4 cells) cover column i, if any
-            const int r4 = i % w4, r2 = i % w2;
-            uint8_t *h4 = r4 < 4 && i / w4 > 0 ? a4 - Y : (r4 >= w4 - 4 && i / w4 + 1 < n4 ? a4 + Y : nullptr);
-            uint8_t *h2 = r2 < 4 && i / w2 > 0 ? a2 - Y : (r2 >= w2 - 4 && i / w2 + 1 < n2 ? a2 + Y : nullptr);
-            for (int j = 0; j < Y; ++j) {
-                const uint8_t a = (uint8_t)((m[j] != 1) | (b[j] != 0)), nf = m[j] != 0 ? 2 : 0;
-                a4[j] |= a | nf; a2[j] |= a | nf;
-                if (h4) h4[j] |= nf;
-                if (h2) h2[j] |= nf;
+        const int X = ctx->X, Y = ctx->Y;
+        struct Geo { std::vector<uint8_t> *act; int w, halo; } geos[3] = {{&ctx->h_act4, 248, 4}, {&ctx->h_act2, 120, 4}, {&ctx->h_act2w, 124, 2}};
+        for (const Geo &ge : geos) {
+            const int w = ge.w, n = (X + w - 1) / w;
+            ge.act->assign((size_t)n * Y, 0);
+            for (int i = 0; i < X; ++i) {
+                const uint8_t *m = mask_xy + (size_t)i * Y, *b = ctx->h_bcmap.data() + (size_t)i * Y;
+                uint8_t *a = ge.act->data() + (size_t)(i / w) * Y;
+                // the neighbouring wave column whose halo lanes cover column i, if any
+                const int r = i % w;
+                uint8_t *h = r < ge.halo && i / w > 0 ? a - Y : (r >= w - ge.halo && i / w + 1 < n ? a + Y : nullptr);
+                for (int j = 0; j < Y; ++j) {
+                    const uint8_t nf = m[j] != 0 ? 2 : 0;
+                    a[j] |= (uint8_t)((m[j] != 1) | (b[j] != 0)) | nf;
+                    if (h) h[j] |= nf;
+                }
             }
         }
     }
@@ -1186,43 +1226,11 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
     FS_REQUIRE(v_out != fn && v_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
     FS_REQUIRE(ctx->use_march, "the fused gradient+advection pass needs X % 4 == 0 (use the two-kernel form)");
     FS_ROWS();
-    const Grid gg = ctx->grid();
-    FS_DISPATCH(ctx, {
-        if constexpr (sizeof(T) != 4) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
-        else {
-            auto k = make_konst<T>(ctx, dt, dx, 1.0);
-            // register tiles of RT rows (env FS_K34_RT = 2 / 3 / 4), one launch for every row: the tiles load their rows clamped and skip what
-            // lies beyond row_end.  2 rows: 116 VGPRs = 4 waves per SIMD; 3 rows: 146 (3 waves) - 394 against 417 us at bc5 res 4096.
-            const int RT = ctx->k34_rt >= 2 ? ctx->k34_rt : 2;
-            const int jb = row_begin, je = row_end;
-            const int dm = dm_dx(ctx, k);
-#define FS_K34RT(R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_rt<R, DM, PL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
-                (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, \
-                (const uint8_t *)ctx->d_bcmap, full)
-#define FS_K34RT2(DM) FS_K34RT(2, DM, false)
-#define FS_K34RT2P(DM) FS_K34RT(2, DM, true)
-#define FS_K34RT3(DM) FS_K34RT(3, DM, false)
-#define FS_K34RT4(DM) FS_K34RT(4, DM, false)
-            // Compact launch in two parts on large single-GPU grids (as fs_rbsor_pair): the workgroups that see nothing but fluid within
-            // reach run without mask loads, selects and conditional stores (PLAIN), the others the general tile
-            if (!full && RT == 2 && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
-                const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, 2, XCD_ADVECT, 4, true, 1, 2);
-                const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, 2, XCD_ADVECT, 4, true, 2, 2);
-                if (og.g.tiles && ogb.g.tiles) {
-                    int rc = launch(ctx, "cip_grad_advect_rt", [=] { FS_DMX(dm, FS_K34RT2P); });
-                    if (rc) return rc;
-                    { const OvGrid og = ogb; return launch(ctx, "cip_grad_advect_rt_bnd", [=] { FS_DMX(dm, FS_K34RT2); }); }
-                }
-            }
-            const OvGrid og = ov_grid(ctx, jb, je, RT, 2, XCD_ADVECT, !full);      // (the carrying pass visits every tile)
-            return launch(ctx, "cip_grad_advect_rt", [=] {
-                if (RT == 2) FS_DMX(dm, FS_K34RT2); else if (RT == 3) FS_DMX(dm, FS_K34RT3); else FS_DMX(dm, FS_K34RT4);
-            });
-        }
-    })
+    if (ctx->dtype != 0) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
+    return launch_k34<2, false>(ctx, "cip_grad_advect_rt", "cip_grad_advect_rt_bnd", dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, nullptr, full, row_begin, row_end);
 }
 
-// K3 + K4 of the dye in one pass (fs_march.h k_cip_grad_advect_dye): d_out <- advect(fn with the gradients K3 derives from fc -> fn) by v
+// the dye: d_out <- advect(fn with the gradients K3 derives from fc -> fn) by v
 int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, fs_field *gx_out, fs_field *gy_out,
                            const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v,
                            int clamp01, int full, int row_begin, int row_end)
@@ -1233,21 +1241,9 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
     FS_REQUIRE(ctx->use_march, "the fused gradient+advection pass needs X % 4 == 0 (use the two-kernel form)");
     FS_ROWS();
     if (row_begin >= row_end) return FS_OK;
-    const Grid gg = ctx->grid();
-    FS_DISPATCH(ctx, {
-        if constexpr (sizeof(T) != 4) { set_error("the fused dye pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
-        else {
-            auto k = make_konst<T>(ctx, dt, dx, 1.0);
-            constexpr int RT = 2;
-            const OvGrid og = ov_grid(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, !full);
-#define FS_K34D(DM, CL) hipLaunchKernelGGL((k_cip_grad_advect_dye<RT, DM, CL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-                (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, full)
-#define FS_K34D_C(DM) FS_K34D(DM, true)
-#define FS_K34D_N(DM) FS_K34D(DM, false)
-            const int dm = dm_dx(ctx, k);
-            return launch(ctx, "cip_grad_advect_dye", [=] { if (clamp01) FS_DMX(dm, FS_K34D_C); else FS_DMX(dm, FS_K34D_N); });
-        }
-    })
+    if (ctx->dtype != 0) { set_error("the fused dye pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
+    if (clamp01) return launch_k34<3, true>(ctx, "cip_grad_advect_dye", "cip_grad_advect_dye_bnd", dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, full, row_begin, row_end);
+    return launch_k34<3, false>(ctx, "cip_grad_advect_dye", "cip_grad_advect_dye_bnd", dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, full, row_begin, row_end);
 }
 
 // ---- vorticity confinement -------------------------------------------------------------------------------

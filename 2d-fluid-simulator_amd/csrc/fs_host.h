@@ -16,6 +16,7 @@
 #include "fs_march.h"
 #include "fs_rbpair.h"
 #include "fs_jquad.h"
+#include "fs_k34n.h"
 
 namespace fs {
 
@@ -113,7 +114,8 @@ struct fs_ctx {
     // tuning knobs (env FS_MARCH=0: one-cell-per-lane kernels only)
     bool use_march = true;
     bool use_f64div = true;    // env FS_F64DIV=0: IEEE division for the loop-invariant divisors of f32 runs (A/B; the results are the same)
-    int k34_rt = -1;           // env FS_K34_RT: rows per register tile of the fused gradient-update + advection pass (0: one-row form; default 2)
+    int k34_n = 2;             // env FS_K34_N: cells per lane of the fused K3 + K4 pass (fs_k34n.h; 2: tiles of 4 rows, FS_K34_RT=2: 2; 4: tiles of 2 rows)
+    int k34_rt = -1;           // env FS_K34_RT: rows per register tile of that pass at 2 cells per lane (4; 2)
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_group_fam[6] = {0, 0, 0, 0, 0, 0};   // ... of single kernel families (env FS_XCD_GROUP_FAM; 0: xcd_group)
@@ -128,7 +130,7 @@ struct fs_ctx {
     // it per launch geometry (key: lane width, rows per tile, stacked, group size)
     int tile_list_mask = 1 | 4;              // env FS_TILE_LIST: kernel families (XCD_* bits) launched compactly.  Measured at bc5 res 4096:
                                              // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement unchanged, K2 111 -> 117
-    std::vector<uint8_t> h_act4, h_act2;     // [wave column][global row]
+    std::vector<uint8_t> h_act4, h_act2, h_act2w;     // [wave column][global row]
     struct TileList { uint32_t *d = nullptr; int per_xcd = 0; };
     std::map<uint32_t, TileList> tile_lists;
 

@@ -1,0 +1,226 @@
+// fs_k34n.h - K3 + K4 of the CIP solvers in ONE pass, one body for the velocity (C = 2) and the dye (C = 3), on lanes of N cells.
+//
+// Reference: fs/solver.py:242-261 (_non_advection_phase_grad) and :267-332 (_advection_phase / _cip_advect); the dye :378-401.
+//
+// In the reference K3 writes the intermediate gradients into vx.next / vy.next, the buffers swap, and K4 reads them back on a 3x3
+// neighbourhood: 16 B/cell written and 16 B/cell read again, plus the intermediate field read twice.  Here a lane evaluates K3 for rows
+// j0-1 .. j0+RT of its cells in registers (halo recompute) and feeds K4 for rows j0 .. j0+RT-1 directly.  The intermediate gradients are never
+// observable (the buffer that would hold them is overwritten by the next step's K3 before anything reads it), so they are not stored.
+//
+// Buffer choreography (SURVEY.md H5 - contents, not addresses, are what later kernels see): K4's output goes to a THIRD buffer `out`
+// (the unfused code overwrites the pre-K2 buffer `fc` in place, which a fused kernel still has to read at radius 2 in other tiles),
+// carrying fc's values on non-fluid cells exactly as the in-place update would leave them.  The new gradients go to the buffers the
+// reference would use for the intermediates (gxo / gyo), carrying gxc / gyc on inflow / outflow cells; wall cells of the gradient
+// buffers are never written by any kernel.  The caller rotates (f.cur, f.next, spare) and swaps the gradient buffers once.
+//   fn = field after K2 (f.next), fc = field before K2 (f.cur), gxc / gyc = gradients before K3;
+//   C = 2: the field advects itself (the other component is read from fn); C = 3: advected by `v`, the final velocity of the flow step.
+// Every row is loaded CLAMPED (sample() clamps coordinates, fs/differentiation.py:4-9) and a register slot that stands for a row outside
+// the domain takes the K3 result of the edge row it clamps onto, so one launch covers every row.  One channel per wave: the C passes over
+// a tile are adjacent in dispatch order on the SAME XCD and share their input rows through that XCD's L2.
+// PLAIN: the host listed this workgroup as seeing nothing but fluid within its reach (fs_api.hip tile_list, compact launch): no mask
+// loads, constant selectors, unconditional stores - as its own kernel.  CLAMP: clamp_field(dye, 0, 1) (fs/solver.py:46-49) folded into
+// the store of the advected value.
+//
+// Lane width: the round-2 form held 4 cells per lane and RT = 2 rows per tile (N = 4 here, FS_K34_N=4): of the 12
+// 16-byte rows a lane requests per output row 7 are halo rows of the tile (re-read by the tiles above / below), and the gradient update
+// runs on RT + 2 = 2 x the rows it is needed for.  With 2 cells per lane the same registers hold a tile of RT = 4 rows: 8.5 8-byte rows
+// per output row, the gradient update on 1.5 x the rows, and a stacked workgroup covers 16 rows instead of 8 (halo rows shared with
+// OTHER workgroups, i.e. through the L2 at best: 4 of 20 instead of 4 of 12).
+// Lane map of fs_rbpair.h with ONE halo lane per side (the pass reaches 2 cells in x): 62 owner lanes = 124 cells per wave at N = 2.
+#pragma once
+#include "fs_rbpair.h"
+
+namespace fs {
+
+template <int N> __device__ __forceinline__ unsigned lv_sel_nw(uint32_t m)
+{
+    unsigned s = 0u;
+#pragma unroll
+    for (int c = 0; c < N; ++c) s |= ((m >> (8 * c)) & 0xffu) != 1u ? (1u << c) : 0u;
+    return s;
+}
+template <int N> __device__ __forceinline__ unsigned lv_sel_bit7(uint32_t code)
+{
+    unsigned s = 0u;
+#pragma unroll
+    for (int c = 0; c < N; ++c) s |= ((code >> (8 * c + 7)) & 1u) << c;
+    return s;
+}
+template <typename T, int N> __device__ __forceinline__ bool lv_hot1(const LV<T, N> &v)
+{
+    bool h = false;
+#pragma unroll
+    for (int c = 0; c < N; ++c) h = h || hot1(v.a[c]);
+    return h;
+}
+template <typename T, int N> __device__ __forceinline__ void lv_store(T *dst, const LV<T, N> &v) { lv_store_sel<T, N>(dst, v, (1u << N) - 1u); }
+
+template <int N, int ZG, int HL>
+__device__ __forceinline__ bool tile_coords_nz(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg)
+{
+    constexpr int OW = 64 - 2 * HL;
+    int bx, by;
+    if (!band_coords<ZG>(g, nbx, nby_packed, bx, by, cg)) return false;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+    if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
+    else { wave_x = bx * nw + w; tile_y = by; }
+    return wave_x * OW < g.X / N && jb + tile_y * rt < je;
+}
+
+template <int C, int c, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T>
+__device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+                                                       T *out, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                       const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
+{
+    using R = LV<T, N>;
+    constexpr unsigned ALL = (1u << N) - 1u;
+    constexpr int HL = 1;                        // the pass reaches 2 cells in x: ONE halo lane per side (62 owner lanes)
+    constexpr bool SELF = C == 2;                // the field advects itself
+    int wx, ty, cg;
+    if (!tile_coords_nz<N, C, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+
+    unsigned nw[RT + 2], fl[RT];                 // not-wall selectors of rows j0-1 .. j0+RT, fluid selectors of rows j0 .. j0+RT-1
+    bool any_fl = PLAIN;
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        if (PLAIN) { nw[s] = ALL; if (s >= 1 && s <= RT) fl[s - 1] = j0 + s - 1 < je ? ALL : 0u; continue; }
+        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 1 + s));
+        nw[s] = lv_sel_nw<N>(m);
+        if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? lv_sel_fluid<N>(m) : 0u; any_fl |= fl[s - 1] != 0u; }
+    }
+    if (!PLAIN && !__any(any_fl)) {
+        // no fluid cell in this wave's tile: every output is a carried value (out = fc, old gradients on inflow / outflow cells) - and only
+        // cells that SOME kernel writes can differ between fc and out: not-wall cells and, for the velocity, the targets of the velocity
+        // boundary kernel (bit 7 of the recipe byte, fs_api.hip build_bc_ops).  Deep wall rows move nothing (a third of scene 5); `full`:
+        // after an upload the two buffers may differ anywhere - carry every cell once (fs/solver.py, Field.static_id).
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int j = j0 + t;
+            if (j >= je) break;
+            unsigned touch = full ? ALL : nw[t + 1];
+            if (SELF && !full) touch |= lv_sel_bit7<N>(lv_bytes<N>(bcmap, g, i0, clampy(g, j)));
+            if (!__any(lm.owner && touch != 0u)) continue;
+            const R f = lv_field<C, T, N>(fc, g, c, i0, j);
+            if (lm.owner && touch) {
+                if (SELF) raise_hot(hot, lv_hot1<T, N>(f));
+                lv_store<T, N>(out + idx<C, T>(g, c, i0, j), f);
+                if (nw[t + 1]) {
+                    lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), lv_field<C, T, N>(gxc, g, c, i0, j), nw[t + 1]);
+                    lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), lv_field<C, T, N>(gyc, g, c, i0, j), nw[t + 1]);
+                }
+            }
+        }
+        return;
+    }
+
+    // slot u of Nn / Fc <-> row j0 - 2 + u;   slot s of GX / GY / NX / NY and of the advecting rows <-> row j0 - 1 + s
+    // advecting velocity: C = 2: the component at hand is Nn itself, the other one AX (c == 1) / AY (c == 0); C = 3: AX, AY from v
+    R Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        Nn[u] = lv_field<C, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u));
+        Fc[u] = lv_field<C, T, N>(fc, g, c, i0, clampy(g, j0 - 2 + u));
+    }
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const int row = clampy(g, j0 - 1 + s);
+        GX[s] = lv_field<C, T, N>(gxc, g, c, i0, row);
+        GY[s] = lv_field<C, T, N>(gyc, g, c, i0, row);
+        if (SELF) {
+            if (c == 0) AY[s] = lv_field<2, T, N>(fn, g, 1, i0, row); else AX[s] = lv_field<2, T, N>(fn, g, 0, i0, row);
+        } else {
+            AX[s] = lv_field<2, T, N>(v, g, 0, i0, row);
+            AY[s] = lv_field<2, T, N>(v, g, 1, i0, row);
+        }
+    }
+    // ---- K3 on rows j0-1 .. j0+RT: wall cells keep the stored gradient ----
+    R NX[RT + 2], NY[RT + 2];
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const R &n1 = Nn[s + 1], &c1 = Fc[s + 1];
+        const T nl = lv_left<T, N>(lm, n1), nr = lv_right<T, N>(lm, n1);
+        const T cl = lv_left<T, N>(lm, c1), cr = lv_right<T, N>(lm, c1);
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const T nE = q == N - 1 ? nr : n1.a[q == N - 1 ? q : q + 1], nW = q == 0 ? nl : n1.a[q == 0 ? 0 : q - 1];
+            const T cE = q == N - 1 ? cr : c1.a[q == N - 1 ? q : q + 1], cW = q == 0 ? cl : c1.a[q == 0 ? 0 : q - 1];
+            const T sx = ((nE - cE) - nW) + cW;
+            const T sy = ((Nn[s + 2].a[q] - Fc[s + 2].a[q]) - Nn[s].a[q]) + Fc[s].a[q];
+            const bool live = (nw[s] >> q) & 1u;
+            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx) : GX[s].a[q];
+            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx) : GY[s].a[q];
+        }
+    }
+    // a slot that stands for a row outside the domain takes the K3 result of the edge row it clamps onto (wave-uniform)
+    if (j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
+#pragma unroll
+    for (int s = 1; s < RT + 2; ++s)
+        if (j0 - 1 + s > g.jhi) { NX[s] = NX[s - 1]; NY[s] = NY[s - 1]; }
+    // ---- K4 on rows j0 .. j0+RT-1 ----
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        if (j >= je) break;
+        const R &Nm = Nn[t + 1], &Nc = Nn[t + 2], &Np = Nn[t + 3];                                 // value field rows j-1, j, j+1
+        const R &VXm = SELF && c == 0 ? Nm : AX[t], &VXr = SELF && c == 0 ? Nc : AX[t + 1], &VXp = SELF && c == 0 ? Np : AX[t + 2];   // advecting velocity
+        const R &VYm = SELF && c == 1 ? Nm : AY[t], &VYr = SELF && c == 1 ? Nc : AY[t + 1], &VYp = SELF && c == 1 ? Np : AY[t + 2];
+        const T vxl = lv_left<T, N>(lm, VXr), vxr = lv_right<T, N>(lm, VXr);
+        const T vyl = lv_left<T, N>(lm, VYr), vyr = lv_right<T, N>(lm, VYr);
+        const T fl0 = lv_left<T, N>(lm, Nm), fr0 = lv_right<T, N>(lm, Nm);
+        const T fl1 = lv_left<T, N>(lm, Nc), fr1 = lv_right<T, N>(lm, Nc);
+        const T fl2 = lv_left<T, N>(lm, Np), fr2 = lv_right<T, N>(lm, Np);
+        const T fxl = lv_left<T, N>(lm, NX[t + 1]), fxr = lv_right<T, N>(lm, NX[t + 1]);
+        const T fyl = lv_left<T, N>(lm, NY[t + 1]), fyr = lv_right<T, N>(lm, NY[t + 1]);
+        R OV = Fc[t + 2], OX = GX[t + 1], OY = GY[t + 1];           // carry values; fluid cells are replaced below
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            constexpr int L = N - 1;
+            const T vx = VXr.a[q], vy = VYr.a[q];
+            const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
+            const T vxE = q == L ? vxr : VXr.a[q == L ? q : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
+            const T vyE = q == L ? vyr : VYr.a[q == L ? q : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
+            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx);
+            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx);
+            const T fE1 = q == L ? fr1 : Nc.a[q == L ? q : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
+            const T fE0 = q == L ? fr0 : Nm.a[q == L ? q : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
+            const T fE2 = q == L ? fr2 : Np.a[q == L ? q : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
+            const T fxE = q == L ? fxr : NX[t + 1].a[q == L ? q : q + 1], fxW = q == 0 ? fxl : NX[t + 1].a[q == 0 ? 0 : q - 1];
+            const T fyE = q == L ? fyr : NY[t + 1].a[q == L ? q : q + 1], fyW = q == 0 ? fyl : NY[t + 1].a[q == 0 ? 0 : q - 1];
+            const T f00 = Nc.a[q];
+            const T f0m = ny ? Np.a[q] : Nm.a[q];
+            const T fm0 = nx ? fE1 : fW1;
+            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
+            const T fx00 = NX[t + 1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[t + 2].a[q] : NX[t].a[q];
+            const T fy00 = NY[t + 1].a[q], fy0m = ny ? NY[t + 2].a[q] : NY[t].a[q], fym0 = nx ? fyE : fyW;
+            T of, ofx, ofy;
+            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
+            if (CLAMP) of = tmin(tmax(of, (T)0.0), (T)1.0);
+            if ((fl[t] >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
+        }
+        if (lm.owner) {
+            if (SELF) raise_hot(hot, lv_hot1<T, N>(OV));                                   // one component per pass: conservative
+            lv_store<T, N>(out + idx<C, T>(g, c, i0, j), OV);                              // every cell: result or carried value
+            if (nw[t + 1]) {
+                lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), OX, nw[t + 1]);           // fluid: result, inflow/outflow: carried
+                lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), OY, nw[t + 1]);
+            }
+        }
+    }
+}
+
+// blockIdx.y (or, channel groups innermost / compact lists, the block index >> 3) % C = the channel of this workgroup
+template <int C, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T>
+__global__ __launch_bounds__(256) void k_cip_grad_advect_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+                                                           T *out, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                           const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
+{
+    const int yy = (nbx >= 0 && (nby & FS_CG_INNER)) ? ((int)blockIdx.x >> 3) : (int)blockIdx.y;
+    const int ch = yy % C;
+    if (ch == 0) cip_grad_advect_n_body<C, 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    else if (ch == 1) cip_grad_advect_n_body<C, 1, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    else if (C == 3) cip_grad_advect_n_body<C, C == 3 ? 2 : 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+}
+
+}  // namespace fs

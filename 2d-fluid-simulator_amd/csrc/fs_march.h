@@ -655,319 +655,7 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad_quad(Grid g, Konst<T> k
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// K3 + K4 fused for the velocity field: gradient update of the non-advection phase (fs/solver.py:242-261) and CIP
-// advection (fs/solver.py:267-332) in ONE pass, one velocity component per launch slice (blockIdx.y = component).
-//
-// In the reference K3 writes the intermediate gradients into vx.next / vy.next, the buffers swap, and K4 reads them
-// back on a 3x3 neighbourhood: 16 B/cell written and 16 B/cell read again, plus the intermediate velocity read twice.
-// Here a lane evaluates K3 for rows j-1, j, j+1 of its quad in registers (halo recompute) and feeds K4 for row j
-// directly: 66 instead of 96 B/cell over the two kernels.  The intermediate gradients are never observable (the
-// buffer that would hold them is overwritten by the next step's K3 before anything reads it), so they are not stored.
-//
-// Buffer choreography (SURVEY.md H5 - contents, not addresses, are what later kernels see): K4's velocity output goes to
-// a THIRD velocity buffer `vo` (the unfused code overwrites the pre-K2 velocity buffer `fc` in place, which a fused
-// kernel still has to read at radius 2 in other tiles), carrying fc's values on non-fluid cells exactly as the in-place
-// update would leave them.  The new gradients go to the buffers the reference would use for the intermediates
-// (gxo/gyo), carrying gxc/gyc on inflow/outflow cells; wall cells of the gradient buffers are never written by any
-// kernel and are identical in both physical buffers (zero) - the host falls back to the unfused pair if a user
-// uploaded gradient data.  The caller rotates (v.cur, v.next, spare) and swaps vx / vy once.
-//   fn = velocity after K2 (v.next), fc = velocity before K2 (v.cur), gxc/gyc = gradients before K3.
-// ------------------------------------------------------------------------------------------------
-// The same fused pass on a register tile of RT rows (interior rows only: every row j0 - 2 .. j0 + RT + 1 lies inside the domain, so
-// no clamped duplicates).  The gradient update is evaluated for RT + 2 rows per RT output rows instead of 3 per 1 - at RT = 4 the
-// recompute overhead that made the one-row form issue-bound drops from 3x to 1.5x - and the five input planes are requested up front
-// as 5 RT + 14 16-byte loads per lane.  Rows that do not fill a whole tile, and the rows next to the domain edge, take the one-row
-// kernels below.
-// PLAIN: the host listed this workgroup as seeing nothing but fluid within its reach (fs_api.hip tile_list, compact launch): no mask loads,
-// constant selectors, unconditional stores - as its own kernel.
-template <int c, int RT, int DM, bool PLAIN, typename T>
-__device__ __forceinline__ void cip_grad_advect_rt_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
-                                                        T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                        const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
-{
-    int wx, ty, cg;
-    if (!tile_coords<2>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
-    const LaneMap lm = lane_map_wave(g, wx);
-    const int i0 = lm.i0, j0 = jb + ty * RT;
-    constexpr int o = 1 - c;
-
-    unsigned nw[RT + 2], fl[RT];                 // not-wall selectors of rows j0-1 .. j0+RT, fluid selectors of rows j0 .. j0+RT-1
-    bool any_fl = PLAIN;
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        if (PLAIN) { nw[s] = 0xfu; if (s >= 1 && s <= RT) fl[s - 1] = j0 + s - 1 < je ? 0xfu : 0u; continue; }
-        const uint32_t m4 = mask_quad(g, i0, clampy(g, j0 - 1 + s));
-        nw[s] = sel_not_wall(m4);
-        if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? sel_fluid(m4) : 0u; any_fl |= fl[s - 1] != 0u; }
-    }
-    if (!PLAIN && !__any(any_fl)) {
-        // no fluid cell in this wave's tile: every output is a carried value (vo = fc, old gradients on inflow / outflow cells) - and only
-        // cells that SOME kernel writes can differ between fc and vo: not-wall cells and the targets of the velocity boundary kernel
-        // (bit 7 of the recipe byte, fs_api.hip build_bc_ops).  Deep wall rows move nothing (a third of scene 5); `full`: after an
-        // upload the two buffers may differ anywhere - carry every cell once (fs/solver.py, Field.static_id).
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int j = j0 + t;
-            if (j >= je) break;
-            const unsigned touch = full ? 0xfu : (nw[t + 1] | sel_bit7(bcmap_quad(g, bcmap, i0, j)));
-            if (!__any(lm.owner && touch != 0u)) continue;
-            const typename Quad<T>::type f = load_quad<2>(fc, g, c, i0, j);
-            if (lm.owner && touch) {
-                raise_hot(hot, hot1(f.x) || hot1(f.y) || hot1(f.z) || hot1(f.w));
-                *reinterpret_cast<typename Quad<T>::type *>(vo + idx<2, T>(g, c, i0, j)) = f;
-                if (nw[t + 1]) {
-                    store_quad_sel<T>(gxo + idx<2, T>(g, c, i0, j), load_quad<2>(gxc, g, c, i0, j), nw[t + 1]);
-                    store_quad_sel<T>(gyo + idx<2, T>(g, c, i0, j), load_quad<2>(gyc, g, c, i0, j), nw[t + 1]);
-                }
-            }
-        }
-        return;
-    }
-
-    // slot u of N / Fc <-> row j0 - 2 + u;   slot s of NO / GX / GY / NX / NY <-> row j0 - 1 + s
-    Q4<T> N[RT + 4], Fc[RT + 4], NO[RT + 2], GX[RT + 2], GY[RT + 2];
-#pragma unroll
-    for (int u = 0; u < RT + 4; ++u) {
-        N[u] = Q4<T>(load_quad<2>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
-        Fc[u] = Q4<T>(load_quad<2>(fc, g, c, i0, clampy(g, j0 - 2 + u)));
-    }
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        NO[s] = Q4<T>(load_quad<2>(fn, g, o, i0, clampy(g, j0 - 1 + s)));
-        GX[s] = Q4<T>(load_quad<2>(gxc, g, c, i0, clampy(g, j0 - 1 + s)));
-        GY[s] = Q4<T>(load_quad<2>(gyc, g, c, i0, clampy(g, j0 - 1 + s)));
-    }
-    // ---- K3 on rows j0-1 .. j0+RT: wall cells keep the stored gradient ----
-    Q4<T> NX[RT + 2], NY[RT + 2];
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        const Q4<T> &n1 = N[s + 1], &c1 = Fc[s + 1];
-        const T nl = quad_left<T>(lm, n1.quad()), nr = quad_right<T>(lm, n1.quad());
-        const T cl = quad_left<T>(lm, c1.quad()), cr = quad_right<T>(lm, c1.quad());
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T nE = q == 3 ? nr : n1.a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : n1.a[q == 0 ? 0 : q - 1];
-            const T cE = q == 3 ? cr : c1.a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : c1.a[q == 0 ? 0 : q - 1];
-            const T sx = ((nE - cE) - nW) + cW;
-            const T sy = ((N[s + 2].a[q] - Fc[s + 2].a[q]) - N[s].a[q]) + Fc[s].a[q];
-            const bool live = (nw[s] >> q) & 1u;
-            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx) : GX[s].a[q];
-            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx) : GY[s].a[q];
-        }
-    }
-    // every row is loaded clamped (sample() clamps coordinates), so the rows at the domain's first / last row need no launch of their own:
-    // a slot that stands for a row outside the domain takes the K3 result of the edge row it clamps onto (wave-uniform)
-    if (j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
-#pragma unroll
-    for (int s = 1; s < RT + 2; ++s)
-        if (j0 - 1 + s > g.jhi) { NX[s] = NX[s - 1]; NY[s] = NY[s - 1]; }
-    // ---- K4 on rows j0 .. j0+RT-1 ----
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const int j = j0 + t;
-        if (j >= je) break;
-        const Q4<T> &Nm = N[t + 1], &Nc = N[t + 2], &Np = N[t + 3];                                // value field rows j-1, j, j+1
-        const Q4<T> &VXr = c == 0 ? Nc : NO[t + 1], &VYr = c == 0 ? NO[t + 1] : Nc;                 // advecting velocity, row j
-        const Q4<T> &VXm = c == 0 ? Nm : NO[t], &VXp = c == 0 ? Np : NO[t + 2];
-        const Q4<T> &VYm = c == 0 ? NO[t] : Nm, &VYp = c == 0 ? NO[t + 2] : Np;
-        const T vxl = quad_left<T>(lm, VXr.quad()), vxr = quad_right<T>(lm, VXr.quad());
-        const T vyl = quad_left<T>(lm, VYr.quad()), vyr = quad_right<T>(lm, VYr.quad());
-        const T fl0 = quad_left<T>(lm, Nm.quad()), fr0 = quad_right<T>(lm, Nm.quad());
-        const T fl1 = quad_left<T>(lm, Nc.quad()), fr1 = quad_right<T>(lm, Nc.quad());
-        const T fl2 = quad_left<T>(lm, Np.quad()), fr2 = quad_right<T>(lm, Np.quad());
-        const T fxl = quad_left<T>(lm, NX[t + 1].quad()), fxr = quad_right<T>(lm, NX[t + 1].quad());
-        const T fyl = quad_left<T>(lm, NY[t + 1].quad()), fyr = quad_right<T>(lm, NY[t + 1].quad());
-        Q4<T> OV = Fc[t + 2], OX = GX[t + 1], OY = GY[t + 1];       // carry values; fluid cells are replaced below
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T vx = VXr.a[q], vy = VYr.a[q];
-            const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
-            const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
-            const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx);
-            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx);
-            const T fE1 = q == 3 ? fr1 : Nc.a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
-            const T fE0 = q == 3 ? fr0 : Nm.a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
-            const T fE2 = q == 3 ? fr2 : Np.a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
-            const T fxE = q == 3 ? fxr : NX[t + 1].a[q == 3 ? 3 : q + 1], fxW = q == 0 ? fxl : NX[t + 1].a[q == 0 ? 0 : q - 1];
-            const T fyE = q == 3 ? fyr : NY[t + 1].a[q == 3 ? 3 : q + 1], fyW = q == 0 ? fyl : NY[t + 1].a[q == 0 ? 0 : q - 1];
-            const T f00 = Nc.a[q];
-            const T f0m = ny ? Np.a[q] : Nm.a[q];
-            const T fm0 = nx ? fE1 : fW1;
-            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
-            const T fx00 = NX[t + 1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[t + 2].a[q] : NX[t].a[q];
-            const T fy00 = NY[t + 1].a[q], fy0m = ny ? NY[t + 2].a[q] : NY[t].a[q], fym0 = nx ? fyE : fyW;
-            T of, ofx, ofy;
-            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
-            if ((fl[t] >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
-        }
-        if (lm.owner) {
-            raise_hot(hot, hot1(OV.a[0]) || hot1(OV.a[1]) || hot1(OV.a[2]) || hot1(OV.a[3]));     // one component per pass: conservative
-            *reinterpret_cast<typename Quad<T>::type *>(vo + idx<2, T>(g, c, i0, j)) = OV.quad();     // every cell: result or carried value
-            if (nw[t + 1]) {
-                store_quad_sel<T>(gxo + idx<2, T>(g, c, i0, j), OX.quad(), nw[t + 1]);              // fluid: result, inflow/outflow: carried
-                store_quad_sel<T>(gyo + idx<2, T>(g, c, i0, j), OY.quad(), nw[t + 1]);
-            }
-        }
-    }
-}
-
-template <int RT, int DM, bool PLAIN, typename T>
-__global__ __launch_bounds__(256) void k_cip_grad_advect_rt(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
-                                                            T *vo, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                            const T *gxc, const T *gyc, unsigned *hot, const uint8_t *bcmap, int full)
-{
-    // blockIdx.y = (tile row in the XCD group) * 2 + component: the two component passes of a tile are adjacent in dispatch order on
-    // the SAME XCD, so the second one finds the velocity rows both passes read in that XCD's L2 instead of fetching them again.
-    const int comp = (nbx >= 0 && (nby & FS_CG_INNER)) ? (((int)blockIdx.x >> 3) & 1) : ((int)blockIdx.y & 1);
-    if (comp == 0) cip_grad_advect_rt_body<0, RT, DM, PLAIN, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
-    else cip_grad_advect_rt_body<1, RT, DM, PLAIN, T>(g, k, nbx, nby, jb, je, vo, gxo, gyo, fn, fc, gxc, gyc, hot, bcmap, full);
-}
-
-// The same fusion for the dye (C = 3 channels advected by the final velocity of the flow step, fs/solver.py:378-401): K3 on the rows
-// j0-1 .. j0+RT and K4 on j0 .. j0+RT-1 of ONE channel per wave (blockIdx.y % 3; the three passes of a tile are adjacent in dispatch order
-// and share the velocity rows through the L2).  Every row is loaded clamped (sample() clamps coordinates, fs/differentiation.py:4-9), so the
-// rows next to the domain's first / last row need no separate launch: a register slot that stands for a row outside the domain takes the
-// K3 result of the edge row it clamps onto.  CLAMP: clamp_field(dye, 0, 1) (fs/solver.py:46-49) folded into the store of the advected value.
-template <int c, int RT, int DM, bool CLAMP, typename T>
-__device__ __forceinline__ void cip_grad_advect_dye_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
-                                                         T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                         const T *gxc, const T *gyc, const T *v, int full)
-{
-    int wx, ty, cg;
-    if (!tile_coords<3>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
-    const LaneMap lm = lane_map_wave(g, wx);
-    const int i0 = lm.i0, j0 = jb + ty * RT;
-
-    unsigned nw[RT + 2], fl[RT];                 // not-wall selectors of rows j0-1 .. j0+RT, fluid selectors of rows j0 .. j0+RT-1
-    bool any_fl = false;
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        const uint32_t m4 = mask_quad(g, i0, clampy(g, j0 - 1 + s));
-        nw[s] = sel_not_wall(m4);
-        if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? sel_fluid(m4) : 0u; any_fl |= fl[s - 1] != 0u; }
-    }
-    if (!__any(any_fl)) {
-        // no fluid cell in this wave's tile: every output is a carried value (dout = fc, old gradients on inflow / outflow cells); wall cells
-        // of the dye buffers are written by no kernel, so only quads with an inflow / outflow cell have anything to carry (`full`: see above)
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int j = j0 + t;
-            if (j >= je) break;
-            const unsigned touch = full ? 0xfu : nw[t + 1];
-            if (!__any(lm.owner && touch != 0u)) continue;
-            const typename Quad<T>::type f = load_quad<3>(fc, g, c, i0, j);
-            if (lm.owner && touch) {
-                *reinterpret_cast<typename Quad<T>::type *>(dout + idx<3, T>(g, c, i0, j)) = f;
-                if (nw[t + 1]) {
-                    store_quad_sel<T>(gxo + idx<3, T>(g, c, i0, j), load_quad<3>(gxc, g, c, i0, j), nw[t + 1]);
-                    store_quad_sel<T>(gyo + idx<3, T>(g, c, i0, j), load_quad<3>(gyc, g, c, i0, j), nw[t + 1]);
-                }
-            }
-        }
-        return;
-    }
-
-    // slot u of N / Fc <-> row j0 - 2 + u;   slot s of GX / GY / VX / VY / NX / NY <-> row j0 - 1 + s   (rows clamped into the domain)
-    Q4<T> N[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], VX[RT + 2], VY[RT + 2];
-#pragma unroll
-    for (int u = 0; u < RT + 4; ++u) {
-        N[u] = Q4<T>(load_quad<3>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
-        Fc[u] = Q4<T>(load_quad<3>(fc, g, c, i0, clampy(g, j0 - 2 + u)));
-    }
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        const int row = clampy(g, j0 - 1 + s);
-        GX[s] = Q4<T>(load_quad<3>(gxc, g, c, i0, row));
-        GY[s] = Q4<T>(load_quad<3>(gyc, g, c, i0, row));
-        VX[s] = Q4<T>(load_quad<2>(v, g, 0, i0, row));
-        VY[s] = Q4<T>(load_quad<2>(v, g, 1, i0, row));
-    }
-    // ---- K3 on rows j0-1 .. j0+RT: wall cells keep the stored gradient ----
-    Q4<T> NX[RT + 2], NY[RT + 2];
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        const Q4<T> &n1 = N[s + 1], &c1 = Fc[s + 1];
-        const T nl = quad_left<T>(lm, n1.quad()), nr = quad_right<T>(lm, n1.quad());
-        const T cl = quad_left<T>(lm, c1.quad()), cr = quad_right<T>(lm, c1.quad());
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T nE = q == 3 ? nr : n1.a[q == 3 ? 3 : q + 1], nW = q == 0 ? nl : n1.a[q == 0 ? 0 : q - 1];
-            const T cE = q == 3 ? cr : c1.a[q == 3 ? 3 : q + 1], cW = q == 0 ? cl : c1.a[q == 0 ? 0 : q - 1];
-            const T sx = ((nE - cE) - nW) + cW;
-            const T sy = ((N[s + 2].a[q] - Fc[s + 2].a[q]) - N[s].a[q]) + Fc[s].a[q];
-            const bool live = (nw[s] >> q) & 1u;
-            NX[s].a[q] = live ? GX[s].a[q] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx) : GX[s].a[q];
-            NY[s].a[q] = live ? GY[s].a[q] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx) : GY[s].a[q];
-        }
-    }
-    // slots that stand for rows outside the domain: the K3 result of the edge row they clamp onto (wave-uniform)
-    if (j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
-#pragma unroll
-    for (int s = 1; s < RT + 2; ++s)
-        if (j0 - 1 + s > g.jhi) { NX[s] = NX[s - 1]; NY[s] = NY[s - 1]; }
-    // ---- K4 on rows j0 .. j0+RT-1 ----
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const int j = j0 + t;
-        if (j >= je) break;
-        const Q4<T> &Nm = N[t + 1], &Nc = N[t + 2], &Np = N[t + 3];                                // value field rows j-1, j, j+1
-        const Q4<T> &VXm = VX[t], &VXr = VX[t + 1], &VXp = VX[t + 2], &VYm = VY[t], &VYr = VY[t + 1], &VYp = VY[t + 2];
-        const T vxl = quad_left<T>(lm, VXr.quad()), vxr = quad_right<T>(lm, VXr.quad());
-        const T vyl = quad_left<T>(lm, VYr.quad()), vyr = quad_right<T>(lm, VYr.quad());
-        const T fl0 = quad_left<T>(lm, Nm.quad()), fr0 = quad_right<T>(lm, Nm.quad());
-        const T fl1 = quad_left<T>(lm, Nc.quad()), fr1 = quad_right<T>(lm, Nc.quad());
-        const T fl2 = quad_left<T>(lm, Np.quad()), fr2 = quad_right<T>(lm, Np.quad());
-        const T fxl = quad_left<T>(lm, NX[t + 1].quad()), fxr = quad_right<T>(lm, NX[t + 1].quad());
-        const T fyl = quad_left<T>(lm, NY[t + 1].quad()), fyr = quad_right<T>(lm, NY[t + 1].quad());
-        Q4<T> OV = Fc[t + 2], OX = GX[t + 1], OY = GY[t + 1];       // carry values; fluid cells are replaced below
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T vx = VXr.a[q], vy = VYr.a[q];
-            const bool nx = vx < (T)0.0, ny = vy < (T)0.0;
-            const T vxE = q == 3 ? vxr : VXr.a[q == 3 ? 3 : q + 1], vxW = q == 0 ? vxl : VXr.a[q == 0 ? 0 : q - 1];
-            const T vyE = q == 3 ? vyr : VYr.a[q == 3 ? 3 : q + 1], vyW = q == 0 ? vyl : VYr.a[q == 0 ? 0 : q - 1];
-            const T dxx = xdiv<DM>((T)0.5 * (vxE - vxW), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>((T)0.5 * (vyE - vyW), k.dx, k.inv_dx, k.r_dx);
-            const T dyx = xdiv<DM>((T)0.5 * (VXp.a[q] - VXm.a[q]), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>((T)0.5 * (VYp.a[q] - VYm.a[q]), k.dx, k.inv_dx, k.r_dx);
-            const T fE1 = q == 3 ? fr1 : Nc.a[q == 3 ? 3 : q + 1], fW1 = q == 0 ? fl1 : Nc.a[q == 0 ? 0 : q - 1];
-            const T fE0 = q == 3 ? fr0 : Nm.a[q == 3 ? 3 : q + 1], fW0 = q == 0 ? fl0 : Nm.a[q == 0 ? 0 : q - 1];
-            const T fE2 = q == 3 ? fr2 : Np.a[q == 3 ? 3 : q + 1], fW2 = q == 0 ? fl2 : Np.a[q == 0 ? 0 : q - 1];
-            const T fxE = q == 3 ? fxr : NX[t + 1].a[q == 3 ? 3 : q + 1], fxW = q == 0 ? fxl : NX[t + 1].a[q == 0 ? 0 : q - 1];
-            const T fyE = q == 3 ? fyr : NY[t + 1].a[q == 3 ? 3 : q + 1], fyW = q == 0 ? fyl : NY[t + 1].a[q == 0 ? 0 : q - 1];
-            const T f00 = Nc.a[q];
-            const T f0m = ny ? Np.a[q] : Nm.a[q];
-            const T fm0 = nx ? fE1 : fW1;
-            const T fmm = ny ? (nx ? fE2 : fW2) : (nx ? fE0 : fW0);
-            const T fx00 = NX[t + 1].a[q], fxm0 = nx ? fxE : fxW, fx0m = ny ? NX[t + 2].a[q] : NX[t].a[q];
-            const T fy00 = NY[t + 1].a[q], fy0m = ny ? NY[t + 2].a[q] : NY[t].a[q], fym0 = nx ? fyE : fyW;
-            T of, ofx, ofy;
-            cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
-            if (CLAMP) of = tmin(tmax(of, (T)0.0), (T)1.0);
-            if ((fl[t] >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
-        }
-        if (lm.owner) {
-            *reinterpret_cast<typename Quad<T>::type *>(dout + idx<3, T>(g, c, i0, j)) = OV.quad();   // every cell: result or carried value
-            if (nw[t + 1]) {
-                store_quad_sel<T>(gxo + idx<3, T>(g, c, i0, j), OX.quad(), nw[t + 1]);              // fluid: result, inflow/outflow: carried
-                store_quad_sel<T>(gyo + idx<3, T>(g, c, i0, j), OY.quad(), nw[t + 1]);
-            }
-        }
-    }
-}
-
-template <int RT, int DM, bool CLAMP, typename T>
-__global__ __launch_bounds__(256) void k_cip_grad_advect_dye(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
-                                                             T *dout, T *gxo, T *gyo, const T *fn, const T *fc,
-                                                             const T *gxc, const T *gyc, const T *v, int full)
-{
-    const int yy = (nbx >= 0 && (nby & FS_CG_INNER)) ? ((int)blockIdx.x >> 3) : (int)blockIdx.y;
-    const int ly = yy / 3, ch = yy - 3 * ly;      // channel = (blockIdx.y or the block column index) % 3 (the fallback grid: blockIdx.y itself)
-    if (ch == 0) cip_grad_advect_dye_body<0, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
-    else if (ch == 1) cip_grad_advect_dye_body<1, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
-    else cip_grad_advect_dye_body<2, RT, DM, CLAMP, T>(g, k, nbx, nby, jb, je, dout, gxo, gyo, fn, fc, gxc, gyc, v, full);
-}
-
+// (K3 + K4 in one pass - velocity and dye - live in fs_k34n.h)
 
 // ------------------------------------------------------------------------------------------------
 // K8J  JacobiPressureUpdater._update (fs/pressure_updater.py:62-66), overlapped-wave register tile: x-neighbours of the wave-edge quads come

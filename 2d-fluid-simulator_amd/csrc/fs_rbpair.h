@@ -89,12 +89,12 @@ __device__ __forceinline__ void lv_store_sel(T *dst, const LV<T, N> &v, unsigned
         if (sel & (1u << c)) dst[c] = v.a[c];
 }
 
-// overlapped-wave column mapping for lanes of N cells: 4 / N halo lanes on each side (4 cells: the reach of four radius-1 stages)
+// overlapped-wave column mapping for lanes of N cells: HL halo lanes on each side (default 4 / N = 4 cells: the reach of four radius-1 stages)
 template <int N> struct LaneMapN { int i0; bool owner, at_lo, at_hi; };
-template <int N>
+template <int N, int HL = 4 / N>
 __device__ __forceinline__ LaneMapN<N> lane_map_n(const Grid &g, int wave)
 {
-    constexpr int HL = 4 / N, OW = 64 - 2 * HL;
+    constexpr int OW = 64 - 2 * HL;
     const int lane = threadIdx.x & 63, nu = g.X / N;
     int q = wave * OW - HL + lane;
     LaneMapN<N> m;

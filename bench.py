@@ -66,12 +66,12 @@ def algorithmic_bytes(mask, esize=4):
         "cip_nonadv": n + nw * (2 * e + e + 2 * e),                      # v, p -> v'
         "cip_nonadv_grad": n + nw * (4 * e + 4 * e + 4 * e),             # vx,vy,v,v' -> vx',vy'  (8+8+8+8+16 B)
         "cip_advect": n + fl * (6 * e + 6 * e),                          # v,vx,vy -> v',vx',vy'
-        # fused K3 + K4 (csrc/fs_march.h k_cip_grad_advect_rt): mask; fc read and v_out written on the cells some kernel writes (not-wall
+        # fused K3 + K4 (csrc/fs_k34n.h k_cip_grad_advect_n<2>): mask; fc read and v_out written on the cells some kernel writes (not-wall
         # cells and the velocity boundary targets next to them - counted as not-wall; deep wall tiles move nothing since round 3); fn on
         # fluid cells; old gradients read and new gradients written on not-wall cells.  The intermediate gradients the reference's two
         # kernels exchange through HBM (16 B/cell written + read back 3x3) never leave the registers.
         "cip_grad_advect_rt": n + nw * (2 * e + 2 * e) + fl * 2 * e + nw * (4 * e + 4 * e),
-        # the same fusion for the dye (k_cip_grad_advect_dye): 3 channels + the advecting velocity on fluid cells
+        # the same fusion for the dye (k_cip_grad_advect_n<3>): 3 channels + the advecting velocity on fluid cells
         "cip_grad_advect_dye": n + nw * (3 * e + 3 * e) + fl * (3 * e + 2 * e) + nw * (6 * e + 6 * e),
         "vort_calc": n + fl * (2 * e + 2 * e),                           # v -> w, |w|
         "vort_add": n + fl * (2 * e + 2 * e + 2 * e),                    # w,|w|,v -> v'

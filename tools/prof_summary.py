@@ -6,6 +6,7 @@ import csv, glob, os, re, sys, collections
 out = sys.argv[1]
 def short(n):
     n = re.sub(r"^void ", "", n); n = re.sub(r"\(.*", "", n); n = re.sub(r"fs::", "", n)
+    n = n.replace("k_cip_grad_advect_n<2,", "k_cip_grad_advect_rt<").replace("k_cip_grad_advect_n<3,", "k_cip_grad_advect_dye<")   # one body, two fields (fs_k34n.h)
     return re.sub(r"<.*", "", n)
 stats = {}
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
@@ -21,7 +22,7 @@ for sub in ("pmc_fetch", "pmc_write"):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             full[short(r["Kernel_Name"])][r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # kernels launched in two compact parts per logical launch (workgroups that see nothing but fluid / the others: two instantiations)
-SPLIT = {"k_cip_grad_advect_rt", "k_rbsor_pair", "k_jacobi_quad"}
+SPLIT = {"k_cip_grad_advect_rt", "k_cip_grad_advect_dye", "k_rbsor_pair", "k_jacobi_quad"}
 import json
 traffic = {}
 NAMES = {"k_rbsor_pair": "rbsor_pair", "k_jacobi_quad": "jacobi_quad_lazy", "k_cip_grad_advect_dye": "cip_grad_advect_dye", "k_mac_update_quad": "mac_update_kk",
