@@ -591,7 +591,13 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     using T = float;
     auto k = make_konst<T>(ctx, dt, dx, 1.0);
     const int dm = dm_dx(ctx, k);
-    const int N = ctx->k34_n, RT = N == 2 ? (ctx->k34_rt == 2 ? 2 : 4) : 2, geo = N == 2 ? 3 : 4;
+    // geometry by grid size unless FS_K34_N / FS_K34_RT say otherwise (K3+K4 of the velocity, us):   2 cells x 4 rows   4 x 2   2 x 2
+    //   >= 8 M cells (two-part launch): bc5 res 4096 / bc5 res 2048 / bc2 res 3000                   307 / 103 / 258    325 / 106 / 267   - / 113 / 282
+    //   2 - 8 M cells: bc2 res 1600 / bc5 res 1024 (the boundary kernel of 2 x 4 holds 4 waves per SIMD)  90.7 / 26.5   81.6 / 27.8   90.3 / 26.4
+    //   smaller: bc2 res 800 / res 400 (workgroups of half the size)                                  28.2 / 14.5        26.6 / 13.7       24.8 / 12.9
+    const size_t cells = (size_t)ctx->X * ctx->rows;      // (this context's slab)
+    const int N = ctx->k34_n ? ctx->k34_n : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4);
+    const int RT = N == 4 ? 2 : (ctx->k34_rt ? ctx->k34_rt : (cells >= ((size_t)1 << 23) ? 4 : 2)), geo = N == 2 ? 3 : 4;
 #define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
         (T *)f_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v ? (const T *)v->d : (const T *)nullptr, \
         f_out->hot, (const uint8_t *)ctx->d_bcmap, full)
@@ -655,14 +661,14 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
-    if (const char *s = getenv("FS_VORT_RT")) { const int v = atoi(s); if (v >= 3 && v <= 6) c->vort_rt = v; }
     if (const char *s = getenv("FS_RBSOR_RT")) { const int v = atoi(s); if (v >= 2 && v <= 4) c->rbsor_rt = v; }
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
-    if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : 4;
-    if (const char *s = getenv("FS_K34_N")) c->k34_n = atoi(s) == 4 ? 4 : 2;
+    if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : (atoi(s) == 4 ? 4 : 0);
+    if (const char *s = getenv("FS_MAC_RT")) { const int v = atoi(s); c->mac_rt = v == 2 || v == 4 ? v : 0; }
+    if (const char *s = getenv("FS_K34_N")) c->k34_n = atoi(s) == 4 ? 4 : (atoi(s) == 2 ? 2 : 0);
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
     c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
@@ -1027,8 +1033,6 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
         hipLaunchKernelGGL(kern, cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, __VA_ARGS__); \
     });
 
-#define FS_K2M(SS, PP) hipLaunchKernelGGL((k_mac_update_quad<SS, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-            (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot)
 int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_field *vn, const fs_field *vc,
                   const fs_field *pc, int row_begin, int row_end)
 {
@@ -1040,11 +1044,19 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, re);
         if (ctx->use_march) {
-            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
+            // lanes of 2 cells (fs_k34n.h k_mac_update_n), tiles of 4 rows on large f32 grids (KK at bc3 res 4096: 178 -> 162 us against the one-row quad
+            // form it replaces; f64: 424 -> 306 with 2-row tiles), 2 rows on small grids (more workgroups) and for f64 (registers)
+            const int rt = ctx->mac_rt ? ctx->mac_rt : (sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2);
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_NONADV, 3);
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
-#define FS_K2M_UP(DM) FS_K2M(0, DM)
-#define FS_K2M_KK(DM) FS_K2M(1, DM)
-                if (scheme == FS_UPWIND) FS_DMA(dm_all(ctx, k), FS_K2M_UP); else FS_DMA(dm_all(ctx, k), FS_K2M_KK);
+#define FS_K2MN(SS, RR, PP) hipLaunchKernelGGL((k_mac_update_n<SS, 2, RR, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+            (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot)
+#define FS_K2MN_UP4(DM) FS_K2MN(0, 4, DM)
+#define FS_K2MN_KK4(DM) FS_K2MN(1, 4, DM)
+#define FS_K2MN_UP2(DM) FS_K2MN(0, 2, DM)
+#define FS_K2MN_KK2(DM) FS_K2MN(1, 2, DM)
+                if (rt == 2) { if (scheme == FS_UPWIND) FS_DMA(dm_all(ctx, k), FS_K2MN_UP2); else FS_DMA(dm_all(ctx, k), FS_K2MN_KK2); }
+                else { if (scheme == FS_UPWIND) FS_DMA(dm_all(ctx, k), FS_K2MN_UP4); else FS_DMA(dm_all(ctx, k), FS_K2MN_KK4); }
             });
         }
         if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_update_upwind", (k_mac_update<0, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot) }
@@ -1091,10 +1103,12 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, re);
         if (ctx->use_march) {
-            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
+            // lanes of 2 cells, tiles of 4 rows (fs_k34n.h k_cip_nonadv_n), compact launch: 116 -> 102 us at bc5 res 4096 against the one-row quad form
+            // it replaces (2 rows: 112, 8 rows: 106-110)
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_NONADV, 3);
             return launch(ctx, "cip_nonadv", [=] {
-#define FS_K2Q(DM) hipLaunchKernelGGL((k_cip_nonadv_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
-                FS_DMA(dm_all(ctx, k), FS_K2Q);
+#define FS_K2N4(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
+                FS_DMA(dm_all(ctx, k), FS_K2N4);
             });
         }
         if (k.p2) { FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<true, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot) }
@@ -1111,7 +1125,7 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, re);
         if (ctx->use_march) {
-            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV);
+            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV, false);
             return launch(ctx, "cip_nonadv_dye", [=] {
 #define FS_K12Q(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
                 FS_DMA(dm_all(ctx, k), FS_K12Q);
@@ -1285,18 +1299,17 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
         if (rc) return rc;
         return fs_vort_add(ctx, dt, dx, weight, vn, vc, vort, vort_abs, row_begin, row_end);
     }
-    const int rt = ctx->vort_rt;
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_VORT);
-    const dim3 grid = og.grid;
+    // lanes of 2 cells (fs_k34n.h k_vort_n), 4-row tiles, compact launch: 100 -> 95 us at bc5 res 4096 against the quad form it replaces (6 / 8 rows:
+    // 102 / 103; f64 at bc3 res 4096: 251 -> 224)
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_VORT, 3);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
         const int dm = dm_dx(ctx, k);
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
-#define FS_VORT(RT, DM, ST) hipLaunchKernelGGL((k_vort_fused<RT, DM, ST, T>), grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
-#define FS_VORT_RT(DM, ST) do { if (rt == 5) FS_VORT(5, DM, ST); else if (rt == 6) FS_VORT(6, DM, ST); else if (rt == 3) FS_VORT(3, DM, ST); else FS_VORT(4, DM, ST); } while (0)
-#define FS_VORT_S(DM) FS_VORT_RT(DM, true)
-#define FS_VORT_N(DM) FS_VORT_RT(DM, false)
-        return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORT_S); else FS_DMX(dm, FS_VORT_N); });
+#define FS_VORTN(DM, ST) hipLaunchKernelGGL((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
+#define FS_VORTN_S(DM) FS_VORTN(DM, true)
+#define FS_VORTN_N(DM) FS_VORTN(DM, false)
+        return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORTN_S); else FS_DMX(dm, FS_VORTN_N); });
     })
 }
 

@@ -79,7 +79,6 @@ struct fs_ctx {
     int rbpair_rt = 4;                       // rows per tile of that pass (env FS_RBPAIR_RT = 4, 6)
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
-    int vort_rt = 4;                         // rows per tile of the fused vorticity confinement (env FS_VORT_RT = 3 .. 6)
     int rbsor_rt = 3;                        // rows per tile of the fused red-black iteration (env FS_RBSOR_RT = 2, 3, 4)
     int pair_rt = 3;                         // rows per tile of the two-sweep kernel (env FS_PAIR_RT = 1 .. 4; 3: within 2 % of the best of 2 / 3 / 4 from res 1024 to 4096)
     int nwx = 0;                   // wave columns of 62 quads across a row
@@ -114,8 +113,9 @@ struct fs_ctx {
     // tuning knobs (env FS_MARCH=0: one-cell-per-lane kernels only)
     bool use_march = true;
     bool use_f64div = true;    // env FS_F64DIV=0: IEEE division for the loop-invariant divisors of f32 runs (A/B; the results are the same)
-    int k34_n = 2;             // env FS_K34_N: cells per lane of the fused K3 + K4 pass (fs_k34n.h; 2: tiles of 4 rows, FS_K34_RT=2: 2; 4: tiles of 2 rows)
-    int k34_rt = -1;           // env FS_K34_RT: rows per register tile of that pass at 2 cells per lane (4; 2)
+    int mac_rt = 0;            // env FS_MAC_RT: rows per tile (2 / 4) of K2' (upwind / KK update); 0: by grid size and precision
+    int k34_n = 0;             // env FS_K34_N: cells per lane (2 / 4) of the fused K3 + K4 pass (fs_k34n.h); 0: by grid size (fs_api.hip launch_k34)
+    int k34_rt = 0;            // env FS_K34_RT: rows per register tile (2 / 4) of that pass at 2 cells per lane; 0: by grid size
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_group_fam[6] = {0, 0, 0, 0, 0, 0};   // ... of single kernel families (env FS_XCD_GROUP_FAM; 0: xcd_group)
@@ -128,8 +128,8 @@ struct fs_ctx {
     // compact launches (fs_device.h Grid::tiles): per-cell activity of the scene on the host (bit 0: some cell of wave column wx - 248
     // cells - in row j is not deep wall, bit 1: the same for the 120-cell wave columns of the 2-cell-lane kernels), and the lists built from
     // it per launch geometry (key: lane width, rows per tile, stacked, group size)
-    int tile_list_mask = 1 | 4;              // env FS_TILE_LIST: kernel families (XCD_* bits) launched compactly.  Measured at bc5 res 4096:
-                                             // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement unchanged, K2 111 -> 117
+    int tile_list_mask = 1 | 2 | 4 | 8;              // env FS_TILE_LIST: kernel families (XCD_* bits) launched compactly.  Measured at bc5 res 4096:
+                                             // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement (2-cell lanes) 97 -> 95, K2 (2-cell lanes) 105 -> 102
     std::vector<uint8_t> h_act4, h_act2, h_act2w;     // [wave column][global row]
     struct TileList { uint32_t *d = nullptr; int per_xcd = 0; };
     std::map<uint32_t, TileList> tile_lists;

@@ -223,4 +223,254 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_n(Grid g, Konst<T> k, i
     else if (C == 3) cip_grad_advect_n_body<C, C == 3 ? 2 : 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2  CipMacSolver._non_advection_phase (fs/solver.py:229-240, 263-265) on lanes of N cells, tiles of RT rows: rows j0-1 .. j0+RT of v
+// (2 planes) and p are requested up front; not-wall cells get  fn = fc + ((-grad p) + lap(fc)/re) * dt.   One halo lane per side.
+// (The quad form with one row per tile, fs_march.h cip_nonadv_quad_tile, requests 9 16-byte rows per output row: 36 B per cell for 12 B
+// of input; 2 cells x 4 rows: 18 B per cell.)
+// ------------------------------------------------------------------------------------------------
+template <int N, int RT, int DM, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
+{
+    using R = LV<T, N>;
+    constexpr int HL = 1, L = N - 1;
+    int wx, ty, cg;
+    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    unsigned nw[RT];
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        nw[t] = j0 + t < je ? lv_sel_nw<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
+        any = any || (lm.owner && nw[t] != 0u);
+    }
+    if (!__any(any)) return;
+    R F[2][RT + 2], P[RT + 2];
+#pragma unroll
+    for (int u = 0; u < RT + 2; ++u) {
+        const int row = clampy(g, j0 - 1 + u);
+        F[0][u] = lv_field<2, T, N>(fc, g, 0, i0, row);
+        F[1][u] = lv_field<2, T, N>(fc, g, 1, i0, row);
+        P[u] = lv_field<1, T, N>(pc, g, 0, i0, row);
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        if (j >= je) break;
+        const T pl = lv_left<T, N>(lm, P[t + 1]), pr = lv_right<T, N>(lm, P[t + 1]);
+        R O[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const R &fm = F[c][t], &f1 = F[c][t + 1], &fp = F[c][t + 2];
+            const T l = lv_left<T, N>(lm, f1), r = lv_right<T, N>(lm, f1);
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+                const T fE = q == L ? r : f1.a[q == L ? q : q + 1], fW = q == 0 ? l : f1.a[q == 0 ? 0 : q - 1];
+                const T f0 = f1.a[q];
+                const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+                const T d2y = xdiv<DM>((fp.a[q] - (T)2.0 * f0) + fm.a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+                const T dif = cdiv<DM>(d2x + d2y, k.re, k.r_re);
+                T gp;
+                if (c == 0) {
+                    const T pE = q == L ? pr : P[t + 1].a[q == L ? q : q + 1], pW = q == 0 ? pl : P[t + 1].a[q == 0 ? 0 : q - 1];
+                    gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx);
+                } else {
+                    gp = xdiv<DM>((T)0.5 * (P[t + 2].a[q] - P[t].a[q]), k.dx, k.inv_dx, k.r_dx);
+                }
+                const T gg = (-gp) + dif;
+                O[c].a[q] = f0 + gg * k.dt;
+            }
+        }
+        if (lm.owner && nw[t]) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) raise_hot(hot, ((nw[t] >> q) & 1u) && hot2(O[0].a[q], O[1].a[q]));
+            lv_store_sel<T, N>(fn + idx<2, T>(g, 0, i0, j), O[0], nw[t]);
+            lv_store_sel<T, N>(fn + idx<2, T>(g, 1, i0, j), O[1], nw[t]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 + K6 fused: vorticity confinement in one pass on lanes of N cells (fs/vorticity_confinement.py:27-55; the unfused pair of kernels
+// remains available and is what the literal-mode parity tests compare with):
+//   w(i,j)  = fluid ? diff_x(v).y - diff_y(v).x : 0
+//   vn(i,j) = v + dt*weight * clamp((n.y, -n.x) * w, +-0.1),  n = grad|w| / |grad|w||       on fluid cells
+// A lane computes w for RT+2 rows of its cells from RT+4 rows of v, takes the x-neighbours of |w| from the adjacent lanes (DPP) and
+// writes RT rows of vn; w / |w| never touch HBM unless STORE_W.  One halo lane per side (the pass reaches 2 cells in x).
+// ------------------------------------------------------------------------------------------------
+template <int N, int RT, int DM, bool STORE_W, typename T>
+__global__ __launch_bounds__(256) void k_vort_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot)
+{
+    using R = LV<T, N>;
+    constexpr int HL = 1, L = N - 1;
+    int wx, ty, cg;
+    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+
+    unsigned fl[RT + 2];   // fluid selectors of rows j0-1 .. j0+RT (clamped rows repeat)
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        fl[r] = lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 1 + r)));
+        if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
+    }
+    if (!__any(any)) return;
+
+    R VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1
+#pragma unroll
+    for (int r = 0; r < RT + 4; ++r) {
+        const int j = clampy(g, j0 - 2 + r);
+        VX[r] = lv_field<2, T, N>(vc, g, 0, i0, j);
+        VY[r] = lv_field<2, T, N>(vc, g, 1, i0, j);
+    }
+    // vorticity of rows j0-1 .. j0+RT  (index r <-> v slot r+1): rows were loaded with clamped indices, so for an in-domain row the slots
+    // r, r+1, r+2 hold exactly sample()'s rows clamp(j-1), j, clamp(j+1); out-of-domain virtual rows are never consumed (see wm / wp)
+    R W[RT + 2];
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        const R &yc = VY[r + 1], &xm = VX[r], &xp = VX[r + 2];
+        const T yl = lv_left<T, N>(lm, yc), yr = lv_right<T, N>(lm, yc);
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const T yE = q == L ? yr : yc.a[q == L ? q : q + 1], yW = q == 0 ? yl : yc.a[q == 0 ? 0 : q - 1];
+            const T w = div_dx<DM>((T)0.5 * (yE - yW), k) - div_dx<DM>((T)0.5 * (xp.a[q] - xm.a[q]), k);
+            W[r].a[q] = (fl[r] >> q) & 1u ? w : (T)0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int j = j0 + r;
+        if (j >= je) break;
+        const unsigned f = fl[r + 1];
+        const R &wc = W[r + 1];
+        // |w| of the clamped neighbour rows: for the first / last domain row the neighbour is the row itself
+        const R &wm = (j - 1 < g.jlo) ? W[r + 1] : W[r];
+        const R &wp = (j + 1 > g.jhi) ? W[r + 1] : W[r + 2];
+        R a;
+#pragma unroll
+        for (int q = 0; q < N; ++q) a.a[q] = tabs(wc.a[q]);
+        const T al = lv_left<T, N>(lm, a), ar = lv_right<T, N>(lm, a);
+        if (STORE_W && lm.owner && f) {
+            lv_store_sel<T, N>(vort + idx<1, T>(g, 0, i0, j), wc, f);
+            lv_store_sel<T, N>(vort_abs + idx<1, T>(g, 0, i0, j), a, f);
+        }
+        R ox, oy;
+        bool h = false;
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const T aE = q == L ? ar : a.a[q == L ? q : q + 1], aW = q == 0 ? al : a.a[q == 0 ? 0 : q - 1];
+            T gx = div_dx<DM>((T)0.5 * (aE - aW), k);
+            T gy = div_dx<DM>((T)0.5 * (tabs(wp.a[q]) - tabs(wm.a[q])), k);
+            const T nrm = tsqrt(gx * gx + gy * gy);
+            gx = gx / nrm; gy = gy / nrm;
+            T f0 = gy * wc.a[q], f1 = (-gx) * wc.a[q];
+            f0 = tmax(tmin(f0, (T)0.1), (T)-0.1);
+            f1 = tmax(tmin(f1, (T)0.1), (T)-0.1);
+            ox.a[q] = VX[r + 2].a[q] + k.dtw * f0;
+            oy.a[q] = VY[r + 2].a[q] + k.dtw * f1;
+            h = h || (((f >> q) & 1u) && hot2(ox.a[q], oy.a[q]));
+        }
+        if (lm.owner && f) {
+            raise_hot(hot, h);
+            lv_store_sel<T, N>(vn + idx<2, T>(g, 0, i0, j), ox, f);
+            lv_store_sel<T, N>(vn + idx<2, T>(g, 1, i0, j), oy, f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2'  MacSolver._update_velocities (fs/solver.py:94-107) on lanes of N cells, tiles of RT rows: upwind (fs/advection.py:12-24, +-1
+// stencil) or Kawamura-Kuwahara (fs/advection.py:27-60, +-2 stencil: two DPP hops give the two cells left / right of the lane's).
+// ------------------------------------------------------------------------------------------------
+template <int SCHEME, int N, int RT, int DM, typename T>
+__global__ __launch_bounds__(256) void k_mac_update_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
+{
+    using Rw = LV<T, N>;
+    constexpr int R = SCHEME == 0 ? 1 : 2;          // stencil radius
+    constexpr int HL = 1, L = N - 1;
+    int wx, ty, cg;
+    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    unsigned fl[RT];
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        fl[t] = j0 + t < je ? lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
+        any = any || (lm.owner && fl[t] != 0u);
+    }
+    if (!__any(any)) return;
+    Rw V[2][RT + 2 * R], P[RT + 2];                 // slot u of V <-> row j0 - R + u, slot u of P <-> row j0 - 1 + u
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int u = 0; u < RT + 2 * R; ++u) V[c][u] = lv_field<2, T, N>(vc, g, c, i0, clampy(g, j0 - R + u));
+#pragma unroll
+    for (int u = 0; u < RT + 2; ++u) P[u] = lv_field<1, T, N>(pc, g, 0, i0, clampy(g, j0 - 1 + u));
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        if (j >= je) break;
+        const T pl = lv_left<T, N>(lm, P[t + 1]), pr = lv_right<T, N>(lm, P[t + 1]);
+        Rw O[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const Rw &row = V[c][t + R];
+            // the two cells left / right of the lane's (sample()-clamped at the domain edge: BOTH onto the edge cell)
+            const T l1 = lv_left<T, N>(lm, row), r1 = lv_right<T, N>(lm, row);
+            T l2 = l1, r2 = r1;
+            if (SCHEME == 1) {
+                l2 = lane_prev(row.a[N - 2]); if (lm.at_lo) l2 = row.a[0];
+                r2 = lane_next(row.a[1]); if (lm.at_hi) r2 = row.a[L];
+            }
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+                const T ux = V[0][t + R].a[q], uy = V[1][t + R].a[q];
+                const T f0 = row.a[q];
+                const T fE = q == L ? r1 : row.a[q == L ? q : q + 1], fW = q == 0 ? l1 : row.a[q == 0 ? 0 : q - 1];
+                const T fN = V[c][t + R + 1].a[q], fS = V[c][t + R - 1].a[q];
+                T adv;
+                if (SCHEME == 0) {
+                    const T ax = ux * xdiv<DM>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx, k.r_dx);
+                    const T ay = uy * xdiv<DM>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx, k.r_dx);
+                    adv = ax + ay;
+                } else {
+                    const T fEE = q + 2 <= L ? row.a[q + 2 <= L ? q + 2 : L] : (q + 2 == N ? r1 : r2);
+                    const T fWW = q >= 2 ? row.a[q >= 2 ? q - 2 : 0] : (q == 1 ? l1 : l2);
+                    const bool nx = ux < (T)0;
+                    T w0 = nx ? (T)-2 : (T)1, w1 = nx ? (T)10 : (T)-2, w2 = nx ? (T)-9 : (T)9, w3 = nx ? (T)2 : (T)-10, w4 = nx ? (T)-1 : (T)2;
+                    T acc = fEE * w0;
+                    acc = acc + fE * w1; acc = acc + f0 * w2; acc = acc + fW * w3; acc = acc + fWW * w4;
+                    const T a = cdiv<DM>(acc, k.six_dx, k.r_six_dx);
+                    const bool ny = uy < (T)0;
+                    w0 = ny ? (T)-2 : (T)1; w1 = ny ? (T)10 : (T)-2; w2 = ny ? (T)-9 : (T)9; w3 = ny ? (T)2 : (T)-10; w4 = ny ? (T)-1 : (T)2;
+                    acc = V[c][t + 2 * R].a[q] * w0;
+                    acc = acc + fN * w1; acc = acc + f0 * w2; acc = acc + fS * w3; acc = acc + V[c][t].a[q] * w4;
+                    const T b = cdiv<DM>(acc, k.six_dx, k.r_six_dx);
+                    adv = ux * a + uy * b;
+                }
+                T gp;
+                if (c == 0) {
+                    const T pE = q == L ? pr : P[t + 1].a[q == L ? q : q + 1], pW = q == 0 ? pl : P[t + 1].a[q == 0 ? 0 : q - 1];
+                    gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx);
+                } else {
+                    gp = xdiv<DM>((T)0.5 * (P[t + 2].a[q] - P[t].a[q]), k.dx, k.inv_dx, k.r_dx);
+                }
+                const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+                const T d2y = xdiv<DM>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+                const T lap = cdiv<DM>(d2x + d2y, k.re, k.r_re);
+                O[c].a[q] = f0 + k.dt * (((-adv) - gp) + lap);
+            }
+        }
+        if (lm.owner && fl[t]) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) raise_hot(hot, ((fl[t] >> q) & 1u) && hot2(O[0].a[q], O[1].a[q]));
+            lv_store_sel<T, N>(vn + idx<2, T>(g, 0, i0, j), O[0], fl[t]);
+            lv_store_sel<T, N>(vn + idx<2, T>(g, 1, i0, j), O[1], fl[t]);
+        }
+    }
+}
+
 }  // namespace fs

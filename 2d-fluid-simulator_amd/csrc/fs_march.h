@@ -233,101 +233,7 @@ __device__ __forceinline__ T quad_right(const LaneMap &m, const typename Quad<T>
 template <int DM, typename T>
 __device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return xdiv<DM & (DM_P2 | DM_F64)>(x, k.dx, k.inv_dx, k.r_dx); }   // P2 only when k.p2
 
-// ------------------------------------------------------------------------------------------------
-// K5 + K6 fused: vorticity confinement in one pass (fs/vorticity_confinement.py:27-55).
-//   w(i,j)  = fluid ? diff_x(v).y - diff_y(v).x : 0          (the reference's vorticity field is zero-initialised
-//                                                              and only ever written on fluid cells)
-//   vn(i,j) = v + dt*weight * clamp((n.y, -n.x) * w, +-0.1),  n = grad|w| / |grad|w||       on fluid cells
-// A lane computes w for RT+2 rows of its quad from RT+4 rows of v, takes the x-neighbours of |w| from the adjacent
-// lanes (DPP) and writes RT rows of vn.  w / |w| never touch HBM unless STORE_W (they are public attributes of
-// VorticityConfinement; the unfused pair of kernels remains available and is what parity tests compare with).
-// ------------------------------------------------------------------------------------------------
-template <int RT, int DM, bool STORE_W, typename T>
-__global__ __launch_bounds__(256) void k_vort_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot)
-{
-    using V = typename Quad<T>::type;
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
-    const LaneMap lm = lane_map_wave(g, bx);
-    const int i0 = lm.i0;
-    const int j0 = jb + by * RT;
-
-    unsigned fl[RT + 2];   // fluid selectors of rows j0-1 .. j0+RT (clamped rows repeat)
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < RT + 2; ++r) {
-        const int j = clampy(g, j0 - 1 + r);
-        fl[r] = sel_fluid(mask_quad(g, i0, j));
-        if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
-    }
-    if (!__any(any)) return;
-
-    V VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1
-#pragma unroll
-    for (int r = 0; r < RT + 4; ++r) {
-        const int j = clampy(g, j0 - 2 + r);
-        VX[r] = load_quad<2>(vc, g, 0, i0, j);
-        VY[r] = load_quad<2>(vc, g, 1, i0, j);
-    }
-    // vorticity of rows j0-1 .. j0+RT  (index r <-> v slot r+1)
-    V W[RT + 2];
-#pragma unroll
-    for (int r = 0; r < RT + 2; ++r) {
-        // rows were loaded with clamped indices, so for an in-domain row j0-1+r the slots r, r+1, r+2 hold exactly
-        // sample()'s rows clamp(j-1), j, clamp(j+1); out-of-domain virtual rows are never consumed (see wm / wp).
-        const V &yc = VY[r + 1], &xm = VX[r], &xp = VX[r + 2];
-        const T yl = quad_left<T>(lm, yc), yr = quad_right<T>(lm, yc);
-        V w;
-        w.x = div_dx<DM>((T)0.5 * (yc.y - yl), k) - div_dx<DM>((T)0.5 * (xp.x - xm.x), k);
-        w.y = div_dx<DM>((T)0.5 * (yc.z - yc.x), k) - div_dx<DM>((T)0.5 * (xp.y - xm.y), k);
-        w.z = div_dx<DM>((T)0.5 * (yc.w - yc.y), k) - div_dx<DM>((T)0.5 * (xp.z - xm.z), k);
-        w.w = div_dx<DM>((T)0.5 * (yr - yc.z), k) - div_dx<DM>((T)0.5 * (xp.w - xm.w), k);
-        const unsigned f = fl[r];
-        w.x = (f & 1u) ? w.x : (T)0; w.y = (f & 2u) ? w.y : (T)0; w.z = (f & 4u) ? w.z : (T)0; w.w = (f & 8u) ? w.w : (T)0;
-        W[r] = w;
-    }
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int j = j0 + r;
-        if (j >= je) break;
-        const unsigned f = fl[r + 1];
-        const V &wc = W[r + 1];
-        // |w| of the clamped neighbour rows: for the first / last domain row the neighbour is the row itself
-        const V &wm = (j - 1 < g.jlo) ? W[r + 1] : W[r];
-        const V &wp = (j + 1 > g.jhi) ? W[r + 1] : W[r + 2];
-        V a; a.x = tabs(wc.x); a.y = tabs(wc.y); a.z = tabs(wc.z); a.w = tabs(wc.w);
-        const T al = quad_left<T>(lm, a), ar = quad_right<T>(lm, a);
-        if (STORE_W && lm.owner && f) {
-            store_quad_sel<T>(vort + idx<1, T>(g, 0, i0, j), wc, f);
-            store_quad_sel<T>(vort_abs + idx<1, T>(g, 0, i0, j), a, f);
-        }
-        V ox, oy;
-        const V &cx = VX[r + 2], &cy = VY[r + 2];
-#define FS_VC_CELL(comp, aE, aW)                                                              \
-        {                                                                                     \
-            T gx = div_dx<DM>((T)0.5 * ((aE) - (aW)), k);                                     \
-            T gy = div_dx<DM>((T)0.5 * (tabs(wp.comp) - tabs(wm.comp)), k);                   \
-            T nrm = tsqrt(gx * gx + gy * gy);                                                 \
-            gx = gx / nrm; gy = gy / nrm;                                                     \
-            T f0 = gy * wc.comp, f1 = (-gx) * wc.comp;                                        \
-            f0 = tmax(tmin(f0, (T)0.1), (T)-0.1);                                             \
-            f1 = tmax(tmin(f1, (T)0.1), (T)-0.1);                                             \
-            ox.comp = cx.comp + k.dtw * f0;                                                   \
-            oy.comp = cy.comp + k.dtw * f1;                                                   \
-        }
-        FS_VC_CELL(x, a.y, al)
-        FS_VC_CELL(y, a.z, a.x)
-        FS_VC_CELL(z, a.w, a.y)
-        FS_VC_CELL(w, ar, a.z)
-#undef FS_VC_CELL
-        if (lm.owner && f) {
-            raise_hot(hot, ((f & 1u) && hot2(ox.x, oy.x)) || ((f & 2u) && hot2(ox.y, oy.y)) || ((f & 4u) && hot2(ox.z, oy.z)) || ((f & 8u) && hot2(ox.w, oy.w)));
-            store_quad_sel<T>(vn + idx<2, T>(g, 0, i0, j), ox, f);
-            store_quad_sel<T>(vn + idx<2, T>(g, 1, i0, j), oy, f);
-        }
-    }
-}
-
+// (K5 + K6 fused and K2 live in fs_k34n.h, on lanes of 2 cells)
 
 // ------------------------------------------------------------------------------------------------
 // K8R fused: one red-black SOR iteration (odd pass p.cur -> p.next, then even pass in place on p.next;
@@ -549,60 +455,6 @@ __global__ __launch_bounds__(256) void k_cip_advect_quad(Grid g, Konst<T> k, int
     cip_advect_quad_tile<C, NC, SELF, DM, CLAMP01, T>(g, k, nbx, nby, jb, je, fn, fxn, fyn, fc, fxc, fyc, v, hot);
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// K2  CipMacSolver._non_advection_phase (fs/solver.py:229-240, 263-265), quad form: rows j-1, j, j+1 of v (2 planes)
-// and p are requested up front; not-wall cells get  fn = fc + ((-grad p) + lap(fc)/re) * dt.
-// ------------------------------------------------------------------------------------------------
-template <int DM, typename T>
-__device__ __forceinline__ void cip_nonadv_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
-{
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
-    const LaneMap lm = lane_map_wave(g, bx);
-    const int i0 = lm.i0, j = jb + by;
-    const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
-    if (!__any(nw != 0u)) return;
-    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
-    Q4<T> F[2][3], P[3];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { F[c][0] = Q4<T>(load_quad<2>(fc, g, c, i0, jm)); F[c][1] = Q4<T>(load_quad<2>(fc, g, c, i0, j)); F[c][2] = Q4<T>(load_quad<2>(fc, g, c, i0, jp)); }
-    P[0] = Q4<T>(load_quad<1>(pc, g, 0, i0, jm)); P[1] = Q4<T>(load_quad<1>(pc, g, 0, i0, j)); P[2] = Q4<T>(load_quad<1>(pc, g, 0, i0, jp));
-    const T pl = quad_left<T>(lm, P[1].quad()), pr = quad_right<T>(lm, P[1].quad());
-    Q4<T> O[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const T l = quad_left<T>(lm, F[c][1].quad()), r = quad_right<T>(lm, F[c][1].quad());
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T fE = q == 3 ? r : F[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : F[c][1].a[q == 0 ? 0 : q - 1];
-            const T f0 = F[c][1].a[q];
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-            const T d2y = xdiv<DM>((F[c][2].a[q] - (T)2.0 * f0) + F[c][0].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-            const T dif = cdiv<DM>(d2x + d2y, k.re, k.r_re);
-            T gp;
-            if (c == 0) {
-                const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
-                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx);
-            } else {
-                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, k.r_dx);
-            }
-            const T gg = (-gp) + dif;
-            O[c].a[q] = f0 + gg * k.dt;
-        }
-    }
-    if (lm.owner && nw) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) raise_hot(hot, ((nw >> q) & 1u) && hot2(O[0].a[q], O[1].a[q]));
-        store_quad_sel<T>(fn + idx<2, T>(g, 0, i0, j), O[0].quad(), nw);
-        store_quad_sel<T>(fn + idx<2, T>(g, 1, i0, j), O[1].quad(), nw);
-    }
-}
-template <int DM, typename T>
-__global__ __launch_bounds__(256) void k_cip_nonadv_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
-{
-    cip_nonadv_quad_tile<DM, T>(g, k, nbx, nby, jb, je, fn, fc, pc, hot);
-}
 
 // ------------------------------------------------------------------------------------------------
 // K3  _non_advection_phase_grad (fs/solver.py:242-261), quad form, NC channels [c0, c0+NC) per lane (blockIdx.y = group).
@@ -1075,95 +927,6 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(Grid g, int nbx, int nby, i
 #pragma unroll
     for (int r = 0; r < RT; ++r)
         if (lm.owner && sel[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j0 + r), o[r].quad(), sel[r]);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// K2'  MacSolver._update_velocities (fs/solver.py:94-107), quad form: upwind (fs/advection.py:12-24, +-1 stencil) or
-// Kawamura-Kuwahara (fs/advection.py:27-60, +-2 stencil: two DPP hops give the cells i0-2 .. i0+5 of a row).
-// ------------------------------------------------------------------------------------------------
-template <int SCHEME, int DM, typename T>
-__device__ __forceinline__ void mac_update_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
-{
-    constexpr int R = SCHEME == 0 ? 1 : 2;          // stencil radius
-    constexpr int NR = 2 * R + 1;
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
-    const LaneMap lm = lane_map_wave(g, bx);
-    const int i0 = lm.i0, j = jb + by;
-    const unsigned fl = sel_fluid(mask_quad(g, i0, j));
-    if (!__any(fl != 0u)) return;
-    Q4<T> V[2][NR], P[3];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < NR; ++r) V[c][r] = Q4<T>(load_quad<2>(vc, g, c, i0, clampy(g, j - R + r)));
-#pragma unroll
-    for (int r = 0; r < 3; ++r) P[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, clampy(g, j - 1 + r)));
-    const T pl = quad_left<T>(lm, P[1].quad()), pr = quad_right<T>(lm, P[1].quad());
-    Q4<T> O[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const Q4<T> &row = V[c][R];
-        // row[-2], row[-1], row[4], row[5]: the two cells left / right of the quad (sample()-clamped at the domain edge)
-        const T l1 = quad_left<T>(lm, row.quad()), r1 = quad_right<T>(lm, row.quad());
-        T l2 = l1, r2 = r1;
-        if (SCHEME == 1) {
-            l2 = lane_prev(row.a[2]); if (lm.at_lo) l2 = row.a[0];
-            r2 = lane_next(row.a[1]); if (lm.at_hi) r2 = row.a[3];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T ux = V[0][R].a[q], uy = V[1][R].a[q];
-            const T f0 = row.a[q];
-            const T fE = q == 3 ? r1 : row.a[q == 3 ? 3 : q + 1], fW = q == 0 ? l1 : row.a[q == 0 ? 0 : q - 1];
-            const T fN = V[c][R + 1].a[q], fS = V[c][R - 1].a[q];
-            T adv;
-            if (SCHEME == 0) {
-                const T ax = ux * xdiv<DM>(ux < (T)0.0 ? (fE - f0) : (f0 - fW), k.dx, k.inv_dx, k.r_dx);
-                const T ay = uy * xdiv<DM>(uy < (T)0.0 ? (fN - f0) : (f0 - fS), k.dx, k.inv_dx, k.r_dx);
-                adv = ax + ay;
-            } else {
-                // cells i+2 / i-2 of the row: inside the quad, or one of the two DPP'd neighbours; at the domain edge sample() clamps
-                // BOTH i-1 and i-2 (resp. i+1, i+2) onto the edge cell, which quad_left / l2 already return
-                const T fEE = q <= 1 ? row.a[q <= 1 ? q + 2 : 3] : (q == 2 ? r1 : r2);
-                const T fWW = q >= 2 ? row.a[q >= 2 ? q - 2 : 0] : (q == 1 ? l1 : l2);
-                const bool nx = ux < (T)0;
-                T w0 = nx ? (T)-2 : (T)1, w1 = nx ? (T)10 : (T)-2, w2 = nx ? (T)-9 : (T)9, w3 = nx ? (T)2 : (T)-10, w4 = nx ? (T)-1 : (T)2;
-                T acc = fEE * w0;
-                acc = acc + fE * w1; acc = acc + f0 * w2; acc = acc + fW * w3; acc = acc + fWW * w4;
-                const T a = cdiv<DM>(acc, k.six_dx, k.r_six_dx);
-                const bool ny = uy < (T)0;
-                w0 = ny ? (T)-2 : (T)1; w1 = ny ? (T)10 : (T)-2; w2 = ny ? (T)-9 : (T)9; w3 = ny ? (T)2 : (T)-10; w4 = ny ? (T)-1 : (T)2;
-                acc = V[c][R + 2 > NR - 1 ? NR - 1 : R + 2].a[q] * w0;
-                acc = acc + fN * w1; acc = acc + f0 * w2; acc = acc + fS * w3; acc = acc + V[c][R - 2 < 0 ? 0 : R - 2].a[q] * w4;
-                const T b = cdiv<DM>(acc, k.six_dx, k.r_six_dx);
-                adv = ux * a + uy * b;
-            }
-            T gp;
-            if (c == 0) {
-                const T pE = q == 3 ? pr : P[1].a[q == 3 ? 3 : q + 1], pW = q == 0 ? pl : P[1].a[q == 0 ? 0 : q - 1];
-                gp = xdiv<DM>((T)0.5 * (pE - pW), k.dx, k.inv_dx, k.r_dx);
-            } else {
-                gp = xdiv<DM>((T)0.5 * (P[2].a[q] - P[0].a[q]), k.dx, k.inv_dx, k.r_dx);
-            }
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-            const T d2y = xdiv<DM>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-            const T lap = cdiv<DM>(d2x + d2y, k.re, k.r_re);
-            O[c].a[q] = f0 + k.dt * (((-adv) - gp) + lap);
-        }
-    }
-    if (lm.owner && fl) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) raise_hot(hot, ((fl >> q) & 1u) && hot2(O[0].a[q], O[1].a[q]));
-        store_quad_sel<T>(vn + idx<2, T>(g, 0, i0, j), O[0].quad(), fl);
-        store_quad_sel<T>(vn + idx<2, T>(g, 1, i0, j), O[1].quad(), fl);
-    }
-}
-template <int SCHEME, int DM, typename T>
-__global__ __launch_bounds__(256) void k_mac_update_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
-{
-    mac_update_quad_tile<SCHEME, DM, T>(g, k, nbx, nby, jb, je, vn, vc, pc, hot);
 }
 
 

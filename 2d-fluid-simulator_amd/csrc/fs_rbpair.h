@@ -40,6 +40,7 @@ template <typename T, int N> struct LV { T a[N]; };
 template <typename T, int N> struct LVec;
 template <> struct LVec<float, 4> { using type = float4; };
 template <> struct LVec<float, 2> { using type = float2; };
+template <> struct LVec<double, 2> { using type = double2; };
 template <int N> struct LMaskWord;
 template <> struct LMaskWord<4> { using type = uint32_t; };
 template <> struct LMaskWord<2> { using type = uint16_t; };

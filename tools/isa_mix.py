@@ -15,7 +15,7 @@ def main():
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w",
                     "-I/opt/rocm/include", "--cuda-device-only", "-S", os.path.join(CSRC, "fs_api.hip"), "-o", asm], check=True)
     lines = open(asm).read().split("\n")
-    subs = sys.argv[1:] or ["k_rbsor_fused", "k_cip_advect_quad", "k_vort_fused", "k_cip_nonadv_grad_quad", "k_cip_nonadv_quad", "k_jacobi_ov", "k_limit_quad"]
+    subs = sys.argv[1:] or ["k_rbsor_pair", "k_cip_grad_advect_n", "k_vort_n", "k_cip_nonadv_n", "k_jacobi_ov", "k_jacobi_quad", "k_limit_quad"]
     i = 0
     while i < len(lines):
         m = re.match(r"^(_ZN2fs\w+):", lines[i])
