@@ -547,7 +547,7 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
                 if (oi >= 0 && oi < X && oj >= 0 && oj < Y && M(oi, oj) == 0) thin = true;
             }
         }
-        c->rb_pair_ok = c->lazy_ok && !thin;
+        c->rb_pair_ok = ok && !thin;            // (lanes of 2 cells: any even width - fs_rbsor_pair_ok adds use_pairs)
         // Four Jacobi sweeps per pass (fs_jquad.h): the same condition with every cell whose RAW value is live as a reader - fluid cells and
         // the sources of recipes (an inflow cell of column 1 is computed by the sweep and read, raw, by the recipe of column 0)
         {
@@ -564,7 +564,7 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
                     if (oi >= 0 && oi < X && oj >= 0 && oj < Y && live[(size_t)oi * Y + oj]) thin_live = true;
                 }
             }
-            c->jq_ok = c->lazy_ok && !thin_live;
+            c->jq_ok = ok && !thin_live;
         }
         c->h_bcmap.swap(map);            // uploaded by fs_upload_mask (same transpose path as the mask), then dropped
     }
@@ -596,7 +596,7 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     //   2 - 8 M cells: bc2 res 1600 / bc5 res 1024 (the boundary kernel of 2 x 4 holds 4 waves per SIMD)  90.7 / 26.5   81.6 / 27.8   90.3 / 26.4
     //   smaller: bc2 res 800 / res 400 (workgroups of half the size)                                  28.2 / 14.5        26.6 / 13.7       24.8 / 12.9
     const size_t cells = (size_t)ctx->X * ctx->rows;      // (this context's slab)
-    const int N = ctx->k34_n ? ctx->k34_n : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4);
+    const int N = ctx->X % 4 != 0 ? 2 : (ctx->k34_n ? ctx->k34_n : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4));
     const int RT = N == 4 ? 2 : (ctx->k34_rt ? ctx->k34_rt : (cells >= ((size_t)1 << 23) ? 4 : 2)), geo = N == 2 ? 3 : 4;
 #define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
         (T *)f_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v ? (const T *)v->d : (const T *)nullptr, \
@@ -681,7 +681,8 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
         int f, v, n = 0;
         while (sscanf(s, "%d:%d%n", &f, &v, &n) == 2) { if (f >= 0 && f < 6 && v >= 1 && v <= 128) c->xcd_group_fam[f] = v; s += n; if (*s == ',') ++s; else break; }
     }
-    if (nx % 4 != 0) c->use_march = false;   // quads need 16-byte aligned rows
+    c->use_pairs = c->use_march && nx % 2 == 0;   // the kernels on lanes of 2 cells (fs_k34n.h, fs_rbpair.h, fs_jquad.h): any even width, i.e. any `res`
+    if (nx % 4 != 0) c->use_march = false;        // quads need 16-byte aligned rows
     *out = c;
     return FS_OK;
 }
@@ -797,7 +798,7 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     // boundary kernel writes - workgroups made of such cells only have nothing to do in any kernel
     tile_lists_free(ctx);
     ctx->h_act4.clear(); ctx->h_act2.clear(); ctx->h_act2w.clear();
-    if (ctx->halo == 0 && ctx->X % 4 == 0 && ctx->tile_list_mask) {
+    if (ctx->halo == 0 && ctx->X % 2 == 0 && ctx->tile_list_mask) {
         const int X = ctx->X, Y = ctx->Y;
         struct Geo { std::vector<uint8_t> *act; int w, halo; } geos[3] = {{&ctx->h_act4, 248, 4}, {&ctx->h_act2, 120, 4}, {&ctx->h_act2w, 124, 2}};
         for (const Geo &ge : geos) {
@@ -1043,7 +1044,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, re);
-        if (ctx->use_march) {
+        if (ctx->use_pairs) {
             // lanes of 2 cells (fs_k34n.h k_mac_update_n), tiles of 4 rows on large f32 grids (KK at bc3 res 4096: 178 -> 162 us against the one-row quad
             // form it replaces; f64: 424 -> 306 with 2-row tiles), 2 rows on small grids (more workgroups) and for f64 (registers)
             const int rt = ctx->mac_rt ? ctx->mac_rt : (sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2);
@@ -1102,7 +1103,7 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, re);
-        if (ctx->use_march) {
+        if (ctx->use_pairs) {
             // lanes of 2 cells, tiles of 4 rows (fs_k34n.h k_cip_nonadv_n), compact launch: 116 -> 102 us at bc5 res 4096 against the one-row quad form
             // it replaces (2 rows: 112, 8 rows: 106-110)
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_NONADV, 3);
@@ -1238,7 +1239,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
     FS_REQUIRE(ctx, "ctx is null");
     FS_FIELD(v_out, 2); FS_FIELD(gx_out, 2); FS_FIELD(gy_out, 2); FS_FIELD(fn, 2); FS_FIELD(fc, 2); FS_FIELD(gxc, 2); FS_FIELD(gyc, 2);
     FS_REQUIRE(v_out != fn && v_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
-    FS_REQUIRE(ctx->use_march, "the fused gradient+advection pass needs X % 4 == 0 (use the two-kernel form)");
+    FS_REQUIRE(ctx->use_pairs, "the fused gradient+advection pass needs an even X (use the two-kernel form)");
     FS_ROWS();
     if (ctx->dtype != 0) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
     return launch_k34<2, false>(ctx, "cip_grad_advect_rt", "cip_grad_advect_rt_bnd", dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, nullptr, full, row_begin, row_end);
@@ -1252,7 +1253,7 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
     FS_REQUIRE(ctx, "ctx is null");
     FS_FIELD(d_out, 3); FS_FIELD(gx_out, 3); FS_FIELD(gy_out, 3); FS_FIELD(fn, 3); FS_FIELD(fc, 3); FS_FIELD(gxc, 3); FS_FIELD(gyc, 3); FS_FIELD(v, 2);
     FS_REQUIRE(d_out != fn && d_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
-    FS_REQUIRE(ctx->use_march, "the fused gradient+advection pass needs X % 4 == 0 (use the two-kernel form)");
+    FS_REQUIRE(ctx->use_pairs, "the fused gradient+advection pass needs an even X (use the two-kernel form)");
     FS_ROWS();
     if (row_begin >= row_end) return FS_OK;
     if (ctx->dtype != 0) { set_error("the fused dye pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
@@ -1293,8 +1294,8 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
     FS_REQUIRE((vort == nullptr) == (vort_abs == nullptr), "pass both vort and vort_abs or neither");
     if (vort) { FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1); }
     FS_ROWS();
-    if (!ctx->use_march) {   // rows not 16-byte aligned (odd res): the unfused pair
-        if (!vort) { set_error("fused vorticity confinement needs X % 4 == 0 or explicit vort fields"); return FS_ERR_UNSUPPORTED; }
+    if (!ctx->use_pairs) {   // odd width: the unfused pair
+        if (!vort) { set_error("fused vorticity confinement needs an even X or explicit vort fields"); return FS_ERR_UNSUPPORTED; }
         int rc = fs_vort_calc(ctx, dx, vort, vort_abs, vc, std::max(row_begin - 1, 0), std::min(row_end + 1, ctx->rows));
         if (rc) return rc;
         return fs_vort_add(ctx, dt, dx, weight, vn, vc, vort, vort_abs, row_begin, row_end);
@@ -1511,7 +1512,7 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
 int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
-    *ok = ctx->mask_set && ctx->rb_pair_ok && ctx->use_march && ctx->use_lazy && ctx->dtype == 0 ? 1 : 0;
+    *ok = ctx->mask_set && ctx->rb_pair_ok && ctx->use_pairs && ctx->use_lazy && ctx->dtype == 0 ? 1 : 0;
     return FS_OK;
 }
 
@@ -1524,7 +1525,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     FS_FIELD(pc_out, 1); FS_FIELD(pn_out, 1); FS_FIELD(pc, 1); FS_FIELD(pn, 1); FS_FIELD(vc, 2);
     FS_REQUIRE(pc_out != pn_out && pc_out != pc && pc_out != pn && pn_out != pc && pn_out != pn && pc != pn, "the two-iteration pass needs four distinct pressure fields");
     FS_ROWS();
-    if (!(ctx->rb_pair_ok && ctx->use_march && ctx->dtype == 0)) {
+    if (!(ctx->rb_pair_ok && ctx->use_pairs && ctx->dtype == 0)) {
         set_error("this mask / precision does not admit the two-iteration red-black pass (fs_rbsor_pair_ok)");
         return FS_ERR_UNSUPPORTED;
     }

@@ -112,6 +112,7 @@ struct fs_ctx {
     std::vector<fs_field *> deferred_free;   // fs_field_free during a hipGraph capture: released when the capture ends
     // tuning knobs (env FS_MARCH=0: one-cell-per-lane kernels only)
     bool use_march = true;
+    bool use_pairs = true;     // lanes of 2 cells: even widths (every `res`); use_march: the quad kernels, X % 4 == 0
     bool use_f64div = true;    // env FS_F64DIV=0: IEEE division for the loop-invariant divisors of f32 runs (A/B; the results are the same)
     int mac_rt = 0;            // env FS_MAC_RT: rows per tile (2 / 4) of K2' (upwind / KK update); 0: by grid size and precision
     int k34_n = 0;             // env FS_K34_N: cells per lane (2 / 4) of the fused K3 + K4 pass (fs_k34n.h); 0: by grid size (fs_api.hip launch_k34)

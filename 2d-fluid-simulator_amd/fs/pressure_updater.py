@@ -112,8 +112,8 @@ class RedBlackSorPressureUpdater(PressureUpdater):
         self._n_iter = n_iter
         self._relaxation_factor = relaxation_factor
         # fused: odd + even pass of one iteration in a single kernel (same bits, fewer bytes)
-        self._fused = (fused and not precompute_source and boundary_condition.get_resolution()[0] % 4 == 0
-                       and os.environ.get("FS_MARCH", "1") != "0")
+        fast = fused and not precompute_source and os.environ.get("FS_MARCH", "1") != "0"
+        self._fused = fast and boundary_condition.get_resolution()[0] % 4 == 0          # (a quad kernel; the pair pass below: any even width)
         self._precompute = bool(precompute_source)
         self._src = self._dev.alloc(2) if self._precompute else None
         # pair: TWO iterations and the two boundary passes between them in one pass over HBM (csrc/fs_rbpair.h; same bits, 25 instead of
@@ -124,7 +124,7 @@ class RedBlackSorPressureUpdater(PressureUpdater):
         # 11-step pattern no tape can hold (tools/slab_period.py), which costs more than the pass saves on an eighth of the grid.
         if pair is None:
             pair = os.environ.get("FS_RBSOR_PAIR", "1" if self._dev.nranks == 1 else "0") == "1"
-        self._pair = (bool(pair) and self._fused and n_iter >= 2 and getattr(self._dev, "rb_pair_ok", False)
+        self._pair = (bool(pair) and fast and n_iter >= 2 and getattr(self._dev, "rb_pair_ok", False)
                       and (self._dev.nranks == 1 or self._dev.halo >= 4))
         self._spare = (self._dev.alloc(1), self._dev.alloc(1)) if self._pair else None
 

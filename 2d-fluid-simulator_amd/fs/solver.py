@@ -123,7 +123,7 @@ class CipMacSolver(Solver):
         # (fused_transport=False or FS_FUSE_TRANSPORT=0 gives the reference's two launches and its intermediate buffers).
         if fused_transport is None:
             fused_transport = os.environ.get("FS_FUSE_TRANSPORT", "1") == "1"
-        self._fused_transport = (bool(fused_transport) and self.resolution[0] % 4 == 0 and self._dev.dtype == np.float32
+        self._fused_transport = (bool(fused_transport) and self.resolution[0] % 2 == 0 and self._dev.dtype == np.float32
                                  and os.environ.get("FS_MARCH", "1") != "0")      # (f64: 256 VGPRs per tile - the two-kernel form)
         self._v_spare = self._dev.alloc(2) if self._fused_transport else None
 

@@ -29,7 +29,7 @@ class VorticityConfinement:
 
     def apply(self, v):
         """Writes v.next only; the caller swaps (fs/vorticity_confinement.py:57-59, fs/solver.py:84-86)."""
-        if self._fused and self._resolution[0] % 4 == 0:
+        if self._fused and self._resolution[0] % 2 == 0:
             if self._store_fields:
                 self._dev.vort_confine(self.dt, self.dx, self.weight, v.next, v.current, self.vorticity, self.vorticity_abs)
             else:

@@ -1,0 +1,42 @@
+"""Odd resolutions (X = 2 res not a multiple of 4): the kernels on lanes of 2 cells (csrc/fs_k34n.h, fs_rbpair.h) need an even width only,
+so the default solvers keep their fused passes there - bit-identical to the CPU oracle, and the launches are the fused ones."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bc_id,res", [(1, 51), (2, 75), (5, 125), (3, 81)])
+@pytest.mark.parametrize("scheme", ["cip", "kk"])
+def test_odd_resolution_runs_the_fused_passes(bc_id, res, scheme, hip_lib):
+    import fs
+    from fs.boundary_condition import BoundaryCondition, create_scene_arrays
+    from oracle import oracle as O
+    const, mask, _ = create_scene_arrays(bc_id, res)
+    assert mask.shape[0] % 4 == 2
+    dt, dx, re, vc = 0.05 / res, 1.0 / res, 1000.0, 5.0
+    fs.runtime.init(gpu=0, dtype="f32")
+    bc = BoundaryCondition(const, mask)
+    dev = bc.device
+    vcobj = fs.VorticityConfinement(bc, dt, dx, vc)
+    pu = fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2)
+    solver = (fs.CipMacSolver(bc, pu, dt, dx, re, vcobj) if scheme == "cip"
+              else fs.MacSolver(bc, pu, fs.advect_kk_scheme, dt, dx, re, vcobj))
+    ref = O.make_simulator(const, mask, None, scheme=scheme, dt=dt, dx=dx, re=re, vor_eps=vc, updater=("rbsor", 1.3, 2))
+    try:
+        dev.profile(True)
+        for step in range(8):
+            solver.update()
+            ref.update()
+            for a, e, name in zip([f.to_numpy() for f in solver.get_fields()], list(ref.fields().values()), ("v", "p")):
+                assert np.array_equal(a, e, equal_nan=True), f"bc{bc_id} res {res} {scheme} step {step + 1} {name}"
+        names = set(dev.profile_report())
+        assert "vort_confine" in names, names
+        if scheme == "cip":
+            assert {"cip_nonadv", "cip_grad_advect_rt"} <= names and "cip_advect" not in names, names
+        else:
+            assert "mac_update_kk" in names, names
+        if dev.rb_pair_ok:
+            assert "rbsor_pair" in names, names
+    finally:
+        dev.close()
