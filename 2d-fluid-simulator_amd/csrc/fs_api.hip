@@ -661,7 +661,6 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
-    if (const char *s = getenv("FS_RBSOR_RT")) { const int v = atoi(s); if (v >= 2 && v <= 4) c->rbsor_rt = v; }
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
@@ -1427,25 +1426,19 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
     FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(vc, 2);
     FS_REQUIRE(pn != pc, "the fused iteration needs distinct p.next / p.current");
     FS_ROWS();
-    if (!ctx->use_march) {
+    if (!ctx->use_pairs) {
         int rc = fs_rbsor_halfsweep(ctx, dt, dx, omega, 1, pn, pc, vc, std::max(row_begin - 1, 0), std::min(row_end + 1, ctx->rows));
         if (rc) return rc;
         return fs_rbsor_halfsweep(ctx, dt, dx, omega, 0, pn, pn, vc, row_begin, row_end);
     }
-    const int rt = ctx->rbsor_rt;
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_RBSOR);
+    // lanes of 2 cells, 4-row tiles (fs_k34n.h k_rbsor_iter_n): 119 -> 115 us at bc5 res 4096 against the 3-row quad tiles it replaces, f64 (bc3 res
+    // 4096) 318 -> 289; 2 / 6 rows: 129 / 115
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 3, false);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-#define FS_RBF_RT(RT, DM) hipLaunchKernelGGL((k_rbsor_fused<RT, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBN4(DM) hipLaunchKernelGGL((k_rbsor_iter_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
-#define FS_RBF2(DM) FS_RBF_RT(2, DM)
-#define FS_RBF3(DM) FS_RBF_RT(3, DM)
-#define FS_RBF4(DM) FS_RBF_RT(4, DM)
-        return launch(ctx, "rbsor_iteration", [=] {
-            if (rt == 3) FS_DMC(dm_const(ctx, k), FS_RBF3);
-            else if (rt == 4) FS_DMC(dm_const(ctx, k), FS_RBF4);
-            else FS_DMC(dm_const(ctx, k), FS_RBF2);
-        });
+        return launch(ctx, "rbsor_iteration", [=] { FS_DMC(dm_const(ctx, k), FS_RBN4); });
     })
 }
 

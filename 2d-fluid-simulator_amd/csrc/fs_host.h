@@ -79,7 +79,6 @@ struct fs_ctx {
     int rbpair_rt = 4;                       // rows per tile of that pass (env FS_RBPAIR_RT = 4, 6)
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
-    int rbsor_rt = 3;                        // rows per tile of the fused red-black iteration (env FS_RBSOR_RT = 2, 3, 4)
     int pair_rt = 3;                         // rows per tile of the two-sweep kernel (env FS_PAIR_RT = 1 .. 4; 3: within 2 % of the best of 2 / 3 / 4 from res 1024 to 4096)
     int nwx = 0;                   // wave columns of 62 quads across a row
     void *d_bc_const = nullptr, *d_bc_dye = nullptr;

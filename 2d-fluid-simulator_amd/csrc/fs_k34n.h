@@ -473,4 +473,104 @@ __global__ __launch_bounds__(256) void k_mac_update_n(Grid g, Konst<T> k, int nb
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K8R fused on lanes of N cells: one red-black SOR iteration (odd pass p.cur -> p.next, then even pass in place on p.next;
+// fs/pressure_updater.py:92-114) as ONE kernel.
+//
+// Even cell (i, j) reads its four (odd) neighbours of p.next AFTER the odd pass.  A lane therefore first
+// forms "pnO" = p.next as it stands after the odd pass for rows j0-1 .. j0+RT of its cells:
+//     odd fluid cell : (1-w) p.cur + w predict_p(p.cur)       (recomputed redundantly in the halo rows / lanes)
+//     any other cell : the stored p.next value                 (stale data the reference also reads, H5)
+// and then relaxes the even fluid cells of rows j0 .. j0+RT-1 from pnO, taking x-neighbours from the adjacent
+// lanes (DPP).  Only cells this lane owns are stored.  Concurrent tiles never consume a value another tile
+// stores: halo pnO values are either recomputed from p.cur (read-only here) or belong to non-fluid cells
+// (never written).  Traffic: mask 1 + p.cur 4 + p.next 4 + v 8 read, p.next 4 written = 21 B/cell per
+// iteration instead of 2 x 17 for the two half-sweep launches.  One halo lane per side.
+// ------------------------------------------------------------------------------------------------
+// one colour of one row: cells c with ((c + PAR) & 1) == COLOR and a fluid bit are relaxed from centre row pc, neighbours pm (j-1), pp (j+1)
+template <int PAR, int COLOR, int DM, typename T, int N>
+__device__ __forceinline__ void lv_rb_relax_row(const Konst<T> &k, const LaneMapN<N> &lm, unsigned fluid,
+                                                const LV<T, N> &pm, const LV<T, N> &pc, const LV<T, N> &pp,
+                                                const LV<T, N> &xm, const LV<T, N> &xc, const LV<T, N> &xp,
+                                                const LV<T, N> &ym, const LV<T, N> &yc, const LV<T, N> &yp, LV<T, N> &out)
+{
+    constexpr int L = N - 1;
+    const T pl = lv_left<T, N>(lm, pc), pr = lv_right<T, N>(lm, pc);
+    const T xl = lv_left<T, N>(lm, xc), xr = lv_right<T, N>(lm, xc);
+    const T yl = lv_left<T, N>(lm, yc), yr = lv_right<T, N>(lm, yc);
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        if (((c + PAR) & 1) != COLOR) continue;
+        const T pE = c == L ? pr : pc.a[c == L ? c : c + 1], pW = c == 0 ? pl : pc.a[c == 0 ? 0 : c - 1];
+        const T xE = c == L ? xr : xc.a[c == L ? c : c + 1], xW = c == 0 ? xl : xc.a[c == 0 ? 0 : c - 1];
+        const T yE = c == L ? yr : yc.a[c == L ? c : c + 1], yW = c == 0 ? yl : yc.a[c == 0 ? 0 : c - 1];
+        T s2, s3;
+        source_from<DM>(k, xE, xW, yE, yW, xp.a[c], xm.a[c], yp.a[c], ym.a[c], s2, s3);
+        const T pred = predict_from(pE, pW, pp.a[c], pm.a[c], s2, s3);
+        const T val = k.om1 * pc.a[c] + k.om * pred;
+        out.a[c] = (fluid & (1u << c)) ? val : out.a[c];
+    }
+}
+
+template <int N, int RT, int DM, typename T>
+__global__ __launch_bounds__(256) void k_rbsor_iter_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
+{
+    using R = LV<T, N>;
+    constexpr int HL = 1;
+    int wx, ty, cg;
+    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+
+    unsigned fl[RT + 2];   // rows j0-1 .. j0+RT
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        fl[r] = lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 1 + r)));
+        if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
+    }
+    if (!__any(any)) return;
+
+    R PC[RT + 4], VX[RT + 4], VY[RT + 4];        // rows j0-2 .. j0+RT+1 (clamped)
+#pragma unroll
+    for (int r = 0; r < RT + 4; ++r) {
+        const int j = clampy(g, j0 - 2 + r);
+        PC[r] = lv_field<1, T, N>(pc, g, 0, i0, j);
+        VX[r] = lv_field<2, T, N>(vc, g, 0, i0, j);
+        VY[r] = lv_field<2, T, N>(vc, g, 1, i0, j);
+    }
+    R PO[RT + 2];                                // p.next after the odd pass, rows j0-1 .. j0+RT
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) PO[r] = lv_field<1, T, N>(pn, g, 0, i0, clampy(g, j0 - 1 + r));
+    // odd pass on rows j0-1 .. j0+RT (slot r <-> field slot r+1); i0 is even, so the colour of cell c in row j is (c + ybase + j) & 1
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        const int j = j0 - 1 + r;
+        if (j < g.jlo || j > g.jhi) continue;    // virtual row outside the domain: never consumed
+        if ((g.ybase + j) & 1) lv_rb_relax_row<1, 1, DM>(k, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
+        else                   lv_rb_relax_row<0, 1, DM>(k, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
+    }
+    // even pass on rows j0 .. j0+RT-1, in place on the odd-pass state; the clamped neighbour of the first / last domain row is the row itself.
+    // All rows are relaxed BEFORE anything is stored: pn is input and output of this kernel.
+    R OUT[RT];
+#pragma unroll
+    for (int r = 1; r <= RT; ++r) {
+        const int j = j0 - 1 + r;
+        if (j >= je) break;
+        const R &pm = (j - 1 < g.jlo) ? PO[r] : PO[r - 1];
+        const R &pp = (j + 1 > g.jhi) ? PO[r] : PO[r + 1];
+        const R ctr = PO[r];
+        R out = ctr;
+        if ((g.ybase + j) & 1) lv_rb_relax_row<1, 0, DM>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
+        else                   lv_rb_relax_row<0, 0, DM>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
+        OUT[r - 1] = out;
+    }
+#pragma unroll
+    for (int r = 1; r <= RT; ++r) {
+        const int j = j0 - 1 + r;
+        if (j >= je) break;
+        if (lm.owner && fl[r]) lv_store_sel<T, N>(pn + idx<1, T>(g, 0, i0, j), OUT[r - 1], fl[r]);
+    }
+}
+
 }  // namespace fs

@@ -235,20 +235,8 @@ __device__ __forceinline__ T div_dx(T x, const Konst<T> &k) { return xdiv<DM & (
 
 // (K5 + K6 fused and K2 live in fs_k34n.h, on lanes of 2 cells)
 
-// ------------------------------------------------------------------------------------------------
-// K8R fused: one red-black SOR iteration (odd pass p.cur -> p.next, then even pass in place on p.next;
-// fs/pressure_updater.py:92-114) as ONE kernel.
-//
-// Even cell (i, j) reads its four (odd) neighbours of p.next AFTER the odd pass.  A lane therefore first
-// forms "pnO" = p.next as it stands after the odd pass for rows j0-1 .. j0+RT of its quad:
-//     odd fluid cell : (1-w) p.cur + w predict_p(p.cur)       (recomputed redundantly in the halo rows / lanes)
-//     any other cell : the stored p.next value                 (stale data the reference also reads, H5)
-// and then relaxes the even fluid cells of rows j0 .. j0+RT-1 from pnO, taking x-neighbours from the adjacent
-// lanes (DPP).  Only cells this lane owns are stored.  Concurrent tiles never consume a value another tile
-// stores: halo pnO values are either recomputed from p.cur (read-only here) or belong to non-fluid cells
-// (never written).  Traffic: mask 1 + p.cur 4 + p.next 4 + v 8 read, p.next 4 written = 21 B/cell per
-// iteration instead of 2 x 17 for the two half-sweep launches.
-// ------------------------------------------------------------------------------------------------
+// (the fused red-black iteration lives in fs_k34n.h, on lanes of 2 cells)
+
 template <typename T>
 struct Q4 {
     T a[4];
@@ -256,101 +244,6 @@ struct Q4 {
     __device__ __forceinline__ Q4(const typename Quad<T>::type &q) { a[0] = q.x; a[1] = q.y; a[2] = q.z; a[3] = q.w; }
     __device__ __forceinline__ typename Quad<T>::type quad() const { typename Quad<T>::type q; q.x = a[0]; q.y = a[1]; q.z = a[2]; q.w = a[3]; return q; }
 };
-
-// one colour of one row: cells k with ((k + PAR) & 1) == COLOR ... relax from centre row C, neighbours M (j-1), P (j+1)
-template <int PAR, int COLOR, int DM, typename T>
-__device__ __forceinline__ void rb_relax_row(const Konst<T> &k, const LaneMap &lm, unsigned fluid,
-                                             const Q4<T> &pm, const Q4<T> &pc, const Q4<T> &pp,     // pressure rows j-1, j, j+1
-                                             const Q4<T> &xm, const Q4<T> &xc, const Q4<T> &xp,     // v.x rows
-                                             const Q4<T> &ym, const Q4<T> &yc, const Q4<T> &yp,     // v.y rows
-                                             Q4<T> &out)                                            // updated in place (starts as the old row)
-{
-    const T pl = quad_left<T>(lm, pc.quad()), pr = quad_right<T>(lm, pc.quad());
-    const T xl = quad_left<T>(lm, xc.quad()), xr = quad_right<T>(lm, xc.quad());
-    const T yl = quad_left<T>(lm, yc.quad()), yr = quad_right<T>(lm, yc.quad());
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (((c + PAR) & 1) != COLOR) continue;
-        if (!(fluid & (1u << c))) continue;
-        const T pE = c == 3 ? pr : pc.a[c == 3 ? 3 : c + 1], pW = c == 0 ? pl : pc.a[c == 0 ? 0 : c - 1];
-        const T xE = c == 3 ? xr : xc.a[c == 3 ? 3 : c + 1], xW = c == 0 ? xl : xc.a[c == 0 ? 0 : c - 1];
-        const T yE = c == 3 ? yr : yc.a[c == 3 ? 3 : c + 1], yW = c == 0 ? yl : yc.a[c == 0 ? 0 : c - 1];
-        T s2, s3;
-        source_from<DM>(k, xE, xW, yE, yW, xp.a[c], xm.a[c], yp.a[c], ym.a[c], s2, s3);
-        const T pred = predict_from(pE, pW, pp.a[c], pm.a[c], s2, s3);
-        out.a[c] = k.om1 * pc.a[c] + k.om * pred;
-    }
-}
-
-template <int RT, int DM, typename T>
-__device__ __forceinline__ void rbsor_fused_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
-{
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, RT, bx, by)) return;   // bx: wave column, by: tile row
-    const LaneMap lm = lane_map_wave(g, bx);
-    const int i0 = lm.i0;
-    const int j0 = jb + by * RT;
-
-    unsigned fl[RT + 2];   // rows j0-1 .. j0+RT
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < RT + 2; ++r) {
-        fl[r] = sel_fluid(mask_quad(g, i0, clampy(g, j0 - 1 + r)));
-        if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
-    }
-    if (!__any(any)) return;
-
-    Q4<T> PC[RT + 4], VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1 (clamped)
-#pragma unroll
-    for (int r = 0; r < RT + 4; ++r) {
-        const int j = clampy(g, j0 - 2 + r);
-        PC[r] = Q4<T>(load_quad<1>(pc, g, 0, i0, j));
-        VX[r] = Q4<T>(load_quad<2>(vc, g, 0, i0, j));
-        VY[r] = Q4<T>(load_quad<2>(vc, g, 1, i0, j));
-    }
-    Q4<T> PO[RT + 2];                            // p.next after the odd pass, rows j0-1 .. j0+RT
-#pragma unroll
-    for (int r = 0; r < RT + 2; ++r) PO[r] = Q4<T>(load_quad<1>(pn, g, 0, i0, clampy(g, j0 - 1 + r)));
-
-    // odd pass on rows j0-1 .. j0+RT (slot r <-> field slot r+1)
-#pragma unroll
-    for (int r = 0; r < RT + 2; ++r) {
-        const int j = j0 - 1 + r;
-        if (j < g.jlo || j > g.jhi) continue;    // virtual row outside the domain: never consumed
-        const int par = (g.ybase + j) & 1;
-        if (par) rb_relax_row<1, 1, DM>(k, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
-        else     rb_relax_row<0, 1, DM>(k, lm, fl[r], PC[r], PC[r + 1], PC[r + 2], VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], PO[r]);
-    }
-    // even pass on rows j0 .. j0+RT-1, in place on pnO; the clamped neighbour of the first / last domain row is the row itself.
-    // All rows are relaxed BEFORE anything is stored: pn is input and output of this kernel, and a tile whose reciprocal divisions
-    // left their exact range is redone from the untouched buffers.
-    Q4<T> OUT[RT];
-#pragma unroll
-    for (int r = 1; r <= RT; ++r) {
-        const int j = j0 - 1 + r;
-        if (j >= je) break;
-        const Q4<T> &pm = (j - 1 < g.jlo) ? PO[r] : PO[r - 1];
-        const Q4<T> &pp = (j + 1 > g.jhi) ? PO[r] : PO[r + 1];
-        const Q4<T> ctr = PO[r];
-        Q4<T> out = ctr;
-        const int par = (g.ybase + j) & 1;
-        if (par) rb_relax_row<1, 0, DM>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
-        else     rb_relax_row<0, 0, DM>(k, lm, fl[r], pm, ctr, pp, VX[r], VX[r + 1], VX[r + 2], VY[r], VY[r + 1], VY[r + 2], out);
-        OUT[r - 1] = out;
-    }
-#pragma unroll
-    for (int r = 1; r <= RT; ++r) {
-        const int j = j0 - 1 + r;
-        if (j >= je) break;
-        if (lm.owner && fl[r]) store_quad_sel<T>(pn + idx<1, T>(g, 0, i0, j), OUT[r - 1].quad(), fl[r]);
-    }
-}
-template <int RT, int DM, typename T>
-__global__ __launch_bounds__(256) void k_rbsor_fused(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *pn, const T *pc, const T *vc)
-{
-    rbsor_fused_tile<RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vc);
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // K4  CIP advection (fs/solver.py:267-332), quad form.  A lane advects NC channels [c0, c0+NC) of a C-channel

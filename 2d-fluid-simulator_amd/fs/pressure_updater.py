@@ -113,7 +113,7 @@ class RedBlackSorPressureUpdater(PressureUpdater):
         self._relaxation_factor = relaxation_factor
         # fused: odd + even pass of one iteration in a single kernel (same bits, fewer bytes)
         fast = fused and not precompute_source and os.environ.get("FS_MARCH", "1") != "0"
-        self._fused = fast and boundary_condition.get_resolution()[0] % 4 == 0          # (a quad kernel; the pair pass below: any even width)
+        self._fused = fast and boundary_condition.get_resolution()[0] % 2 == 0          # (lanes of 2 cells: any even width, like the pair pass below)
         self._precompute = bool(precompute_source)
         self._src = self._dev.alloc(2) if self._precompute else None
         # pair: TWO iterations and the two boundary passes between them in one pass over HBM (csrc/fs_rbpair.h; same bits, 25 instead of

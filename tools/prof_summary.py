@@ -26,7 +26,7 @@ SPLIT = {"k_cip_grad_advect_rt", "k_cip_grad_advect_dye", "k_rbsor_pair", "k_jac
 import json
 traffic = {}
 NAMES = {"k_rbsor_pair": "rbsor_pair", "k_jacobi_quad": "jacobi_quad_lazy", "k_cip_grad_advect_dye": "cip_grad_advect_dye", "k_mac_update_n": "mac_update_kk",
-         "k_cip_grad_advect_rt": "cip_grad_advect_rt", "k_cip_advect_quad": "cip_advect", "k_rbsor_fused": "rbsor_iteration", "k_cip_nonadv_grad_quad": "cip_nonadv_grad",
+         "k_cip_grad_advect_rt": "cip_grad_advect_rt", "k_cip_advect_quad": "cip_advect", "k_rbsor_iter_n": "rbsor_iteration", "k_cip_nonadv_grad_quad": "cip_nonadv_grad",
          "k_cip_nonadv_n": "cip_nonadv", "k_vort_n": "vort_confine", "k_limit": "limit_field", "k_limit_quad": "limit_field",
          "k_jacobi_pair": "jacobi_pair_lazy", "k_jacobi_lazy": "jacobi_sweep_lazy"}
 print(f"{'kernel':28s} {'calls':>6s} {'avg_us':>9s} {'fetch_MB(x2)':>13s} {'write_MB':>9s} {'L2hit%':>7s} {'HBM GB/s':>9s}")
