@@ -113,4 +113,86 @@ __global__ __launch_bounds__(256) void k_jacobi_quad(Grid g, int nbx, int nby, i
     else jacobi_quad_tile<N, RT, true, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The LAST two rounds of a lazily-bounded run in one pass.  The reference ends with
+//     K7(A = p.current: iterate n-2);  B[not wall] = sweep(A);  swap;     K7(B: iterate n-1);  A[not wall] = sweep(B);  swap
+// which leaves   p.current = A: iterate n on the not-wall cells, K7(iterate n-2) on the wall cells with a recipe,
+//                p.next    = B: iterate n-1 with K7 applied (wall targets, inflow = its right neighbour, outflow = 0).
+// Run as launches that is 2 x (boundary kernel + sweep) - 47 of the 585 us of a BASELINE configs[1] step.  Here a lane reads rows j0-2 ..
+// j0+RT+1 of the raw iterate n-2, forms view -> sweep -> view -> sweep in registers and stores both buffers' final content: B in place (this
+// pass does not read it), A's content into a THIRD buffer C (other tiles still read A's rows in their halo; the caller rotates
+// p.current <- C, spare <- A).  Every cell some kernel writes (not-wall cells and recipe targets) is stored, the others are equal in
+// all three buffers (Field.static_id, checked by the caller).  Same validity conditions as the four-sweep pass.
+// ------------------------------------------------------------------------------------------------
+template <int N, int RT, bool BND, typename T>
+__device__ __forceinline__ void jacobi_finish_tile(const Grid &g, const LaneMapN<N> &lm, int i0, int j0, int je, const unsigned (&nw)[RT + 4],
+                                                   const uint8_t *bcmap, T *pc_out, T *pn, const T *pc, const T *src)
+{
+    constexpr int W = RT + 4;                  // window rows w = 0 .. W-1  <->  local rows j0-2 .. j0+RT+1 (clamped into the domain)
+    using R = LV<T, N>;
+    constexpr unsigned ALL = (1u << N) - 1u;
+#define FS_NW(w) (BND ? nw[w] : ALL)
+    R P[W], S2[W], S3[W];
+    uint32_t code[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int j = clampy(g, j0 - 2 + w);
+        P[w] = lv_field<1, T, N>(pc, g, 0, i0, j);
+        if (w >= 1 && w <= W - 2) {
+            S2[w] = lv_field<2, T, N>(src, g, 0, i0, j);
+            S3[w] = lv_field<2, T, N>(src, g, 1, i0, j);
+        }
+        code[w] = BND ? lv_bytes<N>(bcmap, g, i0, j) : 0u;
+    }
+    // view of iterate n-2 (what K7 leaves in A), sweep -> iterate n-1 on rows 1 .. W-2
+    R V0[W], P1[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) V0[w] = BND ? lv_bc_row<T, N>(lm, P[w == 0 ? w : w - 1], P[w], P[w == W - 1 ? w : w + 1], code[w]) : P[w];
+#pragma unroll
+    for (int w = 1; w <= W - 2; ++w) P1[w] = jq_row<T, N>(lm, FS_NW(w), V0[w - 1], V0[w], V0[w + 1], S2[w], S3[w]);
+    // view of iterate n-1 (B's final content), sweep -> iterate n on rows 2 .. W-3
+    R V1[W];
+#pragma unroll
+    for (int w = 1; w <= W - 2; ++w) V1[w] = BND ? lv_bc_row<T, N>(lm, P1[w == 1 ? w : w - 1], P1[w], P1[w == W - 2 ? w : w + 1], code[w]) : P1[w];
+#pragma unroll
+    for (int w = 2; w <= W - 3; ++w) {
+        const int j = j0 - 2 + w;
+        if (j >= je) break;
+        const R p2 = jq_row<T, N>(lm, FS_NW(w), V1[w - 1], V1[w], V1[w + 1], S2[w], S3[w]);
+        const unsigned nwb = FS_NW(w), sel = nwb | (BND ? lv_sel_target<N>(code[w]) : 0u);      // not-wall cells and recipe targets
+        if (lm.owner && sel) {
+            R c;                                                                                // A's final content: iterate n, K7(iterate n-2) on walls
+#pragma unroll
+            for (int q = 0; q < N; ++q) c.a[q] = (nwb >> q) & 1u ? p2.a[q] : V0[w].a[q];
+            lv_store_sel<T, N>(pc_out + idx<1, T>(g, 0, i0, j), c, sel);
+            lv_store_sel<T, N>(pn + idx<1, T>(g, 0, i0, j), V1[w], sel);
+        }
+    }
+#undef FS_NW
+}
+
+template <int N, int RT, typename T>
+__global__ __launch_bounds__(256) void k_jacobi_finish(Grid g, int nbx, int nby, int jb, int je, const uint8_t *bcmap, T *pc_out, T *pn, const T *pc, const T *src)
+{
+    constexpr int W = RT + 4;
+    int wx, ty;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty)) return;
+    const LaneMapN<N> lm = lane_map_n<N>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    unsigned nw[W];
+    bool near = false, all_fluid = true;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + w));
+        nw[w] = lv_sel_not_wall<N>(m);
+        all_fluid = all_fluid && m == 0u;
+        if (w >= 1 && w <= W - 2) near = near || nw[w] != 0u;
+    }
+    // a cell this tile stores is a not-wall cell or a recipe target, i.e. a wall cell next to a not-wall cell: none without a not-wall cell
+    // in the rows around the tile's (halo lanes included)
+    if (!__any(near)) return;
+    if (__all(all_fluid)) jacobi_finish_tile<N, RT, false, T>(g, lm, i0, j0, je, nw, bcmap, pc_out, pn, pc, src);
+    else jacobi_finish_tile<N, RT, true, T>(g, lm, i0, j0, je, nw, bcmap, pc_out, pn, pc, src);
+}
+
 }  // namespace fs

@@ -66,6 +66,10 @@ class JacobiPressureUpdater(PressureUpdater):
             self.form = "four sweeps per pass"
         if tentative and not self._pairs:
             self._precompute, self._src, self._lazy = False, None, False
+        # The last two rounds - 2 x (boundary kernel + sweep), which leave both buffers as the reference does - in ONE pass into a third
+        # buffer (fs_jacobi_finish; bc2 res 1600: 47 -> 25 us of a 585 us step).  Single GPU, masks that admit the four-sweep pass.
+        self._finish = self._quads and self._dev.nranks == 1 and os.environ.get("FS_JACOBI_FINISH", "1") == "1"
+        self._spare = (self._dev.alloc(1),) if self._finish else None      # (a tuple, like RedBlackSorPressureUpdater's: FluidSimulator._signature)
 
     def update(self, p, v_current):
         if self._precompute:
@@ -90,6 +94,12 @@ class JacobiPressureUpdater(PressureUpdater):
         for _ in range(n_lazy - 2 * n_pairs):
             self._dev.jacobi_sweep_lazy(p.next, p.current, self._src)
             p.swap()
+        if (self._finish and n_real == 2 and self._n_iter - 2 >= 4
+                and p.current.static_id == p.next.static_id == self._spare[0].static_id and not (p.current.user_data or p.next.user_data)):
+            # (the pass stores the cells some kernel writes; the rest must agree in the three buffers: no uploads / fills in between)
+            self._dev.jacobi_finish(self._spare[0], p.next, p.current, self._src)
+            p.current, self._spare = self._spare[0], (p.current,)
+            return
         for _ in range(n_real):
             self._bc.set_pressure_boundary_condition(p.current)
             self._update(p.next, p.current, v_current)

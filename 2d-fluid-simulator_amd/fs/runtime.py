@@ -627,6 +627,11 @@ class DeviceBase:
         """Four lazily-bounded sweeps in one pass, pn[not wall] <- sweep^4(pc) (csrc/fs_jquad.h)."""
         self._run("jacobi_quad_lazy", (pn._h, pc._h, src._h), reads=[(pc, 4), (src, 3)], writes=[pn])
 
+    def jacobi_finish(self, pc_out, pn, pc, src):
+        """The last two (K7, sweep, swap) rounds of a lazily-bounded run in one pass (csrc/fs_jquad.h k_jacobi_finish): pc = raw iterate n-2;
+        pc_out <- what the reference leaves in p.current, pn <- what it leaves in p.next."""
+        self._run("jacobi_finish", (pc_out._h, pn._h, pc._h, src._h), reads=[(pc, 2), (src, 1)], writes=[pc_out, pn])
+
     def rbsor_halfsweep_src(self, omega, parity, pn, pc, src):
         self._run("rbsor_halfsweep_src", (omega, parity, pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
 

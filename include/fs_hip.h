@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 4
+#define FS_ABI_VERSION 5
 
 typedef struct fs_ctx fs_ctx;
 typedef struct fs_field fs_field;
@@ -204,6 +204,11 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
  * its target as seen from a cell whose value is used; otherwise FS_ERR_UNSUPPORTED - use fs_jacobi_pair_lazy / fs_jacobi_sweep_lazy.  */
 int fs_jacobi_quad_ok(const fs_ctx *ctx, int *ok);
 int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end);
+/* The LAST two rounds (K7, sweep, swap; K7, sweep, swap - fs/pressure_updater.py:56-66) of such a run in one pass: pc holds the raw iterate
+ * n-2; pc_out (a third buffer) receives what the reference leaves in p.current (iterate n on the not-wall cells, K7(iterate n-2) on the wall
+ * cells with a recipe), pn what it leaves in p.next (iterate n-1 with K7 applied).  Cells no kernel writes are not stored: they must be
+ * equal in the three buffers.  Same conditions as fs_jacobi_quad_lazy; pc is read 2 rows beyond the written range, src 1. */
+int fs_jacobi_finish(fs_ctx *ctx, fs_field *pc_out, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end);
 int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc,
                            const fs_field *src, int row_begin, int row_end);
 /* Residual diagnostic (new; the reference never measures convergence): sum over owned not-wall cells of
