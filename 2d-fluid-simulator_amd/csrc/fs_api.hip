@@ -1594,6 +1594,11 @@ int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
+        if (ctx->use_pairs && !getenv("FS_SRC_CELLS")) {
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_JACOBI, 3, false);
+#define FS_PSN(DM) hipLaunchKernelGGL((k_poisson_source_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)src->d, (const T *)vc->d)
+            return launch(ctx, "poisson_source", [=] { FS_DMC(dm_const(ctx, k), FS_PSN); });
+        }
         FS_LAUNCH_CELLS("poisson_source", (k_poisson_source<T>), ctx->grid(), k, row_begin, (T *)src->d, (const T *)vc->d)
     })
 }

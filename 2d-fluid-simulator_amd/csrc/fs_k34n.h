@@ -573,4 +573,44 @@ __global__ __launch_bounds__(256) void k_rbsor_iter_n(Grid g, Konst<T> k, int nb
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Source pair of predict_p (fs/pressure_updater.py:23-38) for every cell of the row range, once per step for the Jacobi runs that read
+// it (fs_kernels.h k_poisson_source is the one-cell-per-lane form): lanes of N cells, tiles of RT rows, one halo lane per side.
+// ------------------------------------------------------------------------------------------------
+template <int N, int RT, int DM, typename T>
+__global__ __launch_bounds__(256) void k_poisson_source_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *src, const T *vc)
+{
+    using R = LV<T, N>;
+    constexpr int HL = 1, L = N - 1;
+    int wx, ty, cg;
+    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    R VX[RT + 2], VY[RT + 2];                    // rows j0-1 .. j0+RT (clamped: sample())
+#pragma unroll
+    for (int u = 0; u < RT + 2; ++u) {
+        const int row = clampy(g, j0 - 1 + u);
+        VX[u] = lv_field<2, T, N>(vc, g, 0, i0, row);
+        VY[u] = lv_field<2, T, N>(vc, g, 1, i0, row);
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        if (j >= je) break;
+        const T xl = lv_left<T, N>(lm, VX[t + 1]), xr = lv_right<T, N>(lm, VX[t + 1]);
+        const T yl = lv_left<T, N>(lm, VY[t + 1]), yr = lv_right<T, N>(lm, VY[t + 1]);
+        R S2, S3;
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const T xE = c == L ? xr : VX[t + 1].a[c == L ? c : c + 1], xW = c == 0 ? xl : VX[t + 1].a[c == 0 ? 0 : c - 1];
+            const T yE = c == L ? yr : VY[t + 1].a[c == L ? c : c + 1], yW = c == 0 ? yl : VY[t + 1].a[c == 0 ? 0 : c - 1];
+            source_from<DM>(k, xE, xW, yE, yW, VX[t + 2].a[c], VX[t].a[c], VY[t + 2].a[c], VY[t].a[c], S2.a[c], S3.a[c]);
+        }
+        if (lm.owner) {
+            lv_store<T, N>(src + idx<2, T>(g, 0, i0, j), S2);
+            lv_store<T, N>(src + idx<2, T>(g, 1, i0, j), S3);
+        }
+    }
+}
+
 }  // namespace fs
