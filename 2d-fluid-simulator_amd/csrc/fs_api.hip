@@ -1124,11 +1124,12 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, re);
-        if (ctx->use_march) {
-            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_NONADV, false);
+        if (ctx->use_pairs) {
+            // lanes of 2 cells, 4-row tiles (fs_k34n.h k_cip_nonadv_dye_n), compact launch: 141 -> 122-130 us at bc5 res 4096 against the one-row quad form
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_NONADV, 3);
             return launch(ctx, "cip_nonadv_dye", [=] {
-#define FS_K12Q(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_quad<DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
-                FS_DMA(dm_all(ctx, k), FS_K12Q);
+#define FS_K12N(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
+                FS_DMA(dm_all(ctx, k), FS_K12N);
             });
         }
         FS_LAUNCH_CELLS("cip_nonadv_dye", (k_cip_nonadv_dye<T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d)

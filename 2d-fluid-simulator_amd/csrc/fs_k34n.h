@@ -613,4 +613,52 @@ __global__ __launch_bounds__(256) void k_poisson_source_n(Grid g, Konst<T> k, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K12  DyeCipMacSolver._non_advection_phase_dye (fs/solver.py:378-383) on lanes of N cells, tiles of RT rows: dn = dc + (lap(dc)/re) dt on
+// not-wall cells, the three channels one after the other.  One halo lane per side.
+// ------------------------------------------------------------------------------------------------
+template <int N, int RT, int DM, typename T>
+__global__ __launch_bounds__(256) void k_cip_nonadv_dye_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
+{
+    using R = LV<T, N>;
+    constexpr int HL = 1, L = N - 1;
+    int wx, ty, cg;
+    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    unsigned nw[RT];
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        nw[t] = j0 + t < je ? lv_sel_nw<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
+        any = any || (lm.owner && nw[t] != 0u);
+    }
+    if (!__any(any)) return;
+    R D[3][RT + 2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < RT + 2; ++u) D[c][u] = lv_field<3, T, N>(dc, g, c, i0, clampy(g, j0 - 1 + u));
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int j = j0 + t;
+            if (j >= je) break;
+            const R &f1 = D[c][t + 1];
+            const T l = lv_left<T, N>(lm, f1), r = lv_right<T, N>(lm, f1);
+            R O;
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+                const T f0 = f1.a[q];
+                const T fE = q == L ? r : f1.a[q == L ? q : q + 1], fW = q == 0 ? l : f1.a[q == 0 ? 0 : q - 1];
+                const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+                const T d2y = xdiv<DM>((D[c][t + 2].a[q] - (T)2.0 * f0) + D[c][t].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+                const T dif = cdiv<DM>(d2x + d2y, k.re, k.r_re);
+                O.a[q] = f0 + dif * k.dt;
+            }
+            if (lm.owner && nw[t]) lv_store_sel<T, N>(dn + idx<3, T>(g, c, i0, j), O, nw[t]);
+        }
+}
+
 }  // namespace fs

@@ -852,48 +852,6 @@ __global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, int je, T li
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K12  DyeCipMacSolver._non_advection_phase_dye (fs/solver.py:378-383), quad form: dn = dc + (lap(dc)/re) dt on not-wall cells.
-// ------------------------------------------------------------------------------------------------
-template <int DM, typename T>
-__device__ __forceinline__ void cip_nonadv_dye_quad_tile(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
-{
-    int bx, by;
-    if (!tile_coords(g, nbx, nby, jb, je, 1, bx, by)) return;   // bx: wave column, by: tile row
-    const LaneMap lm = lane_map_wave(g, bx);
-    const int i0 = lm.i0, j = jb + by;
-    const unsigned nw = sel_not_wall(mask_quad(g, i0, j));
-    if (!__any(nw != 0u)) return;
-    const int jm = clampy(g, j - 1), jp = clampy(g, j + 1);
-    Q4<T> D[3][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        D[c][0] = Q4<T>(load_quad<3>(dc, g, c, i0, jm));
-        D[c][1] = Q4<T>(load_quad<3>(dc, g, c, i0, j));
-        D[c][2] = Q4<T>(load_quad<3>(dc, g, c, i0, jp));
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const T l = quad_left<T>(lm, D[c][1].quad()), r = quad_right<T>(lm, D[c][1].quad());
-        Q4<T> O;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const T f0 = D[c][1].a[q];
-            const T fE = q == 3 ? r : D[c][1].a[q == 3 ? 3 : q + 1], fW = q == 0 ? l : D[c][1].a[q == 0 ? 0 : q - 1];
-            const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-            const T d2y = xdiv<DM>((D[c][2].a[q] - (T)2.0 * f0) + D[c][0].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-            const T dif = cdiv<DM>(d2x + d2y, k.re, k.r_re);
-            O.a[q] = f0 + dif * k.dt;
-        }
-        if (lm.owner && nw) store_quad_sel<T>(dn + idx<3, T>(g, c, i0, j), O.quad(), nw);
-    }
-}
-template <int DM, typename T>
-__global__ __launch_bounds__(256) void k_cip_nonadv_dye_quad(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
-{
-    cip_nonadv_dye_quad_tile<DM, T>(g, k, nbx, nby, jb, je, dn, dc);
-}
-
 // clamp_field restricted to the inflow cells (op list of the dye boundary kernel): with the clamp folded into the advection
 // store these are the only other cells of the dye buffer whose value can lie outside [low, high] (the dye BC rewrites them
 // with the scene colour every step).
