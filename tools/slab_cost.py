@@ -70,6 +70,13 @@ def main():
         el = time.perf_counter() - t0
         print(f"res {res} slab {rank}/{world} halo {halo}: {el / steps * 1e6:.1f} us/step compute, "
               f"{(dev.n_exchanges - n0) / steps:.2f} exchanges/step, {(dev.n_exchanged_bytes - b0) / steps / 1024:.0f} KB/step/neighbour (no-op here)", flush=True)
+        dev.profile(True); dev.profile_reset()
+        for _ in range(60):
+            solver.update()
+        dev.sync()
+        rep = dev.profile_report()
+        print("    per step (HIP events, us): " + "  ".join(f"{k}={ms / 60 * 1e3:.1f}x{n / 60:g}" for k, (n, ms) in rep.items())
+              + f"   sum {sum(ms for _, ms in rep.values()) / 60 * 1e3:.1f}", flush=True)
         dev.close()
 
 
