@@ -27,7 +27,7 @@ KEY = b"fs-bench-test"
 
 def _mesh():
     conns = {}
-    listener = Listener(("127.0.0.1", PORT + RANK), authkey=KEY)
+    listener = Listener(("127.0.0.1", PORT + RANK), authkey=KEY, backlog=64)     # (the default backlog of 1 drops the connections of 7 ranks arriving at once)
     for j in range(RANK):                       # connect to every lower rank
         t0 = time.time()
         while True:
