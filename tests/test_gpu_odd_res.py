@@ -40,3 +40,34 @@ def test_odd_resolution_runs_the_fused_passes(bc_id, res, scheme, hip_lib):
             assert "rbsor_pair" in names, names
     finally:
         dev.close()
+
+
+@pytest.mark.parametrize("scheme", ["cip", "upwind"])
+def test_odd_resolution_with_dye(scheme, hip_lib):
+    """The dye solvers at an odd resolution: fused dye passes (CIP) / the generic dye update (upwind), against the oracle."""
+    import fs
+    from fs.boundary_condition import DyeBoundaryCondition, create_scene_arrays
+    from oracle import oracle as O
+    res = 57
+    const, mask, dye = create_scene_arrays(2, res)
+    dt, dx, re, vc = 0.05 / res, 1.0 / res, 1000.0, 5.0
+    fs.runtime.init(gpu=0, dtype="f32")
+    bc = DyeBoundaryCondition(const, dye, mask)
+    dev = bc.device
+    vcobj = fs.VorticityConfinement(bc, dt, dx, vc)
+    pu = fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2)
+    solver = (fs.DyeCipMacSolver(bc, pu, dt, dx, re, vcobj) if scheme == "cip"
+              else fs.DyeMacSolver(bc, pu, fs.advect_upwind, dt, dx, re, vcobj))
+    ref = O.make_simulator(const, mask, dye, scheme=scheme, dt=dt, dx=dx, re=re, vor_eps=vc, updater=("rbsor", 1.3, 2))
+    try:
+        dev.profile(True)
+        for step in range(6):
+            solver.update()
+            ref.update()
+            for a, e, name in zip([f.to_numpy() for f in solver.get_fields()], list(ref.fields().values()), ("v", "p", "dye")):
+                assert np.array_equal(a, e, equal_nan=True), f"{scheme} step {step + 1} {name}"
+        names = set(dev.profile_report())
+        if scheme == "cip":
+            assert {"cip_grad_advect_dye", "cip_nonadv_dye", "cip_grad_advect_rt"} <= names, names
+    finally:
+        dev.close()
