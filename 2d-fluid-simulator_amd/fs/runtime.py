@@ -562,13 +562,13 @@ class DeviceBase:
                   reads=[(fc, 1), (fxc, 1), (fyc, 1), (v, 1)], writes=[fn, fxn, fyn])
 
     def cip_grad_advect(self, dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, full=False):
-        """K3 + K4 of the velocity field in one pass (build-side fusion): see csrc/fs_march.h k_cip_grad_advect.  v_out receives every
+        """K3 + K4 of the velocity field in one pass (build-side fusion): see csrc/fs_k34n.h k_cip_grad_advect_n.  v_out receives every
         cell that can differ from fc (full: every cell - the carrying pass after an upload, include/fs_hip.h)."""
         self._run("cip_grad_advect", (dt, dx, v_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, 1 if full else 0),
                   reads=[(fn, 2), (fc, 2), (gxc, 1), (gyc, 1)], writes=[gx_out, gy_out], full_writes=[v_out])
 
     def cip_grad_advect_dye(self, dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=False, full=False):
-        """K3 + K4 of the dye in one pass (csrc/fs_march.h k_cip_grad_advect_dye); clamp01 folds clamp_field(dye, 0, 1) into the store."""
+        """K3 + K4 of the dye in one pass (csrc/fs_k34n.h k_cip_grad_advect_n<3>); clamp01 folds clamp_field(dye, 0, 1) into the store."""
         self._run("cip_grad_advect_dye", (dt, dx, d_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, v._h, 1 if clamp01 else 0, 1 if full else 0),
                   reads=[(fn, 2), (fc, 2), (gxc, 1), (gyc, 1), (v, 1)], writes=[gx_out, gy_out], full_writes=[d_out])
 
