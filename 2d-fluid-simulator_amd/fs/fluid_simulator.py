@@ -107,7 +107,8 @@ class FluidSimulator:
                 self._counted_step()
             return
         entry = self._graphs.get(self._signature())
-        if entry is None and nsteps >= 16:
+        if entry is None and nsteps >= 16:          # (periods 1 - 6 need at most 16 steps to be found; 12 - an odd red-black count with the pair pass
+            # on top of the fused transport - is only tried when the chunk has 28)
             nsteps -= self.capture_period(budget=nsteps)
             entry = self._graphs.get(self._signature())
         if entry is not None:
@@ -136,7 +137,7 @@ class FluidSimulator:
         self._graph = (signature, graph id, period) - also cached for run() - or None if nothing within the budget repeats."""
         dev, done = self._dev, 0
         self._graph = None
-        for period in (1, 2, 3, 4, 6):
+        for period in (1, 2, 3, 4, 6, 12):
             if done + period > budget:
                 break
             sig = self._signature()

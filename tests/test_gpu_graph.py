@@ -115,3 +115,37 @@ def test_run_in_odd_chunks_keeps_one_graph_per_phase(hip_lib):
     finally:
         eager._solver._bc.device.close()
         graph._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("scheme,n_iter,expect", [("cip", 3, 12), ("kk", 3, 4), ("cip", 5, 6)])
+def test_long_periods_of_the_buffer_rotation(scheme, n_iter, expect, hip_lib):
+    """An odd red-black iteration count on top of the two-iteration pass: the pressure pairs come back after 4 steps, with the fused
+    transport's three velocity buffers after 12.  run() must find that period (a 2-step capture replayed twice - what the fuzzer did by
+    hand until round 3 - reads the wrong buffers from the third step on)."""
+    import fs
+    from fs.boundary_condition import BoundaryCondition, create_scene_arrays
+    res = 64
+    const, mask, _ = create_scene_arrays(2, res)
+    dt, dx, re = 0.05 / res, 1.0 / res, 1e4
+    fs.runtime.init(gpu=0, dtype="f32")
+    sims = []
+    for _ in range(2):
+        bc = BoundaryCondition(const, mask)
+        pu = fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, n_iter)
+        vc = fs.VorticityConfinement(bc, dt, dx, 5.0)
+        solver = (fs.CipMacSolver(bc, pu, dt, dx, re, vc) if scheme == "cip" else fs.MacSolver(bc, pu, fs.advect_kk_scheme, dt, dx, re, vc))
+        sims.append(fs.FluidSimulator(solver))
+    eager, graph = sims
+    try:
+        if not graph._dev.rb_pair_ok:
+            pytest.skip("this scene does not admit the two-iteration pass")
+        graph.run(64, graph=True)
+        assert graph._graph is not None and graph._graph[2] == expect, graph._graph
+        for _ in range(64):
+            eager.step()
+        for name in ("v", "p"):
+            a, b = getattr(eager._solver, name), getattr(graph._solver, name)
+            assert np.array_equal(a.current.to_numpy(), b.current.to_numpy()), name
+            assert np.array_equal(a.next.to_numpy(), b.next.to_numpy()), name + ".next"
+    finally:
+        eager._dev.close(); graph._dev.close()

@@ -90,11 +90,12 @@ def one_case(seed, max_cells, debug=False):
         solver.v.current.from_numpy(v0); ref.v.current[...] = v0
         solver.p.current.from_numpy(p0); ref.p.current[...] = p0
         if os.environ["FS_FUSE_TRANSPORT"] == "0" and rng.random() < 0.15:
-            # hipGraph mode (what bench.py times): a captured pair of steps replayed twice = 4 steps, compared at the end
-            dev = bc.device
-            gid = dev.capture(lambda: (solver.update(), solver.update()))
-            dev.replay(gid, 2)
-            for _ in range(4):
+            # hipGraph mode (what bench.py times): FluidSimulator.run finds the period of the solver's buffer rotation (1 - 12 steps, depending on
+            # the fusions in use), captures it and replays; compared at the end.  (Until round 3 this captured two steps by hand and replayed
+            # them twice - valid only while every rotation has a period that divides 2.)
+            nsteps = 28
+            fs.FluidSimulator(solver).run(nsteps, graph=True)
+            for _ in range(nsteps):
                 ref.update()
             for a, e, name in zip([f.to_numpy() for f in solver.get_fields()], list(ref.fields().values()), ("v", "p", "dye")):
                 if not np.array_equal(a, e, equal_nan=True):
