@@ -128,8 +128,8 @@ struct fs_ctx {
     // compact launches (fs_device.h Grid::tiles): per-cell activity of the scene on the host (bit 0: some cell of wave column wx - 248
     // cells - in row j is not deep wall, bit 1: the same for the 120-cell wave columns of the 2-cell-lane kernels), and the lists built from
     // it per launch geometry (key: lane width, rows per tile, stacked, group size)
-    int tile_list_mask = 1 | 2 | 4 | 8;              // env FS_TILE_LIST: kernel families (XCD_* bits) launched compactly.  Measured at bc5 res 4096:
-                                             // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement (2-cell lanes) 97 -> 95, K2 (2-cell lanes) 105 -> 102
+    int tile_list_mask = 1 | 2 | 4 | 8 | 32;              // env FS_TILE_LIST: kernel families (XCD_* bits) launched compactly.  Measured at bc5 res 4096:
+                                             // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement (2-cell lanes) 97 -> 95, K2 (2-cell lanes) 105 -> 102, the plain Jacobi sweeps 87.2 -> 85.8 (reading v) / 75.5 -> 74.1 (source pair)
     std::vector<uint8_t> h_act4, h_act2, h_act2w;     // [wave column][global row]
     struct TileList { uint32_t *d = nullptr; int per_xcd = 0; };
     std::map<uint32_t, TileList> tile_lists;

@@ -156,7 +156,8 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
                        const fs_field *vc, int row_begin, int row_end);
 /* Source-term precompute (build-side optimisation; the source of predict_p depends only on v and is
  * constant over the sweeps of one step).  src has 2 channels: (s2, s3) with predict_p = (0.25*sum + s2) - s3,
- * i.e. the reference's operation order is kept and results stay bit-identical to the v-reading kernels. */
+ * i.e. the reference's operation order is kept and results stay bit-identical to the v-reading kernels.  src is defined on every
+ * cell a sweep reads it at (not-wall cells and everything within a few cells of one); regions of nothing but wall may be left untouched. */
 int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs_field *vc,
                       int row_begin, int row_end);
 int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src,
