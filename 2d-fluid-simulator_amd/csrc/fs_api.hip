@@ -23,24 +23,28 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 }
 
 // ---- f64-multiply division (fs_device.h f64div): the identity checked ON THE DEVICE for one divisor -------------------------------
-// every significand of x in 9 binades (tiny, denormal quotients, huge), both signs, plus 2^24 arbitrary bit patterns (NaN compared as NaN)
-__global__ __launch_bounds__(256) static void k_verify_f64div(float d, double rd, unsigned *bad)
+// every significand of x in 9 binades (tiny, denormal quotients, huge), both signs; the dividends x = d (m + 1/2) 2^-149 whose quotient
+// is (when the product is an f32 number: exactly) a TIE between two denormals - the case an unguarded f64 product gets wrong; plus 2^24
+// arbitrary bit patterns (NaN compared as NaN)
+__global__ __launch_bounds__(256) static void k_verify_f64div(float d, double rd, int guarded, unsigned *bad)
 {
-    const unsigned m = blockIdx.x * 256u + threadIdx.x;          // 2^23 significands; blockIdx.y: the binade / the random sweep
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;          // 2^23 significands; blockIdx.y: the binade / the ties / the random sweeps
     float x;
     if (blockIdx.y < 9) {
         const int e[9] = {0, -60, -100, -126, 60, 100, -20, 20, 127};
         x = __uint_as_float(0x3f800000u | m);
         x = ldexpf(x, e[blockIdx.y]);
         if (blockIdx.y == 3) x = __uint_as_float(m);             // the denormals themselves
+    } else if (blockIdx.y == 9) {
+        x = (float)(ldexp((double)m + 0.5, -149) * (double)fabsf(d));   // (m + 1/2) ulp_denormal * |d|: exact in f64, an f32 number for many m
     } else {
-        unsigned h = (m + 0x9e3779b9u * (blockIdx.y - 8u)) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        unsigned h = (m + 0x9e3779b9u * (blockIdx.y - 9u)) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
         x = __uint_as_float(h);
     }
 #pragma unroll
     for (int sgn = 0; sgn < 2; ++sgn) {
         const float xs = sgn ? -x : x;
-        const float q = f64div(xs, rd), t = xs / d;
+        const float q = guarded ? f64div_guarded(xs, d, rd) : f64div(xs, rd), t = xs / d;
         const bool same = __float_as_uint(q) == __float_as_uint(t) || (q != q && t != t);
         if (!same) atomicAdd(bad, 1u);
     }
@@ -113,7 +117,7 @@ static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c-
 
 // overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
 struct OvGrid { int nbx, nby; dim3 grid; Grid g; };
-enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16, XCD_JACOBI = 32 };
+enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16, XCD_JACOBI = 32, XCD_MARCH = 64 };   // XCD_MARCH: the row-marching passes - one strip row per XCD group, workgroups side by side
 // Compact list of the workgroups of a dense XCD-band launch that have anything to do (Grid::tiles), built once per geometry from the
 // host-side activity maps of the scene.  lanes = cells per lane (4: wave columns of 248 cells, 2: of 120), rt = rows per tile.
 // cls: 0 = every workgroup with work; 1 / 2 = those whose tiles see nothing but fluid within `reach` rows and the halo lanes ("plain":
@@ -197,7 +201,7 @@ static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroup
     if (c->xcd_mask & family) {
         // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords)
         int xg = c->xcd_group;
-        for (int f = 0; f < 6; ++f) if ((family >> f) & 1) xg = c->xcd_group_fam[f] > 0 ? c->xcd_group_fam[f] : xg;
+        for (int f = 0; f < 7; ++f) if ((family >> f) & 1) xg = c->xcd_group_fam[f] > 0 ? c->xcd_group_fam[f] : xg;
         const int group = stacked ? std::max(1, xg / 4) : xg;     // the same number of field rows per XCD group
         const int groups = (o.nby + group - 1) / group;
         const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && jb == 0 && je == c->rows ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach) : nullptr;
@@ -669,12 +673,15 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
+    if (const char *s = getenv("FS_RBMARCH")) c->use_rbmarch = atoi(s);
+    if (const char *s = getenv("FS_RBM_L")) { const int v = atoi(s); if (v >= 14 && v <= 254 && (v + 10) % 12 == 0) c->rbm_L = v; }
+    if (const char *s = getenv("FS_RBM_PF")) { const int v = atoi(s); if (v == 1 || v == 3) c->rbm_pf = v; }
     if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : (atoi(s) == 4 ? 4 : 0);
     if (const char *s = getenv("FS_MAC_RT")) { const int v = atoi(s); c->mac_rt = v == 2 || v == 4 ? v : 0; }
     if (const char *s = getenv("FS_K34_N")) c->k34_n = atoi(s) == 4 ? 4 : (atoi(s) == 2 ? 2 : 0);
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
-    c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
+    c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI | XCD_MARCH;
     if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);
     c->stack_mask = XCD_RBSOR | XCD_ADVECT | XCD_GRAD;      // measured per family: K4 313 -> 301 us, K3 246 -> 243, RB-SOR 129 -> 127.5; the others lose 1 %
     if (const char *s = getenv("FS_STACK")) c->stack_mask = atoi(s);
@@ -682,7 +689,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
     if (const char *s = getenv("FS_XCD_GROUP_FAM")) {      // "bit:rows,bit:rows": tile rows per XCD group of single kernel families (XCD_* bit numbers 0 .. 5)
         int f, v, n = 0;
-        while (sscanf(s, "%d:%d%n", &f, &v, &n) == 2) { if (f >= 0 && f < 6 && v >= 1 && v <= 128) c->xcd_group_fam[f] = v; s += n; if (*s == ',') ++s; else break; }
+        while (sscanf(s, "%d:%d%n", &f, &v, &n) == 2) { if (f >= 0 && f < 7 && v >= 1 && v <= 128) c->xcd_group_fam[f] = v; s += n; if (*s == ',') ++s; else break; }
     }
     c->use_pairs = c->use_march && nx % 2 == 0;   // the kernels on lanes of 2 cells (fs_k34n.h, fs_rbpair.h, fs_jquad.h): any even width, i.e. any `res`
     if (nx % 4 != 0) c->use_march = false;        // quads need 16-byte aligned rows
@@ -713,6 +720,7 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_acc) hipFree(ctx->d_acc);
     if (ctx->d_bcmap) hipFree(ctx->d_bcmap);
     if (ctx->d_lazyflags) hipFree(ctx->d_lazyflags);
+    if (ctx->d_rbcode) hipFree(ctx->d_rbcode);
     if (ctx->d_pairlist) hipFree(ctx->d_pairlist);
     if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -797,8 +805,19 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     FS_HIP(hipMemsetAsync(ctx->d_bcmap, 0, (size_t)ctx->rows * ctx->Pm, ctx->stream));
     FS_HIP(hipMemsetAsync(ctx->d_lazyflags, 63, (size_t)std::max(ctx->nwx, 1) * ctx->rows, ctx->stream));
     rc = upload_global(ctx, ctx->d_bcmap, 1, 1, ctx->h_bcmap.data(), ctx->Pm);
+    if (rc == FS_OK) {       // the marching red-black pass reads ONE byte per cell: recipe bits 0-6 + "not fluid" (rows outside the domain: wall)
+        if (!ctx->d_rbcode) FS_HIP(hipMalloc(&ctx->d_rbcode, (size_t)ctx->rows * ctx->Pm));
+        FS_HIP(hipMemsetAsync(ctx->d_rbcode, 0x80, (size_t)ctx->rows * ctx->Pm, ctx->stream));
+        std::vector<uint8_t> rb((size_t)ctx->X * ctx->Y);
+        for (size_t q = 0; q < rb.size(); ++q) rb[q] = (uint8_t)((ctx->h_bcmap[q] & 0x7f) | (mask_xy[q] != 0 ? 0x80 : 0));
+        rc = upload_global(ctx, ctx->d_rbcode, 1, 1, rb.data(), ctx->Pm);
+    }
     // activity of the scene per (wave column, row) for the compact launches: a cell is "deep wall" when it is a wall cell that no
     // boundary kernel writes - workgroups made of such cells only have nothing to do in any kernel
+    // captured graphs and recorded tapes hold the device pointers of the lists (and the launch geometry of the old scene): a new mask
+    // invalidates them - a later fs_graph_launch / fs_tape_replay of such an id is an error, not a read through a dangling pointer
+    for (auto &gexec : ctx->graphs) if (gexec) { hipGraphExecDestroy(gexec); gexec = nullptr; }
+    for (auto &tp : ctx->tapes) if (tp) { delete tp; tp = nullptr; }
     tile_lists_free(ctx);
     ctx->h_act4.clear(); ctx->h_act2.clear(); ctx->h_act2w.clear();
     if (ctx->halo == 0 && ctx->X % 2 == 0 && ctx->tile_list_mask) {
@@ -1459,13 +1478,86 @@ int fs_selftest_f64div(fs_ctx *ctx, double divisor, int *mismatches)
     FS_HIP(hipMalloc(&flag, sizeof(unsigned)));
     hipError_t e = hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_verify_f64div, dim3(1u << 15, 9 + 2), dim3(256), 0, ctx->stream, d, 1.0 / (double)d, flag);
+        hipLaunchKernelGGL(k_verify_f64div, dim3(1u << 15, 10 + 2), dim3(256), 0, ctx->stream, d, 1.0 / (double)d, tie_free((double)d) ? 0 : 1, flag);   // the form the library uses for this divisor
         e = hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(flag);
     if (e != hipSuccess) return hip_fail(e, "fs_selftest_f64div", __FILE__, __LINE__);
     *mismatches = (int)std::min<unsigned>(h, 0x7fffffffu);
+    return FS_OK;
+}
+
+// ---- what THIS box streams at (measurement hygiene: the pool's boxes differ by several per cent) ---------------------
+// float4 read of one buffer and float4 copy between two buffers of `bytes` each (step-sized: beyond the 256 MiB Infinity Cache), timed with
+// HIP events on the context's stream for about budget_ms each.  bench.py prints both next to every roofline fraction.
+__global__ __launch_bounds__(256) static void k_box_read(const float4 *__restrict__ a, float *sink, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const size_t k = i + u * stride; v[u] = k < n ? a[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
+    if (s == 1.2345f) sink[0] = s;
+}
+__global__ __launch_bounds__(256) static void k_box_copy(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v0 = a[i], v1 = a[i + 1], v2 = a[i + 2], v3 = a[i + 3];
+        b[i] = v0; b[i + 1] = v1; b[i + 2] = v2; b[i + 3] = v3;
+    }
+}
+
+int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps, double *copy_GBps)
+{
+    FS_REQUIRE(ctx && read_GBps && copy_GBps, "null argument");
+    FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "fs_box_rates during graph capture / tape recording");
+    FS_REQUIRE(bytes >= (1u << 20) && budget_ms > 0.0, "need at least 1 MiB and a positive time budget");
+    FS_HIP(hipSetDevice(ctx->device));
+    bytes = bytes / 4096 * 4096;
+    const size_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    float *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&a, bytes);
+    if (e == hipSuccess) e = hipMalloc(&b, bytes);
+    if (e == hipSuccess) e = hipMalloc(&sink, sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    auto timed = [&](bool copy, double *out) {
+        // one launch to learn the rate, then as many as fit the budget
+        int reps = 1;
+        for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+            (void)hipEventRecord(e0, ctx->stream);
+            for (int r = 0; r < reps; ++r) {
+                if (copy) hipLaunchKernelGGL(k_box_copy, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, a, b, n);
+                else hipLaunchKernelGGL(k_box_read, dim3(2048), dim3(256), 0, ctx->stream, a, sink, n);
+            }
+            (void)hipEventRecord(e1, ctx->stream);
+            e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) return;
+            *out = (copy ? 2.0 : 1.0) * (double)bytes * reps / (ms * 1e-3) / 1e9;
+            reps = std::max(1, std::min(1000, (int)(budget_ms / std::max((double)ms / reps, 1e-3))));
+        }
+    };
+    if (e == hipSuccess) timed(false, read_GBps);
+    if (e == hipSuccess) timed(true, copy_GBps);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    if (sink) hipFree(sink);
+    if (e != hipSuccess) return hip_fail(e, "fs_box_rates", __FILE__, __LINE__);
     return FS_OK;
 }
 
@@ -1552,6 +1644,17 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 (FS_RBPAIR_RT=6: 6) rows per tile.  The carrying
     // pass after an upload (full) is rare: one configuration.
     const int rt = full ? 4 : ctx->rbpair_rt;
+    if (!full && ctx->use_rbmarch) {
+        // the row-marching form (fs_rbmarch.h): strips of L rows, one wave column each, plain and boundary rows in one kernel; the compact
+        // list leaves out the strips of nothing but deep wall
+        const int L = ctx->rbm_L, pf = ctx->rbm_pf;
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, L, 1, XCD_MARCH, 2, true, 0);
+        const RbmArgs a{(const uint8_t *)ctx->d_rbcode, pc_out->d, pn_out->d, pc->d, pn->d, vc->d};
+#define FS_RBM_K(PF, PAR, DM) hipLaunchKernelGGL((k_rbsor_march<2, PF, PAR, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, L, a)
+#define FS_RBM_PAR(PF, DM) do { if (par0) FS_RBM_K(PF, 1, DM); else FS_RBM_K(PF, 0, DM); } while (0)
+#define FS_RBM_DM(PF) do { if (dm & DM_F64) FS_RBM_PAR(PF, 4); else FS_RBM_PAR(PF, 0); } while (0)
+        return launch(ctx, "rbsor_pair", [=] { if (pf == 1) FS_RBM_DM(1); else FS_RBM_DM(3); });
+    }
 #define FS_RBP_K(RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBP_PAR(RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, PATH, FULL); else FS_RBP_K(RT, 0, DM, PATH, FULL); } while (0)

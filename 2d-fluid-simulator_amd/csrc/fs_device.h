@@ -58,21 +58,53 @@ struct Konst {
 // (Round 2's reciprocal-FMA sequence with its range guard, redo path and exhaustive per-divisor check - bit 1 - is gone: the f64
 //  multiplication is shorter, needs no guard and measured faster everywhere, MAC update included: 176 against 208 / 194 us.)
 constexpr int DM_IEEE = 0, DM_P2 = 1, DM_F64 = 4;
-// The f32 quotient x / d through ONE f64 multiplication: with R = RN64(1 / d), RN32(RN64(x R)) == RN32(x / d) for EVERY f32 x (zeros
-// with their sign, denormals, infinities and NaN included) and every f32 d != 0: x R misses the real quotient by less than 2^-52
-// relative (R's rounding + the product's), while the quotient of two 24-bit numbers is either exactly a rounding boundary of the f32
-// grid or at least ~2^-49 relative away from one - the argument that makes double rounding innocuous for division once the wide format
-// has 2 p + 2 bits (Figueroa) - and a boundary value x / d = m exactly means x = d m exactly, which the f64 product reproduces to within
-// half an f64 ulp of m, i.e. rounds to m.  3 instructions (v_cvt_f64_f32, v_mul_f64, v_cvt_f32_f64) against 11, no range guard, no redo
-// path.  Checked anyway: tests/test_f64div.py (numpy: all 2^23 significands of several binades + random bit patterns, divisors of
-// several resolutions) and on the device (fs_selftest_f64div: ~2^28 dividends per divisor).
+// The f32 quotient x / d through ONE f64 multiplication: with R = RN64(1 / d), RN32(RN64(x R)) == RN32(x / d) for every f32 x unless x / d
+// is EXACTLY a rounding boundary (tie) of the f32 grid: x R misses the real quotient by less than 2^-52 relative (R's rounding + the
+// product's), while a quotient of two 24-bit numbers that is not a tie stays at least 2^-49 relative away from one - the argument that
+// makes double rounding innocuous for division once the wide format has 2 p + 2 bits (Figueroa).  3 instructions (v_cvt_f64_f32,
+// v_mul_f64, v_cvt_f32_f64) against 11.
+// Exact ties.  A NORMAL quotient is never one (a 25-bit tie times the divisor does not fit a 24-bit dividend).  Among the
+// denormals the grid is coarser, and x / d = (m + 1/2) 2^-149 happens for f32 x exactly when d = D 2^e with D odd and e >= 1 - an EVEN
+// INTEGER (x = D (2 m + 1) 2^(e - 150) must be a multiple of 2^-149).  RN64(x R) can then sit one f64 ulp beside the tie, on the side
+// round-to-even would not have taken (d = 1e5, x = 9.108440018111311e-40).  Of this library's loop-invariant divisors only the Reynolds
+// number can be an even integer in practice (1e6, 1000, 1e8 ...); dx, 2 dx, dx^2, dx^3, 6 dx are below one, 8 dt is unless dt >= 1/4.  So:
+//   * tie_free(d) is decided per divisor on the host (fs_host.h): the plain three-instruction form is used only for divisors that admit
+//     no tie; a launch whose dx- / dt-derived divisors fail the test falls back to the IEEE division (never seen outside the tests);
+//   * the division by Re (rdiv below) always takes the guarded form: a result that came out denormal is recomputed by the IEEE division.  That catches every wrong answer: the wrong and the right result of a tie are neighbours, and of such a pair one
+//     is always a denormal (the tie between the largest denormal and 2^-126 resolves to 2^-126, the one between 0 and 2^-149 to 0 - the
+//     wrong answer is the denormal).  One v_cmp_class and a branch no healthy wave takes, on ONE division per cell and component.
+// Checked: tests/test_f64div.py (numpy: all significands of several binades, random bit patterns, and every tie dividend of even-integer
+// divisors against the guarded form) and on the device per divisor (fs_selftest_f64div runs the form the library would use for it).
 __device__ __forceinline__ float f64div(float x, double rd) { return (float)((double)x * rd); }
 __device__ __forceinline__ double f64div(double x, double) { return x; }                    // f64 fields: never selected
-// x / d for a dx-derived divisor / for any other loop-invariant divisor
+#ifndef FS_RDIV_FIX
+#define FS_RDIV_FIX 2
+#endif
+__device__ __forceinline__ float f64div_guarded(float x, float d, double rd)
+{
+#if FS_RDIV_FIX == 1      // (A/B) branch-free: one Newton step makes the f64 quotient exact for exact cases - two f64 FMAs on every division
+    const double xd = (double)x;
+    double p = xd * rd;
+    const double r = __builtin_fma(-p, (double)d, xd);
+    p = __builtin_fma(r, rd, p);
+    return (float)p;
+#elif FS_RDIV_FIX == 2
+    float q = (float)((double)x * rd);
+    if (__builtin_expect(__builtin_amdgcn_class(q, 0x90), 0)) q = x / d;       // 0x90: -denormal | +denormal
+    return q;
+#else                     // (A/B) round 3's unguarded form
+    (void)d;
+    return (float)((double)x * rd);
+#endif
+}
+__device__ __forceinline__ double f64div_guarded(double x, double, double) { return x; }
+// x / d for a dx-derived divisor / for any other loop-invariant divisor / for the Reynolds number (always guarded: one division per cell and component)
 template <int DM, typename T>
 __device__ __forceinline__ T xdiv(T x, T d, T inv_d, double rd) { return (DM & DM_P2) ? x * inv_d : ((DM & DM_F64) ? f64div(x, rd) : x / d); }
 template <int DM, typename T>
 __device__ __forceinline__ T cdiv(T x, T d, double rd) { return (DM & DM_F64) ? f64div(x, rd) : x / d; }
+template <int DM, typename T>
+__device__ __forceinline__ T rdiv(T x, T d, double rd) { return (DM & DM_F64) ? f64div_guarded(x, d, rd) : x / d; }
 
 
 template <typename T> __device__ __forceinline__ T tmin(T a, T b);

@@ -15,6 +15,7 @@
 #include "fs_kernels.h"
 #include "fs_march.h"
 #include "fs_rbpair.h"
+#include "fs_rbmarch.h"
 #include "fs_jquad.h"
 #include "fs_k34n.h"
 
@@ -69,6 +70,9 @@ struct fs_ctx {
     uint8_t *d_mask = nullptr;
     uint8_t *d_bcmap = nullptr;    // [rows][Pm] recipe byte of the pressure boundary condition per cell (fs_march.h k_jacobi_lazy)
     uint8_t *d_lazyflags = nullptr;   // [nwx][rows] tile needs the lazy evaluation
+    uint8_t *d_rbcode = nullptr;   // [rows][Pm] bits 0-6 of the recipe byte + bit 7 "mask != 0": the ONE byte plane of the marching red-black pass (fs_rbmarch.h)
+    int use_rbmarch = 0;           // env FS_RBMARCH=1: the two-iteration red-black pass as a row-marching pipeline (fs_rbmarch.h) instead of register tiles (fs_rbpair.h)
+    int rbm_L = 38, rbm_pf = 3;    // env FS_RBM_L (12 m - 10: 14, 26, 38, 50, 62 ...), FS_RBM_PF (1 / 3): strip height and prefetch distance of the marching form
     std::vector<uint8_t> h_bcmap;  // host copy between build_bc_ops and the upload
     bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
     bool rb_pair_ok = false;                 // mask admits the two-iteration red-black pass (fs_rbpair.h; decided in build_bc_ops)
@@ -118,7 +122,7 @@ struct fs_ctx {
     int k34_rt = 0;            // env FS_K34_RT: rows per register tile (2 / 4) of that pass at 2 cells per lane; 0: by grid size
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
-    int xcd_group_fam[6] = {0, 0, 0, 0, 0, 0};   // ... of single kernel families (env FS_XCD_GROUP_FAM; 0: xcd_group)
+    int xcd_group_fam[7] = {0, 0, 0, 0, 0, 0, 1};   // ... of single kernel families (env FS_XCD_GROUP_FAM; 0: xcd_group)
     int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
     int stack_mask = 0;       // env FS_STACK: kernel families (XCD_* bits) launched with stacked workgroups
     int cg_inner_mask = 0;    // env FS_CG_INNER: kernel families whose channel-group passes over one tile are consecutive workgroups of one XCD
@@ -192,10 +196,24 @@ inline Konst<T> make_konst(fs_ctx *ctx, double dt, double dx, double re, double 
     return k;
 }
 
+// fs_device.h f64div: x / d can be EXACTLY a tie between two f32 denormals iff d is an even integer (d = D 2^e, D odd, e >= 1); the plain
+// f64-multiply division is used only for divisors that admit no such tie
+inline bool tie_free(double d)
+{
+    if (!(d == d) || d == 0.0 || std::isinf(d)) return false;
+    int e;
+    double m = std::frexp(std::fabs(d), &e);          // |d| = m 2^e, 0.5 <= m < 1
+    while (m != std::floor(m)) { m *= 2.0; --e; }     // -> odd integer m times 2^e
+    return e < 1;
+}
 // division mode of a launch (fs_device.h DM_*): which kinds of divisors a kernel has decides how many modes it instantiates
-template <typename T> inline int f64_mode(const fs_ctx *c) { return sizeof(T) == 4 && c->use_f64div ? DM_F64 : DM_IEEE; }      // f32 fields: the f64-multiply division
-template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k) { return (k.p2 ? DM_P2 : 0) | f64_mode<T>(c); }   // dx-derived AND other divisors
-template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k) { return k.p2 ? DM_P2 : f64_mode<T>(c); }          // dx-derived divisors only
-template <typename T> inline int dm_const(const fs_ctx *c, const Konst<T> &) { return f64_mode<T>(c); }                      // no dx-derived divisor
+template <typename T> inline int f64_mode(const fs_ctx *c, const Konst<T> &k)      // f32 fields: the f64-multiply division, if every dx- / dt-derived divisor is tie-free
+{
+    const bool ok = tie_free(k.dx) && tie_free(k.two_dx) && tie_free(k.dx_sq) && tie_free(k.dx2_fold) && tie_free(k.dx3_fold) && tie_free(k.six_dx) && tie_free(k.eight_dt);
+    return sizeof(T) == 4 && c->use_f64div && ok ? DM_F64 : DM_IEEE;
+}
+template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k) { return (k.p2 ? DM_P2 : 0) | f64_mode<T>(c, k); }   // dx-derived AND other divisors
+template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k) { return k.p2 ? DM_P2 : f64_mode<T>(c, k); }          // dx-derived divisors only
+template <typename T> inline int dm_const(const fs_ctx *c, const Konst<T> &k) { return f64_mode<T>(c, k); }                      // no dx-derived divisor
 
 }  // namespace fs

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nb
                 const T f0 = f1.a[q];
                 const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
                 const T d2y = xdiv<DM>((fp.a[q] - (T)2.0 * f0) + fm.a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-                const T dif = cdiv<DM>(d2x + d2y, k.re, k.r_re);
+                const T dif = rdiv<DM>(d2x + d2y, k.re, k.r_re);
                 T gp;
                 if (c == 0) {
                     const T pE = q == L ? pr : P[t + 1].a[q == L ? q : q + 1], pW = q == 0 ? pl : P[t + 1].a[q == 0 ? 0 : q - 1];
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_mac_update_n(Grid g, Konst<T> k, int nb
                 }
                 const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
                 const T d2y = xdiv<DM>((fN - (T)2.0 * f0) + fS, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-                const T lap = cdiv<DM>(d2x + d2y, k.re, k.r_re);
+                const T lap = rdiv<DM>(d2x + d2y, k.re, k.r_re);
                 O[c].a[q] = f0 + k.dt * (((-adv) - gp) + lap);
             }
         }
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_dye_n(Grid g, Konst<T> k, in
                 const T fE = q == L ? r : f1.a[q == L ? q : q + 1], fW = q == 0 ? l : f1.a[q == 0 ? 0 : q - 1];
                 const T d2x = xdiv<DM>((fE - (T)2.0 * f0) + fW, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
                 const T d2y = xdiv<DM>((D[c][t + 2].a[q] - (T)2.0 * f0) + D[c][t].a[q], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-                const T dif = cdiv<DM>(d2x + d2y, k.re, k.r_re);
+                const T dif = rdiv<DM>(d2x + d2y, k.re, k.r_re);
                 O.a[q] = f0 + dif * k.dt;
             }
             if (lm.owner && nw[t]) lv_store_sel<T, N>(dn + idx<3, T>(g, c, i0, j), O, nw[t]);

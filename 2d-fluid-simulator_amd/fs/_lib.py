@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libfs_hip.so")     # FS_LIB: A/B builds (tools/)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -97,6 +97,7 @@ _PROTOS = {
     "fs_tape_length": [_c_vp, _c_int, _P(_c_int)],
     "fs_tape_replay": [_c_vp, _c_int, _c_int],
     "fs_tape_free": [_c_vp, _c_int],
+    "fs_box_rates": [_c_vp, _c_sz, _c_dbl, _P(_c_dbl), _P(_c_dbl)],
     "fs_prof_enable": [_c_vp, _c_int],
     "fs_prof_reset": [_c_vp],
     "fs_prof_count": [_c_vp, _P(_c_int)],

@@ -52,9 +52,11 @@ class FluidSimulator:
         self._graphs = {}          # signature -> (graph id, period)
         self._tapes = {}           # (signature, ghost-row bookkeeping state) -> tape
         self._steps = 0
+        self._eager_seen = False   # one step has run outside a capture (the library's compact launch lists exist)
 
     def step(self):
         self._solver.update()
+        self._eager_seen = True        # (captures call the solver directly: see capture_period)
 
     def _counted_step(self):
         self.step()
@@ -93,8 +95,11 @@ class FluidSimulator:
             tape = self._tapes.get(key)
             if tape is None:
                 before = self._steps
-                tape = dev.tape_period(self._counted_step, nsteps=2)
+                # the search executes the steps it logs: at most 2 * tries of them, never more than this call was asked for (ADVICE r3:
+                # with the default of 14 blocks a run(24 .. 27) that found no period took 28 steps)
+                tape = dev.tape_period(self._counted_step, nsteps=2, tries=min(14, nsteps // 2))
                 nsteps -= self._steps - before
+                assert nsteps >= 0, "tape_period executed more steps than run() was asked for"
                 if tape is not None:
                     self._remember(self._tapes, (self._signature(), dev._state_signature()), tape, lambda t: dev.free_tape(t))
             if tape is not None:
@@ -137,11 +142,17 @@ class FluidSimulator:
         self._graph = (signature, graph id, period) - also cached for run() - or None if nothing within the budget repeats."""
         dev, done = self._dev, 0
         self._graph = None
+        if not self._eager_seen and budget >= 2:
+            # libfs_hip builds the compact tile lists of a launch geometry the first time the geometry is launched EAGERLY (building one
+            # synchronises the stream, which a capture forbids): a graph captured before any eager step would carry the dense launches for
+            # life (ADVICE r3).  One eager step first - it counts as one of the steps this call takes.
+            self.step()
+            done = 1
         for period in (1, 2, 3, 4, 6, 12):
             if done + period > budget:
                 break
             sig = self._signature()
-            gid = dev.capture(lambda: [self.step() for _ in range(period)])       # host-side swaps happen, nothing executes
+            gid = dev.capture(lambda: [self._solver.update() for _ in range(period)])       # host-side swaps happen, nothing executes
             back = self._signature() == sig
             dev.replay(gid, 1)                                                    # now the captured steps run once
             done += period

@@ -2,7 +2,9 @@
 
 Only ONE thing has to travel outside RCCL: the 128-byte ncclUniqueId from rank 0 to the others.  The ranks
 of a `torch.distributed.run` (or any) single-node launch share a parent process and MASTER_PORT, which key a
-file in /tmp: rank 0 writes it atomically, the others poll.  Everything after that (barriers, max-over-ranks
+file in /tmp: rank 0 writes it atomically, the others poll.  A launcher that knows better exports FS_RDZV_NONCE, one
+value per job (`bench.py --gpus N` does when it starts its own ranks): it becomes part of the key, and two jobs of one
+long-lived parent on one port can no longer see each other's files.  Everything after that (barriers, max-over-ranks
 of the timings) goes through the communicator itself (Device.barrier / Device.allgather_scalars), so the
 benchmark process needs no torch / MPI import at all.
 """
@@ -46,11 +48,16 @@ class FileRendezvous:
         if key is None:      # launcher identity + restart generation: a worker group restarted by the same launcher gets new files
             key = "_".join([os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "0"),
                             str(os.getppid()), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")])
+            nonce = os.environ.get("FS_RDZV_NONCE", "")
+            if nonce:        # per-job token from the launcher: nothing an earlier job left behind can carry it
+                key += "_" + "".join(c for c in nonce if c.isalnum() or c in "-_")[:64]
         self.base = os.path.join(_private_dir(), f"fs_rdzv_{key}")
         self.calls = 0
         if rank == 0:
-            # leftovers of a crashed earlier job whose key repeats (a long-lived parent launching several jobs on the same MASTER_PORT):
-            # rank 0 removes them before it writes anything - a reader can then only ever see this job's files or none
+            # leftovers of a crashed earlier job whose key repeats (a long-lived parent launching several jobs on the same MASTER_PORT
+            # WITHOUT an FS_RDZV_NONCE): rank 0 removes them before it writes anything.  That narrows the window, it does not close
+            # it - a rank that starts before rank 0 can still read such a file if it is younger than the launcher; the ranks would
+            # then wait in ncclCommInitRank until FS_COMM_TIMEOUT.  Launchers that start several jobs export FS_RDZV_NONCE.
             import glob
             for old in glob.glob(self.base + "_*"):
                 try:

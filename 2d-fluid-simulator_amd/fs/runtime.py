@@ -262,13 +262,26 @@ class DeviceBase:
             return list(values)
         raise NotImplementedError("this backend needs _p_max_over_ranks for slab runs")
 
+    _BIG = 1 << 40      # far above any count that is agreed on (tape lengths, periods); exact in the f64 the collectives carry
+
     def _p_min_max_over_ranks(self, value):
-        """(min, max) of one small non-negative integer over all ranks (collective; built on _p_max_over_ranks)."""
+        """(min, max) of one non-negative integer below 2^40 over all ranks (collective; built on _p_max_over_ranks)."""
         if self.nranks == 1:
             return value, value
-        big = 1 << 20
-        hi, neg_lo = self._p_max_over_ranks([value, big - value])
-        return big - int(neg_lo), int(hi)
+        if not 0 <= value < self._BIG:
+            raise ValueError("_p_min_max_over_ranks: value out of range")
+        hi, neg_lo = self._p_max_over_ranks([value, self._BIG - value])
+        return self._BIG - int(neg_lo), int(hi)
+
+    def _p_same_over_ranks(self, values):
+        """True iff every rank passed the same list of non-negative integers (ONE collective: [v, BIG - v] per element - element-wise
+        maxima agree with the local values exactly when minimum and maximum coincide)."""
+        if self.nranks == 1:
+            return True
+        if any(not 0 <= v < self._BIG for v in values):
+            raise ValueError("_p_same_over_ranks: value out of range")
+        got = self._p_max_over_ranks([x for v in values for x in (v, self._BIG - v)])
+        return all(int(got[2 * k]) == v and int(got[2 * k + 1]) == self._BIG - v for k, v in enumerate(values))
 
     def _run(self, name, args, reads=(), writes=(), pointwise=False, full_writes=(), split=True):
         """Launch one kernel on this slab.
@@ -406,8 +419,9 @@ class DeviceBase:
                     log = [op for blk in b for op in blk[2]]
                     per_period = tuple(sum(blk[3][k] for blk in b) for k in range(3))
                     tape = self._compile_tape(log, found * nsteps, per_period, hoist)
-                    np_lo, np_hi = self._p_min_max_over_ranks(len(tape["prologue"]) * 1000 + len(tape["ops"]))
-                    if np_lo != np_hi:
+                    # the shape of the compiled tape must be the same on every rank (the two lengths travel as separate
+                    # elements - packed into one number, tapes of 1000 operations and more would alias)
+                    if not self._p_same_over_ranks([len(tape["prologue"]), len(tape["ops"])]):
                         self.free_tape(tape)
                         return None
                     return tape
@@ -860,6 +874,12 @@ class Device(DeviceBase):
         if tape.get("id") is not None and self._ctx is not None:
             _lib.call("fs_tape_free", self._ctx, tape["id"])
             tape["id"] = None
+
+    def box_rates(self, nbytes, budget_ms=30.0):
+        """(float4 read GB/s, float4 copy GB/s) of this GPU on buffers of `nbytes`, ~budget_ms each (measurement hygiene, include/fs_hip.h)."""
+        rd, cp = ctypes.c_double(), ctypes.c_double()
+        _lib.call("fs_box_rates", self._ctx, ctypes.c_size_t(int(nbytes)), float(budget_ms), ctypes.byref(rd), ctypes.byref(cp))
+        return rd.value, cp.value
 
     # -- per-kernel HIP-event timing ---------------------------------------------------------------------
     def profile(self, on=True):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 5
+#define FS_ABI_VERSION 6
 
 typedef struct fs_ctx fs_ctx;
 typedef struct fs_field fs_field;
@@ -286,6 +286,11 @@ int fs_tape_end(fs_ctx *ctx, int *tape_id);
 int fs_tape_length(fs_ctx *ctx, int tape_id, int *nops);
 int fs_tape_replay(fs_ctx *ctx, int tape_id, int times);
 int fs_tape_free(fs_ctx *ctx, int tape_id);
+
+/* Measurement hygiene (new; no reference counterpart): what THIS GPU streams at - float4 read of one buffer and float4 copy between two
+ * buffers of `bytes` each, about budget_ms of GPU time per leg, HIP events on the context's stream.  bench.py prints the two rates and
+ * `frac_of_box_copy` next to every roofline fraction, so that a slow box is not mistaken for a regression. */
+int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps, double *copy_GBps);
 
 /* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) --------------- */
 int fs_prof_enable(fs_ctx *ctx, int on);          /* record an event pair around every launch      */

@@ -65,3 +65,20 @@ def test_bench_as_n_ranks_matches_single_rank(world, halo, single):
     assert d["halo_exchanges_per_step"]["grouped_launches"] > 0
     assert d["roofline"]["frac"] > 0 and d["poisson_jacobi_sweep"]["frac"] > 0
     assert "cpu_baseline" not in d and single["value"] > 0
+
+
+def test_bench_gpus_2_as_one_command(single):
+    """`python bench.py --gpus 2 ...` with no launcher around it.  The parent never touches the GPU: it starts the two
+    ranks itself (here the socket stand-in as the rank program, both pinned to GPU 0), relays rank 0's single JSON line and exits 0."""
+    port = random.randint(20000, 50000)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(FS_BENCH_WORKER=os.path.join(REPO, "tests", "bench_socket_worker.py"), FS_BENCH_LOCAL_RANK="0", FS_FAKE_PORT=str(port),
+               FS_BENCH_TIMEOUT="600")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "y-slab x2"
+    assert d["state_checksum"] == single["state_checksum"]
+    assert d["box"]["copy_GBps"] > 100 and d["roofline"]["frac_of_box_copy"] > 0

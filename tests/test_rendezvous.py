@@ -68,3 +68,77 @@ def test_default_directory_is_private(monkeypatch):
     d = rendezvous._private_dir()
     st = os.lstat(d)
     assert stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o077)
+
+
+def test_job_nonce_separates_jobs_of_one_parent(tmp_path, monkeypatch):
+    """two jobs started by ONE long-lived parent on ONE MASTER_PORT.  A fresh file of the first job (younger than the
+    parent, so the age test cannot reject it) must not reach the second job's ranks: FS_RDZV_NONCE is part of the key."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2d-fluid-simulator_amd"))
+    monkeypatch.setenv("FS_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    from fs.rendezvous import FileRendezvous
+    monkeypatch.setenv("FS_RDZV_NONCE", "job-1")
+    a0 = FileRendezvous(0, 2)
+    a0.bcast(b"id of job 1")                      # job 1 dies here: its file stays
+    monkeypatch.setenv("FS_RDZV_NONCE", "job-2")
+    b1 = FileRendezvous(1, 2, timeout=0.3)        # job 2's rank 1 is up before its rank 0
+    try:
+        b1.bcast(None)
+        raise AssertionError("rank 1 of job 2 read job 1's payload")
+    except TimeoutError:
+        pass
+    b0 = FileRendezvous(0, 2)
+    b0.bcast(b"id of job 2")
+    b1 = FileRendezvous(1, 2, timeout=5)
+    assert b1.bcast(None) == b"id of job 2"
+    assert a0.base != b0.base
+
+
+def _bench_module():
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(repo, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_WORKER = """
+import os, sys, time
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and os.environ["FS_RDZV_NONCE"]
+assert os.environ["LOCAL_RANK"] == (os.environ.get("FS_BENCH_LOCAL_RANK") or str(r))
+mode = os.environ.get("T_MODE", "ok")
+if mode == "die" and r == 1:
+    sys.exit(3)
+if mode in ("die", "hang") and r != 1:
+    time.sleep(600)
+print(f"rank {r} of {w} args {sys.argv[1:]}" if r else '{"n_gpus": %d}' % w, flush=True)
+"""
+
+
+def test_bench_starts_its_own_ranks(tmp_path, monkeypatch, capfd):
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts N child ranks, relays rank 0's single line and returns the
+    worst status; a rank that dies, or a job that hangs, ends with the others killed and a non-zero status (no GPU involved here:
+    FS_BENCH_WORKER swaps the rank program for a stub)."""
+    import sys
+    import time
+    bench = _bench_module()
+    worker = tmp_path / "worker.py"
+    worker.write_text(_WORKER)
+    monkeypatch.setenv("FS_BENCH_WORKER", str(worker))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "7"])
+    assert bench.spawn_ranks(3) == 0
+    out = capfd.readouterr()
+    assert out.out.strip() == '{"n_gpus": 3}'                       # rank 0's line, and nothing else, on stdout
+    assert "rank 1 of 3 args ['--gpus', '3', '--steps', '7']" in out.err and "rank 2 of 3" in out.err
+    monkeypatch.setenv("T_MODE", "die")
+    t0 = time.time()
+    rc = bench.spawn_ranks(3)
+    assert rc == 3 and time.time() - t0 < 60                        # the sleeping ranks were killed after the grace period
+    monkeypatch.setenv("T_MODE", "hang")
+    monkeypatch.setenv("FS_BENCH_TIMEOUT", "2")
+    t0 = time.time()
+    assert bench.spawn_ranks(2) == 124 and time.time() - t0 < 30
