@@ -97,6 +97,33 @@ static int launch(fs_ctx *c, const char *name, F &&f)
     return FS_OK;
 }
 
+// the same event pair for work that is not a single kernel launch (fs_comm.hip: the pack -> RCCL -> unpack chain of a ghost-row exchange),
+// on the stream that work is queued on
+ProfRec prof_span_begin(fs_ctx *c, const char *name, hipStream_t stream)
+{
+    ProfRec rec{};
+    rec.name_id = -1;
+    if (!(c->prof_on && !c->capturing)) return rec;
+    auto it = c->prof_ids.find(name);
+    if (it == c->prof_ids.end()) {
+        it = c->prof_ids.emplace(name, (int)c->prof_names.size()).first;
+        c->prof_names.push_back(name);
+        c->prof_launches.push_back(0);
+        c->prof_ms.push_back(0.0);
+    }
+    rec.name_id = it->second;
+    rec.start = prof_event(c);
+    rec.stop = prof_event(c);
+    (void)hipEventRecord(rec.start, stream);
+    return rec;
+}
+void prof_span_end(fs_ctx *c, const ProfRec &rec, hipStream_t stream)
+{
+    if (rec.name_id < 0) return;
+    (void)hipEventRecord(rec.stop, stream);
+    c->prof_recs.push_back(rec);
+}
+
 static int prof_drain(fs_ctx *c)
 {
     if (c->prof_recs.empty()) return FS_OK;
@@ -116,7 +143,7 @@ static int prof_drain(fs_ctx *c)
 static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
 
 // overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
-struct OvGrid { int nbx, nby; dim3 grid; Grid g; };
+struct OvGrid { int nbx, nby; dim3 grid; Grid g; int threads = 256; };    // threads: 64 x waves per workgroup
 enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16, XCD_JACOBI = 32, XCD_MARCH = 64 };   // XCD_MARCH: the row-marching passes - one strip row per XCD group, workgroups side by side
 // Compact list of the workgroups of a dense XCD-band launch that have anything to do (Grid::tiles), built once per geometry from the
 // host-side activity maps of the scene.  lanes = cells per lane (4: wave columns of 248 cells, 2: of 120), rt = rows per tile.
@@ -125,16 +152,18 @@ enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 1
 // `lanes` names the wave geometry: 4 = quads, 62 owner lanes (248 cells, 4 halo cells per side); 2 = pairs, 60 owner lanes (120 cells, 4 halo
 // cells); 3 = pairs, 62 owner lanes (124 cells, 2 halo cells)
 static inline int geo_cells(int lanes) { return lanes == 4 ? 4 : 2; }
-static inline int geo_owners(int lanes) { return lanes == 2 ? 60 : 62; }
-static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls = 0, int reach = 0)
+static inline int geo_owners(int lanes) { return lanes == 2 ? 60 : (lanes == 5 ? 58 : (lanes == 6 ? 56 : 62)); }   // 5 / 6: pairs with 3 / 4 halo lanes per side (the 6- / 8-sweep marching passes; no compact lists)
+static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls = 0, int reach = 0, int wgw = 4, int jb = 0, int je = -1)
 {
-    if (c->halo != 0 || c->h_act4.empty() || nbx > 0xfff || nby > 0xfffff) return nullptr;
-    const uint32_t key = (uint32_t)lanes | ((uint32_t)rt << 4) | ((uint32_t)stacked << 12) | ((uint32_t)group << 16) | ((uint32_t)cls << 24) | ((uint32_t)reach << 26);
+    if (c->h_act4.empty() || nbx > 0xfff || nby > 0xfffff || lanes > 4 || c->rows > 0xffff) return nullptr;
+    if (je < 0) je = c->rows;
+    const uint32_t key0 = (uint32_t)lanes | ((uint32_t)rt << 4) | ((uint32_t)stacked << 12) | ((uint32_t)group << 16) | ((uint32_t)cls << 24) | ((uint32_t)reach << 26) | ((uint32_t)(wgw & 7) << 29);
+    const std::pair<uint32_t, uint32_t> key(key0, ((uint32_t)jb << 16) | (uint32_t)je);      // slab launches cover varying row ranges: one list per range
     auto it = c->tile_lists.find(key);
     if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
     if (c->capturing || c->tape_rec) return nullptr;      // (building one synchronises the stream: not inside a capture - the dense grid then)
     const std::vector<uint8_t> &act = lanes == 4 ? c->h_act4 : (lanes == 2 ? c->h_act2 : c->h_act2w);
-    const int ow = geo_owners(lanes), waves = (c->X / geo_cells(lanes) + ow - 1) / ow, Y = c->Y;
+    const int ow = geo_owners(lanes), waves = (c->X / geo_cells(lanes) + ow - 1) / ow, Y = c->rows;       // (activity maps are indexed by LOCAL row)
     std::vector<uint32_t> per[8];
     const int groups = (nby + group - 1) / group;
     // inside a group the workgroups are listed column by column: vertically adjacent workgroups, which re-read each other's halo rows, are
@@ -148,8 +177,8 @@ static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stac
                 if (by >= nby) continue;
                 {
                     // wave columns / rows of this workgroup (4 waves: side by side, or stacked = 4 tile rows of one column)
-                    const int wx0 = stacked ? bx : bx * 4, wx1 = std::min(waves, stacked ? bx + 1 : bx * 4 + 4);
-                    const int j0 = (stacked ? by * 4 : by) * rt, j1 = std::min(Y, (stacked ? by * 4 + 4 : by + 1) * rt);
+                    const int wx0 = stacked ? bx : bx * wgw, wx1 = std::min(waves, stacked ? bx + 1 : bx * wgw + wgw);
+                    const int j0 = jb + (stacked ? by * wgw : by) * rt, j1 = std::min(je, jb + (stacked ? by * wgw + wgw : by + 1) * rt);
                     bool any = false;
                     for (int wx = wx0; wx < wx1 && !any; ++wx)
                         for (int j = j0; j < j1; ++j)
@@ -189,22 +218,24 @@ static void tile_lists_free(fs_ctx *c)
 
 // XCD-band launch geometry of a tile kernel family (fs_march.h band_coords); `lanes`: cells per lane.  When the launch covers the whole
 // single-GPU grid, the workgroups without anything to do are left out (compact list, Grid::tiles).
-static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true, int cls = 0, int reach = 0)
+static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true, int cls = 0, int reach = 0, int wgw = 4)
 {
     OvGrid o;
     o.g = c->grid();
     const int ow = geo_owners(lanes);
     const int nu = c->X / geo_cells(lanes), waves = (nu + ow - 1) / ow, tiles = (je - jb + rt - 1) / rt;
     const bool stacked = (c->stack_mask & family) != 0;    // the 4 waves of a workgroup: 4 tile rows of one wave column
-    o.nbx = stacked ? waves : (waves + 3) / 4;
-    o.nby = stacked ? (tiles + 3) / 4 : tiles;
+    o.threads = 64 * wgw;
+    o.nbx = stacked ? waves : (waves + wgw - 1) / wgw;
+    o.nby = stacked ? (tiles + wgw - 1) / wgw : tiles;
     if (c->xcd_mask & family) {
         // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords)
         int xg = c->xcd_group;
         for (int f = 0; f < 7; ++f) if ((family >> f) & 1) xg = c->xcd_group_fam[f] > 0 ? c->xcd_group_fam[f] : xg;
-        const int group = stacked ? std::max(1, xg / 4) : xg;     // the same number of field rows per XCD group
+        const int group = stacked ? std::max(1, xg / wgw) : xg;     // the same number of field rows per XCD group
         const int groups = (o.nby + group - 1) / group;
-        const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && jb == 0 && je == c->rows ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach) : nullptr;
+        const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && ((jb == 0 && je == c->rows) || (c->halo != 0 && cls == 0))
+                                         ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach, wgw, jb, je) : nullptr;
         const bool inner = zgroups > 1 && (tl || (c->cg_inner_mask & family) != 0);
         if (tl) { o.grid = dim3(8 * tl->per_xcd * zgroups, 1, 1); o.g.tiles = tl->d; }
         else o.grid = inner ? dim3(8 * o.nbx * zgroups, group, (groups + 7) / 8) : dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
@@ -606,7 +637,7 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     const size_t cells = (size_t)ctx->X * ctx->rows;      // (this context's slab)
     const int N = ctx->X % 4 != 0 ? 2 : (ctx->k34_n ? ctx->k34_n : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4));
     const int RT = N == 4 ? 2 : (ctx->k34_rt ? ctx->k34_rt : (cells >= ((size_t)1 << 23) ? 4 : 2)), geo = N == 2 ? 3 : 4;
-#define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
+#define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
         (T *)f_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v ? (const T *)v->d : (const T *)nullptr, \
         f_out->hot, (const uint8_t *)ctx->d_bcmap, full)
 #define FS_K34_24(DM) FS_K34(2, 4, DM, false)
@@ -619,8 +650,8 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     // Compact launch in two parts on large single-GPU grids (as fs_rbsor_pair): the workgroups that see nothing but fluid within
     // reach run without mask loads, selects and conditional stores (PLAIN), the others the general tile
     if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
-        const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 1, 2);
-        const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 2, 2);
+        const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 1, 2, ctx->split_wgw);
+        const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 2, 2, ctx->split_wgw);
         if (og.g.tiles && ogb.g.tiles) {
             int rc = launch(ctx, name, [=] { FS_K34_ANY(P); });
             if (rc) return rc;
@@ -673,8 +704,11 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
+    if (const char *s = getenv("FS_SPLIT_WGW")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->split_wgw = v; }
     if (const char *s = getenv("FS_RBMARCH")) c->use_rbmarch = atoi(s);
     if (const char *s = getenv("FS_RBM_L")) { const int v = atoi(s); if (v >= 14 && v <= 254 && (v + 10) % 12 == 0) c->rbm_L = v; }
+    if (const char *s = getenv("FS_JM_L")) { const int v = atoi(s); if (v >= 2 && v <= 254 && v % 2 == 0) c->jm_L = v; }
+    if (const char *s = getenv("FS_JM_PF")) { const int v = atoi(s); if (v == 1 || v == 3) c->jm_pf = v; }
     if (const char *s = getenv("FS_RBM_PF")) { const int v = atoi(s); if (v == 1 || v == 3) c->rbm_pf = v; }
     if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : (atoi(s) == 4 ? 4 : 0);
     if (const char *s = getenv("FS_MAC_RT")) { const int v = atoi(s); c->mac_rt = v == 2 || v == 4 ? v : 0; }
@@ -721,6 +755,7 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_bcmap) hipFree(ctx->d_bcmap);
     if (ctx->d_lazyflags) hipFree(ctx->d_lazyflags);
     if (ctx->d_rbcode) hipFree(ctx->d_rbcode);
+    if (ctx->d_jcode) hipFree(ctx->d_jcode);
     if (ctx->d_pairlist) hipFree(ctx->d_pairlist);
     if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -811,6 +846,12 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
         std::vector<uint8_t> rb((size_t)ctx->X * ctx->Y);
         for (size_t q = 0; q < rb.size(); ++q) rb[q] = (uint8_t)((ctx->h_bcmap[q] & 0x7f) | (mask_xy[q] != 0 ? 0x80 : 0));
         rc = upload_global(ctx, ctx->d_rbcode, 1, 1, rb.data(), ctx->Pm);
+        if (rc == FS_OK) {   // ... and the marching Jacobi passes recipe bits + "wall" (the sweep computes every cell that is not a wall)
+            if (!ctx->d_jcode) FS_HIP(hipMalloc(&ctx->d_jcode, (size_t)ctx->rows * ctx->Pm));
+            FS_HIP(hipMemsetAsync(ctx->d_jcode, 0x80, (size_t)ctx->rows * ctx->Pm, ctx->stream));
+            for (size_t q = 0; q < rb.size(); ++q) rb[q] = (uint8_t)((ctx->h_bcmap[q] & 0x7f) | (mask_xy[q] == 1 ? 0x80 : 0));
+            rc = upload_global(ctx, ctx->d_jcode, 1, 1, rb.data(), ctx->Pm);
+        }
     }
     // activity of the scene per (wave column, row) for the compact launches: a cell is "deep wall" when it is a wall cell that no
     // boundary kernel writes - workgroups made of such cells only have nothing to do in any kernel
@@ -820,22 +861,25 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     for (auto &tp : ctx->tapes) if (tp) { delete tp; tp = nullptr; }
     tile_lists_free(ctx);
     ctx->h_act4.clear(); ctx->h_act2.clear(); ctx->h_act2w.clear();
-    if (ctx->halo == 0 && ctx->X % 2 == 0 && ctx->tile_list_mask) {
-        const int X = ctx->X, Y = ctx->Y;
+    if (ctx->X % 2 == 0 && ctx->tile_list_mask && ctx->rows <= 0xffff) {
+        // indexed by LOCAL row (a slab: its ghost rows included; rows outside the domain are deep wall)
+        const int X = ctx->X, Y = ctx->Y, R = ctx->rows, g0 = ctx->y0 - ctx->halo;
         struct Geo { std::vector<uint8_t> *act; int w, halo; } geos[3] = {{&ctx->h_act4, 248, 4}, {&ctx->h_act2, 120, 4}, {&ctx->h_act2w, 124, 2}};
         for (const Geo &ge : geos) {
             const int w = ge.w, n = (X + w - 1) / w;
-            ge.act->assign((size_t)n * Y, 0);
+            ge.act->assign((size_t)n * R, 0);
             for (int i = 0; i < X; ++i) {
                 const uint8_t *m = mask_xy + (size_t)i * Y, *b = ctx->h_bcmap.data() + (size_t)i * Y;
-                uint8_t *a = ge.act->data() + (size_t)(i / w) * Y;
+                uint8_t *a = ge.act->data() + (size_t)(i / w) * R;
                 // the neighbouring wave column whose halo lanes cover column i, if any
                 const int r = i % w;
-                uint8_t *h = r < ge.halo && i / w > 0 ? a - Y : (r >= w - ge.halo && i / w + 1 < n ? a + Y : nullptr);
-                for (int j = 0; j < Y; ++j) {
+                uint8_t *h = r < ge.halo && i / w > 0 ? a - R : (r >= w - ge.halo && i / w + 1 < n ? a + R : nullptr);
+                for (int lr = 0; lr < R; ++lr) {
+                    const int j = g0 + lr;
+                    if (j < 0 || j >= Y) { a[lr] |= 2; if (h) h[lr] |= 2; continue; }
                     const uint8_t nf = m[j] != 0 ? 2 : 0;
-                    a[j] |= (uint8_t)((m[j] != 1) | (b[j] != 0)) | nf;
-                    if (h) h[j] |= nf;
+                    a[lr] |= (uint8_t)((m[j] != 1) | (b[j] != 0)) | nf;
+                    if (h) h[lr] |= nf;
                 }
             }
         }
@@ -1599,6 +1643,35 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     });
 }
 
+// `sweeps` (4, 6 or 8) lazily-bounded Jacobi sweeps in one row-marching pass (fs_jmarch.h): pn[not wall] <- sweep^S(pc); the conditions of
+// the four-sweep pass (fs_jacobi_quad_ok).  Strip height: 12 m - 2 S rows (the 12-step loop body then runs whole), the tallest that still
+// gives every SIMD of the chip a few waves (FS_JM_L overrides).
+int fs_jacobi_march(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int sweeps, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
+    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
+    FS_REQUIRE(sweeps == 4 || sweeps == 6 || sweeps == 8, "sweeps per pass: 4, 6 or 8");
+    FS_ROWS();
+    if (!(ctx->jq_ok && ctx->use_pairs && ctx->dtype == 0)) { set_error("this mask / precision does not admit the multi-sweep Jacobi passes (fs_jacobi_quad_ok)"); return FS_ERR_UNSUPPORTED; }
+    using T = float;
+    int L = ctx->jm_L;
+    if (L <= 0) {
+        const int ow = 64 - sweeps, cols = (ctx->X / 2 + ow - 1) / ow, rows = row_end - row_begin;
+        L = 12 - 2 * sweeps > 0 ? 12 - 2 * sweeps : 24 - 2 * sweeps;
+        while (L + 12 <= 254 && (long long)cols * (rows / (L + 12)) >= 2048) L += 12;       // at least ~2 waves per SIMD
+    }
+    const int pf = ctx->jm_pf;
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, L, 1, XCD_MARCH, sweeps == 4 ? 2 : (sweeps == 6 ? 5 : 6), true, 0);
+    const JmArgs a{(const uint8_t *)ctx->d_jcode, pn->d, pc->d, src->d};
+#define FS_JM_K(S, PF) hipLaunchKernelGGL((k_jacobi_march<2, S, PF, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, L, a)
+    return launch(ctx, "jacobi_march", [=] {
+        if (sweeps == 4) { if (pf == 3) FS_JM_K(4, 3); else FS_JM_K(4, 1); }
+        else if (sweeps == 6) { if (pf == 3) FS_JM_K(6, 3); else FS_JM_K(6, 1); }
+        else FS_JM_K(8, 1);            // (8 sweeps: the code-word ring of 12 rows holds S + 2 + PF = 11)
+    });
+}
+
 // the last two rounds of a lazily-bounded Jacobi run in one pass (fs_jquad.h k_jacobi_finish): from pc = raw iterate n-2,
 //   pc_out <- iterate n (not-wall cells) + K7(iterate n-2) (wall cells with a recipe);  pn <- iterate n-1 as K7 leaves it
 int fs_jacobi_finish(fs_ctx *ctx, fs_field *pc_out, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end)
@@ -1655,15 +1728,15 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
 #define FS_RBM_DM(PF) do { if (dm & DM_F64) FS_RBM_PAR(PF, 4); else FS_RBM_PAR(PF, 0); } while (0)
         return launch(ctx, "rbsor_pair", [=] { if (pf == 1) FS_RBM_DM(1); else FS_RBM_DM(3); });
     }
-#define FS_RBP_K(RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBP_K(RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBP_PAR(RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, PATH, FULL); else FS_RBP_K(RT, 0, DM, PATH, FULL); } while (0)
 #define FS_RBP_DM(RT, PATH) do { if (dm & DM_F64) FS_RBP_PAR(RT, 4, PATH, false); else FS_RBP_PAR(RT, 0, PATH, false); } while (0)
     // Compact launch in two parts where the lists exist (single GPU, whole grid): the workgroups that see nothing but fluid within reach run
     // the plain path as its own kernel (PATH 3: no mask loads, 126 VGPRs = 4 waves per SIMD), the others the kernel with both paths.
     if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4);
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw);
         if (og.g.tiles && ogb.g.tiles) {
             int rc = launch(ctx, "rbsor_pair", [=] { FS_RBP_DM(4, 3); });
             if (rc) return rc;

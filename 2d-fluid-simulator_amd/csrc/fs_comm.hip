@@ -371,7 +371,9 @@ static int begin(fs_ctx *ctx, fs_field *const *fields, const int *valid, int nfi
     if (depth == 0 || nfields == 0 || (lower < 0 && upper < 0)) { cm->in_flight = true; cm->armed = false; cm->marked = false; return FS_OK; }
     if (!cm->own_stream) {      // in line on the compute stream: ordered by the stream itself, nothing to wait for later
         cm->marked = false;
+        const ProfRec span = prof_span_begin(ctx, "halo_exchange", ctx->stream);       // pack -> grouped send / recv -> unpack, as one span
         rc = exchange(ctx, ctx->stream, fields, valid, nfields, depth, lower, upper);
+        prof_span_end(ctx, span, ctx->stream);
         if (rc) return rc;
         cm->in_flight = true;
         cm->armed = false;
@@ -380,7 +382,9 @@ static int begin(fs_ctx *ctx, fs_field *const *fields, const int *valid, int nfi
     if (!cm->marked) FS_HIP(hipEventRecord(cm->ev_compute, ctx->stream));   // everything queued so far produces the rows we send
     cm->marked = false;
     FS_HIP(hipStreamWaitEvent(cm->stream, cm->ev_compute, 0));
+    const ProfRec span = prof_span_begin(ctx, "halo_exchange", cm->stream);
     rc = exchange(ctx, cm->stream, fields, valid, nfields, depth, lower, upper);
+    prof_span_end(ctx, span, cm->stream);
     if (rc) return rc;
     FS_HIP(hipEventRecord(cm->ev_comm, cm->stream));
     cm->in_flight = true;

@@ -16,6 +16,7 @@
 #include "fs_march.h"
 #include "fs_rbpair.h"
 #include "fs_rbmarch.h"
+#include "fs_jmarch.h"
 #include "fs_jquad.h"
 #include "fs_k34n.h"
 
@@ -71,6 +72,8 @@ struct fs_ctx {
     uint8_t *d_bcmap = nullptr;    // [rows][Pm] recipe byte of the pressure boundary condition per cell (fs_march.h k_jacobi_lazy)
     uint8_t *d_lazyflags = nullptr;   // [nwx][rows] tile needs the lazy evaluation
     uint8_t *d_rbcode = nullptr;   // [rows][Pm] bits 0-6 of the recipe byte + bit 7 "mask != 0": the ONE byte plane of the marching red-black pass (fs_rbmarch.h)
+    uint8_t *d_jcode = nullptr;    // [rows][Pm] bits 0-6 of the recipe byte + bit 7 "wall" (mask == 1): the byte plane of the marching Jacobi passes (fs_jmarch.h)
+    int jm_L = 0, jm_pf = 1;       // env FS_JM_L (rows per strip; 0: by grid size), FS_JM_PF (1 / 3): strip height and prefetch distance of those passes
     int use_rbmarch = 0;           // env FS_RBMARCH=1: the two-iteration red-black pass as a row-marching pipeline (fs_rbmarch.h) instead of register tiles (fs_rbpair.h)
     int rbm_L = 38, rbm_pf = 3;    // env FS_RBM_L (12 m - 10: 14, 26, 38, 50, 62 ...), FS_RBM_PF (1 / 3): strip height and prefetch distance of the marching form
     std::vector<uint8_t> h_bcmap;  // host copy between build_bc_ops and the upload
@@ -81,6 +84,7 @@ struct fs_ctx {
     int rbpair_split = 1;                    // plain and boundary workgroups of that pass (and of the four-sweep Jacobi pass) as two compact
                                              // launches: env FS_RBPAIR_SPLIT = 0 never, 1 on grids of 8 M cells or more, 2 always
     int rbpair_rt = 4;                       // rows per tile of that pass (env FS_RBPAIR_RT = 4, 6)
+    int split_wgw = 1;                       // env FS_SPLIT_WGW = 1 / 2 / 4: waves per workgroup of the two-part launches - the plain / boundary classification is per workgroup
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
     int pair_rt = 3;                         // rows per tile of the two-sweep kernel (env FS_PAIR_RT = 1 .. 4; 3: within 2 % of the best of 2 / 3 / 4 from res 1024 to 4096)
@@ -134,9 +138,9 @@ struct fs_ctx {
     // it per launch geometry (key: lane width, rows per tile, stacked, group size)
     int tile_list_mask = 1 | 2 | 4 | 8 | 32;              // env FS_TILE_LIST: kernel families (XCD_* bits) launched compactly.  Measured at bc5 res 4096:
                                              // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement (2-cell lanes) 97 -> 95, K2 (2-cell lanes) 105 -> 102, the plain Jacobi sweeps 87.2 -> 85.8 (reading v) / 75.5 -> 74.1 (source pair)
-    std::vector<uint8_t> h_act4, h_act2, h_act2w;     // [wave column][global row]
+    std::vector<uint8_t> h_act4, h_act2, h_act2w;     // [wave column][local row]
     struct TileList { uint32_t *d = nullptr; int per_xcd = 0; };
-    std::map<uint32_t, TileList> tile_lists;
+    std::map<std::pair<uint32_t, uint32_t>, TileList> tile_lists;     // key: (geometry, row range)
 
     fs::Grid grid() const
     {
@@ -161,6 +165,10 @@ struct fs_field {
 };
 
 namespace fs {
+
+// HIP-event pair around a span of stream work that is not one kernel launch (fs_api.hip; the ghost-row exchange chain of fs_comm.hip)
+ProfRec prof_span_begin(fs_ctx *c, const char *name, hipStream_t stream);
+void prof_span_end(fs_ctx *c, const ProfRec &rec, hipStream_t stream);
 
 // dx (as rounded to T) is an exact power of two: division by it may be replaced by multiplication
 template <typename T>

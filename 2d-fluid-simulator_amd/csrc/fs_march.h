@@ -24,11 +24,13 @@ template <typename T> struct Quad;
 template <> struct Quad<float> { using type = float4; };
 template <> struct Quad<double> { using type = double4; };
 
-// value of the previous / next lane (undefined in lane 0 / lane 63: the caller patches those)
+// value of the previous / next lane (0 in lane 0 / lane 63 and where the source lane is switched off: the caller patches those).
+// bound_ctrl:1 says exactly that - with bound_ctrl:0 and an `old` operand of 0 the compiler emitted a v_mov_b32 0 in front of every shift
+// (round 4: one VALU instruction less per neighbour exchange in every tile kernel, 5 - 6 % of their VALU count; same values).
 __device__ __forceinline__ float lane_prev(float x)
-{ return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, false)); }   // wave_shr:1
+{ return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true)); }   // wave_shr:1
 __device__ __forceinline__ float lane_next(float x)
-{ return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, false)); }   // wave_shl:1
+{ return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true)); }   // wave_shl:1
 __device__ __forceinline__ double lane_prev(double x) { return __shfl_up(x, 1, 64); }
 __device__ __forceinline__ double lane_next(double x) { return __shfl_down(x, 1, 64); }
 
@@ -67,8 +69,8 @@ __device__ __forceinline__ typename Quad<T>::type load_quad_if(bool need, const 
     return q;
 }
 
-__device__ __forceinline__ unsigned lane_prev_u(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned lane_next_u(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned lane_prev_u(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned lane_next_u(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, true); }
 // does this lane, or a lane next to it, have any active cell?  (its loads feed the neighbours through DPP)
 __device__ __forceinline__ bool lane_needed(unsigned active) { return (active | lane_prev_u(active) | lane_next_u(active)) != 0u; }
 

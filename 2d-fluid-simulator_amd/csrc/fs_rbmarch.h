@@ -37,39 +37,52 @@ template <int N> __device__ __forceinline__ unsigned rbm_sel_fluid(uint32_t cw)
     return s;
 }
 
-// Row loads of the marching loop.  fs_march.h load_row_quad gets the `saddr` form (scalar row base + one 32-bit lane offset) because base and
-// offset meet in one basic block; here the lane offset is loop-invariant, gets hoisted - zero-extended to 64 bits - out of the loop, and
-// instruction selection, which works block by block, no longer sees a 32-bit offset: every load then costs a 64-bit VALU add and an address
-// register pair.  The empty asm makes the offset opaque at each use, so the extension stays next to the load.
-template <typename Q, typename T>
-__device__ __forceinline__ Q rbm_load_row(const T *row, unsigned byte_off)
+// ---- loads the compiler does not schedule ---------------------------------------------------------------------------------------
+// The rings only pay if a row is REQUESTED PF steps before it is used and nothing waits for it in between.  hipcc's own s_waitcnt
+// insertion cannot be held to that in these loops (dozens of wave-uniform branches per step: after the merges it waits with vmcnt(0)
+// right behind the loads it has just issued - measured: the same time per step for PF = 1 and 3, 0.59 of the wave cycles parked).  So the
+// ring loads are inline asm (invisible to that pass) and the waits are ours:
+//   * every step issues the SAME number of ring loads (rows past the window are clamped onto its last row: an L1 hit) - the counter
+//     arithmetic below depends on it;
+//   * mwait<K>() = s_waitcnt vmcnt(K) with K = loads issued SINCE the ones that are needed: memory operations retire in order, and the
+//     stores in between (compiler-issued, a varying number) only make the wait stricter;
+//   * the registers of the arriving row pass through an empty asm ("+v") behind the wait, so no use can move in front of it;
+//   * an in-flight value lives in ONE 64-bit register pair from request to arrival (fs_f2, not two floats: a sub-register copy the
+//     allocator might place behind the load would read the pair before it has landed), and the loop's back edge waits for everything
+//     (vmcnt(0) once per 12 steps), so copies the allocator places there see landed data.
+typedef float fs_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mload2(fs_f2 &dst, const float *row, unsigned byte_off)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(byte_off));
-    return *reinterpret_cast<__attribute__((address_space(1))) const Q *>((fs_gcptr)uniform64((uint64_t)row) + byte_off);
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(uniform64((uint64_t)row)) : "memory");
 #else
-    return *reinterpret_cast<const Q *>((const char *)row + byte_off);
+    dst = *(const fs_f2 *)((const char *)row + byte_off);
 #endif
 }
-template <int C, typename T, int N>
-__device__ __forceinline__ LV<T, N> rbm_field(const T *f, const Grid &g, int c, int i0, int j)
+__device__ __forceinline__ void mload_u16(uint32_t &dst, const uint8_t *row, unsigned byte_off)
 {
-    const typename LVec<T, N>::type q = rbm_load_row<typename LVec<T, N>::type, T>(f + ((size_t)j * C + c) * g.P, (unsigned)i0 * (unsigned)sizeof(T));
-    LV<T, N> r;
-    if constexpr (N == 4) { r.a[0] = q.x; r.a[1] = q.y; r.a[2] = q.z; r.a[3] = q.w; }
-    else { r.a[0] = q.x; r.a[1] = q.y; }
-    return r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_ushort %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(uniform64((uint64_t)row)) : "memory");
+#else
+    dst = *(const uint16_t *)(row + byte_off);
+#endif
 }
-template <int N>
-__device__ __forceinline__ uint32_t rbm_bytes(const uint8_t *plane, const Grid &g, int i0, int j)
-{ return (uint32_t)rbm_load_row<typename LMaskWord<N>::type, uint8_t>(plane + (size_t)j * g.Pm, (unsigned)i0); }
+template <int K> __device__ __forceinline__ void mwait()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K) : "memory");
+#endif
+}
+__device__ __forceinline__ LV<float, 2> lv_of(const fs_f2 &v) { LV<float, 2> r; r.a[0] = v.x; r.a[1] = v.y; return r; }
+__device__ __forceinline__ fs_f2 f2_of(const LV<float, 2> &v) { fs_f2 r; r.x = v.a[0]; r.y = v.a[1]; return r; }
+__device__ __forceinline__ const float *row_ptr(const void *f, const Grid &g, int C, int c, int j) { return (const float *)f + ((size_t)j * C + c) * g.P; }
 
-template <typename T, int N, int PF>
+template <int PF>
 struct RbmState {
     static constexpr int DR = 3 + PF;      // raw rows t-2 .. t+PF
-    using R = LV<T, N>;
-    R PA[DR], VX[DR], VY[DR];
-    R PB[DR];                              // rows t-4 .. t-2+PF: raw until stage 1 has run on the row, then the state after iteration 1's odd pass
+    using R = LV<float, 2>;
+    fs_f2 PA[DR], VX[DR], VY[DR];          // requested PF steps ahead (mload2)
+    fs_f2 PB[DR];                          // rows t-4 .. t-2+PF: raw until stage 1 has run on the row, then the state after iteration 1's odd pass
     R VA[6];                               // view(A), rows t-5 .. t-1
     R S2[6], S3[6];                        // Poisson source, rows t-6 .. t-1
     R P2[3];                               // after iteration 1's even pass, rows t-5 .. t-3
@@ -92,30 +105,34 @@ struct RbmArgs {
     const void *A, *B, *v;
 };
 
-// U = t mod 12 (compile time), t = step (wave-uniform)
-template <int U, int N, int PF, int PAR0, int DM, typename T>
-__device__ __forceinline__ void rbm_step(RbmState<T, N, PF> &s, const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm, int i0, int j0, int je, int t, int W,
+// U = t mod 12 (compile time), t = step (wave-uniform).  Ring loads per step: 5.
+template <int U, int PF, int PAR0, int DM>
+__device__ __forceinline__ void rbm_step(RbmState<PF> &s, const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, unsigned off4, unsigned off1, int j0, int je, int t, int W,
                                          const RbmArgs &a)
 {
-    constexpr int DR = 3 + PF;
-    constexpr unsigned ALL = (1u << N) - 1u;
+    constexpr int DR = 3 + PF, N = 2;
+    constexpr unsigned ALL = 3u;
+    using T = float;
     using R = LV<T, N>;
-    {   // prefetch: window row t + PF of A, v and the code plane, row t + PF - 2 of B
-        const int j = clampy(g, j0 - 4 + t + PF), jb = clampy(g, j0 - 4 + t + PF - 2);
+    {   // request window row t + PF of A, v and the code plane, row t + PF - 2 of B (rows past the window: its last row again - an L1 hit)
+        const int wr = t + PF < W ? t + PF : W - 1, wb = t + PF - 2 < W ? t + PF - 2 : W - 1;
+        const int j = clampy(g, j0 - 4 + wr), jb = clampy(g, j0 - 4 + wb);
         constexpr int sl = (U + PF) % DR;
-        if (t + PF < W) {                  // (rows past the window: nothing valid reads them)
-            s.PA[sl] = rbm_field<1, T, N>((const T *)a.A, g, 0, i0, j);
-            s.VX[sl] = rbm_field<2, T, N>((const T *)a.v, g, 0, i0, j);
-            s.VY[sl] = rbm_field<2, T, N>((const T *)a.v, g, 1, i0, j);
-            s.CW[(U + PF) % 12] = rbm_bytes<N>(a.rbcode, g, i0, j);
-        }
-        if (t + PF - 2 < W - 1) s.PB[(U + PF - 2 + 12) % DR] = rbm_field<1, T, N>((const T *)a.B, g, 0, i0, jb);
+        mload2(s.PA[sl], row_ptr(a.A, g, 1, 0, j), off4);
+        mload2(s.VX[sl], row_ptr(a.v, g, 2, 0, j), off4);
+        mload2(s.VY[sl], row_ptr(a.v, g, 2, 1, j), off4);
+        mload_u16(s.CW[(U + PF) % 12], a.rbcode + (size_t)j * g.Pm, off1);
+        mload2(s.PB[(U + PF - 2 + 12) % DR], row_ptr(a.B, g, 1, 0, jb), off4);
     }
-    __builtin_amdgcn_sched_barrier(0);
     constexpr int r0 = U + 12;             // (U - k + 12) % depth: non-negative operands
+    // rows t of A / v / code and t - 2 of B were requested PF steps ago: 5 PF loads have been issued since
+    mwait<5 * PF>();
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(s.PA[r0 % DR]), "+v"(s.VX[r0 % DR]), "+v"(s.VY[r0 % DR]), "+v"(s.CW[r0 % 12]), "+v"(s.PB[(r0 - 2) % DR]));
+#endif
     {   // Poisson source of row t-1 from v rows t-2, t-1, t (fs/pressure_updater.py:25-38), once per cell for all four half sweeps
-        const R &xm = s.VX[(r0 - 2) % DR], &xc = s.VX[(r0 - 1) % DR], &xp = s.VX[r0 % DR];
-        const R &ym = s.VY[(r0 - 2) % DR], &yc = s.VY[(r0 - 1) % DR], &yp = s.VY[r0 % DR];
+        const R xm = lv_of(s.VX[(r0 - 2) % DR]), xc = lv_of(s.VX[(r0 - 1) % DR]), xp = lv_of(s.VX[r0 % DR]);
+        const R ym = lv_of(s.VY[(r0 - 2) % DR]), yc = lv_of(s.VY[(r0 - 1) % DR]), yp = lv_of(s.VY[r0 % DR]);
         const T xl = lv_left<T, N>(lm, xc), xr = lv_right<T, N>(lm, xc), yl = lv_left<T, N>(lm, yc), yr = lv_right<T, N>(lm, yc);
         R &s2 = s.S2[(r0 - 1) % 6], &s3 = s.S3[(r0 - 1) % 6];
 #pragma unroll
@@ -126,20 +143,22 @@ __device__ __forceinline__ void rbm_step(RbmState<T, N, PF> &s, const Grid &g, c
         }
     }
     // view(A) of row t-1 (lv_bc_row returns the raw row unless the wave's row holds a target)
-    s.VA[(r0 - 1) % 6] = lv_bc_row<T, N>(lm, s.PA[(r0 - 2) % DR], s.PA[(r0 - 1) % DR], s.PA[r0 % DR], s.CW[(r0 - 1) % 12]);
+    s.VA[(r0 - 1) % 6] = lv_bc_row<T, N>(lm, lv_of(s.PA[(r0 - 2) % DR]), lv_of(s.PA[(r0 - 1) % DR]), lv_of(s.PA[r0 % DR]), s.CW[(r0 - 1) % 12]);
     // stage 1: odd pass of iteration 1 on row t-2, B[odd] <- view(A); in place in the ring
     {
         constexpr int PAR = (PAR0 + U + 10) & 1;       // parity of window row t-2
+        R pb = lv_of(s.PB[(r0 - 2) % DR]);
         rbp_relax<PAR, 1>(k, lm, rbm_sel_fluid<N>(s.CW[(r0 - 2) % 12]), s.VA[(r0 - 3) % 6], s.VA[(r0 - 2) % 6], s.VA[(r0 - 1) % 6],
-                          s.S2[(r0 - 2) % 6], s.S3[(r0 - 2) % 6], s.PB[(r0 - 2) % DR]);
+                          s.S2[(r0 - 2) % 6], s.S3[(r0 - 2) % 6], pb);
+        s.PB[(r0 - 2) % DR] = f2_of(pb);
     }
     // stage 2: even pass of iteration 1 on row t-3, from the stage-1 state of rows t-4, t-3, t-2
     {
         constexpr int PAR = (PAR0 + U + 9) & 1;
         R &o = s.P2[(r0 - 3) % 3];
-        o = s.PB[(r0 - 3) % DR];
-        rbp_relax<PAR, 0>(k, lm, rbm_sel_fluid<N>(s.CW[(r0 - 3) % 12]), s.PB[(r0 - 4) % DR], s.PB[(r0 - 3) % DR], s.PB[(r0 - 2) % DR],
-                          s.S2[(r0 - 3) % 6], s.S3[(r0 - 3) % 6], o);
+        const R bm = lv_of(s.PB[(r0 - 4) % DR]), bc = lv_of(s.PB[(r0 - 3) % DR]), bp = lv_of(s.PB[(r0 - 2) % DR]);
+        o = bc;
+        rbp_relax<PAR, 0>(k, lm, rbm_sel_fluid<N>(s.CW[(r0 - 3) % 12]), bm, bc, bp, s.S2[(r0 - 3) % 6], s.S3[(r0 - 3) % 6], o);
     }
     // view(B') of row t-4
     s.VB[(r0 - 4) % 3] = lv_bc_row<T, N>(lm, s.P2[(r0 - 5) % 3], s.P2[(r0 - 4) % 3], s.P2[(r0 - 3) % 3], s.CW[(r0 - 4) % 12]);
@@ -161,7 +180,7 @@ __device__ __forceinline__ void rbm_step(RbmState<T, N, PF> &s, const Grid &g, c
         const int w = t - 6, j = j0 - 4 + w;
         if (w >= 4 && w <= W - 5 && j < je) {
             const unsigned sel = fl | lv_sel_target<N>(cw);
-            T *pc = (T *)a.C + idx<1, T>(g, 0, i0, j), *pd = (T *)a.D + idx<1, T>(g, 0, i0, j);
+            T *pc = (T *)a.C + (size_t)j * g.P + lm.i0, *pd = (T *)a.D + (size_t)j * g.P + lm.i0;
             if (__all(sel == ALL)) {       // the common row: every cell of the wave is stored - one vector store per lane and plane
                 if (lm.owner) {
                     lv_store_sel<T, N>(pc, o, ALL);
@@ -175,48 +194,51 @@ __device__ __forceinline__ void rbm_step(RbmState<T, N, PF> &s, const Grid &g, c
     }
 }
 
-template <int U, int N, int PF, int PAR0, int DM, typename T>
+template <int U, int PF, int PAR0, int DM>
 struct RbmUnroll {
-    static __device__ __forceinline__ void run(RbmState<T, N, PF> &s, const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm, int i0, int j0, int je, int t0, int W, const RbmArgs &a)
+    static __device__ __forceinline__ void run(RbmState<PF> &s, const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, unsigned off4, unsigned off1, int j0, int je, int t0, int W, const RbmArgs &a)
     {
-        rbm_step<U, N, PF, PAR0, DM, T>(s, g, k, lm, i0, j0, je, t0 + U, W, a);
-        if constexpr (U + 1 < 12) RbmUnroll<U + 1, N, PF, PAR0, DM, T>::run(s, g, k, lm, i0, j0, je, t0, W, a);
+        rbm_step<U, PF, PAR0, DM>(s, g, k, lm, off4, off1, j0, je, t0 + U, W, a);
+        if constexpr (U + 1 < 12) RbmUnroll<U + 1, PF, PAR0, DM>::run(s, g, k, lm, off4, off1, j0, je, t0, W, a);
     }
 };
 
-// grid: workgroups of 4 waves = 4 neighbouring wave columns (60 owner lanes of N cells) of ONE strip of L rows; dense XCD-band launch or
-// compact list (band_coords).  PAR0: parity of (g.ybase + jb - 4), a launch constant because L is even.
+// grid: workgroups of 4 waves = 4 neighbouring wave columns (60 owner lanes of 2 cells) of ONE strip of L rows; dense XCD-band launch or
+// compact list (band_coords).  PAR0: parity of (g.ybase + jb - 4), a launch constant because L is even.  f32, lanes of 2 cells.
 template <int N, int PF, int PAR0, int DM, typename T>
 __global__ __launch_bounds__(256) void k_rbsor_march(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, int L, RbmArgs a)
 {
+    static_assert(N == 2 && sizeof(T) == 4, "the marching passes are built for f32 on lanes of 2 cells");
     int wx, ty;
     if (!tile_coords_n<N>(g, nbx, nby, jb, je, L, wx, ty)) return;
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
-    const int i0 = lm.i0, j0 = jb + ty * L, W = L + 8;
-    RbmState<T, N, PF> s;
+    const int j0 = jb + ty * L, W = L + 8;
+    const unsigned off4 = (unsigned)lm.i0 * 4u, off1 = (unsigned)lm.i0;
+    RbmState<PF> s;
     constexpr int DR = 3 + PF;
 #pragma unroll
-    for (int r = 0; r < DR; ++r) { s.PA[r] = lv_zero<T, N>(); s.VX[r] = lv_zero<T, N>(); s.VY[r] = lv_zero<T, N>(); s.PB[r] = lv_zero<T, N>(); }
+    for (int r = 0; r < DR; ++r) { s.PA[r] = fs_f2{0.f, 0.f}; s.VX[r] = fs_f2{0.f, 0.f}; s.VY[r] = fs_f2{0.f, 0.f}; s.PB[r] = fs_f2{0.f, 0.f}; }
 #pragma unroll
     for (int r = 0; r < 6; ++r) { s.VA[r] = lv_zero<T, N>(); s.S2[r] = lv_zero<T, N>(); s.S3[r] = lv_zero<T, N>(); }
 #pragma unroll
     for (int r = 0; r < 3; ++r) { s.P2[r] = lv_zero<T, N>(); s.VB[r] = lv_zero<T, N>(); s.P3[r] = lv_zero<T, N>(); }
 #pragma unroll
     for (int r = 0; r < 12; ++r) s.CW[r] = 0x80808080u;          // "not fluid, no recipe": rows that were never loaded relax nothing
-    // rows 0 .. PF-1 of A, v and the code plane, rows 0 .. PF-3 of B: what steps -PF .. -1 would have requested
+    // what steps -PF .. -1 would have requested (5 loads each: the counter arithmetic of rbm_step holds from the first step on)
 #pragma unroll
     for (int r = 0; r < PF; ++r) {
-        const int j = clampy(g, j0 - 4 + r);
-        s.PA[r % DR] = rbm_field<1, T, N>((const T *)a.A, g, 0, i0, j);
-        s.VX[r % DR] = rbm_field<2, T, N>((const T *)a.v, g, 0, i0, j);
-        s.VY[r % DR] = rbm_field<2, T, N>((const T *)a.v, g, 1, i0, j);
-        s.CW[r % 12] = rbm_bytes<N>(a.rbcode, g, i0, j);
-        if (r < PF - 2) s.PB[r % DR] = rbm_field<1, T, N>((const T *)a.B, g, 0, i0, j);
+        const int j = clampy(g, j0 - 4 + r), jb2 = clampy(g, j0 - 4 + (r >= 2 ? r - 2 : 0));
+        mload2(s.PA[r % DR], row_ptr(a.A, g, 1, 0, j), off4);
+        mload2(s.VX[r % DR], row_ptr(a.v, g, 2, 0, j), off4);
+        mload2(s.VY[r % DR], row_ptr(a.v, g, 2, 1, j), off4);
+        mload_u16(s.CW[r % 12], a.rbcode + (size_t)j * g.Pm, off1);
+        mload2(s.PB[(r - 2 + 12) % DR], row_ptr(a.B, g, 1, 0, jb2), off4);
     }
-    __builtin_amdgcn_sched_barrier(0);
     // the last stored row is window row W - 5 = step W + 1: L + 10 steps, a whole number of 12-step bodies when L = 12 m - 10
-    for (int t0 = 0; t0 < W + 2; t0 += 12)
-        RbmUnroll<0, N, PF, PAR0, DM, T>::run(s, g, k, lm, i0, j0, je, t0, W, a);
+    for (int t0 = 0; t0 < W + 2; t0 += 12) {
+        RbmUnroll<0, PF, PAR0, DM>::run(s, g, k, lm, off4, off1, j0, je, t0, W, a);
+        mwait<0>();          // the back edge: whatever copies the register allocator places there must see landed data
+    }
 }
 
 }  // namespace fs

@@ -61,6 +61,7 @@ _PROTOS = {
     "fs_jacobi_pair_lazy": [_c_vp, _c_vp, _c_vp, _c_vp, _c_int] + _ROWS,
     "fs_jacobi_quad_ok": [_c_vp, _P(_c_int)],
     "fs_jacobi_quad_lazy": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_jacobi_march": [_c_vp, _c_vp, _c_vp, _c_vp, _c_int] + _ROWS,
     "fs_jacobi_finish": [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_lazy_flags": [_c_vp, _c_vp, _c_int, _P(_c_int), _P(_c_int), _P(_c_int)],
     "fs_selftest_f64div": [_c_vp, _c_dbl, _P(_c_int)],

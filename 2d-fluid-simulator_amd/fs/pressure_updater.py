@@ -64,6 +64,12 @@ class JacobiPressureUpdater(PressureUpdater):
         self._quads = (self._pairs and n_iter >= 10 and os.environ.get("FS_JACOBI_QUADS", "1") == "1" and getattr(self._dev, "jacobi_quad_ok", False))
         if self._quads:
             self.form = "four sweeps per pass"
+        # S sweeps per pass as a row-marching pipeline (fs_jacobi_march, csrc/fs_jmarch.h) where the four-sweep pass is admitted: a strip of
+        # L rows costs L + 2 S rows of loads and of every sweep, a 4-row tile 12 and 10.  FS_JACOBI_MARCH = 0 / 4 / 6 / 8 (sweeps per pass).
+        want_m = os.environ.get("FS_JACOBI_MARCH", "0")
+        self._march = int(want_m) if (self._quads and want_m in ("4", "6", "8") and n_iter - 2 >= int(want_m)) else 0
+        if self._march:
+            self.form = f"{self._march} sweeps per pass, row-marching"
         if tentative and not self._pairs:
             self._precompute, self._src, self._lazy = False, None, False
         # The last two rounds - 2 x (boundary kernel + sweep), which leave both buffers as the reference does - in ONE pass into a third
@@ -79,6 +85,11 @@ class JacobiPressureUpdater(PressureUpdater):
         if self._quads and p.current.static_id == p.next.static_id:
             # four sweeps per pass (the pass writes not-wall cells only: the wall cells nothing writes must be equal in the two buffers,
             # Field.static_id); what does not fill a pass runs as single lazily-bounded sweeps
+            if self._march:
+                for _ in range(n_lazy // self._march):
+                    self._dev.jacobi_march(p.next, p.current, self._src, self._march)
+                    p.swap()
+                n_lazy %= self._march
             for _ in range(n_lazy // 4):
                 self._dev.jacobi_quad_lazy(p.next, p.current, self._src)
                 p.swap()
@@ -129,11 +140,13 @@ class RedBlackSorPressureUpdater(PressureUpdater):
         # pair: TWO iterations and the two boundary passes between them in one pass over HBM (csrc/fs_rbpair.h; same bits, 25 instead of
         # 2 x 21 B per fluid cell and two launches less).  Out of place: the pressure rotates through a second pair of buffers.  Needs a
         # mask that admits it (Device.rb_pair_ok: no one-cell-thin walls between fluid regions), f32, and on slabs a halo of 4 rows.
-        # Slab runs keep the single iterations by default: the pass wants v and p.current 4 rows deep at the END of the step, where the
-        # ghost rows are at their shallowest - at halo 16 the tracker then exchanges 1.5 times per step instead of once every step with an
-        # 11-step pattern no tape can hold (tools/slab_period.py), which costs more than the pass saves on an eighth of the grid.
+        # Slab runs: the pass wants v and p.current 4 rows deep at the END of the step, where the ghost rows are at their shallowest.  At halo 16
+        # the tracker then exchanges 0.6 times per step in a 5-step pattern that, times the 6-step buffer rotation, no tape can hold; at halo 20
+        # (the default for slabs of 160 rows and more since round 4) the pattern is one exchange every 2 steps with and without the pass
+        # (tools/slab_period.py) and the pass is on - loop-back, middle slab of the 8-way cut of bc5 res 4096: 131-132 us per step against
+        # 133-134 at halo 16 without it (profiles/r3_loopback_slab_step.txt).  Shallower halos keep the single iterations.
         if pair is None:
-            pair = os.environ.get("FS_RBSOR_PAIR", "1" if self._dev.nranks == 1 else "0") == "1"
+            pair = os.environ.get("FS_RBSOR_PAIR", "1" if (self._dev.nranks == 1 or self._dev.halo >= 20) else "0") == "1"
         self._pair = (bool(pair) and fast and n_iter >= 2 and getattr(self._dev, "rb_pair_ok", False)
                       and (self._dev.nranks == 1 or self._dev.halo >= 4))
         self._spare = (self._dev.alloc(1), self._dev.alloc(1)) if self._pair else None

@@ -148,7 +148,9 @@ class DeviceBase:
     """Slab geometry + ghost-row bookkeeping + one method per reference kernel (backend-agnostic)."""
 
     MIN_HALO = 2       # deepest stencil on the path: Kawamura-Kuwahara / velocity-BC mirror (fs/advection.py:39-55)
-    DEFAULT_HALO = 16  # slabs: ghost rows per side.  Deeper = fewer, larger exchanges (6 / 3 / 2 / 1 grouped send/recv
+    DEFAULT_HALO = 20  # slabs: ghost rows per side (round 4: 20 for slabs of 160 rows and more, 16 from 128 rows: at 20 the exchange pattern of
+                       # the default solver is one grouped exchange every 2 steps WITH the two-iteration red-black pass, whose reach of 4 rows
+                       # breaks the period of the pattern at 16 - tools/slab_period.py).  Deeper = fewer, larger exchanges (6 / 3 / 2 / 1 grouped send/recv
                        # launches per CIP+VC step at depth 2 / 4 / 8 / 16) for (depth/rows) redundant compute.  One grouped
                        # exchange costs ~45 us of GPU-side latency (pack, RCCL kernel, unpack, stream hand-offs) whatever
                        # its size, a 512-row slab step 130 us: the fewest exchanges win (tools/overlap_bench.py).
@@ -164,7 +166,7 @@ class DeviceBase:
             # the default must be the SAME number on every rank (neighbours exchange `halo` rows with each other and run the
             # same validity bookkeeping): derive it from the thinnest slab of the decomposition, not from this rank's own height
             thinnest = self.ny // nranks
-            halo = 0 if nranks == 1 else int(os.environ.get("FS_HALO", self.DEFAULT_HALO if thinnest >= 128 else min(8, thinnest)))
+            halo = 0 if nranks == 1 else int(os.environ.get("FS_HALO", self.DEFAULT_HALO if thinnest >= 160 else (16 if thinnest >= 128 else min(8, thinnest))))
         self.halo = int(halo)
         if nranks > 1 and self.halo < self.MIN_HALO:
             raise ValueError(f"slab decomposition needs halo >= {self.MIN_HALO}")
@@ -640,6 +642,10 @@ class DeviceBase:
     def jacobi_quad_lazy(self, pn, pc, src):
         """Four lazily-bounded sweeps in one pass, pn[not wall] <- sweep^4(pc) (csrc/fs_jquad.h)."""
         self._run("jacobi_quad_lazy", (pn._h, pc._h, src._h), reads=[(pc, 4), (src, 3)], writes=[pn])
+
+    def jacobi_march(self, pn, pc, src, sweeps):
+        """`sweeps` (4, 6, 8) lazily-bounded sweeps in one row-marching pass, pn[not wall] <- sweep^S(pc) (csrc/fs_jmarch.h)."""
+        self._run("jacobi_march", (pn._h, pc._h, src._h, int(sweeps)), reads=[(pc, sweeps), (src, sweeps - 1)], writes=[pn])
 
     def jacobi_finish(self, pc_out, pn, pc, src):
         """The last two (K7, sweep, swap) rounds of a lazily-bounded run in one pass (csrc/fs_jquad.h k_jacobi_finish): pc = raw iterate n-2;

@@ -415,6 +415,23 @@ def main():
                 entry["frac_of_box_copy"] = round(entry["GBps"] / box["copy_GBps"], 4)
         kernels[name] = entry
     dominant = max((k for k in kernels if "GBps" in kernels[k]), key=lambda k: kernels[k]["share"] * 1.0, default=None)
+    # slab runs: what an exchange costs in line (pack -> grouped RCCL send / recv -> unpack, one HIP-event span on the stream it is queued
+    # on) against the longest kernel that could cover it if the exchange ran on the communication stream (FS_OVERLAP=1): the model the
+    # overlap decision is taken from - not from a loop-back run, where the RCCL kernel competes with the compute kernels for the same CUs
+    exchange_model = None
+    if "halo_exchange" in kernels:
+        ex = kernels["halo_exchange"]
+        compute = {k: v for k, v in kernels.items() if k != "halo_exchange"}
+        longest = max(compute, key=lambda k: compute[k]["avg_us"]) if compute else None
+        chain_step = ex["avg_us"] * ex["launches_per_step"]
+        exchange_model = {
+            "chain_us": ex["avg_us"], "exchanges_per_step": ex["launches_per_step"], "chain_us_per_step": round(chain_step, 2),
+            "compute_us_per_step": round(sum(v["avg_us"] * v["launches_per_step"] for v in compute.values()), 2),
+            "longest_kernel": longest, "longest_kernel_us": compute[longest]["avg_us"] if longest else None,
+            "coverable_us_per_step": round(min(ex["avg_us"], compute[longest]["avg_us"]) * ex["launches_per_step"], 2) if longest else 0.0,
+            "overlap": "on (FS_OVERLAP=1)" if dev.overlap_stream else "off (in line on the compute stream)",
+            "reading": "an exchange on the communication stream can hide at most min(chain, longest kernel) per exchange, and costs two more strip "
+                       "launches and three stream hand-offs (~8 us each, DESIGN.md 6): worth it when coverable_us_per_step exceeds ~25 us x exchanges_per_step"}
 
     # ---- isolated Poisson Jacobi sweep (the roofline-graded kernel): S sweeps ping-ponging two p buffers ---
     # Two bit-identical forms: reading v like the reference, and reading the per-step precomputed source pair
@@ -502,6 +519,7 @@ def main():
         "box": box,
         "state_checksum": checksum,
         "poisson_residual": residual,
+        "exchange_model": exchange_model,
         "halo_exchanges_per_step": None if world == 1 else {
             "grouped_launches": round(dev.n_exchanges / max(total_steps, 1), 2),
             "fields": round(dev.n_exchanged_fields / max(total_steps, 1), 2),
