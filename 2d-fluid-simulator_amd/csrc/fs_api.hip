@@ -693,6 +693,8 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     e = hipMalloc(&c->d_mask, (size_t)c->rows * c->Pm);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_mask, 1, (size_t)c->rows * c->Pm, c->stream);   // never the null stream: see upload_ops
     if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&c->d_sync, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_sync, 0, 4 * sizeof(unsigned), c->stream);
     c->nwx = (nx / 4 + 61) / 62;
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
@@ -752,6 +754,7 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_bc_dye) hipFree(ctx->d_bc_dye);
     if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->d_acc) hipFree(ctx->d_acc);
+    if (ctx->d_sync) hipFree(ctx->d_sync);
     if (ctx->d_bcmap) hipFree(ctx->d_bcmap);
     if (ctx->d_lazyflags) hipFree(ctx->d_lazyflags);
     if (ctx->d_rbcode) hipFree(ctx->d_rbcode);
@@ -941,8 +944,8 @@ int fs_field_alloc(fs_ctx *ctx, int nchan, fs_field **out)
     f->bytes = (size_t)ctx->rows * nchan * ctx->P * ctx->esize;
     hipError_t e = hipMalloc(&f->d, f->bytes);
     if (e == hipSuccess) e = hipMemsetAsync(f->d, 0, f->bytes, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&f->hot, sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemsetAsync(f->hot, 0, sizeof(unsigned), ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&f->hot, 2 * sizeof(unsigned));       // [0]: the flag; [1]: raised INSIDE a k_velocity_bc_limit launch, folded into [0] when that launch ends
+    if (e == hipSuccess) e = hipMemsetAsync(f->hot, 0, 2 * sizeof(unsigned), ctx->stream);
     if (e != hipSuccess) { if (f->d) hipFree(f->d); if (f->hot) hipFree(f->hot); delete f; return hip_fail(e, "hipMalloc(field)", __FILE__, __LINE__); }
     ctx->fields.insert(f);
     *out = f;
@@ -1060,6 +1063,35 @@ int fs_velocity_bc(fs_ctx *ctx, fs_field *v, int row_begin, int row_end)
         return launch(ctx, "velocity_bc", [=] {
             hipLaunchKernelGGL(k_velocity_bc<T>, dim3((ctx->ops_vel.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, (T *)v->d, (const T *)ctx->d_bc_const, v->hot);
+        });
+    })
+}
+
+// limit_field(v, limit) of the step before + the velocity boundary kernel of this step in one launch (fs_march.h k_velocity_bc_limit):
+// the same result as fs_limit_field over [limit_begin, limit_end) followed by fs_velocity_bc over [row_begin, row_end)
+int fs_velocity_bc_limit_ok(const fs_ctx *ctx, int *ok)
+{
+    FS_REQUIRE(ctx && ok, "null argument");
+    const int wgs = (ctx->ops_vel.lanes() + 255) / 256;
+    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && wgs >= 1 && wgs <= 1024 ? 1 : 0;     // (every workgroup resident: the grid barrier of the rare path)
+    return FS_OK;
+}
+
+int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int limit_begin, int limit_end, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(v, 2);
+    FS_ROWS();
+    FS_REQUIRE(limit_begin >= 0 && limit_begin <= limit_end && limit_end <= ctx->rows, "bad row range of the limit pass");
+    if (!ctx->d_bc_const) { set_error("bc_const not uploaded"); return FS_ERR_STATE; }
+    int rc = bc_guard(ctx); if (rc) return rc;
+    int ok = 0;
+    fs_velocity_bc_limit_ok(ctx, &ok);
+    if (!ok || !((float)limit * (float)limit > FS_HOT_SQ)) { set_error("fs_velocity_bc_limit is not available for this context / limit (fs_velocity_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "velocity_bc", [=] {
+            hipLaunchKernelGGL(k_velocity_bc_limit<T>, dim3((ctx->ops_vel.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, limit_begin, limit_end, (T)limit, (T *)v->d, (const T *)ctx->d_bc_const, v->hot, ctx->d_sync);
         });
     })
 }

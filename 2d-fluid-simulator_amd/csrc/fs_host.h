@@ -96,6 +96,7 @@ struct fs_ctx {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     double *d_acc = nullptr;  // 2 doubles (residual)
+    unsigned *d_sync = nullptr;   // k_velocity_bc_limit: arrive / depart counters of the grid barrier of its rare path, exit ticket (zero between launches)
     double *d_partial = nullptr;   // per-block partial (sum, count) pairs of the residual reduction
     size_t partial_cap = 0;        // pairs
     // graphs
@@ -161,7 +162,7 @@ struct fs_field {
     int C = 1;
     void *d = nullptr;
     size_t bytes = 0;
-    unsigned *hot = nullptr;   // device word: "may hold a speed above 8" (fs_device.h); meaningful for 2-channel fields
+    unsigned *hot = nullptr;   // device words: [0] "may hold a speed above 8" (fs_device.h; meaningful for 2-channel fields), [1] the same, raised inside a k_velocity_bc_limit launch
 };
 
 namespace fs {

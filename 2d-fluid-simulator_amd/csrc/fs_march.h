@@ -854,6 +854,73 @@ __global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, int je, T li
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// limit_field of step n and set_velocity_boundary_condition of step n + 1 in ONE launch (round 4; fs/solver.py:38-43 + :79-81,
+// fs/boundary_condition.py:16-39).  The limit pass is the last kernel of a step and, behind its flag, does nothing in a healthy run - yet
+// on small grids its launch is a fifth of the step (BASELINE configs[0]: 4 launches of ~6 us).  The host defers it (fs/runtime.py: the
+// velocity field carries a pending limit until somebody looks at it) and the boundary kernel of the next step starts with the gate:
+//   flag down (always, in a healthy run): one scalar load, then the op list as in k_velocity_bc;
+//   flag up: the workgroups of this launch - the op list is O(perimeter): a few hundred at most, all resident - share the rows of the
+//   limit pass among them, meet at a grid barrier (arrive / depart counters, agent-scope fences: MI355X_MICROARCH.md "barrier-counter"),
+//   and run the op list on limited values.  Same arithmetic as k_limit_quad, cell by cell.
+// ------------------------------------------------------------------------------------------------
+// The gate must read the SAME value in every workgroup (those that see the flag up wait for all the others at the barrier), and the op list
+// itself may raise the flag (an inflow constant above the limit) while later workgroups have not started yet: inside this launch the op
+// list raises hot[1] instead, and the workgroup that finishes last (exit ticket) folds it into hot[0] for the launches that follow.
+template <typename T>
+__global__ __launch_bounds__(256) void k_velocity_bc_limit(Grid g, BcOps ops, int jb, int je, int lb, int le, T lim, T *v, const T *bc_const, unsigned *hot, unsigned *sync)
+{
+    if (*hot != 0u) {
+        for (int j = lb + (int)blockIdx.x; j < le; j += (int)gridDim.x)
+            for (int i0 = (int)threadIdx.x << 2; i0 < g.X; i0 += 1024) {
+                T *px = v + idx<2, T>(g, 0, i0, j), *py = v + idx<2, T>(g, 1, i0, j);
+                const Q4<T> X(*reinterpret_cast<const typename Quad<T>::type *>(px)), Y(*reinterpret_cast<const typename Quad<T>::type *>(py));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const T x = X.a[q], y = Y.a[q];
+                    const T nrm = tsqrt(x * x + y * y);
+                    if (nrm > lim) {
+                        px[q] = lim * (x / nrm);
+                        py[q] = lim * (y / nrm);
+                    }
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();                                                     // my rows are out (agent scope) before I arrive
+            atomicAdd(&sync[0], 1u);
+            while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(4);
+            __threadfence();                                                     // ... and this CU's L1 forgets what it held of the others' rows
+            if (atomicAdd(&sync[1], 1u) == gridDim.x - 1u) {                     // the last one out resets both counters: everybody has left the spin
+                __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < ops.nsimple) {
+        const int4 o = ops.simple[n];
+        const int trow = o.w >> 2;
+        // a simple mirror / outflow op reads a cell of the same row or of the row +-2 / +-1 next to it: its row travels in .z
+        if (trow >= jb && trow < je) velocity_bc_op(g, o.w & 3, o.x, trow, o.y, o.z, v, bc_const, hot + 1);
+    } else {
+        n -= ops.nsimple;
+        if (n < ops.ncomp && !(ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je))
+            for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o)
+                velocity_bc_op(g, ops.kind[o], ops.tgt[o], ops.row[o], ops.s1[o], ops.srow[o], v, bc_const, hot + 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&sync[2], 1u) == gridDim.x - 1u) {                         // exit ticket: the last workgroup publishes what the op list raised
+            if (__hip_atomic_load(hot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicOr(hot, 1u);
+            __hip_atomic_store(hot + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // clamp_field restricted to the inflow cells (op list of the dye boundary kernel): with the clamp folded into the advection
 // store these are the only other cells of the dye buffer whose value can lie outside [low, high] (the dye BC rewrites them
 // with the scene colour every step).

@@ -37,6 +37,8 @@ _PROTOS = {
     "fs_field_copy": [_c_vp, _c_vp],
     "fs_field_devptr": [_c_vp, _P(_c_vp), _P(_c_sz)],
     "fs_velocity_bc": [_c_vp, _c_vp] + _ROWS,
+    "fs_velocity_bc_limit_ok": [_c_vp, _P(_c_int)],
+    "fs_velocity_bc_limit": [_c_vp, _c_dbl, _c_vp, _c_int, _c_int] + _ROWS,
     "fs_pressure_bc": [_c_vp, _c_vp] + _ROWS,
     "fs_dye_bc": [_c_vp, _c_vp] + _ROWS,
     "fs_mac_update": [_c_vp, _c_int, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,

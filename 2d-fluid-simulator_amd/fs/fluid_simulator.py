@@ -53,10 +53,18 @@ class FluidSimulator:
         self._tapes = {}           # (signature, ghost-row bookkeeping state) -> tape
         self._steps = 0
         self._eager_seen = False   # one step has run outside a capture (the library's compact launch lists exist)
+        self._pending_after_step = False
 
     def step(self):
         self._solver.update()
         self._eager_seen = True        # (captures call the solver directly: see capture_period)
+        self._pending_after_step = self._limit_pending()
+
+    def _limit_pending(self):
+        """Does the velocity field owe a deferred limit_field (runtime.DeviceBase.limit_field)?  After a step of the plain solvers it does;
+        the dye solvers' own kernels read the velocity and have made it run."""
+        v = getattr(self._solver, "v", None)
+        return v is not None and v.current.pending_limit is not None
 
     def _counted_step(self):
         self.step()
@@ -72,7 +80,7 @@ class FluidSimulator:
             if db is not None:
                 for f in (db.current, db.next):
                     # serial: a Field's identity for life (id() is recycled); static_id: which carry decisions the capture baked in
-                    sig.append((f.serial, f.user_data, f.static_id))
+                    sig.append((f.serial, f.user_data, f.static_id, f.pending_limit))      # (pending_limit: a deferred limit_field, runtime.DeviceBase.limit_field)
         for spare in (getattr(s, "_v_spare", None), getattr(s, "_dye_spare", None)) + tuple(getattr(s.pressure_updater, "_spare", None) or ()):
             sig.append((spare.serial, spare.static_id) if spare is not None else 0)
         return tuple(sig)
@@ -111,6 +119,9 @@ class FluidSimulator:
             for _ in range(nsteps):
                 self._counted_step()
             return
+        if nsteps > 0 and self._eager_seen and self._limit_pending() != self._pending_after_step:
+            self._counted_step()        # (the cached graphs start from the state a step leaves behind, see capture_period)
+            nsteps -= 1
         entry = self._graphs.get(self._signature())
         if entry is None and nsteps >= 16:          # (periods 1 - 6 need at most 16 steps to be found; 12 - an odd red-black count with the pair pass
             # on top of the fused transport - is only tried when the chunk has 28)
@@ -142,7 +153,9 @@ class FluidSimulator:
         self._graph = (signature, graph id, period) - also cached for run() - or None if nothing within the budget repeats."""
         dev, done = self._dev, 0
         self._graph = None
-        if not self._eager_seen and budget >= 2:
+        if (not self._eager_seen or self._limit_pending() != self._pending_after_step) and budget >= 2:
+            # (also: the steady state of a run with deferred limit passes starts every step with one pending - after a download there is
+            #  none, and a period captured from there would not close)
             # libfs_hip builds the compact tile lists of a launch geometry the first time the geometry is launched EAGERLY (building one
             # synchronises the stream, which a capture forbids): a graph captured before any eager step would carry the dense launches for
             # life (ADVICE r3).  One eager step first - it counts as one of the steps this call takes.

@@ -90,6 +90,8 @@ class Field:
         dev._handle_serial[id(self._h)] = self.serial
         self.valid = dev.halo          # ghost rows valid to this depth (zero-filled == consistent everywhere)
         self.user_data = False         # set once the user uploads / fills data (disables fusions that rely on invariants)
+        self.pending_limit = None      # limit_field(self, limit) issued by the solver but not launched yet: it rides with the next step's velocity
+                                       # boundary kernel (DeviceBase.limit_field); anything else that touches the field launches it first
         self.static_id = 0             # content class of the cells NO kernel ever writes (deep wall cells): 0 = still the zeros of the
                                        # allocation, a fresh token after every upload / fill.  Passes that store only the cells that can
                                        # change (fs_rbsor_pair, the fused gradient + advection pass) need source and target buffer in
@@ -103,6 +105,7 @@ class Field:
         return (self.dev.nx, nrows) if self.nchan == 1 else (self.dev.nx, nrows, self.nchan)
 
     def fill(self, value):
+        self.pending_limit = None      # (every cell is overwritten: what the deferred limit would have done is gone either way)
         self.dev._p_fill(self._h, float(value))
         self.valid = self.dev.halo
         self.static_id = next(_serials)
@@ -115,6 +118,7 @@ class Field:
         if arr.shape != self._full_shape(dev.ny):
             raise ValueError(f"expected array of shape {self._full_shape(dev.ny)}, got {arr.shape}")
         win = np.ascontiguousarray(arr[:, dev.g_lo:dev.g_hi], dtype=dev.dtype)
+        self.pending_limit = None      # (as fill)
         dev._p_upload(self._h, self.nchan, win, dev.g_lo - (dev.y0 - dev.halo), dev.g_hi - dev.g_lo)
         self.valid = dev.halo
         self.user_data = True
@@ -123,6 +127,7 @@ class Field:
     def to_numpy(self, local=False):
         """Global (X, Y[, C]) array (gathered over slabs) or, with local=True, this slab's owned rows."""
         dev = self.dev
+        dev.flush_limit(self)
         mine = dev._p_download(self._h, self.nchan, dev.halo, dev.nyl).reshape(self._full_shape(dev.nyl))
         if local or dev.nranks == 1:
             return mine
@@ -133,6 +138,7 @@ class Field:
     def local_window(self):
         """All local rows that lie inside the global domain (ghost rows included) - diagnostics/tests."""
         dev = self.dev
+        dev.flush_limit(self)
         r0, n = dev.g_lo - (dev.y0 - dev.halo), dev.g_hi - dev.g_lo
         return dev._p_download(self._h, self.nchan, r0, n).reshape(self._full_shape(n))
 
@@ -199,6 +205,7 @@ class DeviceBase:
         # step (compute alone 116); the price is +47 % bytes per step and neighbour (4.05 instead of 2.77 MB) - FS_EXCHANGE_ALL=0 for a
         # link-bound node.
         self.exchange_all = os.environ.get("FS_EXCHANGE_ALL", "1") == "1"
+        self.limit_deferral = False   # set by upload_scene: limit_field may ride with the next step's velocity boundary kernel (limit_field below)
 
     # ---- ghost-row bookkeeping --------------------------------------------------------------------
     def exchange(self, field, depth=None):
@@ -297,6 +304,10 @@ class DeviceBase:
         but the op-list boundary kernels) that exchange runs behind the kernel's own interior rows: mark -> rows [2H, nyl)
         -> begin -> wait -> the two edge strips.
         """
+        if name != "velocity_bc_limit":      # a deferred limit_field runs before anything else looks at (or writes into) its field
+            for f in [f for f, _ in reads] + list(writes) + list(full_writes):
+                if f.pending_limit is not None:
+                    self.flush_limit(f)
         multi = self.nranks > 1
         off = self.y0 - self.halo
         # (identities, not the fields: a reference kept here would postpone the release of a temporary field to the NEXT launch - which may
@@ -536,6 +547,7 @@ class DeviceBase:
         rv, rp, no_lazy, no_pair = self._p_max_over_ranks([rv, rp, 0 if self._p_lazy_bc_ok() else 1, 0 if self._p_rb_pair_ok() else 1])
         self.lazy_bc_ok = not no_lazy
         self.rb_pair_ok = not no_pair
+        self.limit_deferral = self.nranks == 1 and os.environ.get("FS_LIMIT_DEFER", "1") == "1" and self._p_limit_deferral_ok()
         self.bc_radius_v, self.bc_radius_p = max(2, int(rv)), max(1, int(rp))
         if self.nranks > 1 and max(self.bc_radius_v, self.bc_radius_p) > self.halo:
             raise RuntimeError(
@@ -544,7 +556,21 @@ class DeviceBase:
 
     # ---- one wrapper per reference kernel: (C-ABI name, scalars + fields, reads with radius, writes) ----
     def velocity_bc(self, v):                                   # fs/boundary_condition.py:16-39
+        if v.pending_limit is not None and self.nranks == 1:
+            # the limit_field the last step ended with + this step's boundary kernel in one launch (csrc/fs_march.h k_velocity_bc_limit)
+            limit, v.pending_limit = v.pending_limit, None
+            self._run("velocity_bc_limit", (limit, v._h, 0, self.rows), reads=[(v, self.bc_radius_v)], writes=[v], split=False)
+            return
         self._run("velocity_bc", (v._h,), reads=[(v, self.bc_radius_v)], writes=[v], split=False)   # op list with serial hazards
+
+    def _p_limit_deferral_ok(self):      # backends without the merged kernel
+        return False
+
+    def flush_limit(self, f):
+        """Launch the limit_field a field still owes (see limit_field)."""
+        if f.pending_limit is not None:
+            limit, f.pending_limit = f.pending_limit, None
+            self._run("limit_field", (limit, f._h), pointwise=True, writes=[f])
 
     def pressure_bc(self, p):                                   # fs/boundary_condition.py:41-65
         self._run("pressure_bc", (p._h,), reads=[(p, self.bc_radius_p)], writes=[p], split=False)
@@ -655,7 +681,15 @@ class DeviceBase:
     def rbsor_halfsweep_src(self, omega, parity, pn, pc, src):
         self._run("rbsor_halfsweep_src", (omega, parity, pn._h, pc._h, src._h), reads=[(pc, 1), (src, 0)], writes=[pn])
 
-    def limit_field(self, limit, v):                            # fs/solver.py:38-43
+    def limit_field(self, limit, v, defer=False):               # fs/solver.py:38-43
+        """defer=True (the solvers' end-of-step call, single GPU): the pass is not launched now - behind the buffer's flag it does nothing
+        in a healthy run, yet its launch is a fifth of a small-grid step - but rides with the next kernel that touches the field: the
+        velocity boundary kernel of the next step takes it along in its own launch (velocity_bc above), anything else - downloads,
+        visualisation, the dye kernels, a hipGraph boundary - makes it run first (_run / Field.to_numpy).  Same results, one launch less."""
+        if defer and self.limit_deferral and v.pending_limit is None and float(limit) ** 2 > 64.0:
+            v.pending_limit = float(limit)
+            return
+        self.flush_limit(v)
         self._run("limit_field", (limit, v._h), pointwise=True, writes=[v])
 
     def clamp_field(self, low, high, f):                        # fs/solver.py:46-49
@@ -684,6 +718,7 @@ class DeviceBase:
 
     def poisson_residual(self, dt, dx, p, vc):
         """(sum of squared Jacobi residuals, cell count) over all not-wall cells of the GLOBAL grid."""
+        self.flush_limit(vc)
         if self.nranks > 1:
             stale = [f for f in (p, vc) if f.valid < 1]
             if stale:
@@ -774,6 +809,11 @@ class Device(DeviceBase):
     def _p_rb_pair_ok(self):
         ok = ctypes.c_int()
         _lib.call("fs_rbsor_pair_ok", self._ctx, ctypes.byref(ok))
+        return bool(ok.value)
+
+    def _p_limit_deferral_ok(self):
+        ok = ctypes.c_int()
+        _lib.call("fs_velocity_bc_limit_ok", self._ctx, ctypes.byref(ok))
         return bool(ok.value)
 
     @property

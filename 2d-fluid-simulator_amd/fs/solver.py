@@ -35,9 +35,10 @@ class Solver(metaclass=ABCMeta):
         return self._bc.is_fluid_domain(i, j)
 
 
-def limit_field(field, limit):
-    """Cap the velocity magnitude (fs/solver.py:38-43)."""
-    field.dev.limit_field(limit, field)
+def limit_field(field, limit, defer=False):
+    """Cap the velocity magnitude (fs/solver.py:38-43).  defer: the end-of-step call of the solvers - the launch may ride with the next
+    step's velocity boundary kernel (runtime.DeviceBase.limit_field; same results)."""
+    field.dev.limit_field(limit, field, defer=defer)
 
 
 def clamp_field(field, low, high):
@@ -67,7 +68,7 @@ class MacSolver(Solver):
             self.vorticity_confinement.apply(self.v)
             self.v.swap()
         self.pressure_updater.update(self.p, self.v.current)
-        limit_field(self.v.current, VELOCITY_LIMIT)
+        limit_field(self.v.current, VELOCITY_LIMIT, defer=True)
 
     def update(self):
         self._flow_step()
@@ -134,8 +135,9 @@ class CipMacSolver(Solver):
             self.vorticity_confinement.apply(self.v)
             self.v.swap()
         self.pressure_updater.update(self.p, self.v.current)
-        limit_field(self.v.current, VELOCITY_LIMIT)
-        if self._v_spare is not None and self._v_spare.static_id != 0:
+        spare_too = self._v_spare is not None and self._v_spare.static_id != 0
+        limit_field(self.v.current, VELOCITY_LIMIT, defer=not spare_too)
+        if spare_too:
             # limit_field is the one kernel that rewrites wall cells nothing else touches (uploaded data above the limit).  The fused
             # transport pass relies on those cells being EQUAL in v.current and the spare buffer it writes next (it carries only what
             # some kernel writes): limit the spare's copy of them the same way.  Only in runs that uploaded a velocity field.

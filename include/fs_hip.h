@@ -82,6 +82,13 @@ int fs_field_devptr(const fs_field *f, void **ptr, size_t *bytes);
 /* ---- boundary-condition kernels -------------------------------------------------------------- */
 /* BoundaryCondition.set_velocity_boundary_condition   fs/boundary_condition.py:16-39  (in place) */
 int fs_velocity_bc(fs_ctx *ctx, fs_field *v, int row_begin, int row_end);
+/* limit_field of step n + set_velocity_boundary_condition of step n+1 in ONE launch (new: fs/solver.py:38-43 then fs/boundary_condition.py:16-39;
+ * the reference issues them as the last kernel of one step and the first of the next).  Behind the velocity buffer's flag the limit pass
+ * does nothing in a healthy run, yet its launch is a fifth of a small-grid step; the Python shell defers it (the field carries a pending
+ * limit until anything else looks at it) and this entry point runs gate + limit (rare) + boundary op list.  Same bits as fs_limit_field
+ * over [limit_begin, limit_end) followed by fs_velocity_bc over [row_begin, row_end).  fs_velocity_bc_limit_ok: available for this context. */
+int fs_velocity_bc_limit_ok(const fs_ctx *ctx, int *ok);
+int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int limit_begin, int limit_end, int row_begin, int row_end);
 /* BoundaryCondition.set_pressure_boundary_condition   fs/boundary_condition.py:41-65  (in place) */
 int fs_pressure_bc(fs_ctx *ctx, fs_field *p, int row_begin, int row_end);
 /* DyeBoundaryCondition.set_dye_boundary_condition     fs/boundary_condition.py:94-99  (in place) */

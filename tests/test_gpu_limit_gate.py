@@ -108,3 +108,50 @@ def test_gate_on_equals_gate_off(hip_lib, monkeypatch):
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
     assert float(np.abs(outs[0]["vcurrent"]).max()) < 8.0      # a healthy run never comes near the gate's threshold
+
+
+@pytest.mark.parametrize("scheme,vc,res,graph", [("cip", 5.0, 64, False), ("upwind", None, 130, False), ("kk", 5.0, 512, False), ("cip", 5.0, 512, True),
+                                                 ("upwind", None, 64, True)])
+def test_deferred_limit_rides_with_the_next_boundary_kernel(scheme, vc, res, graph, hip_lib, monkeypatch):
+    """Round 4: the solvers' end-of-step limit_field is deferred and runs inside the NEXT step's velocity boundary launch
+    (csrc/fs_march.h k_velocity_bc_limit) unless something looks at the field first.  Nothing looks here for several steps, and the inflow
+    of 30 keeps the buffer's flag up: every step takes the kernel's rare path - the limit pass shared among the boundary kernel's
+    workgroups (hundreds at res 512) and a grid barrier - and must still be the reference's result, eagerly and as a replayed hipGraph."""
+    from fs.boundary_condition import create_scene_arrays
+    const, mask, _ = create_scene_arrays(2, res)
+    const = const.copy()
+    const[mask == 2] *= np.float32(30.0) / max(float(np.abs(const[mask == 2]).max()), 1e-6)
+    steps = 40 if graph else 7
+    monkeypatch.setenv("FS_LIMIT_DEFER", "1")
+    sim, ref = _pair(const, mask, scheme, vc, 0.05 / res, 1.0 / res)
+    monkeypatch.setenv("FS_LIMIT_DEFER", "0")
+    plain, _ = _pair(const, mask, scheme, vc, 0.05 / res, 1.0 / res)
+    try:
+        dev = sim._solver._bc.device
+        assert dev.limit_deferral and not plain._solver._bc.device.limit_deferral
+        if graph:
+            sim.run(steps)                    # one eager step, the capture of a period, replays, eager remainder
+        else:
+            for _ in range(steps):
+                sim.step()
+        assert sim._solver.v.current.pending_limit is not None      # still owed: nobody has looked
+        for _ in range(steps):
+            plain.step()
+            if res <= 130:
+                ref.update()
+        out, exp = sim.field_to_numpy(), plain.field_to_numpy()
+        assert sim._solver.v.current.pending_limit is None
+        for k in exp:
+            assert np.array_equal(out[k], exp[k], equal_nan=True), f"deferred vs immediate: {k}"
+            if res <= 130:
+                assert np.array_equal(out[k], ref.fields()[k], equal_nan=True), f"deferred vs oracle: {k}"
+        for name in ("v", "p"):
+            for which in ("current", "next"):
+                a, b = getattr(getattr(sim._solver, name), which).to_numpy(), getattr(getattr(plain._solver, name), which).to_numpy()
+                assert np.array_equal(a, b, equal_nan=True), f"{name}.{which}"
+        speed = np.sqrt((out["v"] ** 2).sum(-1))
+        if np.isfinite(speed).all():          # (an inflow of 30 blows the long runs up - identically on both sides, which is all that matters here)
+            assert speed.max() <= 10.0001 and speed.max() > 9.99
+    finally:
+        sim._solver._bc.device.close()
+        plain._solver._bc.device.close()
