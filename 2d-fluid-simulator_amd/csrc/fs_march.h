@@ -475,6 +475,11 @@ __global__ __launch_bounds__(256) void k_jacobi_ov(Grid g, Konst<T> k, int nbx, 
     jacobi_ov_tile<SRC, RT, DM, T>(g, k, nbx, nby, jb, je, pn, pc, vs);
 }
 
+// (Round 4 built the same sweep on ALIGNED wave columns - every lane an owner, the row segment exactly 8 lines of 128 B, the cell beyond each
+// end fetched by lanes 0 / 63 with one two-lane load per row and plane - to take the 8 % of read traffic the overlapped mapping pays for
+// straddling a ninth line (profiles/r4_marchbw.txt).  Bit-identical, and slower: 96.8 against 84.0 us reading v, 89.6 against 72.1 us on
+// the source pair at bc5 res 4096 - the exec-masked edge loads and their dependent selects cost more than the line.  Removed.)
+
 
 // ------------------------------------------------------------------------------------------------
 // K8J with the pressure boundary condition evaluated ON THE FLY ("lazy" K7), for long Jacobi runs (BASELINE configs[1]: 50 sweeps
