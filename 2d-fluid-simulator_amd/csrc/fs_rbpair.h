@@ -288,4 +288,7 @@ __global__ __launch_bounds__(256) void k_rbsor_pair(Grid g, Konst<T> k, int nbx,
     rbsor_pair_wave<N, RT, PAR0, DM, PATH, FULL, T>(g, k, nbx, nby, jb, je, bcmap, C, D, A, B, v);
 }
 
+// (Round 4: since the DPP shifts lost their init moves the plain part needs 97 VGPRs, one more than the 96 that admit a fifth wave per SIMD;
+//  built with __launch_bounds__(256, 5): 95 VGPRs, no scratch, 5 waves - and the same 182-187 us: the pass is bound by its traffic, not by occupancy.)
+
 }  // namespace fs
