@@ -153,12 +153,14 @@ enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 1
 // cells); 3 = pairs, 62 owner lanes (124 cells, 2 halo cells)
 static inline int geo_cells(int lanes) { return lanes == 4 ? 4 : 2; }
 static inline int geo_owners(int lanes) { return lanes == 2 ? 60 : (lanes == 5 ? 58 : (lanes == 6 ? 56 : 62)); }   // 5 / 6: pairs with 3 / 4 halo lanes per side (the 6- / 8-sweep marching passes; no compact lists)
-static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls = 0, int reach = 0, int wgw = 4, int jb = 0, int je = -1)
+static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls = 0, int reach = 0, int wgw = 4, int jb = 0, int je = -1, int parent_rt = 0)
 {
     if (c->h_act4.empty() || nbx > 0xfff || nby > 0xfffff || lanes > 4 || c->rows > 0xffff) return nullptr;
     if (je < 0) je = c->rows;
     const uint32_t key0 = (uint32_t)lanes | ((uint32_t)rt << 4) | ((uint32_t)stacked << 12) | ((uint32_t)group << 16) | ((uint32_t)cls << 24) | ((uint32_t)reach << 26) | ((uint32_t)(wgw & 7) << 29);
-    const std::pair<uint32_t, uint32_t> key(key0, ((uint32_t)jb << 16) | (uint32_t)je);      // slab launches cover varying row ranges: one list per range
+    if (parent_rt == rt) parent_rt = 0;
+    if (parent_rt && (wgw != 1 || parent_rt % rt != 0 || parent_rt > 64)) return nullptr;      // (a coarser plain tiling is defined for one-wave workgroups)
+    const std::pair<uint32_t, uint32_t> key(key0 ^ ((uint32_t)parent_rt << 5), ((uint32_t)jb << 16) | (uint32_t)je);      // slab launches cover varying row ranges: one list per range
     auto it = c->tile_lists.find(key);
     if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
     if (c->capturing || c->tape_rec) return nullptr;      // (building one synchronises the stream: not inside a capture - the dense grid then)
@@ -184,9 +186,13 @@ static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stac
                         for (int j = j0; j < j1; ++j)
                             if (act[(size_t)wx * Y + j] & 1) { any = true; break; }
                     if (any && cls) {
-                        bool plain = true;        // bit 1 of the activity byte: a non-fluid cell within the wave column's lanes (halo lanes included)
+                        // plain: no non-fluid cell (bit 1 of the activity byte; halo lanes included) within `reach` rows of the tile - or, for the
+                        // boundary list of a launch whose plain part runs on tiles of parent_rt rows, of the parent tile this tile lies in
+                        int p0 = j0, p1 = j1;
+                        if (parent_rt) { p0 = jb + (j0 - jb) / parent_rt * parent_rt; p1 = std::min(je, p0 + parent_rt); }
+                        bool plain = true;
                         for (int wx = wx0; wx < wx1 && plain; ++wx)
-                            for (int j = std::max(0, j0 - reach); j < std::min(Y, j1 + reach); ++j)
+                            for (int j = std::max(0, p0 - reach); j < std::min(Y, p1 + reach); ++j)
                                 if (act[(size_t)wx * Y + j] & 2) { plain = false; break; }
                         any = plain == (cls == 1);
                     }
@@ -218,7 +224,7 @@ static void tile_lists_free(fs_ctx *c)
 
 // XCD-band launch geometry of a tile kernel family (fs_march.h band_coords); `lanes`: cells per lane.  When the launch covers the whole
 // single-GPU grid, the workgroups without anything to do are left out (compact list, Grid::tiles).
-static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true, int cls = 0, int reach = 0, int wgw = 4)
+static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true, int cls = 0, int reach = 0, int wgw = 4, int parent_rt = 0)
 {
     OvGrid o;
     o.g = c->grid();
@@ -235,7 +241,7 @@ static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroup
         const int group = stacked ? std::max(1, xg / wgw) : xg;     // the same number of field rows per XCD group
         const int groups = (o.nby + group - 1) / group;
         const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && ((jb == 0 && je == c->rows) || (c->halo != 0 && cls == 0))
-                                         ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach, wgw, jb, je) : nullptr;
+                                         ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach, wgw, jb, je, parent_rt) : nullptr;
         const bool inner = zgroups > 1 && (tl || (c->cg_inner_mask & family) != 0);
         if (tl) { o.grid = dim3(8 * tl->per_xcd * zgroups, 1, 1); o.g.tiles = tl->d; }
         else o.grid = inner ? dim3(8 * o.nbx * zgroups, group, (groups + 7) / 8) : dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
@@ -706,6 +712,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
+    if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8) c->rbpair_plain_rt = v; }
     if (const char *s = getenv("FS_SPLIT_WGW")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->split_wgw = v; }
     if (const char *s = getenv("FS_RBMARCH")) c->use_rbmarch = atoi(s);
     if (const char *s = getenv("FS_RBM_L")) { const int v = atoi(s); if (v >= 14 && v <= 254 && (v + 10) % 12 == 0) c->rbm_L = v; }
@@ -1770,10 +1777,13 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     // Compact launch in two parts where the lists exist (single GPU, whole grid): the workgroups that see nothing but fluid within reach run
     // the plain path as its own kernel (PATH 3: no mask loads, 126 VGPRs = 4 waves per SIMD), the others the kernel with both paths.
     if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw);
+        // the plain part on tiles of 8 rows (round 4: 125 VGPRs, still 4 waves per SIMD, since the DPP shifts lost their init moves - 2 rows
+        // of window per output row instead of 3), the boundary part on tiles of 4 rows that lie in no plain 8-row tile; one wave per workgroup
+        const int prt = ctx->split_wgw == 1 && ctx->rbpair_plain_rt == 8 ? 8 : rt;
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw, prt);
         if (og.g.tiles && ogb.g.tiles) {
-            int rc = launch(ctx, "rbsor_pair", [=] { FS_RBP_DM(4, 3); });
+            int rc = launch(ctx, "rbsor_pair", [=] { if (prt == 8) FS_RBP_DM(8, 3); else FS_RBP_DM(4, 3); });      // (12-row tiles: 151 VGPRs = 3 waves, 188 against 177 us)
             if (rc) return rc;
             { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_DM(4, 2); }); }
         }

@@ -84,6 +84,7 @@ struct fs_ctx {
     int rbpair_split = 1;                    // plain and boundary workgroups of that pass (and of the four-sweep Jacobi pass) as two compact
                                              // launches: env FS_RBPAIR_SPLIT = 0 never, 1 on grids of 8 M cells or more, 2 always
     int rbpair_rt = 4;                       // rows per tile of that pass (env FS_RBPAIR_RT = 4, 6)
+    int rbpair_plain_rt = 8;                 // env FS_RBPAIR_PLAIN_RT = 4 / 8: rows per tile of the pair pass's PLAIN part (two-part launch, one-wave workgroups)
     int split_wgw = 1;                       // env FS_SPLIT_WGW = 1 / 2 / 4: waves per workgroup of the two-part launches - the plain / boundary classification is per workgroup
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
