@@ -1666,13 +1666,13 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     const Grid gg = ctx->grid();
     // lanes of 2 cells (116 VGPRs = 4 waves per SIMD at 4 rows; quads: 182 = 2 waves, 44.9 against 34.3 us per pass at bc2 res 1600)
     const int rt = ctx->jquad_rt;
-#define FS_JQ(RT, PATH) hipLaunchKernelGGL((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
+#define FS_JQ(RT, PATH) hipLaunchKernelGGL((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
     // plain and boundary workgroups as two compact launches (as fs_rbsor_pair) - on large grids: a second launch costs ~5 us, which a
     // cache-resident grid does not earn back (bc2 res 1600: 18.1 + 21.3 against 34.6 us; bc5 res 4096: 81.4 + 49.8 against 137.5)
     if ((ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4);
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw);
         if (og.g.tiles && ogb.g.tiles) {
             int rc = launch(ctx, "jacobi_quad_lazy", [=] { FS_JQ(4, 3); });
             if (rc) return rc;
@@ -1734,7 +1734,7 @@ int fs_jacobi_finish(fs_ctx *ctx, fs_field *pc_out, fs_field *pn, const fs_field
 int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
-    *ok = ctx->mask_set && ctx->rb_pair_ok && ctx->use_pairs && ctx->use_lazy && ctx->dtype == 0 ? 1 : 0;
+    *ok = ctx->mask_set && ctx->rb_pair_ok && ctx->use_pairs && ctx->use_lazy ? 1 : 0;      // (f32 and, since round 4, f64)
     return FS_OK;
 }
 
@@ -1747,13 +1747,34 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     FS_FIELD(pc_out, 1); FS_FIELD(pn_out, 1); FS_FIELD(pc, 1); FS_FIELD(pn, 1); FS_FIELD(vc, 2);
     FS_REQUIRE(pc_out != pn_out && pc_out != pc && pc_out != pn && pn_out != pc && pn_out != pn && pc != pn, "the two-iteration pass needs four distinct pressure fields");
     FS_ROWS();
-    if (!(ctx->rb_pair_ok && ctx->use_pairs && ctx->dtype == 0)) {
-        set_error("this mask / precision does not admit the two-iteration red-black pass (fs_rbsor_pair_ok)");
+    if (!(ctx->rb_pair_ok && ctx->use_pairs)) {
+        set_error("this mask does not admit the two-iteration red-black pass (fs_rbsor_pair_ok)");
         return FS_ERR_UNSUPPORTED;
     }
-    using T = float;
     const Grid gg = ctx->grid();
     const int par0 = (gg.ybase + row_begin) & 1;
+    if (ctx->dtype == 1) {
+        // f64 (round 4; BASELINE configs[4]'s truth leg): the same body on double2 lanes.  A lane's window costs twice the registers, so the
+        // tiles are 2 rows high (230 VGPRs with both paths = 2 waves per SIMD; the plain part on 4-row tiles: 220) - against 2 x (K7 + single
+        // iteration) at 137 VGPRs that is still one pass over p and v instead of two.
+        using T = double;
+        auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
+#define FS_RBPD_K(RT, PAR, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, 0, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+                               (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
+#define FS_RBPD(RT, PATH, FULL) do { if (par0) FS_RBPD_K(RT, 1, PATH, FULL); else FS_RBPD_K(RT, 0, PATH, FULL); } while (0)
+        if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && ctx->split_wgw == 1) {
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2, true, 1, 4, 1);
+            const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_RBSOR, 2, true, 2, 4, 1, 4);
+            if (og.g.tiles && ogb.g.tiles) {
+                int rc = launch(ctx, "rbsor_pair", [=] { FS_RBPD(4, 3, false); });
+                if (rc) return rc;
+                { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBPD(2, 2, false); }); }
+            }
+        }
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_RBSOR, 2, !full);
+        return launch(ctx, "rbsor_pair", [=] { if (full) FS_RBPD(2, 2, true); else FS_RBPD(2, 2, false); });
+    }
+    using T = float;
     auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
     const int dm = dm_const(ctx, k);
     // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 (FS_RBPAIR_RT=6: 6) rows per tile.  The carrying

@@ -31,8 +31,17 @@ __device__ __forceinline__ float lane_prev(float x)
 { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true)); }   // wave_shr:1
 __device__ __forceinline__ float lane_next(float x)
 { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true)); }   // wave_shl:1
-__device__ __forceinline__ double lane_prev(double x) { return __shfl_up(x, 1, 64); }
-__device__ __forceinline__ double lane_next(double x) { return __shfl_down(x, 1, 64); }
+// f64: the two halves through the same DPP shifts (round 4; __shfl_up / __shfl_down went through ds_bpermute)
+__device__ __forceinline__ double lane_prev(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_next(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 
 // Addressing of the quad accesses: wave-uniform row base (an SGPR pair) + ONE 32-bit lane offset shared by every access of the lane - the
 // `saddr` form of global_load / global_store.  Left to itself the compiler reassociates base + row + lane into (base + lane), a 64-bit

@@ -26,11 +26,11 @@ def thick_scene(rng, X, Y, boxes=8, outflow=True):
     return const, mask
 
 
-def build(const, mask, n_iter, pair, res=64, vc=5.0, scheme="cip", omega=1.3):
+def build(const, mask, n_iter, pair, res=64, vc=5.0, scheme="cip", omega=1.3, dtype="f32"):
     import fs
     from fs.boundary_condition import BoundaryCondition
     dt, dx, re = 0.05 / res, 1.0 / res, 1000.0
-    fs.runtime.init(gpu=0, dtype="f32")
+    fs.runtime.init(gpu=0, dtype=dtype)
     bc = BoundaryCondition(const, mask)
     vcobj = fs.VorticityConfinement(bc, dt, dx, vc) if vc else None
     pu = fs.RedBlackSorPressureUpdater(bc, dt, dx, omega, n_iter, pair=pair)
@@ -165,3 +165,34 @@ def test_thin_walls_are_refused(hip_lib):
         s.update()
     finally:
         s._dev.close()
+
+
+@pytest.mark.parametrize("X,Y,n_iter,split", [(64, 16, 2, "0"), (252, 41, 3, "2"), (500, 37, 4, "2"), (1000, 12, 2, "0"), (124, 130, 5, "2")])
+def test_pair_pass_in_f64(X, Y, n_iter, split, hip_lib, monkeypatch):
+    """Round 4: the pass on double2 lanes (2-row tiles; the plain part on 4-row tiles where the two-part launch is on) - BASELINE
+    configs[4]'s fp64 truth leg runs it.  Against the f64 single iterations and the f64 oracle, every pressure buffer bit for bit."""
+    from oracle import oracle as O
+    monkeypatch.setenv("FS_RBPAIR_SPLIT", split)
+    rng = np.random.default_rng(X + Y * 7 + n_iter)
+    const, mask = thick_scene(rng, X, Y, boxes=9, outflow=n_iter % 2 == 0)
+    a, b = build(const, mask, n_iter, True, dtype="f64"), build(const, mask, n_iter, False, dtype="f64")
+    res = 64
+    ref = O.make_simulator(const.astype(np.float64), mask, None, scheme="cip", dt=0.05 / res, dx=1.0 / res, re=1000.0, vor_eps=5.0,
+                           updater=("rbsor", 1.3, n_iter), dtype=np.float64)
+    try:
+        assert a._dev.rb_pair_ok and a.pressure_updater._pair and not b.pressure_updater._pair
+        v0 = rng.uniform(-1, 1, (X, Y, 2))
+        p0 = rng.uniform(-1, 1, (X, Y))
+        for s in (a, b):
+            s.v.current.from_numpy(v0)
+            s.p.current.from_numpy(p0)
+        ref.v.current[...] = v0
+        ref.p.current[...] = p0
+        for step in range(4):
+            a.update(); b.update(); ref.update()
+            same_pressure(a, b, f"f64 {X}x{Y} n_iter {n_iter} step {step + 1}")
+            assert np.array_equal(a.p.current.to_numpy(), ref.p.current, equal_nan=True), f"f64 vs oracle p, step {step + 1}"
+            assert np.array_equal(a.p.next.to_numpy(), ref.p.next, equal_nan=True), f"f64 vs oracle p.next, step {step + 1}"
+    finally:
+        a._dev.close()
+        b._dev.close()
