@@ -699,8 +699,8 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     e = hipMalloc(&c->d_mask, (size_t)c->rows * c->Pm);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_mask, 1, (size_t)c->rows * c->Pm, c->stream);   // never the null stream: see upload_ops
     if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&c->d_sync, 4 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_sync, 0, 4 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMalloc(&c->d_sync, 16 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_sync, 0, 16 * sizeof(unsigned), c->stream);
     c->nwx = (nx / 4 + 61) / 62;
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
@@ -1080,9 +1080,8 @@ int fs_velocity_bc_limit_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
     const int wgs = (ctx->ops_vel.lanes() + 255) / 256;
-    // (every workgroup resident: the grid barrier of the rare path; and few of them: the exit ticket - one atomic per workgroup on one
-    //  word, ~12 ns each - costs more than the launch it saves from ~100 workgroups on: bc5 res 4096, 400 workgroups: 22.6 us against 11.5 + 6)
-    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && wgs >= 1 && wgs <= 96 ? 1 : 0;
+    // every workgroup resident: the grid barrier of the rare path
+    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && ctx->d_bc_const && wgs >= 1 && wgs <= 1024 ? 1 : 0;
     return FS_OK;
 }
 
