@@ -43,7 +43,10 @@ def test_reference_scenes(S, bc, res, hip_lib, monkeypatch):
     const, mask, _ = create_scene_arrays(bc, res)
     solver, ref, pu = build(const, mask, 20, res=res)
     try:
-        assert pu._march == S
+        if res % 2:       # (X = 2 res not a multiple of 4: the multi-sweep passes are not admitted - the updater keeps its other forms, same bits)
+            assert pu._march == 0
+        else:
+            assert pu._march == S
         compare(solver, ref, 4, f"S {S} bc{bc} res {res}")
     finally:
         solver._dev.close()
