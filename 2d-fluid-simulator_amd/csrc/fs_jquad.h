@@ -45,11 +45,12 @@ __device__ __forceinline__ LV<T, N> jq_row(const LaneMapN<N> &lm, unsigned compu
 }
 
 template <int N, int RT, bool BND, typename T>
-__device__ __forceinline__ void jacobi_quad_tile(const Grid &g, const LaneMapN<N> &lm, int i0, int j0, int je, const unsigned (&nw)[RT + 8],
+__device__ __forceinline__ void jacobi_quad_tile(const Grid &g, const LaneMapN<N> &lm_in, int i0, int j0, int je, const unsigned (&nw)[RT + 8],
                                                  const uint8_t *bcmap, T *pn, const T *pc, const T *src)
 {
     constexpr int W = RT + 8;                  // window rows w = 0 .. W-1  <->  local rows j0-4 .. j0+RT+3 (clamped into the domain)
     using R = LV<T, N>;
+    const LaneMapN<N> lm = BND ? lm_in : LaneMapN<N>{lm_in.i0, lm_in.owner, false, false};      // (no lane of an all-fluid tile sits at a domain end: fs_rbpair.h rbsor_pair_tile)
     constexpr unsigned ALL = (1u << N) - 1u;
 #define FS_NW(w) (BND ? nw[w] : ALL)
     R P[W], S2[W], S3[W];
@@ -125,11 +126,12 @@ __global__ __launch_bounds__(256) void k_jacobi_quad(Grid g, int nbx, int nby, i
 // all three buffers (Field.static_id, checked by the caller).  Same validity conditions as the four-sweep pass.
 // ------------------------------------------------------------------------------------------------
 template <int N, int RT, bool BND, typename T>
-__device__ __forceinline__ void jacobi_finish_tile(const Grid &g, const LaneMapN<N> &lm, int i0, int j0, int je, const unsigned (&nw)[RT + 4],
+__device__ __forceinline__ void jacobi_finish_tile(const Grid &g, const LaneMapN<N> &lm_in, int i0, int j0, int je, const unsigned (&nw)[RT + 4],
                                                    const uint8_t *bcmap, T *pc_out, T *pn, const T *pc, const T *src)
 {
     constexpr int W = RT + 4;                  // window rows w = 0 .. W-1  <->  local rows j0-2 .. j0+RT+1 (clamped into the domain)
     using R = LV<T, N>;
+    const LaneMapN<N> lm = BND ? lm_in : LaneMapN<N>{lm_in.i0, lm_in.owner, false, false};
     constexpr unsigned ALL = (1u << N) - 1u;
 #define FS_NW(w) (BND ? nw[w] : ALL)
     R P[W], S2[W], S3[W];

@@ -78,7 +78,9 @@ __device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Kons
     constexpr bool SELF = C == 2;                // the field advects itself
     int wx, ty, cg;
     if (!tile_coords_nz<N, C, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
-    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
+    // (PLAIN: no lane at the domain's first / last column - the clamp of the x-neighbours folds away, fs_rbpair.h rbsor_pair_tile)
+    const LaneMapN<N> lm = PLAIN ? LaneMapN<N>{lm_in.i0, lm_in.owner, false, false} : lm_in;
     const int i0 = lm.i0, j0 = jb + ty * RT;
 
     unsigned nw[RT + 2], fl[RT];                 // not-wall selectors of rows j0-1 .. j0+RT, fluid selectors of rows j0 .. j0+RT-1

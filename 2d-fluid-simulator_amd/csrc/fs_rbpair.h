@@ -158,12 +158,16 @@ __device__ __forceinline__ void rbp_relax(const Konst<T> &k, const LaneMapN<N> &
 // PAR0: parity of (g.ybase + j0 - 4), the first window row - a launch constant because RT is even and all tiles start at jb + k RT.
 // BND: the tile has non-fluid cells within reach (K7 views are evaluated); FULL: store every cell (carry pass after an upload).
 template <int N, int RT, int PAR0, int DM, bool BND, bool FULL, typename T>
-__device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm, int i0, int j0, int je, const unsigned (&fl)[RT + 8],
+__device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm_in, int i0, int j0, int je, const unsigned (&fl)[RT + 8],
                                                 const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
 {
     constexpr int W = RT + 8;                  // window rows w = 0 .. W-1  <->  local rows j0-4 .. j0+RT+3 (clamped into the domain)
     using R = LV<T, N>;
     constexpr unsigned ALL = (1u << N) - 1u;
+    // A tile without a non-fluid cell within reach (halo lanes included) holds no lane at the domain's first / last column - those cells are
+    // inflow, outflow or wall in every scene and a clamped halo lane repeats them: the sample() clamp of the x-neighbours (one v_cndmask per
+    // DPP shift) folds away (round 4: 64 of the plain kernel's 680 VALU instructions).
+    const LaneMapN<N> lm = BND ? lm_in : LaneMapN<N>{lm_in.i0, lm_in.owner, false, false};
     // fluid selector of window row w: in a tile without a single non-fluid cell within reach it is a constant (no registers, no selects)
 #define FS_FL(w) (BND ? fl[w] : ALL)
     R PA[W], VX[W], VY[W], PB[W];              // PB[w] is loaded for w = 1 .. W-2
