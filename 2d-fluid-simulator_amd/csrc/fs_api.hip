@@ -285,7 +285,7 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
 {
     // overlapped-wave register tiles of 1 - 4 rows (FS_JACOBI=21 .. 24).  Default (0): the source-pair
     // form streams best with 1-row tiles at 8 waves/SIMD (76 vs 79 us), the v-reading form with 2-row tiles (89 vs 95 us)
-    const int v = ctx->jacobi_variant ? ctx->jacobi_variant : (SRC ? 21 : 22);
+    const int v = ctx->jacobi_variant ? ctx->jacobi_variant : (SRC ? 21 : 24);      // (round 4, after the DPP diet: 4-row tiles for the v-reading form: 84.7 against 85.9-86.4 us)
     const int rt = v == 24 ? 4 : (v == 21 ? 1 : (v == 23 ? 3 : 2));
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
     const int dm = SRC ? 0 : dm_const(ctx, k);           // the source-pair form divides nothing

@@ -199,7 +199,7 @@ __device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Kons
             T of, ofx, ofy;
             cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
             if (CLAMP) of = tmin(tmax(of, (T)0.0), (T)1.0);
-            if ((fl[t] >> q) & 1u) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }
+            if (PLAIN || ((fl[t] >> q) & 1u)) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }      // (PLAIN: rows past je have left the loop above)
         }
         if (lm.owner) {
             if (SELF) raise_hot(hot, lv_hot1<T, N>(OV));                                   // one component per pass: conservative
