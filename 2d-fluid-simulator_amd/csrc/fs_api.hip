@@ -489,6 +489,13 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
         pos = end;
     }
     h_begin.push_back((int)h_kind.size());
+    if (getenv("FS_BC_STATS")) {        // (debug: how long the serial chains of this op list are)
+        std::map<int, int> hist;
+        for (size_t k = 0; k + 1 < h_begin.size(); ++k) hist[h_begin[k + 1] - h_begin[k]]++;
+        fprintf(stderr, "fs: bc op list: %zu simple, %zu chains:", h_simple.size(), h_rlo.size());
+        for (auto &kv : hist) fprintf(stderr, " %dx len %d", kv.second, kv.first);
+        fprintf(stderr, "\n");
+    }
     out.ncomp = (int)h_rlo.size();
     out.nops = (int)h_kind.size();
     // Stream-ordered like every other memory operation of a context: its stream is non-blocking, so work on the null stream
@@ -711,7 +718,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
-    if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 4 || v == 6) c->rbpair_rt = v; }
+    if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6) c->rbpair_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8) c->rbpair_plain_rt = v; }
     if (const char *s = getenv("FS_SPLIT_WGW")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->split_wgw = v; }
     if (const char *s = getenv("FS_RBMARCH")) c->use_rbmarch = atoi(s);
@@ -951,8 +958,8 @@ int fs_field_alloc(fs_ctx *ctx, int nchan, fs_field **out)
     f->bytes = (size_t)ctx->rows * nchan * ctx->P * ctx->esize;
     hipError_t e = hipMalloc(&f->d, f->bytes);
     if (e == hipSuccess) e = hipMemsetAsync(f->d, 0, f->bytes, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&f->hot, 2 * sizeof(unsigned));       // [0]: the flag; [1]: raised INSIDE a k_velocity_bc_limit launch, folded into [0] when that launch ends
-    if (e == hipSuccess) e = hipMemsetAsync(f->hot, 0, 2 * sizeof(unsigned), ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&f->hot, 4 * sizeof(unsigned));       // [0]: the flag; [1], [2]: raised by the op list of a k_velocity_bc_limit launch of parity 0 / 1 (fs_march.h)
+    if (e == hipSuccess) e = hipMemsetAsync(f->hot, 0, 4 * sizeof(unsigned), ctx->stream);
     if (e != hipSuccess) { if (f->d) hipFree(f->d); if (f->hot) hipFree(f->hot); delete f; return hip_fail(e, "hipMalloc(field)", __FILE__, __LINE__); }
     ctx->fields.insert(f);
     *out = f;
@@ -991,7 +998,7 @@ int fs_field_fill(fs_field *f, double value)
     FS_DISPATCH(ctx, {
         return launch(ctx, "fill", [=] {
             hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value);
-            hipLaunchKernelGGL(k_fill<unsigned>, dim3(1), dim3(64), 0, ctx->stream, f->hot, (size_t)1, hot);
+            hipLaunchKernelGGL(k_fill<unsigned>, dim3(1), dim3(64), 0, ctx->stream, f->hot, (size_t)3, hot);
         });
     })
 }
@@ -1032,11 +1039,17 @@ int fs_field_download(const fs_field *f, void *host_xrc, int row_begin, int nrow
     return FS_OK;
 }
 
+static __global__ void k_hot_fold(unsigned *dst, const unsigned *src)
+{
+    if (threadIdx.x == 0) { dst[0] = (src[0] | src[1] | src[2]) != 0u ? 1u : 0u; dst[1] = 0u; dst[2] = 0u; }
+}
+
 int fs_field_copy(fs_field *dst, const fs_field *src)
 {
     FS_REQUIRE(dst && src && dst->ctx == src->ctx && dst->C == src->C, "copy needs two fields of one context and shape");
     FS_HIP(hipMemcpyAsync(dst->d, src->d, src->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
-    FS_HIP(hipMemcpyAsync(dst->hot, src->hot, sizeof(unsigned), hipMemcpyDeviceToDevice, dst->ctx->stream));
+    hipLaunchKernelGGL(k_hot_fold, dim3(1), dim3(64), 0, dst->ctx->stream, dst->hot, (const unsigned *)src->hot);      // (one word: the copy starts a new parity sequence)
+    FS_HIP(hipGetLastError());
     return FS_OK;
 }
 
@@ -1085,9 +1098,10 @@ int fs_velocity_bc_limit_ok(const fs_ctx *ctx, int *ok)
     return FS_OK;
 }
 
-int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int limit_begin, int limit_end, int row_begin, int row_end)
+int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int parity, int limit_begin, int limit_end, int row_begin, int row_end)
 {
     FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(parity == 0 || parity == 1, "parity must be 0 or 1");
     FS_FIELD(v, 2);
     FS_ROWS();
     FS_REQUIRE(limit_begin >= 0 && limit_begin <= limit_end && limit_end <= ctx->rows, "bad row range of the limit pass");
@@ -1099,7 +1113,7 @@ int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int limit_begin
     FS_DISPATCH(ctx, {
         return launch(ctx, "velocity_bc", [=] {
             hipLaunchKernelGGL(k_velocity_bc_limit<T>, dim3((ctx->ops_vel.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
-                               ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, limit_begin, limit_end, (T)limit, (T *)v->d, (const T *)ctx->d_bc_const, v->hot, ctx->d_sync);
+                               ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, limit_begin, limit_end, (T)limit, (T *)v->d, (const T *)ctx->d_bc_const, v->hot, ctx->d_sync, parity);
         });
     })
 }
@@ -1130,6 +1144,32 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
         return launch(ctx, "dye_bc", [=] {
             hipLaunchKernelGGL(k_dye_bc<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T *)dye->d, (const T *)ctx->d_bc_dye);
+        });
+    })
+}
+
+int fs_dye_bc_limit_ok(const fs_ctx *ctx, int *ok)
+{
+    FS_REQUIRE(ctx && ok, "null argument");
+    const int wgs = (ctx->ops_dye.lanes() + 255) / 256;
+    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && ctx->d_bc_dye && wgs >= 1 && wgs <= 1024 ? 1 : 0;
+    return FS_OK;
+}
+
+int fs_dye_bc_limit(fs_ctx *ctx, double limit, fs_field *v, fs_field *dye, int limit_begin, int limit_end, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(v, 2); FS_FIELD(dye, 3);
+    FS_ROWS();
+    FS_REQUIRE(limit_begin >= 0 && limit_begin <= limit_end && limit_end <= ctx->rows, "bad row range of the limit pass");
+    int ok = 0;
+    fs_dye_bc_limit_ok(ctx, &ok);
+    if (!ok || !((float)limit * (float)limit > FS_HOT_SQ)) { set_error("fs_dye_bc_limit is not available for this context / limit (fs_dye_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
+    FS_DISPATCH(ctx, {
+        return launch(ctx, "dye_bc", [=] {
+            hipLaunchKernelGGL(k_dye_bc_limit<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, limit_begin, limit_end, (T)limit, (T *)v->d, v->hot, ctx->d_sync,
+                               (T *)dye->d, (const T *)ctx->d_bc_dye);
         });
     })
 }
@@ -1778,7 +1818,9 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     const int dm = dm_const(ctx, k);
     // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 (FS_RBPAIR_RT=6: 6) rows per tile.  The carrying
     // pass after an upload (full) is rare: one configuration.
-    const int rt = full ? 4 : ctx->rbpair_rt;
+    // (grids below 1 M cells: 2-row tiles - fewer waves than SIMDs there, the pass takes as long as ONE wave's chain of loads and stages:
+    //  res 200 12.1 -> 9.2 us per launch, BASELINE configs[0] 53.3 -> 62.8 k steps/s; res 1600: 4 rows, 5602 against 5435 steps/s)
+    const int rt = full ? 4 : (ctx->rbpair_rt ? ctx->rbpair_rt : ((size_t)ctx->X * ctx->Y < ((size_t)1 << 20) ? 2 : 4));
     if (!full && ctx->use_rbmarch) {
         // the row-marching form (fs_rbmarch.h): strips of L rows, one wave column each, plain and boundary rows in one kernel; the compact
         // list leaves out the strips of nothing but deep wall
@@ -1812,6 +1854,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     return launch(ctx, "rbsor_pair", [=] {
         if (full) FS_RBP_PAR(4, 0, 2, true);
         else if (rt == 6) FS_RBP_DM(6, 2);
+        else if (rt == 2) FS_RBP_DM(2, 2);
         else FS_RBP_DM(4, 2);
     });
 }

@@ -83,7 +83,7 @@ struct fs_ctx {
     int jquad_rt = 4;                        // its tile height (env FS_JQUAD_RT = 2, 4, 6, 8)
     int rbpair_split = 1;                    // plain and boundary workgroups of that pass (and of the four-sweep Jacobi pass) as two compact
                                              // launches: env FS_RBPAIR_SPLIT = 0 never, 1 on grids of 8 M cells or more, 2 always
-    int rbpair_rt = 4;                       // rows per tile of that pass (env FS_RBPAIR_RT = 4, 6)
+    int rbpair_rt = 0;                       // rows per tile of that pass (env FS_RBPAIR_RT = 2, 4, 6; 0: 2 below 1 M cells, else 4)
     int rbpair_plain_rt = 8;                 // env FS_RBPAIR_PLAIN_RT = 4 / 8: rows per tile of the pair pass's PLAIN part (two-part launch, one-wave workgroups)
     int split_wgw = 1;                       // env FS_SPLIT_WGW = 1 / 2 / 4: waves per workgroup of the two-part launches - the plain / boundary classification is per workgroup
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
@@ -163,7 +163,7 @@ struct fs_field {
     int C = 1;
     void *d = nullptr;
     size_t bytes = 0;
-    unsigned *hot = nullptr;   // device words: [0] "may hold a speed above 8" (fs_device.h; meaningful for 2-channel fields), [1] the same, raised inside a k_velocity_bc_limit launch
+    unsigned *hot = nullptr;   // device words: [0] "may hold a speed above 8" (fs_device.h; meaningful for 2-channel fields), [1], [2] the same, raised by the op list of a k_velocity_bc_limit launch of parity 0 / 1
 };
 
 namespace fs {

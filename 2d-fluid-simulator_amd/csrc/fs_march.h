@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, int je, T li
 {
     // `gated`: the buffer's flag is authoritative for this limit (fs_device.h) - while it is down no cell can exceed it: done.
     // A fixed grid of gridDim.y row lanes keeps the common case a ~3 us launch; the rare full pass strides over the rows.
-    if (gated && *hot == 0u) return;
+    if (gated && (hot[0] | hot[1] | hot[2]) == 0u) return;      // ([1], [2]: raised by the op lists of k_velocity_bc_limit launches)
     const int i0 = (blockIdx.x * 256 + threadIdx.x) << 2;
     if (i0 >= g.X) return;
     for (int j = jb + blockIdx.y; j < je; j += gridDim.y) {
@@ -873,71 +873,83 @@ __global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, int je, T li
 // fs/boundary_condition.py:16-39).  The limit pass is the last kernel of a step and, behind its flag, does nothing in a healthy run - yet
 // on small grids its launch is a fifth of the step (BASELINE configs[0]: 4 launches of ~6 us).  The host defers it (fs/runtime.py: the
 // velocity field carries a pending limit until somebody looks at it) and the boundary kernel of the next step starts with the gate:
-//   flag down (always, in a healthy run): one scalar load, then the op list as in k_velocity_bc;
+//   flag down (always, in a healthy run): two scalar loads, then the op list as in k_velocity_bc;
 //   flag up: the workgroups of this launch - the op list is O(perimeter): a few hundred at most, all resident - share the rows of the
 //   limit pass among them, meet at a grid barrier (arrive / depart counters, agent-scope fences: MI355X_MICROARCH.md "barrier-counter"),
 //   and run the op list on limited values.  Same arithmetic as k_limit_quad, cell by cell.
 // ------------------------------------------------------------------------------------------------
 // The gate must read the SAME value in every workgroup (those that see the flag up wait for all the others at the barrier), and the op list
-// itself may raise the flag (an inflow constant above the limit) while later workgroups have not started yet: inside this launch the op
-// list raises hot[1] instead, and the workgroup that finishes last (exit ticket) folds it into hot[0] for the launches that follow.
+// itself may raise the flag (an inflow constant above the limit) while later workgroups have not started yet.  So the flag has three sticky
+// words: [0] what every other kernel raises, [1] / [2] what the op list of a launch with parity 0 / 1 raises; consecutive launches on one
+// buffer alternate the parity (the caller's contract, fs_hip.h), and a launch reads [0] and the word of the OTHER parity - the one its
+// predecessor raised, which nobody writes now.  A word seen up is folded into [0] behind the barrier, where every workgroup has read the gate:
+// nothing raised is ever lost, and no launch waits for a "last workgroup out" any more (the exit ticket of the first version of this
+// kernel: two dependent atomics at the end of every launch, 0.8 us of a 22 us step).
+// the limit pass of a gate that is up, shared by the workgroups of the launch, and the grid barrier behind it (all of them resident)
 template <typename T>
-__global__ __launch_bounds__(256) void k_velocity_bc_limit(Grid g, BcOps ops, int jb, int je, int lb, int le, T lim, T *v, const T *bc_const, unsigned *hot, unsigned *sync)
+__device__ __forceinline__ void limit_pass_and_barrier(const Grid &g, int lb, int le, T lim, T *v, unsigned *hot, unsigned *sync)
 {
-    if (*hot != 0u) {
-        for (int j = lb + (int)blockIdx.x; j < le; j += (int)gridDim.x)
-            for (int i0 = (int)threadIdx.x << 2; i0 < g.X; i0 += 1024) {
-                T *px = v + idx<2, T>(g, 0, i0, j), *py = v + idx<2, T>(g, 1, i0, j);
-                const Q4<T> X(*reinterpret_cast<const typename Quad<T>::type *>(px)), Y(*reinterpret_cast<const typename Quad<T>::type *>(py));
+    for (int j = lb + (int)blockIdx.x; j < le; j += (int)gridDim.x)
+        for (int i0 = (int)threadIdx.x << 2; i0 < g.X; i0 += 1024) {
+            T *px = v + idx<2, T>(g, 0, i0, j), *py = v + idx<2, T>(g, 1, i0, j);
+            const Q4<T> X(*reinterpret_cast<const typename Quad<T>::type *>(px)), Y(*reinterpret_cast<const typename Quad<T>::type *>(py));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const T x = X.a[q], y = Y.a[q];
-                    const T nrm = tsqrt(x * x + y * y);
-                    if (nrm > lim) {
-                        px[q] = lim * (x / nrm);
-                        py[q] = lim * (y / nrm);
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const T x = X.a[q], y = Y.a[q];
+                const T nrm = tsqrt(x * x + y * y);
+                if (nrm > lim) {
+                    px[q] = lim * (x / nrm);
+                    py[q] = lim * (y / nrm);
                 }
             }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();                                                     // my rows are out (agent scope) before I arrive
-            atomicAdd(&sync[0], 1u);
-            while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(4);
-            __threadfence();                                                     // ... and this CU's L1 forgets what it held of the others' rows
-            if (atomicAdd(&sync[1], 1u) == gridDim.x - 1u) {                     // the last one out resets both counters: everybody has left the spin
-                __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
-        __syncthreads();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                                     // my rows are out (agent scope) before I arrive
+        atomicAdd(&sync[0], 1u);
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(4);
+        __threadfence();                                                     // ... and this CU's L1 forgets what it held of the others' rows
+        if (atomicAdd(&sync[1], 1u) == gridDim.x - 1u) {                     // the last one out resets both counters: everybody has left the spin
+            __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (blockIdx.x == 0) atomicOr(hot, 1u);                              // (every workgroup has read the gate: the fold cannot split it)
     }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_velocity_bc_limit(Grid g, BcOps ops, int jb, int je, int lb, int le, T lim, T *v, const T *bc_const, unsigned *hot, unsigned *sync, int parity)
+{
+    if ((hot[0] | hot[2 - parity]) != 0u) limit_pass_and_barrier<T>(g, lb, le, lim, v, hot, sync);
     int n = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned *raise = hot + 1 + parity;
     if (n < ops.nsimple) {
         const int4 o = ops.simple[n];
         const int trow = o.w >> 2;
         // a simple mirror / outflow op reads a cell of the same row or of the row +-2 / +-1 next to it: its row travels in .z
-        if (trow >= jb && trow < je) velocity_bc_op(g, o.w & 3, o.x, trow, o.y, o.z, v, bc_const, hot + 1);
+        if (trow >= jb && trow < je) velocity_bc_op(g, o.w & 3, o.x, trow, o.y, o.z, v, bc_const, raise);
     } else {
         n -= ops.nsimple;
         if (n < ops.ncomp && !(ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je))
             for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o)
-                velocity_bc_op(g, ops.kind[o], ops.tgt[o], ops.row[o], ops.s1[o], ops.srow[o], v, bc_const, hot + 1);
+                velocity_bc_op(g, ops.kind[o], ops.tgt[o], ops.row[o], ops.s1[o], ops.srow[o], v, bc_const, raise);
     }
-    // exit ticket in two levels (8 shards, then one word: a single counter costs ~12 ns per workgroup, 5 us at the 400 workgroups of res 4096):
-    // the workgroup that leaves last publishes what the op list raised.  hot[1] is raised with device-scope atomics: no fence needed.
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned sh = blockIdx.x & 7u, nsh = (gridDim.x + 7u - sh) >> 3, shards = gridDim.x < 8u ? gridDim.x : 8u;
-        if (atomicAdd(&sync[3 + sh], 1u) == nsh - 1u) {
-            __hip_atomic_store(&sync[3 + sh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (atomicAdd(&sync[2], 1u) == shards - 1u) {
-                if (__hip_atomic_load(hot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicOr(hot, 1u);
-                __hip_atomic_store(hot + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&sync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
+}
+
+// The same for the dye solvers (fs/solver.py:148-155, 385-392: limit_field(v) ends the flow step, set_dye_boundary_condition starts the dye step):
+// the velocity's limit pass rides with the dye boundary kernel - whose op list does not touch the velocity, so the gate reads all three words.
+template <typename T>
+__global__ __launch_bounds__(256) void k_dye_bc_limit(Grid g, BcOps ops, int jb, int je, int lb, int le, T lim, T *v, unsigned *hot, unsigned *sync, T *dye, const T *bc_dye)
+{
+    if ((hot[0] | hot[1] | hot[2]) != 0u) limit_pass_and_barrier<T>(g, lb, le, lim, v, hot, sync);
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= ops.nsimple) return;
+    const int4 o = ops.simple[n];
+    const int trow = o.w >> 2;
+    if (trow < jb || trow >= je) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dye[cell_off(g, o.x, trow, 3, c)] = bc_dye[cell_off(g, o.x, trow, 3, c)];
 }
 
 // clamp_field restricted to the inflow cells (op list of the dye boundary kernel): with the clamp folded into the advection

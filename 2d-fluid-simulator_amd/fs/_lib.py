@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libfs_hip.so")     # FS_LIB: A/B builds (tools/)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -38,7 +38,9 @@ _PROTOS = {
     "fs_field_devptr": [_c_vp, _P(_c_vp), _P(_c_sz)],
     "fs_velocity_bc": [_c_vp, _c_vp] + _ROWS,
     "fs_velocity_bc_limit_ok": [_c_vp, _P(_c_int)],
-    "fs_velocity_bc_limit": [_c_vp, _c_dbl, _c_vp, _c_int, _c_int] + _ROWS,
+    "fs_velocity_bc_limit": [_c_vp, _c_dbl, _c_vp, _c_int, _c_int, _c_int] + _ROWS,
+    "fs_dye_bc_limit_ok": [_c_vp, _P(_c_int)],
+    "fs_dye_bc_limit": [_c_vp, _c_dbl, _c_vp, _c_vp, _c_int, _c_int] + _ROWS,
     "fs_pressure_bc": [_c_vp, _c_vp] + _ROWS,
     "fs_dye_bc": [_c_vp, _c_vp] + _ROWS,
     "fs_mac_update": [_c_vp, _c_int, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,

@@ -59,9 +59,10 @@ class DyeBoundaryCondition(BoundaryCondition):
     def __init__(self, bc_const, bc_dye, bc_mask, device=None):
         self._init_scene(bc_const, bc_mask, bc_dye, device)
 
-    def set_dye_boundary_condition(self, dye):
-        """Inflow cells take the scene's dye colour (fs/boundary_condition.py:94-99)."""
-        self.device.dye_bc(dye)
+    def set_dye_boundary_condition(self, dye, velocity=None):
+        """Inflow cells take the scene's dye colour (fs/boundary_condition.py:94-99).  velocity (new, optional): the velocity field the flow
+        step just ended on - its deferred limit_field rides in this launch (runtime.DeviceBase.dye_bc)."""
+        self.device.dye_bc(dye, velocity)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -49,11 +49,12 @@ class FluidSimulator:
         self.rgb_buf = self._dev.alloc(3)      # image buffer (fs/fluid_simulator.py:16), device resident
         self._wall_color = _WALL_COLOR
         self._graph = None         # (signature, graph id, period) of the most recent capture
-        self._graphs = {}          # signature -> (graph id, period)
+        self._graph_long = None    # (graph id, steps) of the same capture's long form: several periods in one graph (capture_period)
+        self._graphs = {}          # signature -> (graph id, period, long form or None)
         self._tapes = {}           # (signature, ghost-row bookkeeping state) -> tape
         self._steps = 0
         self._eager_seen = False   # one step has run outside a capture (the library's compact launch lists exist)
-        self._pending_after_step = False
+        self._pending_after_step = (False, False)
 
     def step(self):
         self._solver.update()
@@ -61,10 +62,10 @@ class FluidSimulator:
         self._pending_after_step = self._limit_pending()
 
     def _limit_pending(self):
-        """Does the velocity field owe a deferred limit_field (runtime.DeviceBase.limit_field)?  After a step of the plain solvers it does;
-        the dye solvers' own kernels read the velocity and have made it run."""
-        v = getattr(self._solver, "v", None)
-        return v is not None and v.current.pending_limit is not None
+        """What the solver's fields owe: a deferred limit_field of the velocity (runtime.DeviceBase.limit_field; after a step of the plain
+        solvers - the dye solvers' boundary kernel has taken it along), a deferred clamp_inflow of the dye (DeviceBase.clamp_inflow)."""
+        v, dye = getattr(self._solver, "v", None), getattr(self._solver, "dye", None)
+        return (v is not None and v.current.pending_limit is not None, dye is not None and dye.current.pending_clamp is not None)
 
     def _counted_step(self):
         self.step()
@@ -80,11 +81,12 @@ class FluidSimulator:
             if db is not None:
                 for f in (db.current, db.next):
                     # serial: a Field's identity for life (id() is recycled); static_id: which carry decisions the capture baked in
-                    sig.append((f.serial, f.user_data, f.static_id, f.pending_limit))      # (pending_limit: a deferred limit_field, runtime.DeviceBase.limit_field)
+                    sig.append((f.serial, f.user_data, f.static_id, f.pending_limit, f.pending_clamp, f.bc_parity))      # (pending_limit: a deferred limit_field, runtime.DeviceBase.limit_field)
         for spare in (getattr(s, "_v_spare", None), getattr(s, "_dye_spare", None)) + tuple(getattr(s.pressure_updater, "_spare", None) or ()):
-            sig.append((spare.serial, spare.static_id) if spare is not None else 0)
+            sig.append((spare.serial, spare.static_id, spare.bc_parity) if spare is not None else 0)
         return tuple(sig)
 
+    _LONG_STEPS = 16     # steps per long-form graph (capture_period)
     _MAX_CACHED = 8      # captured graphs / tapes kept per simulator (one per phase of the buffer rotation; the oldest is freed first)
 
     def run(self, nsteps, graph=True):
@@ -128,8 +130,11 @@ class FluidSimulator:
             nsteps -= self.capture_period(budget=nsteps)
             entry = self._graphs.get(self._signature())
         if entry is not None:
-            gid, period = entry
-            self._graph = (self._signature(), gid, period)
+            gid, period, long = entry
+            self._graph, self._graph_long = (self._signature(), gid, period), long
+            if long is not None:
+                dev.replay(long[0], nsteps // long[1])
+                nsteps %= long[1]
             dev.replay(gid, nsteps // period)
             nsteps %= period
         for _ in range(nsteps):
@@ -150,9 +155,13 @@ class FluidSimulator:
         gradient + advection pass and vorticity confinement (the velocity rotates through three buffers, the gradients and - with the
         two-iteration red-black pass - the pressure pairs through two).  Periods are tried in increasing order; a capture whose steps
         do not bring every buffer back to its place is still executed once (the host-side swaps have happened) and freed.  Leaves
-        self._graph = (signature, graph id, period) - also cached for run() - or None if nothing within the budget repeats."""
+        self._graph = (signature, graph id, period) - also cached for run() - or None if nothing within the budget repeats.
+
+        Round 4: every replay of a graph costs ~5 us of GPU idle time whatever it holds (tools/r4_chain.py) - a quarter of a res-200 step
+        when the graph is a 2-step period.  Where the budget allows, the same period is therefore captured a second time, repeated to
+        >= 16 steps (self._graph_long = (graph id, steps)); run() and bench.py replay that one and finish with the short one."""
         dev, done = self._dev, 0
-        self._graph = None
+        self._graph = self._graph_long = None
         if (not self._eager_seen or self._limit_pending() != self._pending_after_step) and budget >= 2:
             # (also: the steady state of a run with deferred limit passes starts every step with one pending - after a download there is
             #  none, and a period captured from there would not close)
@@ -170,8 +179,14 @@ class FluidSimulator:
             dev.replay(gid, 1)                                                    # now the captured steps run once
             done += period
             if back:
-                self._remember(self._graphs, sig, (gid, period), lambda e: dev.free_graph(e[0]))
-                self._graph = (sig, gid, period)
+                long, reps = None, -(-self._LONG_STEPS // period)
+                if reps > 1 and done + reps * period <= budget:
+                    lid = dev.capture(lambda: [self._solver.update() for _ in range(reps * period)])
+                    dev.replay(lid, 1)
+                    done += reps * period
+                    long = (lid, reps * period)
+                self._remember(self._graphs, sig, (gid, period, long), lambda e: [dev.free_graph(e[0])] + ([dev.free_graph(e[2][0])] if e[2] else []))
+                self._graph, self._graph_long = (sig, gid, period), long
                 break
             dev.free_graph(gid)
         return done

@@ -92,6 +92,9 @@ class Field:
         self.user_data = False         # set once the user uploads / fills data (disables fusions that rely on invariants)
         self.pending_limit = None      # limit_field(self, limit) issued by the solver but not launched yet: it rides with the next step's velocity
                                        # boundary kernel (DeviceBase.limit_field); anything else that touches the field launches it first
+        self.pending_clamp = None      # clamp_inflow(self, low, high) issued by the dye solver but not launched: the next dye boundary kernel rewrites
+                                       # exactly those cells (DeviceBase.clamp_inflow); anything else that touches the field launches it first
+        self.bc_parity = 0             # parity of the next merged limit + boundary launch on this buffer (DeviceBase.velocity_bc)
         self.static_id = 0             # content class of the cells NO kernel ever writes (deep wall cells): 0 = still the zeros of the
                                        # allocation, a fresh token after every upload / fill.  Passes that store only the cells that can
                                        # change (fs_rbsor_pair, the fused gradient + advection pass) need source and target buffer in
@@ -105,7 +108,7 @@ class Field:
         return (self.dev.nx, nrows) if self.nchan == 1 else (self.dev.nx, nrows, self.nchan)
 
     def fill(self, value):
-        self.pending_limit = None      # (every cell is overwritten: what the deferred limit would have done is gone either way)
+        self.pending_limit = self.pending_clamp = None      # (every cell is overwritten: what the deferred passes would have done is gone either way)
         self.dev._p_fill(self._h, float(value))
         self.valid = self.dev.halo
         self.static_id = next(_serials)
@@ -118,7 +121,7 @@ class Field:
         if arr.shape != self._full_shape(dev.ny):
             raise ValueError(f"expected array of shape {self._full_shape(dev.ny)}, got {arr.shape}")
         win = np.ascontiguousarray(arr[:, dev.g_lo:dev.g_hi], dtype=dev.dtype)
-        self.pending_limit = None      # (as fill)
+        self.pending_limit = self.pending_clamp = None      # (as fill)
         dev._p_upload(self._h, self.nchan, win, dev.g_lo - (dev.y0 - dev.halo), dev.g_hi - dev.g_lo)
         self.valid = dev.halo
         self.user_data = True
@@ -304,9 +307,9 @@ class DeviceBase:
         but the op-list boundary kernels) that exchange runs behind the kernel's own interior rows: mark -> rows [2H, nyl)
         -> begin -> wait -> the two edge strips.
         """
-        if name != "velocity_bc_limit":      # a deferred limit_field runs before anything else looks at (or writes into) its field
+        if name not in ("velocity_bc_limit", "dye_bc_limit"):      # a deferred limit_field / clamp_inflow runs before anything else looks at (or writes into) its field
             for f in [f for f, _ in reads] + list(writes) + list(full_writes):
-                if f.pending_limit is not None:
+                if f.pending_limit is not None or f.pending_clamp is not None:
                     self.flush_limit(f)
         multi = self.nranks > 1
         off = self.y0 - self.halo
@@ -548,6 +551,7 @@ class DeviceBase:
         self.lazy_bc_ok = not no_lazy
         self.rb_pair_ok = not no_pair
         self.limit_deferral = self.nranks == 1 and os.environ.get("FS_LIMIT_DEFER", "1") == "1" and self._p_limit_deferral_ok()
+        self.dye_limit_merge = self.limit_deferral and bc_dye is not None and self._p_dye_bc_limit_ok()
         self.bc_radius_v, self.bc_radius_p = max(2, int(rv)), max(1, int(rp))
         if self.nranks > 1 and max(self.bc_radius_v, self.bc_radius_p) > self.halo:
             raise RuntimeError(
@@ -558,24 +562,40 @@ class DeviceBase:
     def velocity_bc(self, v):                                   # fs/boundary_condition.py:16-39
         if v.pending_limit is not None and self.nranks == 1:
             # the limit_field the last step ended with + this step's boundary kernel in one launch (csrc/fs_march.h k_velocity_bc_limit)
+            # (bc_parity: consecutive merged launches on one buffer alternate it, include/fs_hip.h - part of FluidSimulator._signature, so
+            #  a captured period always holds an even number of them per buffer)
             limit, v.pending_limit = v.pending_limit, None
-            self._run("velocity_bc_limit", (limit, v._h, 0, self.rows), reads=[(v, self.bc_radius_v)], writes=[v], split=False)
+            self._run("velocity_bc_limit", (limit, v._h, v.bc_parity, 0, self.rows), reads=[(v, self.bc_radius_v)], writes=[v], split=False)
+            v.bc_parity ^= 1
             return
         self._run("velocity_bc", (v._h,), reads=[(v, self.bc_radius_v)], writes=[v], split=False)   # op list with serial hazards
 
     def _p_limit_deferral_ok(self):      # backends without the merged kernel
         return False
 
+    def _p_dye_bc_limit_ok(self):        # backends without the merged kernel
+        return False
+
     def flush_limit(self, f):
-        """Launch the limit_field a field still owes (see limit_field)."""
+        """Launch the limit_field / clamp_inflow a field still owes (see limit_field, clamp_inflow)."""
         if f.pending_limit is not None:
             limit, f.pending_limit = f.pending_limit, None
             self._run("limit_field", (limit, f._h), pointwise=True, writes=[f])
+        if f.pending_clamp is not None:
+            (low, high), f.pending_clamp = f.pending_clamp, None
+            self._run("clamp_inflow", (low, high, f._h), pointwise=True, writes=[f])
 
     def pressure_bc(self, p):                                   # fs/boundary_condition.py:41-65
         self._run("pressure_bc", (p._h,), reads=[(p, self.bc_radius_p)], writes=[p], split=False)
 
-    def dye_bc(self, dye):                                      # fs/boundary_condition.py:94-99
+    def dye_bc(self, dye, velocity=None):                       # fs/boundary_condition.py:94-99
+        """velocity: the field whose deferred limit_field (the flow step just ended with it, fs/solver.py:148-155, 385-392) rides in this launch."""
+        if self.nranks == 1:
+            dye.pending_clamp = None        # the op list rewrites exactly the cells a deferred clamp_inflow would clamp, from constants
+        if velocity is not None and velocity.pending_limit is not None and self.dye_limit_merge:
+            limit, velocity.pending_limit = velocity.pending_limit, None
+            self._run("dye_bc_limit", (limit, velocity._h, dye._h, 0, self.rows), reads=[], writes=[dye, velocity], split=False)
+            return
         self._run("dye_bc", (dye._h,), reads=[], writes=[dye], split=False)
 
     def mac_update(self, scheme, dt, dx, re, vn, vc, pc):       # fs/solver.py:94-107
@@ -700,7 +720,14 @@ class DeviceBase:
         self._run("cip_advect_dye_clamped", (dt, dx, fn._h, fxn._h, fyn._h, fc._h, fxc._h, fyc._h, v._h),
                   reads=[(fc, 1), (fxc, 1), (fyc, 1), (v, 1)], writes=[fn, fxn, fyn])
 
-    def clamp_inflow(self, low, high, dye):
+    def clamp_inflow(self, low, high, dye, defer=False):
+        """defer=True (the dye solver's end-of-step call, single GPU): the cells this pass clamps are the targets of the dye boundary op list,
+        which the next step's set_dye_boundary_condition overwrites with the scene's constants before anything reads them - the launch is
+        dropped there (dye_bc), and made up for when anything else touches the field first (_run / Field.to_numpy)."""
+        if defer and self.limit_deferral and dye.pending_clamp is None:
+            dye.pending_clamp = (float(low), float(high))
+            return
+        dye.pending_clamp = None        # (an older pending clamp to the same bounds is subsumed; the solvers use one pair of bounds)
         self._run("clamp_inflow", (low, high, dye._h), pointwise=True, writes=[dye])
 
     # visualisation kernels (fs/fluid_simulator.py:38-58, 121-126): every cell of the computed rows is written
@@ -814,6 +841,11 @@ class Device(DeviceBase):
     def _p_limit_deferral_ok(self):
         ok = ctypes.c_int()
         _lib.call("fs_velocity_bc_limit_ok", self._ctx, ctypes.byref(ok))
+        return bool(ok.value)
+
+    def _p_dye_bc_limit_ok(self):
+        ok = ctypes.c_int()
+        _lib.call("fs_dye_bc_limit_ok", self._ctx, ctypes.byref(ok))
         return bool(ok.value)
 
     @property

@@ -89,7 +89,7 @@ class DyeMacSolver(MacSolver):
 
     def update(self):
         self._flow_step()
-        self._bc.set_dye_boundary_condition(self.dye.current)
+        self._bc.set_dye_boundary_condition(self.dye.current, self.v.current)
         self._update_dye(self.dye.next, self.dye.current, self.v.current)
         self.dye.swap()
         clamp_field(self.dye.current, 0.0, 1.0)
@@ -205,11 +205,11 @@ class DyeCipMacSolver(CipMacSolver):
 
     def update(self):
         self._flow_step()
-        self._bc.set_dye_boundary_condition(self.dye.current)
+        self._bc.set_dye_boundary_condition(self.dye.current, self.v.current)
         fold = self._fused_clamp and not (self.dye.current.user_data or self.dye.next.user_data)
         self._update_dye(self.dye, self.dyex, self.dyey, self.v, clamp=fold)
         if fold:
-            self._dev.clamp_inflow(0.0, 1.0, self.dye.current)
+            self._dev.clamp_inflow(0.0, 1.0, self.dye.current, defer=True)
         else:
             clamp_field(self.dye.current, 0.0, 1.0)
             if self._dye_spare is not None:      # (wall cells of an uploaded dye: clamped in both copies, see _flow_step)

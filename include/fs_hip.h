@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 6
+#define FS_ABI_VERSION 7
 
 typedef struct fs_ctx fs_ctx;
 typedef struct fs_field fs_field;
@@ -86,13 +86,20 @@ int fs_velocity_bc(fs_ctx *ctx, fs_field *v, int row_begin, int row_end);
  * the reference issues them as the last kernel of one step and the first of the next).  Behind the velocity buffer's flag the limit pass
  * does nothing in a healthy run, yet its launch is a fifth of a small-grid step; the Python shell defers it (the field carries a pending
  * limit until anything else looks at it) and this entry point runs gate + limit (rare) + boundary op list.  Same bits as fs_limit_field
- * over [limit_begin, limit_end) followed by fs_velocity_bc over [row_begin, row_end).  fs_velocity_bc_limit_ok: available for this context. */
+ * over [limit_begin, limit_end) followed by fs_velocity_bc over [row_begin, row_end).  fs_velocity_bc_limit_ok: available for this context.
+ * `parity` (0 / 1): consecutive calls on ONE field alternate it - a launch's op list raises the flag word of its parity and its gate reads
+ * the other one, so that every workgroup of a launch takes the same decision (a call that repeats its predecessor's parity would see what
+ * that predecessor's op list raised one call late).  fs_field_copy / fs_field_fill / fs_limit_field read all words: any order there. */
 int fs_velocity_bc_limit_ok(const fs_ctx *ctx, int *ok);
-int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int limit_begin, int limit_end, int row_begin, int row_end);
+int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int parity, int limit_begin, int limit_end, int row_begin, int row_end);
 /* BoundaryCondition.set_pressure_boundary_condition   fs/boundary_condition.py:41-65  (in place) */
 int fs_pressure_bc(fs_ctx *ctx, fs_field *p, int row_begin, int row_end);
 /* DyeBoundaryCondition.set_dye_boundary_condition     fs/boundary_condition.py:94-99  (in place) */
 int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end);
+/* limit_field(v) at the end of the flow step + set_dye_boundary_condition in ONE launch (the dye solvers: fs/solver.py:148-155, 385-392 call
+ * them back to back).  Same bits as fs_limit_field(v) over [limit_begin, limit_end) followed by fs_dye_bc(dye) over [row_begin, row_end). */
+int fs_dye_bc_limit_ok(const fs_ctx *ctx, int *ok);
+int fs_dye_bc_limit(fs_ctx *ctx, double limit, fs_field *v, fs_field *dye, int limit_begin, int limit_end, int row_begin, int row_end);
 
 /* ---- velocity / dye transport ----------------------------------------------------------------- */
 /* MacSolver._update_velocities        fs/solver.py:94-107   (fluid cells; scheme = fs_scheme)   */

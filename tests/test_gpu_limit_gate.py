@@ -155,3 +155,66 @@ def test_deferred_limit_rides_with_the_next_boundary_kernel(scheme, vc, res, gra
     finally:
         sim._solver._bc.device.close()
         plain._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("scheme,res,graph", [("cip", 64, False), ("cip", 130, True), ("upwind", 64, False), ("cip", 400, True)])
+def test_dye_solvers_take_the_limit_along_and_drop_the_inflow_clamp(scheme, res, graph, hip_lib, monkeypatch):
+    """Round 4: in the dye solvers the flow step's limit_field rides with the dye boundary kernel (csrc/fs_march.h k_dye_bc_limit), and the
+    end-of-step clamp of the inflow cells is dropped when the next step's dye boundary kernel overwrites those very cells - or launched
+    when something looks at the dye first.  Inflow of 30 (flag up: every step takes the limit pass + grid barrier on the dye kernel's few
+    workgroups) and a dye colour of 1.7 on the inflow (the clamp matters), eagerly and as a replayed hipGraph, with a look at the fields in
+    mid-run, against the immediate launches and (small grids) the CPU oracle."""
+    import fs
+    from fs.boundary_condition import DyeBoundaryCondition, create_scene_arrays
+    from oracle import oracle as O
+    const, mask, dye0 = create_scene_arrays(2, res)
+    const, dye0 = const.copy(), dye0.copy()
+    const[mask == 2] *= np.float32(30.0) / max(float(np.abs(const[mask == 2]).max()), 1e-6)
+    dye0[mask == 2] *= np.float32(1.7)
+    dt, dx = 0.05 / res, 1.0 / res
+
+    def build():
+        fs.runtime.init(gpu=0, dtype="f32")
+        bc = DyeBoundaryCondition(const, dye0, mask)
+        pu = fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2)
+        vc = fs.VorticityConfinement(bc, dt, dx, 5.0) if scheme == "cip" else None
+        solver = fs.DyeCipMacSolver(bc, pu, dt, dx, 1e6, vc) if scheme == "cip" else fs.DyeMacSolver(bc, pu, fs.advect_upwind, dt, dx, 1e6, vc)
+        return fs.DyeFluidSimulator(solver)
+    monkeypatch.setenv("FS_LIMIT_DEFER", "1")
+    sim = build()
+    monkeypatch.setenv("FS_LIMIT_DEFER", "0")
+    plain = build()
+    ref = O.make_simulator(const, mask, dye0, scheme=scheme, dt=dt, dx=dx, re=1e6, vor_eps=5.0 if scheme == "cip" else None) if res <= 130 else None
+    try:
+        dev = sim._solver._bc.device
+        assert dev.limit_deferral and dev.dye_limit_merge and not plain._solver._bc.device.limit_deferral
+        done = 0
+        for chunk in ((40, 3, 23) if graph else (3, 2, 4)):
+            if graph:
+                sim.run(chunk)
+            else:
+                for _ in range(chunk):
+                    sim.step()
+            done += chunk
+            s = sim._solver
+            assert s.v.current.pending_limit is None                       # the dye boundary kernel has taken it along
+            if scheme == "cip":
+                assert s.dye.current.pending_clamp is not None             # owed until somebody looks
+            for _ in range(chunk):
+                plain.step()
+                if ref is not None:
+                    ref.update()
+            out, exp = sim.field_to_numpy(), plain.field_to_numpy()
+            assert s.dye.current.pending_clamp is None
+            for k in exp:
+                assert np.array_equal(out[k], exp[k], equal_nan=True), f"deferred vs immediate after {done} steps: {k}"
+                if ref is not None:
+                    assert np.array_equal(out[k], ref.fields()[k], equal_nan=True), f"deferred vs oracle after {done} steps: {k}"
+            assert np.nanmax(out["dye"]) <= 1.0
+        for name in ("v", "p", "dye"):
+            for which in ("current", "next"):
+                a, b = getattr(getattr(sim._solver, name), which).to_numpy(), getattr(getattr(plain._solver, name), which).to_numpy()
+                assert np.array_equal(a, b, equal_nan=True), f"{name}.{which}"
+    finally:
+        sim._solver._bc.device.close()
+        plain._solver._bc.device.close()
