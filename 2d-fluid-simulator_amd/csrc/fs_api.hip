@@ -140,6 +140,10 @@ static int prof_drain(fs_ctx *c)
     return FS_OK;
 }
 
+// Grids below 1 M cells have fewer waves than the chip has SIMDs: a launch takes as long as ONE wave's chain of loads, stages and stores, and
+// tiles of half the height halve that chain (round 4, tools/r4_chain.py; env FS_SMALL_TILES=0: the big grids' tile heights everywhere)
+static inline bool small_tiles(const fs_ctx *c) { return c->small_tiles && (size_t)c->X * c->Y < ((size_t)1 << 20); }
+
 static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
 
 // overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
@@ -357,8 +361,9 @@ static void free_ops(BcOpsDev &o)
     int **ptrs[] = {&o.comp_begin, &o.comp_rlo, &o.comp_rhi, &o.kind, &o.tgt, &o.s1, &o.s2, &o.row, &o.srow};
     for (auto pp : ptrs) { if (*pp) hipFree(*pp); *pp = nullptr; }
     if (o.simple) hipFree(o.simple);
-    o.simple = nullptr;
-    o.nsimple = o.ncomp = o.nops = 0;
+    if (o.pair) hipFree(o.pair);
+    o.simple = o.pair = nullptr;
+    o.nsimple = o.npair = o.ncomp = o.nops = 0;
 }
 
 // Group the serial-order op list into hazard components and upload it in local cell offsets.
@@ -402,7 +407,16 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
     auto local_off = [&](long long cell) { return local_row(cell) * c->P + (int)(cell / Y); };
 
     std::vector<int> h_begin, h_rlo, h_rhi, h_kind, h_tgt, h_s1, h_s2, h_row, h_srow;
-    std::vector<int4> h_simple;
+    std::vector<int4> h_simple, h_pair;
+    auto record = [&](const HostOp &op) {
+        const int tr = local_row(op.t);
+        int4 r;
+        r.x = local_off(op.t);
+        r.y = op.s1 >= 0 ? local_off(op.s1) : -1;
+        r.z = rows_in_z ? (op.s1 >= 0 ? local_row(op.s1) : 0) : (op.s2 >= 0 ? local_off(op.s2) : -1);
+        r.w = op.kind | (tr << 2);
+        return r;
+    };
     int pos = 0;
     while (pos < n) {
         int end = pos;
@@ -462,14 +476,10 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
             if (depth <= c->halo - min_radius) c->bc_incomplete = true;   // an owned row, or a ghost row the tracker may rely on
         }
         if (kept.size() == 1) {        // the common case: one assignment, no hazard -> a flat 16-byte record
-            const HostOp &op = ops[kept[0]];
-            const int tr = local_row(op.t);
-            int4 r;
-            r.x = local_off(op.t);
-            r.y = op.s1 >= 0 ? local_off(op.s1) : -1;
-            r.z = rows_in_z ? (op.s1 >= 0 ? local_row(op.s1) : 0) : (op.s2 >= 0 ? local_off(op.s2) : -1);
-            r.w = op.kind | (tr << 2);
-            h_simple.push_back(r);
+            h_simple.push_back(record(ops[kept[0]]));
+        } else if (kept.size() == 2 && !getenv("FS_BC_NOPAIRS")) {      // a chain of two: two flat records side by side (BcOps::pair)
+            h_pair.push_back(record(ops[kept[0]]));
+            h_pair.push_back(record(ops[kept[1]]));
         } else if (!kept.empty()) {
             int klo = INT32_MAX, khi = INT32_MIN;
             for (int o : kept) { const int tr = local_row(ops[o].t); klo = std::min(klo, tr); khi = std::max(khi, tr); }
@@ -492,7 +502,7 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
     if (getenv("FS_BC_STATS")) {        // (debug: how long the serial chains of this op list are)
         std::map<int, int> hist;
         for (size_t k = 0; k + 1 < h_begin.size(); ++k) hist[h_begin[k + 1] - h_begin[k]]++;
-        fprintf(stderr, "fs: bc op list: %zu simple, %zu chains:", h_simple.size(), h_rlo.size());
+        fprintf(stderr, "fs: bc op list: %zu simple, %zu chains of two, %zu longer chains:", h_simple.size(), h_pair.size() / 2, h_rlo.size());
         for (auto &kv : hist) fprintf(stderr, " %dx len %d", kv.second, kv.first);
         fprintf(stderr, "\n");
     }
@@ -518,6 +528,9 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
     out.nsimple = (int)h_simple.size();
     FS_HIP(hipMalloc(&out.simple, std::max<size_t>(h_simple.size(), 1) * sizeof(int4)));
     if (!h_simple.empty()) FS_HIP(hipMemcpyAsync(out.simple, h_simple.data(), h_simple.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    out.npair = (int)h_pair.size() / 2;
+    FS_HIP(hipMalloc(&out.pair, std::max<size_t>(h_pair.size(), 1) * sizeof(int4)));
+    if (!h_pair.empty()) FS_HIP(hipMemcpyAsync(out.pair, h_pair.data(), h_pair.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
     return FS_OK;
 }
@@ -649,7 +662,9 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     //   smaller: bc2 res 800 / res 400 (workgroups of half the size)                                  28.2 / 14.5        26.6 / 13.7       24.8 / 12.9
     const size_t cells = (size_t)ctx->X * ctx->rows;      // (this context's slab)
     const int N = ctx->X % 4 != 0 ? 2 : (ctx->k34_n ? ctx->k34_n : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4));
-    const int RT = N == 4 ? 2 : (ctx->k34_rt ? ctx->k34_rt : (cells >= ((size_t)1 << 23) ? 4 : 2)), geo = N == 2 ? 3 : 4;
+    // (below 1 M cells: 1-row tiles for the dye's three channels - a launch is one wave's chain there, fs_ctx::small_tiles; res 400: 17.6 against
+    //  17.1 k steps/s with the dye; the velocity's pass stays on 2 rows: 29.0 against 28.1 k)
+    const int RT = N == 4 ? 2 : (ctx->k34_rt ? ctx->k34_rt : (cells >= ((size_t)1 << 23) ? 4 : (small_tiles(ctx) && !full && C == 3 ? 1 : 2))), geo = N == 2 ? 3 : 4;
 #define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
         (T *)f_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v ? (const T *)v->d : (const T *)nullptr, \
         f_out->hot, (const uint8_t *)ctx->d_bcmap, full)
@@ -659,10 +674,11 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
 #define FS_K34_22P(DM) FS_K34(2, 2, DM, true)
 #define FS_K34_42(DM) FS_K34(4, 2, DM, false)
 #define FS_K34_42P(DM) FS_K34(4, 2, DM, true)
+#define FS_K34_21(DM) FS_K34(2, 1, DM, false)
 #define FS_K34_ANY(SUF) do { if (N == 4) FS_DMX(dm, FS_K34_42##SUF); else if (RT == 4) FS_DMX(dm, FS_K34_24##SUF); else FS_DMX(dm, FS_K34_22##SUF); } while (0)
     // Compact launch in two parts on large single-GPU grids (as fs_rbsor_pair): the workgroups that see nothing but fluid within
     // reach run without mask loads, selects and conditional stores (PLAIN), the others the general tile
-    if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
+    if (!full && RT != 1 && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
         const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 1, 2, ctx->split_wgw);
         const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 2, 2, ctx->split_wgw);
         if (og.g.tiles && ogb.g.tiles) {
@@ -672,7 +688,7 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
         }
     }
     const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, !full);      // (the carrying pass visits every tile)
-    return launch(ctx, name, [=] { FS_K34_ANY(); });
+    return launch(ctx, name, [=] { if (N == 2 && RT == 1) FS_DMX(dm, FS_K34_21); else FS_K34_ANY(); });
 }
 
 extern "C" {
@@ -718,6 +734,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
+    if (const char *s = getenv("FS_SMALL_TILES")) c->small_tiles = atoi(s) != 0;
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6) c->rbpair_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8) c->rbpair_plain_rt = v; }
     if (const char *s = getenv("FS_SPLIT_WGW")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->split_wgw = v; }
@@ -726,7 +743,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_JM_L")) { const int v = atoi(s); if (v >= 2 && v <= 254 && v % 2 == 0) c->jm_L = v; }
     if (const char *s = getenv("FS_JM_PF")) { const int v = atoi(s); if (v == 1 || v == 3) c->jm_pf = v; }
     if (const char *s = getenv("FS_RBM_PF")) { const int v = atoi(s); if (v == 1 || v == 3) c->rbm_pf = v; }
-    if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : (atoi(s) == 4 ? 4 : 0);
+    if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : (atoi(s) == 4 ? 4 : (atoi(s) == 1 ? 1 : 0));
     if (const char *s = getenv("FS_MAC_RT")) { const int v = atoi(s); c->mac_rt = v == 2 || v == 4 ? v : 0; }
     if (const char *s = getenv("FS_K34_N")) c->k34_n = atoi(s) == 4 ? 4 : (atoi(s) == 2 ? 2 : 0);
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
@@ -1252,10 +1269,13 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
         if (ctx->use_pairs) {
             // lanes of 2 cells, tiles of 4 rows (fs_k34n.h k_cip_nonadv_n), compact launch: 116 -> 102 us at bc5 res 4096 against the one-row quad form
             // it replaces (2 rows: 112, 8 rows: 106-110)
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_NONADV, 3);
+            // (small grids - fewer waves than SIMDs, a launch takes as long as one wave's chain: 2-row tiles, fs_ctx::small_tiles)
+            const bool small = small_tiles(ctx);
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3);
             return launch(ctx, "cip_nonadv", [=] {
 #define FS_K2N4(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
-                FS_DMA(dm_all(ctx, k), FS_K2N4);
+#define FS_K2N2(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
+                if (small) FS_DMA(dm_all(ctx, k), FS_K2N2); else FS_DMA(dm_all(ctx, k), FS_K2N4);
             });
         }
         if (k.p2) { FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<true, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot) }
@@ -1273,10 +1293,12 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
         auto k = make_konst<T>(ctx, dt, dx, re);
         if (ctx->use_pairs) {
             // lanes of 2 cells, 4-row tiles (fs_k34n.h k_cip_nonadv_dye_n), compact launch: 141 -> 122-130 us at bc5 res 4096 against the one-row quad form
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_NONADV, 3);
+            const bool small = small_tiles(ctx);       // (2-row tiles, see fs_cip_nonadv)
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3);
             return launch(ctx, "cip_nonadv_dye", [=] {
 #define FS_K12N(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
-                FS_DMA(dm_all(ctx, k), FS_K12N);
+#define FS_K12N2(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
+                if (small) FS_DMA(dm_all(ctx, k), FS_K12N2); else FS_DMA(dm_all(ctx, k), FS_K12N);
             });
         }
         FS_LAUNCH_CELLS("cip_nonadv_dye", (k_cip_nonadv_dye<T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d)
@@ -1449,7 +1471,8 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
     }
     // lanes of 2 cells (fs_k34n.h k_vort_n), 4-row tiles, compact launch: 100 -> 95 us at bc5 res 4096 against the quad form it replaces (6 / 8 rows:
     // 102 / 103; f64 at bc3 res 4096: 251 -> 224)
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_VORT, 3);
+    const bool small = small_tiles(ctx) && !vort;      // (small grids: 2-row tiles, see fs_cip_nonadv)
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_VORT, 3);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
         const int dm = dm_dx(ctx, k);
@@ -1457,7 +1480,8 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
 #define FS_VORTN(DM, ST) hipLaunchKernelGGL((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
 #define FS_VORTN_S(DM) FS_VORTN(DM, true)
 #define FS_VORTN_N(DM) FS_VORTN(DM, false)
-        return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORTN_S); else FS_DMX(dm, FS_VORTN_N); });
+#define FS_VORTN_2(DM) hipLaunchKernelGGL((k_vort_n<2, 2, DM, false, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
+        return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORTN_S); else if (small) FS_DMX(dm, FS_VORTN_2); else FS_DMX(dm, FS_VORTN_N); });
     })
 }
 
@@ -1820,7 +1844,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     // pass after an upload (full) is rare: one configuration.
     // (grids below 1 M cells: 2-row tiles - fewer waves than SIMDs there, the pass takes as long as ONE wave's chain of loads and stages:
     //  res 200 12.1 -> 9.2 us per launch, BASELINE configs[0] 53.3 -> 62.8 k steps/s; res 1600: 4 rows, 5602 against 5435 steps/s)
-    const int rt = full ? 4 : (ctx->rbpair_rt ? ctx->rbpair_rt : ((size_t)ctx->X * ctx->Y < ((size_t)1 << 20) ? 2 : 4));
+    const int rt = full ? 4 : (ctx->rbpair_rt ? ctx->rbpair_rt : (small_tiles(ctx) ? 2 : 4));
     if (!full && ctx->use_rbmarch) {
         // the row-marching form (fs_rbmarch.h): strips of L rows, one wave column each, plain and boundary rows in one kernel; the compact
         // list leaves out the strips of nothing but deep wall

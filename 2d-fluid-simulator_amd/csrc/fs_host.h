@@ -40,12 +40,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
     } while (0)
 
 struct BcOpsDev {
-    int nsimple = 0, ncomp = 0, nops = 0;
-    int4 *simple = nullptr;
+    int nsimple = 0, npair = 0, ncomp = 0, nops = 0;
+    int4 *simple = nullptr, *pair = nullptr;
     int *comp_begin = nullptr, *comp_rlo = nullptr, *comp_rhi = nullptr;
     int *kind = nullptr, *tgt = nullptr, *s1 = nullptr, *s2 = nullptr, *row = nullptr, *srow = nullptr;
-    int lanes() const { return nsimple + ncomp; }
-    BcOps view() const { return BcOps{nsimple, simple, ncomp, comp_begin, comp_rlo, comp_rhi, kind, tgt, s1, s2, row, srow}; }
+    int lanes() const { return nsimple + npair + ncomp; }
+    BcOps view() const { return BcOps{nsimple, simple, npair, pair, ncomp, comp_begin, comp_rlo, comp_rhi, kind, tgt, s1, s2, row, srow}; }
 };
 
 struct ProfRec {
@@ -83,6 +83,7 @@ struct fs_ctx {
     int jquad_rt = 4;                        // its tile height (env FS_JQUAD_RT = 2, 4, 6, 8)
     int rbpair_split = 1;                    // plain and boundary workgroups of that pass (and of the four-sweep Jacobi pass) as two compact
                                              // launches: env FS_RBPAIR_SPLIT = 0 never, 1 on grids of 8 M cells or more, 2 always
+    bool small_tiles = true;                 // 2-row tiles on grids below 1 M cells (env FS_SMALL_TILES=0)
     int rbpair_rt = 0;                       // rows per tile of that pass (env FS_RBPAIR_RT = 2, 4, 6; 0: 2 below 1 M cells, else 4)
     int rbpair_plain_rt = 8;                 // env FS_RBPAIR_PLAIN_RT = 4 / 8: rows per tile of the pair pass's PLAIN part (two-part launch, one-wave workgroups)
     int split_wgw = 1;                       // env FS_SPLIT_WGW = 1 / 2 / 4: waves per workgroup of the two-part launches - the plain / boundary classification is per workgroup

@@ -442,7 +442,12 @@ struct BcOps {
     // lane, then the data, then the store: two dependent memory round trips instead of four (the kernels are pure latency)
     int nsimple;
     const int4 *simple;
-    // hazard components (several assignments that must run in serial order)
+    // hazard components of TWO assignments (every serial chain of the reference's scenes: a mirror whose source another mirror rewrites):
+    // two records of the simple kind side by side - one round trip brings both, then the two dependent load -> store steps (the general
+    // form below walks five arrays per assignment behind a [begin, end) lookup: five dependent round trips for the same two assignments)
+    int npair;
+    const int4 *pair;       // [2 * npair]
+    // longer hazard components (several assignments that must run in serial order)
     int ncomp;
     const int *comp_begin;  // [ncomp + 1] into the op arrays
     const int *comp_rlo;    // [ncomp] min / max local target row of the component
@@ -477,6 +482,15 @@ __device__ __forceinline__ void velocity_bc_op(const Grid &g, int kind, int t, i
         raise_hot(hot, hot2(x, v[cell_off(g, t, trow, 2, 1)]));
     }
 }
+// a two-assignment chain (BcOps::pair): both run, in order, when the chain's target rows meet [jb, je) - the rule of the general components
+template <typename T>
+__device__ __forceinline__ void velocity_bc_pair(const Grid &g, const int4 a, const int4 b, int jb, int je, T *v, const T *bc_const, unsigned *hot)
+{
+    const int ra = a.w >> 2, rb = b.w >> 2;
+    if ((ra > rb ? ra : rb) < jb || (ra < rb ? ra : rb) >= je) return;
+    velocity_bc_op(g, a.w & 3, a.x, ra, a.y, a.z, v, bc_const, hot);
+    velocity_bc_op(g, b.w & 3, b.x, rb, b.y, b.z, v, bc_const, hot);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_velocity_bc(Grid g, BcOps ops, int jb, int je, T *v, const T *bc_const, unsigned *hot)
 {
@@ -490,6 +504,8 @@ __global__ __launch_bounds__(256) void k_velocity_bc(Grid g, BcOps ops, int jb, 
         return;
     }
     n -= ops.nsimple;
+    if (n < ops.npair) { velocity_bc_pair(g, ops.pair[2 * n], ops.pair[2 * n + 1], jb, je, v, bc_const, hot); return; }
+    n -= ops.npair;
     if (n >= ops.ncomp) return;
     if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
     for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o)
@@ -513,6 +529,22 @@ __global__ __launch_bounds__(256) void k_pressure_bc(Grid g, BcOps ops, int jb, 
         return;
     }
     n -= ops.nsimple;
+    if (n < ops.npair) {
+        const int4 a = ops.pair[2 * n], b = ops.pair[2 * n + 1];
+        const int ra = a.w >> 2, rb = b.w >> 2;
+        if ((ra > rb ? ra : rb) < jb || (ra < rb ? ra : rb) >= je) return;
+        const int4 rec[2] = {a, b};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kind = rec[q].w & 3;
+            T val = (T)0.0;
+            if (kind == 0) val = p[rec[q].y];
+            else if (kind == 1) val = (p[rec[q].y] + p[rec[q].z]) / (T)2.0;
+            p[rec[q].x] = val;
+        }
+        return;
+    }
+    n -= ops.npair;
     if (n >= ops.ncomp) return;
     if (ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je) return;
     for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o) {

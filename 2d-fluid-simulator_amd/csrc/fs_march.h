@@ -929,8 +929,11 @@ __global__ __launch_bounds__(256) void k_velocity_bc_limit(Grid g, BcOps ops, in
         const int trow = o.w >> 2;
         // a simple mirror / outflow op reads a cell of the same row or of the row +-2 / +-1 next to it: its row travels in .z
         if (trow >= jb && trow < je) velocity_bc_op(g, o.w & 3, o.x, trow, o.y, o.z, v, bc_const, raise);
-    } else {
+    } else if (n - ops.nsimple < ops.npair) {
         n -= ops.nsimple;
+        velocity_bc_pair(g, ops.pair[2 * n], ops.pair[2 * n + 1], jb, je, v, bc_const, raise);
+    } else {
+        n -= ops.nsimple + ops.npair;
         if (n < ops.ncomp && !(ops.comp_rhi[n] < jb || ops.comp_rlo[n] >= je))
             for (int o = ops.comp_begin[n]; o < ops.comp_begin[n + 1]; ++o)
                 velocity_bc_op(g, ops.kind[o], ops.tgt[o], ops.row[o], ops.s1[o], ops.srow[o], v, bc_const, raise);
