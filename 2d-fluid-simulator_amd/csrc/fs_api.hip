@@ -140,9 +140,9 @@ static int prof_drain(fs_ctx *c)
     return FS_OK;
 }
 
-// Grids below 1 M cells have fewer waves than the chip has SIMDs: a launch takes as long as ONE wave's chain of loads, stages and stores, and
+// Grids below 2 M cells have few waves per SIMD: a launch takes as long as ONE wave's chain of loads, stages and stores, and
 // tiles of half the height halve that chain (round 4, tools/r4_chain.py; env FS_SMALL_TILES=0: the big grids' tile heights everywhere)
-static inline bool small_tiles(const fs_ctx *c) { return c->small_tiles && (size_t)c->X * c->Y < ((size_t)1 << 20); }
+static inline bool small_tiles(const fs_ctx *c) { return c->small_tiles && (size_t)c->X * c->Y < c->small_cells; }
 
 static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
 
@@ -735,6 +735,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_SMALL_TILES")) c->small_tiles = atoi(s) != 0;
+    if (const char *s = getenv("FS_SMALL_CELLS")) c->small_cells = (size_t)atoll(s);
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6) c->rbpair_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8) c->rbpair_plain_rt = v; }
     if (const char *s = getenv("FS_SPLIT_WGW")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->split_wgw = v; }
@@ -1129,7 +1130,9 @@ int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int parity, int
     if (!ok || !((float)limit * (float)limit > FS_HOT_SQ)) { set_error("fs_velocity_bc_limit is not available for this context / limit (fs_velocity_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
     FS_DISPATCH(ctx, {
         return launch(ctx, "velocity_bc", [=] {
-            hipLaunchKernelGGL(k_velocity_bc_limit<T>, dim3((ctx->ops_vel.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+            // (at least one workgroup per row of the limit pass, up to 64 (the barrier costs ~40 ns per workgroup): with the flag up - a run that has once exceeded a speed of 8 keeps it
+            //  up - the pass is shared by the launch's workgroups; the extra ones find no op and cost nothing while the flag is down)
+            hipLaunchKernelGGL(k_velocity_bc_limit<T>, dim3(std::max((ctx->ops_vel.lanes() + 255) / 256, std::min(64, limit_end - limit_begin))), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, limit_begin, limit_end, (T)limit, (T *)v->d, (const T *)ctx->d_bc_const, v->hot, ctx->d_sync, parity);
         });
     })
@@ -1184,7 +1187,7 @@ int fs_dye_bc_limit(fs_ctx *ctx, double limit, fs_field *v, fs_field *dye, int l
     if (!ok || !((float)limit * (float)limit > FS_HOT_SQ)) { set_error("fs_dye_bc_limit is not available for this context / limit (fs_dye_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
     FS_DISPATCH(ctx, {
         return launch(ctx, "dye_bc", [=] {
-            hipLaunchKernelGGL(k_dye_bc_limit<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_dye_bc_limit<T>, dim3(std::max((ctx->ops_dye.lanes() + 255) / 256, std::min(64, limit_end - limit_begin))), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, limit_begin, limit_end, (T)limit, (T *)v->d, v->hot, ctx->d_sync,
                                (T *)dye->d, (const T *)ctx->d_bc_dye);
         });

@@ -83,7 +83,8 @@ struct fs_ctx {
     int jquad_rt = 4;                        // its tile height (env FS_JQUAD_RT = 2, 4, 6, 8)
     int rbpair_split = 1;                    // plain and boundary workgroups of that pass (and of the four-sweep Jacobi pass) as two compact
                                              // launches: env FS_RBPAIR_SPLIT = 0 never, 1 on grids of 8 M cells or more, 2 always
-    bool small_tiles = true;                 // 2-row tiles on grids below 1 M cells (env FS_SMALL_TILES=0)
+    bool small_tiles = true;                 // 2-row tiles on grids below 2 M cells (env FS_SMALL_TILES=0)
+    size_t small_cells = (size_t)1 << 21;    // ... that threshold (env FS_SMALL_CELLS): res 800 +4.7 %, res 1024 (2 M cells) +0.3 %
     int rbpair_rt = 0;                       // rows per tile of that pass (env FS_RBPAIR_RT = 2, 4, 6; 0: 2 below 1 M cells, else 4)
     int rbpair_plain_rt = 8;                 // env FS_RBPAIR_PLAIN_RT = 4 / 8: rows per tile of the pair pass's PLAIN part (two-part launch, one-wave workgroups)
     int split_wgw = 1;                       // env FS_SPLIT_WGW = 1 / 2 / 4: waves per workgroup of the two-part launches - the plain / boundary classification is per workgroup
