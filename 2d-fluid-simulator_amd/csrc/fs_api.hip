@@ -159,7 +159,7 @@ static inline int geo_cells(int lanes) { return lanes == 4 ? 4 : 2; }
 static inline int geo_owners(int lanes) { return lanes == 2 ? 60 : (lanes == 5 ? 58 : (lanes == 6 ? 56 : 62)); }   // 5 / 6: pairs with 3 / 4 halo lanes per side (the 6- / 8-sweep marching passes; no compact lists)
 static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls = 0, int reach = 0, int wgw = 4, int jb = 0, int je = -1, int parent_rt = 0)
 {
-    if (c->h_act4.empty() || nbx > 0xfff || nby > 0xfffff || lanes > 4 || c->rows > 0xffff) return nullptr;
+    if (c->h_act4.empty() || nbx > 0xfff || nby > 0xffff || lanes > 4 || c->rows > 0xffff) return nullptr;      // (entry: class hints << 28 | by << 12 | bx)
     if (je < 0) je = c->rows;
     const uint32_t key0 = (uint32_t)lanes | ((uint32_t)rt << 4) | ((uint32_t)stacked << 12) | ((uint32_t)group << 16) | ((uint32_t)cls << 24) | ((uint32_t)reach << 26) | ((uint32_t)(wgw & 7) << 29);
     if (parent_rt == rt) parent_rt = 0;
@@ -171,6 +171,7 @@ static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stac
     const std::vector<uint8_t> &act = lanes == 4 ? c->h_act4 : (lanes == 2 ? c->h_act2 : c->h_act2w);
     const int ow = geo_owners(lanes), waves = (c->X / geo_cells(lanes) + ow - 1) / ow, Y = c->rows;       // (activity maps are indexed by LOCAL row)
     std::vector<uint32_t> per[8];
+    bool any_hint = false;
     const int groups = (nby + group - 1) / group;
     // inside a group the workgroups are listed column by column: vertically adjacent workgroups, which re-read each other's halo rows, are
     // neighbours in dispatch order (bc5 res 4096: K3+K4 333 -> 319 us, the red-black pair 195 -> 191; FS_LIST_ROWMAJOR=1: row by row)
@@ -200,13 +201,28 @@ static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stac
                                 if (act[(size_t)wx * Y + j] & 2) { plain = false; break; }
                         any = plain == (cls == 1);
                     }
-                    if (any) per[xcd].push_back(((uint32_t)by << 12) | (uint32_t)bx);
+                    uint32_t hints = 0u;
+                    if (any && !cls && reach > 0 && wgw <= 4) {
+                        // per-wave hint for a kernel that holds both paths (unsplit launches): wave w is plain - no non-fluid cell within `reach` rows
+                        // of ITS tile, halo lanes included - and may skip its mask loads and the classification (band_coords cls)
+                        for (int w = 0; w < wgw; ++w) {
+                            const int wx = stacked ? bx : bx * wgw + w;
+                            const int t0 = jb + (stacked ? by * wgw + w : by) * rt, t1 = std::min(je, t0 + rt);
+                            if (wx >= waves || t0 >= je) continue;
+                            bool plain = true;
+                            for (int j = std::max(0, t0 - reach); j < std::min(Y, t1 + reach) && plain; ++j)
+                                if (act[(size_t)wx * Y + j] & 2) plain = false;
+                            if (plain) hints |= 1u << w;
+                        }
+                        any_hint = any_hint || hints != 0u;
+                    }
+                    if (any) per[xcd].push_back((hints << 28) | ((uint32_t)by << 12) | (uint32_t)bx);
                 }
             }
     size_t K = 0, total = 0;
     for (auto &v : per) { K = std::max(K, v.size()); total += v.size(); }
     fs_ctx::TileList tl;
-    if (K > 0 && (cls || total < (size_t)nbx * nby)) {        // (nothing to skip: the dense grid needs no list)
+    if (K > 0 && (cls || any_hint || total < (size_t)nbx * nby)) {        // (nothing to skip, no hint to give: the dense grid needs no list)
         std::vector<uint32_t> h(K * 8, 0xffffffffu);
         for (int xcd = 0; xcd < 8; ++xcd)
             for (size_t k = 0; k < per[xcd].size(); ++k) h[k * 8 + xcd] = per[xcd][k];
@@ -1745,7 +1761,7 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
             { const OvGrid og = ogb; return launch(ctx, "jacobi_quad_lazy_bnd", [=] { FS_JQ(4, 2); }); }
         }
     }
-    const OvGrid og = ov_grid_n<2>(ctx, row_begin, row_end, rt);
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 0, 4);      // (per-wave plain hints in the list, as fs_rbsor_pair)
     return launch(ctx, "jacobi_quad_lazy", [=] {
         if (rt == 2) FS_JQ(2, 2); else if (rt == 6) FS_JQ(6, 2); else if (rt == 8) FS_JQ(8, 2); else FS_JQ(4, 2);
     });
@@ -1790,7 +1806,7 @@ int fs_jacobi_finish(fs_ctx *ctx, fs_field *pc_out, fs_field *pn, const fs_field
     FS_ROWS();
     if (!(ctx->jq_ok && ctx->use_march && ctx->dtype == 0)) { set_error("this mask / precision does not admit the multi-sweep Jacobi passes (fs_jacobi_quad_ok)"); return FS_ERR_UNSUPPORTED; }
     using T = float;
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2);
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2, true, 0, 2);      // (per-wave plain hints: two sweeps reach 2 rows)
     return launch(ctx, "jacobi_finish", [=] {
         hipLaunchKernelGGL((k_jacobi_finish<2, 4, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
                            (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
@@ -1837,7 +1853,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
                 { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBPD(2, 2, false); }); }
             }
         }
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_RBSOR, 2, !full);
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_RBSOR, 2, !full, 0, 4);
         return launch(ctx, "rbsor_pair", [=] { if (full) FS_RBPD(2, 2, true); else FS_RBPD(2, 2, false); });
     }
     using T = float;
@@ -1877,7 +1893,8 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
             { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_DM(4, 2); }); }
         }
     }
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, !full);
+    // (one launch: the list's entries carry a per-wave "plain" hint - a wave that sees nothing but fluid within 4 rows skips its mask loads)
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, !full, 0, 4);
     return launch(ctx, "rbsor_pair", [=] {
         if (full) FS_RBP_PAR(4, 0, 2, true);
         else if (rt == 6) FS_RBP_DM(6, 2);

@@ -93,25 +93,26 @@ __global__ __launch_bounds__(256) void k_jacobi_quad(Grid g, int nbx, int nby, i
 {
     constexpr int W = RT + 8;
     int wx, ty;
-    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty)) return;
+    bool hint = false;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty, PATH == 2 ? &hint : nullptr)) return;
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[W];
-    if constexpr (PATH == 3) {
-        jacobi_quad_tile<N, RT, false, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
-        return;
-    }
-    bool own = false, all_fluid = true;
+    bool plain = PATH == 3 || hint;            // (hint: this wave's bit of the list entry, fs_march.h band_coords)
+    if (!plain) {
+        bool own = false, all_fluid = true;
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 4 + w));
-        nw[w] = lv_sel_not_wall<N>(m);
-        all_fluid = all_fluid && m == 0u;
-        if (w >= 4 && w <= W - 5 && j0 - 4 + w < je) own = own || (lm.owner && nw[w] != 0u);
+        for (int w = 0; w < W; ++w) {
+            const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 4 + w));
+            nw[w] = lv_sel_not_wall<N>(m);
+            all_fluid = all_fluid && m == 0u;
+            if (w >= 4 && w <= W - 5 && j0 - 4 + w < je) own = own || (lm.owner && nw[w] != 0u);
+        }
+        if (!__any(own)) return;               // no not-wall cell in the rows this tile stores
+        plain = __all(all_fluid);
     }
-    if (!__any(own)) return;                   // no not-wall cell in the rows this tile stores
-    if (__all(all_fluid)) jacobi_quad_tile<N, RT, false, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
-    else jacobi_quad_tile<N, RT, true, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
+    if (plain) jacobi_quad_tile<N, RT, false, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
+    else if constexpr (PATH != 3) jacobi_quad_tile<N, RT, true, T>(g, lm, i0, j0, je, nw, bcmap, pn, pc, src);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -178,22 +179,27 @@ __global__ __launch_bounds__(256) void k_jacobi_finish(Grid g, int nbx, int nby,
 {
     constexpr int W = RT + 4;
     int wx, ty;
-    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty)) return;
+    bool hint = false;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty, &hint)) return;
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[W];
-    bool near = false, all_fluid = true;
+    bool plain = hint;
+    if (!plain) {
+        bool near = false, all_fluid = true;
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + w));
-        nw[w] = lv_sel_not_wall<N>(m);
-        all_fluid = all_fluid && m == 0u;
-        if (w >= 1 && w <= W - 2) near = near || nw[w] != 0u;
+        for (int w = 0; w < W; ++w) {
+            const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + w));
+            nw[w] = lv_sel_not_wall<N>(m);
+            all_fluid = all_fluid && m == 0u;
+            if (w >= 1 && w <= W - 2) near = near || nw[w] != 0u;
+        }
+        // a cell this tile stores is a not-wall cell or a recipe target, i.e. a wall cell next to a not-wall cell: none without a not-wall cell
+        // in the rows around the tile's (halo lanes included)
+        if (!__any(near)) return;
+        plain = __all(all_fluid);
     }
-    // a cell this tile stores is a not-wall cell or a recipe target, i.e. a wall cell next to a not-wall cell: none without a not-wall cell
-    // in the rows around the tile's (halo lanes included)
-    if (!__any(near)) return;
-    if (__all(all_fluid)) jacobi_finish_tile<N, RT, false, T>(g, lm, i0, j0, je, nw, bcmap, pc_out, pn, pc, src);
+    if (plain) jacobi_finish_tile<N, RT, false, T>(g, lm, i0, j0, je, nw, bcmap, pc_out, pn, pc, src);
     else jacobi_finish_tile<N, RT, true, T>(g, lm, i0, j0, je, nw, bcmap, pc_out, pn, pc, src);
 }
 

@@ -156,9 +156,13 @@ struct LaneMap {
 // No integer division in the decode (the first version, a 1-D grid decoded with two divisions per wave, spent ~70 of the ~700
 // instructions of a one-row K2 tile on them).
 constexpr int FS_CG_INNER = 1 << 22;
+// cls (optional): bits 28 .. 31 of a compact list's entry - bit w: the host found wave w of this workgroup to be PLAIN, nothing but fluid within the
+// kernel's reach (fs_api.hip tile_list, lists built with a hint reach; round 4): a kernel that holds both paths takes the plain one
+// without loading a mask byte.  0 where the launch is dense or the list carries no hints.
 template <int ZG = 1>
-__device__ __forceinline__ bool band_coords(const Grid &g, int nbx, int nby_packed, int &bx, int &by, int &cg, int zoff = 0)
+__device__ __forceinline__ bool band_coords(const Grid &g, int nbx, int nby_packed, int &bx, int &by, int &cg, int zoff = 0, unsigned *cls = nullptr)
 {
+    if (cls) *cls = 0u;
     if (g.tiles) {
         // compact launch: blockIdx.x = (k * ZG + cg) * 8 + xcd  ->  the k-th listed workgroup of that XCD, channel group cg (the passes
         // over one tile are consecutive workgroups of one XCD)
@@ -167,7 +171,8 @@ __device__ __forceinline__ bool band_coords(const Grid &g, int nbx, int nby_pack
         cg = ZG == 1 ? 0 : t - k * ZG;
         const uint32_t e = g.tiles[k * 8 + xcd];
         bx = (int)(e & 0xfffu);
-        by = (int)(e >> 12);
+        by = (int)((e >> 12) & 0xffffu);
+        if (cls) *cls = e >> 28;
         return e != 0xffffffffu;
     }
     const int nby = nby_packed & 0x3fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked, bit 22 = channel groups innermost

@@ -111,13 +111,16 @@ template <typename T, int N> __device__ __forceinline__ T lv_left(const LaneMapN
 template <typename T, int N> __device__ __forceinline__ T lv_right(const LaneMapN<N> &m, const LV<T, N> &v)
 { const T r = lane_next(v.a[0]); return m.at_hi ? v.a[N - 1] : r; }
 
+// plain_hint (optional): the host's list says this wave sees nothing but fluid within the kernel's reach (band_coords cls)
 template <int N>
-__device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y)
+__device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, bool *plain_hint = nullptr)
 {
     constexpr int OW = 64 - 2 * (4 / N);
     int bx, by, cg;
-    if (!band_coords<1>(g, nbx, nby_packed, bx, by, cg)) return false;
+    unsigned cls = 0u;
+    if (!band_coords<1>(g, nbx, nby_packed, bx, by, cg, 0, plain_hint ? &cls : nullptr)) return false;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+    if (plain_hint) *plain_hint = ((cls >> w) & 1u) != 0u;
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }
     return wave_x * OW < g.X / N && jb + tile_y * rt < je;
@@ -254,34 +257,37 @@ __device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k
 {
     constexpr int W = RT + 8;
     int wx, ty;
-    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty)) return;
+    bool hint = false;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty, PATH == 2 && !FULL ? &hint : nullptr)) return;
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned fl[W];
-    if constexpr (PATH == 3) {      // the host listed this workgroup as plain: nothing but fluid within reach (fs_api.hip tile_list)
-        rbsor_pair_tile<N, RT, PAR0, DM, false, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
-        return;
-    }
-    bool own_fluid = false, all_fluid = true;
+    // plain: the host listed this workgroup (PATH 3) / this wave (hint) as seeing nothing but fluid within reach (fs_api.hip tile_list) - or the
+    // masks say so.  ONE instance of each path in the kernel.
+    bool plain = PATH == 3 || hint;
+    if (!plain) {
+        bool own_fluid = false, all_fluid = true;
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-        fl[w] = lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 4 + w)));
-        all_fluid = all_fluid && fl[w] == (1u << N) - 1u;
-        if (w >= 4 && w <= W - 5 && j0 - 4 + w < je) own_fluid = own_fluid || (lm.owner && fl[w] != 0u);
-    }
-    if (!FULL && !__any(own_fluid)) {
-        // no fluid cell in the rows this tile stores: only K7 targets could change, and a tile without any has nothing to do
-        bool tgt = false;
+        for (int w = 0; w < W; ++w) {
+            fl[w] = lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 4 + w)));
+            all_fluid = all_fluid && fl[w] == (1u << N) - 1u;
+            if (w >= 4 && w <= W - 5 && j0 - 4 + w < je) own_fluid = own_fluid || (lm.owner && fl[w] != 0u);
+        }
+        if (!FULL && !__any(own_fluid)) {
+            // no fluid cell in the rows this tile stores: only K7 targets could change, and a tile without any has nothing to do
+            bool tgt = false;
 #pragma unroll
-        for (int w = 4; w <= W - 5; ++w)
-            if (j0 - 4 + w < je) tgt = tgt || (lm.owner && lv_sel_target<N>(lv_bytes<N>(bcmap, g, i0, clampy(g, j0 - 4 + w))) != 0u);
-        if (!__any(tgt)) return;
+            for (int w = 4; w <= W - 5; ++w)
+                if (j0 - 4 + w < je) tgt = tgt || (lm.owner && lv_sel_target<N>(lv_bytes<N>(bcmap, g, i0, clampy(g, j0 - 4 + w))) != 0u);
+            if (!__any(tgt)) return;
+        }
+        plain = __all(all_fluid);
     }
-    if (__all(all_fluid)) {
+    if (plain) {
         if constexpr (PATH != 1) rbsor_pair_tile<N, RT, PAR0, DM, false, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
         return;
     }
-    if constexpr (PATH != 0) rbsor_pair_tile<N, RT, PAR0, DM, true, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
+    if constexpr (PATH != 0 && PATH != 3) rbsor_pair_tile<N, RT, PAR0, DM, true, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
 }
 
 template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
