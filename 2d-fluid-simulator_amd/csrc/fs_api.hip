@@ -703,7 +703,9 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
             { const OvGrid og = ogb; return launch(ctx, name_bnd, [=] { FS_K34_ANY(); }); }
         }
     }
-    const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, !full);      // (the carrying pass visits every tile)
+    // (the carrying pass visits every tile.  The per-wave plain hint of fs_rbsor_pair was tried here too: 78.8-79.2 against 77.4-78.8 us at bc2 res 1600 -
+    //  the kernel then holds four tile bodies instead of two)
+    const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, !full);
     return launch(ctx, name, [=] { if (N == 2 && RT == 1) FS_DMX(dm, FS_K34_21); else FS_K34_ANY(); });
 }
 
