@@ -1683,6 +1683,60 @@ __global__ __launch_bounds__(256) static void k_box_copy(const float4 *__restric
     }
 }
 
+// ... and what it ISSUES at: 8 independent chains of dependent f32 multiplies and adds per lane (no memory), 4 waves per SIMD - the shape of the
+// issue-bound part of K3+K4.  Boxes with the same copy rate differ by several per cent here (clock under load), and so does K3+K4.
+__global__ __launch_bounds__(256) static void k_box_valu(float *sink, float a, float b, int iters)
+{
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = a + (float)(threadIdx.x + u);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = x[u] * a;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = x[u] + b;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += x[u];
+    if (s == 1.2345f) sink[0] = s;
+}
+
+int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd)
+{
+    FS_REQUIRE(ctx && ginstr_per_simd, "null argument");
+    FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "fs_box_valu_rate during graph capture / tape recording");
+    FS_REQUIRE(budget_ms > 0.0, "need a positive time budget");
+    FS_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    FS_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    const int cus = prop.multiProcessorCount, iters = 2000;
+    float *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&sink, sizeof(float));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    int reps = 1;
+    for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+        (void)hipEventRecord(e0, ctx->stream);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_box_valu, dim3(cus * 4), dim3(256), 0, ctx->stream, sink, 1.0000001f, 1e-9f, iters);
+        (void)hipEventRecord(e1, ctx->stream);
+        e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) break;
+        // per SIMD: 4 waves x iters x 16 wave-instructions
+        *ginstr_per_simd = 4.0 * iters * 16.0 * reps / (ms * 1e-3) / 1e9;
+        reps = std::max(1, std::min(1000, (int)(budget_ms / std::max((double)ms / reps, 1e-3))));
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (sink) hipFree(sink);
+    if (e != hipSuccess) return hip_fail(e, "fs_box_valu_rate", __FILE__, __LINE__);
+    return FS_OK;
+}
+
 int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps, double *copy_GBps)
 {
     FS_REQUIRE(ctx && read_GBps && copy_GBps, "null argument");

@@ -35,6 +35,10 @@
 
 namespace fs {
 
+#ifndef FS_RBP_MIRROR
+#define FS_RBP_MIRROR 1    // every second row of plain tiles of the two-part launch works bottom-up (rbsor_pair_tile MIRROR; 0: A/B)
+#endif
+
 // N consecutive cells of one row
 template <typename T, int N> struct LV { T a[N]; };
 template <typename T, int N> struct LVec;
@@ -160,11 +164,21 @@ __device__ __forceinline__ void rbp_relax(const Konst<T> &k, const LaneMapN<N> &
 
 // PAR0: parity of (g.ybase + j0 - 4), the first window row - a launch constant because RT is even and all tiles start at jb + k RT.
 // BND: the tile has non-fluid cells within reach (K7 views are evaluated); FULL: store every cell (carry pass after an upload).
-template <int N, int RT, int PAR0, int DM, bool BND, bool FULL, typename T>
+// MIRROR (plain tiles of the two-part launch, every second tile row; round 4): the window is held upside down - w <-> local row j0+RT+3-w - so
+// that the tile works, and asks for its rows, from the bottom up.  The pass is bound by its traffic and a wave's 64 row requests trickle out
+// over most of its ~20 us of life (the window of an 8-row tile is 124 VGPRs: the compiler loads it as registers fall free): the tile below
+// wants the rows it shares with this one FIRST, this one wants them LAST - ten microseconds later they have left the L2 (measured: 36 % hits
+// where 50 % are possible, 590 MB read for 350 algorithmic).  With every second tile row mirrored both sharers want a shared row in the same
+// phase of their lives.  Same expression per cell: only which register holds which row changes.
+template <int N, int RT, int PAR0, int DM, bool BND, bool FULL, typename T, bool MIRROR = false>
 __device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm_in, int i0, int j0, int je, const unsigned (&fl)[RT + 8],
                                                 const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
 {
-    constexpr int W = RT + 8;                  // window rows w = 0 .. W-1  <->  local rows j0-4 .. j0+RT+3 (clamped into the domain)
+    static_assert(!(MIRROR && (BND || FULL)), "only plain tiles are mirrored");
+    constexpr int W = RT + 8;                  // window rows w = 0 .. W-1  <->  local rows j0-4 .. j0+RT+3 (clamped into the domain; MIRROR: j0+RT+3 .. j0-4)
+    constexpr int UP = MIRROR ? -1 : 1;        // window step towards the row above (j + 1)
+    constexpr int PARW = MIRROR ? PAR0 + 1 : PAR0;      // parity of window row w = (PARW + w) & 1  (RT is even: j0+RT+3-w and j0-4+w+1 have the same parity)
+#define FS_ROW(w) (MIRROR ? j0 + RT + 3 - (w) : j0 - 4 + (w))
     using R = LV<T, N>;
     constexpr unsigned ALL = (1u << N) - 1u;
     // A tile without a non-fluid cell within reach (halo lanes included) holds no lane at the domain's first / last column - those cells are
@@ -177,7 +191,7 @@ __device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k
     uint32_t code[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-        const int j = clampy(g, j0 - 4 + w);
+        const int j = clampy(g, FS_ROW(w));
         PA[w] = lv_field<1, T, N>(A, g, 0, i0, j);
         VX[w] = lv_field<2, T, N>(v, g, 0, i0, j);
         VY[w] = lv_field<2, T, N>(v, g, 1, i0, j);
@@ -194,7 +208,7 @@ __device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k
         for (int c = 0; c < N; ++c) {
             const T xE = c == N - 1 ? xr : VX[w].a[c == N - 1 ? c : c + 1], xW = c == 0 ? xl : VX[w].a[c == 0 ? 0 : c - 1];
             const T yE = c == N - 1 ? yr : VY[w].a[c == N - 1 ? c : c + 1], yW = c == 0 ? yl : VY[w].a[c == 0 ? 0 : c - 1];
-            source_from<DM>(k, xE, xW, yE, yW, VX[w + 1].a[c], VX[w - 1].a[c], VY[w + 1].a[c], VY[w - 1].a[c], S2[w].a[c], S3[w].a[c]);
+            source_from<DM>(k, xE, xW, yE, yW, VX[w + UP].a[c], VX[w - UP].a[c], VY[w + UP].a[c], VY[w - UP].a[c], S2[w].a[c], S3[w].a[c]);
         }
     }
     // view(A): rows 0 .. W-1 (a row missing at the window's edge is stood in for by the row itself - see the header)
@@ -204,16 +218,16 @@ __device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k
     // stage 1: odd pass of iteration 1 on rows 1 .. W-2:  B[odd] <- view(A)
 #pragma unroll
     for (int w = 1; w <= W - 2; ++w) {
-        if ((PAR0 + w) & 1) rbp_relax<1, 1>(k, lm, FS_FL(w), VA[w - 1], VA[w], VA[w + 1], S2[w], S3[w], PB[w]);
-        else                rbp_relax<0, 1>(k, lm, FS_FL(w), VA[w - 1], VA[w], VA[w + 1], S2[w], S3[w], PB[w]);
+        if ((PARW + w) & 1) rbp_relax<1, 1>(k, lm, FS_FL(w), VA[w - UP], VA[w], VA[w + UP], S2[w], S3[w], PB[w]);
+        else                rbp_relax<0, 1>(k, lm, FS_FL(w), VA[w - UP], VA[w], VA[w + UP], S2[w], S3[w], PB[w]);
     }
     // stage 2: even pass of iteration 1 on rows 2 .. W-3, in place on B (all rows from the stage-1 state: results go to P2)
     R P2[W];
 #pragma unroll
     for (int w = 2; w <= W - 3; ++w) {
         P2[w] = PB[w];
-        if ((PAR0 + w) & 1) rbp_relax<1, 0>(k, lm, FS_FL(w), PB[w - 1], PB[w], PB[w + 1], S2[w], S3[w], P2[w]);
-        else                rbp_relax<0, 0>(k, lm, FS_FL(w), PB[w - 1], PB[w], PB[w + 1], S2[w], S3[w], P2[w]);
+        if ((PARW + w) & 1) rbp_relax<1, 0>(k, lm, FS_FL(w), PB[w - UP], PB[w], PB[w + UP], S2[w], S3[w], P2[w]);
+        else                rbp_relax<0, 0>(k, lm, FS_FL(w), PB[w - UP], PB[w], PB[w + UP], S2[w], S3[w], P2[w]);
     }
     // view(B') on rows 2 .. W-3
     R VB[W];
@@ -224,21 +238,21 @@ __device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k
 #pragma unroll
     for (int w = 3; w <= W - 4; ++w) {
         P3[w] = VA[w];
-        if ((PAR0 + w) & 1) rbp_relax<1, 1>(k, lm, FS_FL(w), VB[w - 1], VB[w], VB[w + 1], S2[w], S3[w], P3[w]);
-        else                rbp_relax<0, 1>(k, lm, FS_FL(w), VB[w - 1], VB[w], VB[w + 1], S2[w], S3[w], P3[w]);
+        if ((PARW + w) & 1) rbp_relax<1, 1>(k, lm, FS_FL(w), VB[w - UP], VB[w], VB[w + UP], S2[w], S3[w], P3[w]);
+        else                rbp_relax<0, 1>(k, lm, FS_FL(w), VB[w - UP], VB[w], VB[w + UP], S2[w], S3[w], P3[w]);
     }
     // stage 4: even pass of iteration 2 on the tile's own rows 4 .. W-5
     R P4[W];
 #pragma unroll
     for (int w = 4; w <= W - 5; ++w) {
         P4[w] = P3[w];
-        if ((PAR0 + w) & 1) rbp_relax<1, 0>(k, lm, FS_FL(w), P3[w - 1], P3[w], P3[w + 1], S2[w], S3[w], P4[w]);
-        else                rbp_relax<0, 0>(k, lm, FS_FL(w), P3[w - 1], P3[w], P3[w + 1], S2[w], S3[w], P4[w]);
+        if ((PARW + w) & 1) rbp_relax<1, 0>(k, lm, FS_FL(w), P3[w - UP], P3[w], P3[w + UP], S2[w], S3[w], P4[w]);
+        else                rbp_relax<0, 0>(k, lm, FS_FL(w), P3[w - UP], P3[w], P3[w + UP], S2[w], S3[w], P4[w]);
     }
 #pragma unroll
     for (int w = 4; w <= W - 5; ++w) {
-        const int j = j0 - 4 + w;
-        if (j >= je) break;
+        const int j = FS_ROW(w);
+        if (j >= je) continue;
         const unsigned sel = FULL ? ALL : (FS_FL(w) | (BND ? lv_sel_target<N>(code[w]) : 0u));
         if (lm.owner && sel) {
             lv_store_sel<T, N>(C + idx<1, T>(g, 0, i0, j), P4[w], sel);
@@ -246,6 +260,7 @@ __device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k
         }
     }
 #undef FS_FL
+#undef FS_ROW
 }
 
 // PATH: 2 - classify the tile here (mask loads) and take the plain or the boundary path; 3 - the plain path without looking (compact launch
@@ -284,6 +299,9 @@ __device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k
         plain = __all(all_fluid);
     }
     if (plain) {
+        if constexpr (PATH == 3 && FS_RBP_MIRROR && !FULL) {
+            if (ty & 1) { rbsor_pair_tile<N, RT, PAR0, DM, false, FULL, T, true>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v); return; }
+        }
         if constexpr (PATH != 1) rbsor_pair_tile<N, RT, PAR0, DM, false, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
         return;
     }
@@ -291,7 +309,7 @@ __device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k
 }
 
 template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
-__global__ __launch_bounds__(256) void k_rbsor_pair(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+__global__ __launch_bounds__(256, (PATH == 3 && sizeof(T) == 4 ? 4 : 1)) void k_rbsor_pair(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                     const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
 {
     static_assert(RT % 2 == 0, "the row parity of a tile is a launch constant only for even tile heights");

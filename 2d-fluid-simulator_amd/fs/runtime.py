@@ -959,6 +959,13 @@ class Device(DeviceBase):
         _lib.call("fs_box_rates", self._ctx, ctypes.c_size_t(int(nbytes)), float(budget_ms), ctypes.byref(rd), ctypes.byref(cp))
         return rd.value, cp.value
 
+    def box_valu_rate(self, budget_ms=10.0):
+        """1e9 f32 wave-instructions per second and SIMD at 4 waves per SIMD, no memory traffic: the box's clock under load, as the
+        issue-bound kernels see it (include/fs_hip.h fs_box_valu_rate)."""
+        r = ctypes.c_double()
+        _lib.call("fs_box_valu_rate", self._ctx, float(budget_ms), ctypes.byref(r))
+        return r.value
+
     # -- per-kernel HIP-event timing ---------------------------------------------------------------------
     def profile(self, on=True):
         _lib.call("fs_prof_enable", self._ctx, 1 if on else 0)

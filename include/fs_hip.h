@@ -310,6 +310,9 @@ int fs_tape_free(fs_ctx *ctx, int tape_id);
  * buffers of `bytes` each, about budget_ms of GPU time per leg, HIP events on the context's stream.  bench.py prints the two rates and
  * `frac_of_box_copy` next to every roofline fraction, so that a slow box is not mistaken for a regression. */
 int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps, double *copy_GBps);
+/* ... and the rate at which one SIMD issues independent f32 multiplies / adds at 4 waves per SIMD, in 1e9 wave-instructions per second
+ * (no memory traffic): boxes with equal copy rates differ by several per cent here, and the issue-bound K3+K4 pass with them. */
+int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd);
 
 /* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) --------------- */
 int fs_prof_enable(fs_ctx *ctx, int on);          /* record an event pair around every launch      */
