@@ -559,6 +559,16 @@ def main():
                 "fused gradient-update + advection pass: `frac` counts the bytes the fused kernel has to move "
                 "(mask 1 + 32 read + 24 written = 57 B per fluid cell); the reference's two kernels move 98 B per fluid cell for the same result")
             out["roofline"]["unfused_equiv_frac"] = kd["unfused_equiv_frac"]
+        if dominant == "cip_grad_advect_rt" and pmc_traffic and box and box.get("valu_ginstr_per_simd"):
+            # what actually bounds this kernel: its plain part is issue-stalled 60 % of the wave time.  SQ_INSTS_VALU of one launch on the headline
+            # grid (plain + boundary part: 103.25 M + 27.55 M wave-instructions, profiles/r4_sq_wave_cycles.txt) against what one SIMD of THIS box
+            # issues per second (box.valu_ginstr_per_simd, measured in this run): the time the launch needs for issuing alone
+            winst = 130.8e6
+            issue_us = winst / 1024.0 / (box["valu_ginstr_per_simd"] * 1e9) * 1e6
+            out["roofline"]["valu_issue"] = {"wave_insts_per_launch": winst, "per_simd": round(winst / 1024.0), "box_ginstr_per_simd": box["valu_ginstr_per_simd"],
+                                             "issue_us": round(issue_us, 1), "frac_of_kernel_time": round(issue_us / kd["avg_us"], 3),
+                                             "note": "f32 VALU wave-instructions of one launch (PMC, profiles/r4_sq_wave_cycles.txt) / 1024 SIMDs / the box's measured issue rate: "
+                                                     "the kernel is bound by instruction issue (bit-exact CIP arithmetic without FMA contraction), not by HBM"}
     if jac:
         out["poisson_jacobi_sweep"] = jac
     out["kernels"] = kernels
