@@ -88,3 +88,48 @@ def test_tape_shape_agreement_does_not_alias():
     d = Two([7], [9])
     d._p_max_over_ranks = lambda values: [max(values[0], 9), max(values[1], d._BIG - 9)]
     assert d._p_min_max_over_ranks(7) == (7, 9)
+
+
+class _GraphDev:
+    """Single-GPU stand-in with hipGraph capture: a capture runs the host side of the steps (nothing executes), a replay executes them."""
+    nranks = 1
+
+    def __init__(self, solver_ref):
+        self.solver_ref, self.graphs, self.replayed, self.freed = solver_ref, {}, 0, []
+
+    def alloc(self, n):
+        return _Field()
+
+    def capture(self, fn):
+        s = self.solver_ref[0]
+        before = s.updates
+        fn()
+        steps, s.updates = s.updates - before, before      # captured, not executed
+        gid = len(self.graphs)
+        self.graphs[gid] = steps
+        return gid
+
+    def replay(self, gid, times=1):
+        self.replayed += self.graphs[gid] * max(times, 0)
+
+    def free_graph(self, gid):
+        self.freed.append(gid)
+
+
+@pytest.mark.parametrize("n", [1, 7, 15, 16, 17, 18, 33, 34, 35, 64, 100, 101])
+def test_run_with_graphs_takes_exactly_n_steps_and_prefers_the_long_graph(n):
+    """Round 4: capture_period also captures the period repeated to >= 16 steps (a replay costs ~5 us of GPU idle time whatever it holds);
+    run() replays that one first, then single periods, then steps eagerly - n steps in total, whatever n."""
+    ref = [None]
+    dev = _GraphDev(ref)
+    solver = _Solver(dev)
+    ref[0] = solver
+    sim = FluidSimulator(solver)
+    sim.run(n)
+    assert solver.updates + dev.replayed == n, (solver.updates, dev.replayed)
+    if n >= 34:          # 1 eager step + the period (1 step here) + its long form (16 steps) fit the first chunk
+        assert sim._graph is not None and sim._graph_long is not None and sim._graph_long[1] >= 16 and sim._graph_long[1] % sim._graph[2] == 0
+    sim.run(n)
+    assert solver.updates + dev.replayed == 2 * n
+    if sim._graph_long is not None and n >= 16:
+        assert dev.replayed >= 16          # the long graph did the bulk
