@@ -1684,7 +1684,8 @@ __global__ __launch_bounds__(256) static void k_box_copy(const float4 *__restric
 }
 
 // ... and what it ISSUES at: 8 independent chains of dependent f32 multiplies and adds per lane (no memory), 4 waves per SIMD - the shape of the
-// issue-bound part of K3+K4.  Boxes with the same copy rate differ by several per cent here (clock under load), and so does K3+K4.
+// issue-bound part of K3+K4: the rate that kernel is priced against (bench.py roofline.valu_issue).  (The pool's boxes measured alike here, 0.528-0.537 G
+// per second and SIMD, also where the real kernels differed by 5-9 %: DESIGN.md section 8.)
 __global__ __launch_bounds__(256) static void k_box_valu(float *sink, float a, float b, int iters)
 {
     float x[8];

@@ -286,7 +286,7 @@ def main():
     if hasattr(dev, "box_rates"):
         rd, cp = dev.box_rates(2 * 8192 * 4096 * 4, 30.0)
         box = {"read_GBps": round(rd, 1), "copy_GBps": round(cp, 1), "buffer_MB": 268.4, "note": "float4 read / copy measured in this run on this GPU before the timed region"}
-        if hasattr(dev, "box_valu_rate"):      # boxes with the same copy rate differ in what they ISSUE (clock under load): the issue-bound K3+K4 pass follows this number
+        if hasattr(dev, "box_valu_rate"):      # what one SIMD of this box issues per second: the issue-bound K3+K4 pass is priced against it (roofline.valu_issue)
             box["valu_ginstr_per_simd"] = round(dev.box_valu_rate(10.0), 3)
     for _ in range(args.warmup):
         sim.step()

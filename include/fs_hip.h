@@ -311,7 +311,7 @@ int fs_tape_free(fs_ctx *ctx, int tape_id);
  * `frac_of_box_copy` next to every roofline fraction, so that a slow box is not mistaken for a regression. */
 int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps, double *copy_GBps);
 /* ... and the rate at which one SIMD issues independent f32 multiplies / adds at 4 waves per SIMD, in 1e9 wave-instructions per second
- * (no memory traffic): boxes with equal copy rates differ by several per cent here, and the issue-bound K3+K4 pass with them. */
+ * (no memory traffic): what the issue-bound K3+K4 pass is priced against (bench.py roofline.valu_issue). */
 int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd);
 
 /* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) --------------- */
