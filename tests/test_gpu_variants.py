@@ -17,7 +17,8 @@ def _run(monkeypatch, env, what):
     import fs
     from fs.boundary_condition import BoundaryCondition, create_scene_arrays
     from fs.runtime import Device
-    for k in ("FS_MARCH", "FS_JACOBI", "FS_XCD", "FS_XCD_GROUP", "FS_STACK"):
+    for k in ("FS_MARCH", "FS_JACOBI", "FS_XCD", "FS_XCD_GROUP", "FS_STACK", "FS_SMALL_TILES", "FS_SMALL_CELLS", "FS_RBPAIR_RT", "FS_RBPAIR_SPLIT",
+              "FS_RBPAIR_PLAIN_RT", "FS_BC_NOPAIRS", "FS_K34_RT", "FS_TILE_LIST", "FS_SPLIT_WGW"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -68,3 +69,18 @@ def test_block_order_variants(env, hip_lib, monkeypatch):
     for k in ref:
         assert np.array_equal(got[k], ref[k], equal_nan=True), (env, k)
     assert float(np.abs(ref["p"]).max()) > 0
+
+
+@pytest.mark.parametrize("env", [{"FS_SMALL_TILES": "0"}, {"FS_SMALL_CELLS": "0"}, {"FS_RBPAIR_RT": "4"}, {"FS_RBPAIR_RT": "6"}, {"FS_BC_NOPAIRS": "1"},
+                                 {"FS_K34_RT": "1"}, {"FS_K34_RT": "4"}, {"FS_TILE_LIST": "0"},
+                                 {"FS_RBPAIR_SPLIT": "2"}, {"FS_RBPAIR_SPLIT": "2", "FS_SMALL_TILES": "0"}, {"FS_RBPAIR_SPLIT": "2", "FS_RBPAIR_PLAIN_RT": "4"},
+                                 {"FS_RBPAIR_SPLIT": "2", "FS_SPLIT_WGW": "4"}],
+                         ids=lambda e: "-".join(f"{k[3:]}{v}" for k, v in e.items()))
+def test_round4_tile_height_and_list_variants(env, hip_lib, monkeypatch):
+    """Round 4: tile heights by grid size (this grid, 0.54 M cells, takes the small-grid heights by default), flat op-list pairs, the per-wave
+    plain hints of the launch lists (FS_TILE_LIST=0: dense launches without them), the two-part launches with the mirrored 8-row plain tiles
+    of the pair pass forced onto a small grid: the same bits as the one-cell-per-lane kernels."""
+    ref = _run(monkeypatch, {"FS_MARCH": "0"}, "step")
+    got = _run(monkeypatch, env, "step")
+    for k in ref:
+        assert np.array_equal(got[k], ref[k], equal_nan=True), (env, k)
