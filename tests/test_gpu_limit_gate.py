@@ -218,3 +218,38 @@ def test_dye_solvers_take_the_limit_along_and_drop_the_inflow_clamp(scheme, res,
     finally:
         sim._solver._bc.device.close()
         plain._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("scheme,vc,graph", [("cip", 5.0, False), ("kk", 5.0, True)])
+def test_deferred_limit_in_f64_and_on_tiny_grids(scheme, vc, graph, hip_lib, monkeypatch):
+    """The merged limit + boundary launch at double precision, and on a grid with fewer rows (24) than the 64 workgroups the launch may carry:
+    flag up on every step (inflow 30), against the immediate launches and the f64 oracle."""
+    from fs.boundary_condition import create_scene_arrays
+    res = 24
+    const, mask, _ = create_scene_arrays(2, res)
+    const = const.copy()
+    const[mask == 2] *= 30.0 / max(float(np.abs(const[mask == 2]).max()), 1e-6)
+    monkeypatch.setenv("FS_LIMIT_DEFER", "1")
+    sim, ref = _pair(const, mask, scheme, vc, 0.05 / res, 1.0 / res, dtype="f64")
+    monkeypatch.setenv("FS_LIMIT_DEFER", "0")
+    plain, _ = _pair(const, mask, scheme, vc, 0.05 / res, 1.0 / res, dtype="f64")
+    try:
+        assert sim._solver._bc.device.limit_deferral
+        steps = 36 if graph else 6
+        if graph:
+            sim.run(steps)
+        else:
+            for _ in range(steps):
+                sim.step()
+        assert sim._solver.v.current.pending_limit is not None
+        for _ in range(steps):
+            plain.step()
+            ref.update()
+        out, exp = sim.field_to_numpy(), plain.field_to_numpy()
+        for k in exp:
+            assert out[k].dtype == np.float64
+            assert np.array_equal(out[k], exp[k], equal_nan=True), f"f64 deferred vs immediate: {k}"
+            assert np.array_equal(out[k], ref.fields()[k], equal_nan=True), f"f64 deferred vs oracle: {k}"
+    finally:
+        sim._solver._bc.device.close()
+        plain._solver._bc.device.close()
