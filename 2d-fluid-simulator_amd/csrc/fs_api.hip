@@ -1738,6 +1738,61 @@ int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd)
     return FS_OK;
 }
 
+// ... and both at once: a float4 copy with 176 f32 multiplies / adds per 16 bytes on the way - 5.5 lane-operations per byte moved, the instruction
+// density of K3+K4 (131 M wave-instructions for 1.5 GB).  The pure stream and the pure ALU loop above measured alike on boxes whose real kernels
+// differed by 5-9 %; this is the probe that loads the memory system and the SIMDs together.
+__global__ __launch_bounds__(256) static void k_box_mixed(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n, float m, float c)
+{
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i + 768 >= n) return;
+    float4 v[4] = {a[i], a[i + 256], a[i + 512], a[i + 768]};
+#pragma unroll
+    for (int r = 0; r < 22; ++r) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u].x = v[u].x * m; v[u].y = v[u].y * m; v[u].z = v[u].z * m; v[u].w = v[u].w * m; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u].x = v[u].x + c; v[u].y = v[u].y + c; v[u].z = v[u].z + c; v[u].w = v[u].w + c; }
+    }
+    b[i] = v[0]; b[i + 256] = v[1]; b[i + 512] = v[2]; b[i + 768] = v[3];
+}
+
+int fs_box_mixed_rate(fs_ctx *ctx, size_t bytes, double budget_ms, double *GBps)
+{
+    FS_REQUIRE(ctx && GBps, "null argument");
+    FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "fs_box_mixed_rate during graph capture / tape recording");
+    FS_REQUIRE(bytes >= (1u << 20) && budget_ms > 0.0, "need at least 1 MiB and a positive time budget");
+    FS_HIP(hipSetDevice(ctx->device));
+    bytes = bytes / 4096 * 4096;
+    const size_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&a, bytes);
+    if (e == hipSuccess) e = hipMalloc(&b, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    int reps = 1;
+    for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+        (void)hipEventRecord(e0, ctx->stream);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_box_mixed, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, a, b, n, 1.0000001f, 1e-9f);
+        (void)hipEventRecord(e1, ctx->stream);
+        e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) break;
+        *GBps = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;
+        reps = std::max(1, std::min(4000, (int)(budget_ms / std::max((double)ms / reps, 1e-3))));
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    if (e != hipSuccess) return hip_fail(e, "fs_box_mixed_rate", __FILE__, __LINE__);
+    return FS_OK;
+}
+
 int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps, double *copy_GBps)
 {
     FS_REQUIRE(ctx && read_GBps && copy_GBps, "null argument");

@@ -966,6 +966,12 @@ class Device(DeviceBase):
         _lib.call("fs_box_valu_rate", self._ctx, float(budget_ms), ctypes.byref(r))
         return r.value
 
+    def box_mixed_rate(self, nbytes, budget_ms=100.0):
+        """GB/s of a float4 copy with K3+K4's instruction density on the way: memory system and SIMDs loaded together (fs_box_mixed_rate)."""
+        r = ctypes.c_double()
+        _lib.call("fs_box_mixed_rate", self._ctx, ctypes.c_size_t(int(nbytes)), float(budget_ms), ctypes.byref(r))
+        return r.value
+
     # -- per-kernel HIP-event timing ---------------------------------------------------------------------
     def profile(self, on=True):
         _lib.call("fs_prof_enable", self._ctx, 1 if on else 0)

@@ -313,6 +313,9 @@ int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps,
 /* ... and the rate at which one SIMD issues independent f32 multiplies / adds at 4 waves per SIMD, in 1e9 wave-instructions per second
  * (no memory traffic): what the issue-bound K3+K4 pass is priced against (bench.py roofline.valu_issue). */
 int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd);
+/* ... and a float4 copy with 176 f32 multiplies / adds per 16 bytes on the way (5.5 lane-operations per byte moved: the instruction density of the K3+K4 pass): memory system and SIMDs loaded
+ * together, in GB/s of read + written bytes. */
+int fs_box_mixed_rate(fs_ctx *ctx, size_t bytes, double budget_ms, double *GBps);
 
 /* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) --------------- */
 int fs_prof_enable(fs_ctx *ctx, int on);          /* record an event pair around every launch      */
