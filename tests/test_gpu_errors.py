@@ -102,3 +102,19 @@ def test_exchange_misuse(dev, hip_lib):
     with pytest.raises(FsError, match="negative"):
         _lib.call("fs_halo_exchange_begin_partial", dev._ctx, arr, neg, 1, 0)
     _lib.load().fs_comm_destroy(dev._ctx)
+
+
+def test_box_probes_give_plausible_rates_and_refuse_nonsense(dev):
+    """The three probes bench.py runs before its timed region (include/fs_hip.h fs_box_rates, fs_box_valu_rate, fs_box_mixed_rate): on an
+    MI355X a float4 stream moves TB/s, a SIMD issues tenths of a G wave-instruction per second; a zero budget / a buffer below 1 MiB is an error."""
+    from fs._lib import FsError
+    rd, cp = dev.box_rates(64 << 20, 5.0)
+    assert 500.0 < rd < 20000.0 and 500.0 < cp < 20000.0
+    assert 0.05 < dev.box_valu_rate(5.0) < 5.0
+    assert 500.0 < dev.box_mixed_rate(64 << 20, 5.0) < 20000.0
+    with pytest.raises(FsError):
+        dev.box_rates(1024, 5.0)
+    with pytest.raises(FsError):
+        dev.box_valu_rate(0.0)
+    with pytest.raises(FsError):
+        dev.box_mixed_rate(64 << 20, -1.0)
