@@ -99,7 +99,7 @@ struct fs_ctx {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     double *d_acc = nullptr;  // 2 doubles (residual)
-    unsigned *d_sync = nullptr;   // k_velocity_bc_limit: arrive / depart counters of the grid barrier of its rare path [0, 1], exit ticket: top word [2] + 8 shards [3..10] (zero between launches)
+    unsigned *d_sync = nullptr;   // k_velocity_bc_limit / k_dye_bc_limit: arrive / depart counters of the grid barrier of their rare path [0, 1] (zero between launches)
     double *d_partial = nullptr;   // per-block partial (sum, count) pairs of the residual reduction
     size_t partial_cap = 0;        // pairs
     // graphs
