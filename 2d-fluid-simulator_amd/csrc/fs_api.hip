@@ -1030,7 +1030,7 @@ int fs_field_fill(fs_field *f, double value)
     FS_REQUIRE(f, "field is null");
     fs_ctx *ctx = f->ctx;
     const size_t n = f->bytes / ctx->esize;
-    const unsigned hot = 2.0 * value * value > (double)FS_HOT_SQ ? 1u : 0u;      // every channel takes `value`
+    const unsigned hot = 2.0 * value * value > 0.999 * (double)FS_HOT_SQ ? 1u : 0u;      // every channel takes `value` (the margin: x * x + y * y is evaluated in the field type on the device)
     FS_DISPATCH(ctx, {
         return launch(ctx, "fill", [=] {
             hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value);
@@ -1072,6 +1072,22 @@ int fs_field_download(const fs_field *f, void *host_xrc, int row_begin, int nrow
     FS_HIP(hipGetLastError());
     FS_HIP(hipMemcpyAsync(host_xrc, ctx->d_stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+// Is the buffer's "may hold a speed above 9.95" flag up (any of its three words, fs_device.h)?  Synchronises the stream: for the host's decision
+// between launch sequences (fs/fluid_simulator.py: a run that has gone hot takes limit_field as its own full-grid launch again - inside a
+// boundary launch the pass is shared by a few dozen workgroups, 130 us against 47 at res 4096).
+int fs_field_hot(const fs_field *f, int *hot)
+{
+    FS_REQUIRE(f && hot, "null argument");
+    fs_ctx *ctx = f->ctx;
+    FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "fs_field_hot during graph capture / tape recording");
+    FS_HIP(hipSetDevice(ctx->device));
+    unsigned h[3] = {0u, 0u, 0u};
+    FS_HIP(hipMemcpyAsync(h, f->hot, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    *hot = (h[0] | h[1] | h[2]) != 0u ? 1 : 0;
     return FS_OK;
 }
 
@@ -1145,7 +1161,7 @@ int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int parity, int
     int rc = bc_guard(ctx); if (rc) return rc;
     int ok = 0;
     fs_velocity_bc_limit_ok(ctx, &ok);
-    if (!ok || !((float)limit * (float)limit > FS_HOT_SQ)) { set_error("fs_velocity_bc_limit is not available for this context / limit (fs_velocity_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
+    if (!ok || !((float)limit * (float)limit > FS_HOT_GATE_SQ)) { set_error("fs_velocity_bc_limit is not available for this context / limit (fs_velocity_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
     FS_DISPATCH(ctx, {
         return launch(ctx, "velocity_bc", [=] {
             // (at least one workgroup per row of the limit pass, up to 64 (the barrier costs ~40 ns per workgroup): with the flag up - a run that has once exceeded a speed of 8 keeps it
@@ -1202,7 +1218,7 @@ int fs_dye_bc_limit(fs_ctx *ctx, double limit, fs_field *v, fs_field *dye, int l
     FS_REQUIRE(limit_begin >= 0 && limit_begin <= limit_end && limit_end <= ctx->rows, "bad row range of the limit pass");
     int ok = 0;
     fs_dye_bc_limit_ok(ctx, &ok);
-    if (!ok || !((float)limit * (float)limit > FS_HOT_SQ)) { set_error("fs_dye_bc_limit is not available for this context / limit (fs_dye_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
+    if (!ok || !((float)limit * (float)limit > FS_HOT_GATE_SQ)) { set_error("fs_dye_bc_limit is not available for this context / limit (fs_dye_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
     FS_DISPATCH(ctx, {
         return launch(ctx, "dye_bc", [=] {
             hipLaunchKernelGGL(k_dye_bc_limit<T>, dim3(std::max((ctx->ops_dye.lanes() + 255) / 256, std::min(64, limit_end - limit_begin))), dim3(256), 0, ctx->stream,
@@ -2088,8 +2104,8 @@ int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int ro
     FS_ROWS();
     FS_DISPATCH(ctx, {
         if (ctx->use_march) {
-            // gated by the buffer's "hot" flag (fs_device.h): while no writer has stored a speed above 8 the pass has nothing to do
-            const int gated = (T)limit * (T)limit > (T)FS_HOT_SQ && ctx->limit_gate ? 1 : 0;
+            // gated by the buffer's "hot" flag (fs_device.h): while no writer has stored a speed above 9.95 the pass has nothing to do
+            const int gated = (T)limit * (T)limit > (T)FS_HOT_GATE_SQ && ctx->limit_gate ? 1 : 0;
             const int lanes = std::min(row_end - row_begin, 256);
             return launch(ctx, "limit_field", [=] {
                 hipLaunchKernelGGL((k_limit_quad<T>), dim3((ctx->X / 4 + 255) / 256, lanes), dim3(256), 0, ctx->stream,

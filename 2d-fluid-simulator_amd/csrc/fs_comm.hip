@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_halo_pack(PackTable t, char *stage_lo, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
         const uint4 v = src[i];
         dst[i] = v;
-        if (!PACK && hot) {      // ghost rows of a velocity buffer arrive from the neighbour: a speed above 8 there raises OUR flag too
+        if (!PACK && hot) {      // ghost rows of a velocity buffer arrive from the neighbour: a speed above 9.95 there raises OUR flag too
             bool h;              // (component-wise and therefore conservative: the two channels of a cell sit in different rows of the block)
             if (t.f64) {
                 const double a = __hiloint2double((int)v.y, (int)v.x), b = __hiloint2double((int)v.w, (int)v.z);

@@ -121,11 +121,15 @@ __device__ __forceinline__ double tabs(double a) { return fabs(a); }
 // ---- "hot" flag of a velocity buffer --------------------------------------------------------------------------------------
 // limit_field (fs/solver.py:38-43) rewrites the cells whose speed exceeds 10 - in a healthy run none, yet the pass reads the whole
 // velocity field every step (268 MB at res 4096).  Every kernel that writes a 2-channel field raises the buffer's flag word when
-// it stores a value with x*x + y*y > 64 (the same expression limit_field takes the square root of, so speed <= 8 is certain
-// otherwise); the flag is never cleared.  fs_limit_field exits at once while the flag is down (and the limit is above 8): the
-// result is the same for every input, the common case costs a 3 us launch instead of 47 us.  Uploads scan what they bring in,
-// ghost-row exchanges check what they unpack.  NaN never raises the flag - limit_field ignores NaN as well (NaN > limit is false).
-constexpr float FS_HOT_SQ = 64.0f;
+// it stores a value with x*x + y*y > 99 (the same expression limit_field takes the square root of, so speed <= sqrt(99) = 9.9499 is
+// certain otherwise); the flag is never cleared.  fs_limit_field exits at once while the flag is down and the limit's square is above
+// 99.01 (the margin covers the rounding of limit * limit): the result is the same for every input, the common case costs a 3 us launch
+// instead of 47 us.  Uploads scan what they bring in, ghost-row exchanges check what they unpack.  NaN never raises the flag -
+// limit_field ignores NaN as well (NaN > limit is false).  (Round 4: 99 instead of 64.  Kernels that see ONE component per wave - the
+// fused K3+K4 pass - must raise at x*x > 99 / 2, i.e. |x| > 7.04 instead of 5.66: the headline scene passes 5.66 after ~3000 steps
+// without ever needing the limiter, and a raised flag costs the full pass, 54 us = 8 % of its step, from then on.)
+constexpr float FS_HOT_SQ = 99.0f;
+constexpr float FS_HOT_GATE_SQ = 99.01f;      // a limit is gated by the flag when limit * limit exceeds this
 template <typename T> __device__ __forceinline__ bool hot2(T x, T y) { return x * x + y * y > (T)FS_HOT_SQ; }
 template <typename T> __device__ __forceinline__ bool hot1(T x) { return x * x > (T)(0.5f * FS_HOT_SQ); }      // one component alone
 __device__ __forceinline__ void raise_hot(unsigned *hot, bool h) { if (h) atomicOr(hot, 1u); }                  // rare: no wave logic

@@ -165,7 +165,7 @@ struct fs_field {
     int C = 1;
     void *d = nullptr;
     size_t bytes = 0;
-    unsigned *hot = nullptr;   // device words: [0] "may hold a speed above 8" (fs_device.h; meaningful for 2-channel fields), [1], [2] the same, raised by the op list of a k_velocity_bc_limit launch of parity 0 / 1
+    unsigned *hot = nullptr;   // device words: [0] "may hold a speed above 9.95" (fs_device.h; meaningful for 2-channel fields), [1], [2] the same, raised by the op list of a k_velocity_bc_limit launch of parity 0 / 1
 };
 
 namespace fs {

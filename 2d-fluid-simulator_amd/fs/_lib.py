@@ -102,6 +102,7 @@ _PROTOS = {
     "fs_tape_length": [_c_vp, _c_int, _P(_c_int)],
     "fs_tape_replay": [_c_vp, _c_int, _c_int],
     "fs_tape_free": [_c_vp, _c_int],
+    "fs_field_hot": [_c_vp, _P(_c_int)],
     "fs_box_rates": [_c_vp, _c_sz, _c_dbl, _P(_c_dbl), _P(_c_dbl)],
     "fs_box_valu_rate": [_c_vp, _c_dbl, _P(_c_dbl)],
     "fs_box_mixed_rate": [_c_vp, _c_sz, _c_dbl, _P(_c_dbl)],

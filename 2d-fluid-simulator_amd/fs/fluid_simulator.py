@@ -55,11 +55,29 @@ class FluidSimulator:
         self._steps = 0
         self._eager_seen = False   # one step has run outside a capture (the library's compact launch lists exist)
         self._pending_after_step = (False, False)
+        self._since_hot_check = 0
 
     def step(self):
         self._solver.update()
         self._eager_seen = True        # (captures call the solver directly: see capture_period)
         self._pending_after_step = self._limit_pending()
+        self._since_hot_check += 1
+        if self._since_hot_check >= 256:
+            self._check_hot()
+
+    def _check_hot(self):
+        """Deferred limit passes are for runs that never need them.  Once a velocity buffer's flag is up (a speed above 9.95 - or one component above 7.04 - was stored; it stays
+        up) the pass runs on every step, and as its own full-grid launch it is three times faster than inside a boundary launch at res 4096:
+        looked at between launch sequences - at the start of run() / capture_period() and every 256 eager steps (one 12-byte download)."""
+        self._since_hot_check = 0
+        dev = self._dev
+        if not getattr(dev, "limit_deferral", False):
+            return
+        s = self._solver
+        bufs = [f for f in (getattr(getattr(s, "v", None), "current", None), getattr(getattr(s, "v", None), "next", None), getattr(s, "_v_spare", None)) if f is not None]
+        if any(dev.field_hot(f) for f in bufs):
+            dev.stop_limit_deferral(bufs)
+            self._pending_after_step = self._limit_pending()
 
     def _limit_pending(self):
         """What the solver's fields owe: a deferred limit_field of the velocity (runtime.DeviceBase.limit_field; after a step of the plain
@@ -98,6 +116,7 @@ class FluidSimulator:
         period ends in another phase; graphs are therefore cached per phase (at most `period` of them exist) instead of being
         re-captured - and leaked - chunk after chunk, and a capture is only started when the chunk is long enough to pay for it."""
         dev = self._dev
+        self._check_hot()
         if graph and dev.nranks > 1 and nsteps >= 24:
             # slab run: a hipGraph cannot carry the RCCL exchange; the period of the step (launches + exchanges) is logged
             # once and replayed from C++ instead (runtime.py tape_period / replay_tape)
@@ -161,6 +180,7 @@ class FluidSimulator:
         when the graph is a 2-step period.  Where the budget allows, the same period is therefore captured a second time, repeated to
         >= 16 steps (self._graph_long = (graph id, steps)); run() and bench.py replay that one and finish with the short one."""
         dev, done = self._dev, 0
+        self._check_hot()
         self._graph = self._graph_long = None
         if (not self._eager_seen or self._limit_pending() != self._pending_after_step) and budget >= 2:
             # (also: the steady state of a run with deferred limit passes starts every step with one pending - after a download there is

@@ -208,6 +208,7 @@ class DeviceBase:
         # step (compute alone 116); the price is +47 % bytes per step and neighbour (4.05 instead of 2.77 MB) - FS_EXCHANGE_ALL=0 for a
         # link-bound node.
         self.exchange_all = os.environ.get("FS_EXCHANGE_ALL", "1") == "1"
+        self.clamp_deferral = False
         self.limit_deferral = False   # set by upload_scene: limit_field may ride with the next step's velocity boundary kernel (limit_field below)
 
     # ---- ghost-row bookkeeping --------------------------------------------------------------------
@@ -552,6 +553,7 @@ class DeviceBase:
         self.rb_pair_ok = not no_pair
         self.limit_deferral = self.nranks == 1 and os.environ.get("FS_LIMIT_DEFER", "1") == "1" and self._p_limit_deferral_ok()
         self.dye_limit_merge = self.limit_deferral and bc_dye is not None and self._p_dye_bc_limit_ok()
+        self.clamp_deferral = self.limit_deferral        # (the dye's inflow clamp: stays deferred when a hot run stops deferring limit_field)
         self.bc_radius_v, self.bc_radius_p = max(2, int(rv)), max(1, int(rp))
         if self.nranks > 1 and max(self.bc_radius_v, self.bc_radius_p) > self.halo:
             raise RuntimeError(
@@ -575,6 +577,17 @@ class DeviceBase:
 
     def _p_dye_bc_limit_ok(self):        # backends without the merged kernel
         return False
+
+    def field_hot(self, f):              # backends without the flag: never hot
+        return False
+
+    def stop_limit_deferral(self, fields=()):
+        """A run whose velocity has exceeded a speed of 9.95 (one component: 7.04) keeps the buffers' flag up: the limit pass then really runs every step, and inside a
+        boundary launch it is shared by a few dozen workgroups (res 4096: 130 us against 47 as its own full-grid launch).  From here on
+        limit_field is launched where the solvers call it; what the fields still owe is launched now."""
+        self.limit_deferral = self.dye_limit_merge = False
+        for f in fields:
+            self.flush_limit(f)
 
     def flush_limit(self, f):
         """Launch the limit_field / clamp_inflow a field still owes (see limit_field, clamp_inflow)."""
@@ -706,7 +719,7 @@ class DeviceBase:
         in a healthy run, yet its launch is a fifth of a small-grid step - but rides with the next kernel that touches the field: the
         velocity boundary kernel of the next step takes it along in its own launch (velocity_bc above), anything else - downloads,
         visualisation, the dye kernels, a hipGraph boundary - makes it run first (_run / Field.to_numpy).  Same results, one launch less."""
-        if defer and self.limit_deferral and v.pending_limit is None and float(limit) ** 2 > 64.0:
+        if defer and self.limit_deferral and v.pending_limit is None and float(limit) ** 2 > 99.01:
             v.pending_limit = float(limit)
             return
         self.flush_limit(v)
@@ -724,7 +737,7 @@ class DeviceBase:
         """defer=True (the dye solver's end-of-step call, single GPU): the cells this pass clamps are the targets of the dye boundary op list,
         which the next step's set_dye_boundary_condition overwrites with the scene's constants before anything reads them - the launch is
         dropped there (dye_bc), and made up for when anything else touches the field first (_run / Field.to_numpy)."""
-        if defer and self.limit_deferral and dye.pending_clamp is None:
+        if defer and self.clamp_deferral and dye.pending_clamp is None:
             dye.pending_clamp = (float(low), float(high))
             return
         dye.pending_clamp = None        # (an older pending clamp to the same bounds is subsumed; the solvers use one pair of bounds)
@@ -952,6 +965,11 @@ class Device(DeviceBase):
         if tape.get("id") is not None and self._ctx is not None:
             _lib.call("fs_tape_free", self._ctx, tape["id"])
             tape["id"] = None
+
+    def field_hot(self, f):
+        h = ctypes.c_int()
+        _lib.call("fs_field_hot", f._h, ctypes.byref(h))
+        return bool(h.value)
 
     def box_rates(self, nbytes, budget_ms=30.0):
         """(float4 read GB/s, float4 copy GB/s) of this GPU on buffers of `nbytes`, ~budget_ms each (measurement hygiene, include/fs_hip.h)."""

@@ -77,6 +77,8 @@ int fs_field_upload(fs_field *f, const void *host_xrc, int row_begin, int nrows)
 int fs_field_download(const fs_field *f, void *host_xrc, int row_begin, int nrows);
 int fs_field_copy(fs_field *dst, const fs_field *src);
 /* raw device pointer + geometry, for zero-copy interop (hipMemcpy peers, profilers). */
+/* Is the velocity buffer's "may hold a speed above 9.95" flag up?  (Synchronises; lets the host take limit_field as its own launch again in a run that has gone hot.) */
+int fs_field_hot(const fs_field *f, int *hot);
 int fs_field_devptr(const fs_field *f, void **ptr, size_t *bytes);
 
 /* ---- boundary-condition kernels -------------------------------------------------------------- */

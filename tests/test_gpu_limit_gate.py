@@ -253,3 +253,32 @@ def test_deferred_limit_in_f64_and_on_tiny_grids(scheme, vc, graph, hip_lib, mon
     finally:
         sim._solver._bc.device.close()
         plain._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_a_run_that_went_hot_stops_deferring(graph, hip_lib, monkeypatch):
+    """Deferring limit_field is for runs that never need it.  With the buffers' flag up the pass runs on every step, and inside a boundary launch it is
+    shared by a few dozen workgroups (res 4096: 130 us against 47 as its own launch): FluidSimulator looks at the flag between launch sequences
+    (fs_field_hot) and goes back to the separate launch.  Same fields either way."""
+    from fs.boundary_condition import create_scene_arrays
+    res = 64
+    const, mask, _ = create_scene_arrays(2, res)
+    const = const.copy()
+    const[mask == 2] *= np.float32(30.0) / max(float(np.abs(const[mask == 2]).max()), 1e-6)
+    monkeypatch.setenv("FS_LIMIT_DEFER", "1")
+    sim, ref = _pair(const, mask, "cip", 5.0, 0.05 / res, 1.0 / res)
+    try:
+        dev = sim._solver._bc.device
+        assert dev.limit_deferral and not dev.field_hot(sim._solver.v.current)
+        sim.run(20, graph=graph)                       # cold at the start of this call: deferred all the way
+        assert dev.limit_deferral and sim._solver.v.current.pending_limit is not None
+        assert dev.field_hot(sim._solver.v.current) or dev.field_hot(sim._solver.v.next)
+        sim.run(20, graph=graph)                       # hot now: the owed pass is launched, the rest of the run does not defer
+        assert not dev.limit_deferral and sim._solver.v.current.pending_limit is None
+        for _ in range(40):
+            ref.update()
+        out = sim.field_to_numpy()
+        for k, e in ref.fields().items():
+            assert np.array_equal(out[k], e, equal_nan=True), k
+    finally:
+        sim._solver._bc.device.close()
