@@ -144,6 +144,9 @@ static int prof_drain(fs_ctx *c)
 // tiles of half the height halve that chain (round 4, tools/r4_chain.py; env FS_SMALL_TILES=0: the big grids' tile heights everywhere)
 static inline bool small_tiles(const fs_ctx *c) { return c->small_tiles && (size_t)c->X * c->Y < c->small_cells; }
 
+// a launch over every row of a single-GPU grid (what may clear a buffer's "hot" word [3], fs_device.h)
+static inline int whole_grid(const fs_ctx *c, int jb, int je) { return c->halo == 0 && jb == 0 && je == c->rows ? 1 : 0; }
+
 static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
 
 // overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
@@ -1034,7 +1037,7 @@ int fs_field_fill(fs_field *f, double value)
     FS_DISPATCH(ctx, {
         return launch(ctx, "fill", [=] {
             hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value);
-            hipLaunchKernelGGL(k_fill<unsigned>, dim3(1), dim3(64), 0, ctx->stream, f->hot, (size_t)3, hot);
+            hipLaunchKernelGGL(k_fill<unsigned>, dim3(1), dim3(64), 0, ctx->stream, f->hot, (size_t)4, hot);
         });
     })
 }
@@ -1084,16 +1087,16 @@ int fs_field_hot(const fs_field *f, int *hot)
     fs_ctx *ctx = f->ctx;
     FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "fs_field_hot during graph capture / tape recording");
     FS_HIP(hipSetDevice(ctx->device));
-    unsigned h[3] = {0u, 0u, 0u};
+    unsigned h[4] = {0u, 0u, 0u, 0u};
     FS_HIP(hipMemcpyAsync(h, f->hot, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
-    *hot = (h[0] | h[1] | h[2]) != 0u ? 1 : 0;
+    *hot = (h[0] | h[1] | h[2] | h[3]) != 0u ? 1 : 0;
     return FS_OK;
 }
 
 static __global__ void k_hot_fold(unsigned *dst, const unsigned *src)
 {
-    if (threadIdx.x == 0) { dst[0] = (src[0] | src[1] | src[2]) != 0u ? 1u : 0u; dst[1] = 0u; dst[2] = 0u; }
+    if (threadIdx.x == 0) { dst[0] = (src[0] | src[1] | src[2] | src[3]) != 0u ? 1u : 0u; dst[1] = 0u; dst[2] = 0u; dst[3] = 0u; }
 }
 
 int fs_field_copy(fs_field *dst, const fs_field *src)
@@ -1309,9 +1312,10 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
             // (small grids - fewer waves than SIMDs, a launch takes as long as one wave's chain: 2-row tiles, fs_ctx::small_tiles)
             const bool small = small_tiles(ctx);
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3);
+            const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
             return launch(ctx, "cip_nonadv", [=] {
-#define FS_K2N4(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
-#define FS_K2N2(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
+#define FS_K2N4(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
+#define FS_K2N2(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
                 if (small) FS_DMA(dm_all(ctx, k), FS_K2N2); else FS_DMA(dm_all(ctx, k), FS_K2N4);
             });
         }
@@ -1514,10 +1518,11 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
         auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
         const int dm = dm_dx(ctx, k);
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
-#define FS_VORTN(DM, ST) hipLaunchKernelGGL((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
+        const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
+#define FS_VORTN(DM, ST) hipLaunchKernelGGL((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
 #define FS_VORTN_S(DM) FS_VORTN(DM, true)
 #define FS_VORTN_N(DM) FS_VORTN(DM, false)
-#define FS_VORTN_2(DM) hipLaunchKernelGGL((k_vort_n<2, 2, DM, false, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot)
+#define FS_VORTN_2(DM) hipLaunchKernelGGL((k_vort_n<2, 2, DM, false, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
         return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORTN_S); else if (small) FS_DMX(dm, FS_VORTN_2); else FS_DMX(dm, FS_VORTN_N); });
     })
 }

@@ -128,6 +128,11 @@ __device__ __forceinline__ double tabs(double a) { return fabs(a); }
 // limit_field ignores NaN as well (NaN > limit is false).  (Round 4: 99 instead of 64.  Kernels that see ONE component per wave - the
 // fused K3+K4 pass - must raise at x*x > 99 / 2, i.e. |x| > 7.04 instead of 5.66: the headline scene passes 5.66 after ~3000 steps
 // without ever needing the limiter, and a raised flag costs the full pass, 54 us = 8 % of its step, from then on.)
+// Word [3] (round 4): the fused K3+K4 pass sees ONE component per wave and can only test x*x > 99 / 2 - a flow with |u| > 7.04 and a speed
+// below 9.95 would keep the limit pass running for nothing (the headline scene, 6 000 steps in: 57 us = 8 % of its step).  Its FLUID-cell
+// raises therefore go to word [3] of the buffer, which the kernels that rewrite every fluid cell of a buffer with both components in sight
+// (K2, K5+K6: exact test, word [0]) clear when they cover the whole single-GPU grid.  Every gate reads [3] as well: a buffer that goes from
+// K3+K4 straight to limit_field (no vorticity confinement) is judged as conservatively as before.
 constexpr float FS_HOT_SQ = 99.0f;
 constexpr float FS_HOT_GATE_SQ = 99.01f;      // a limit is gated by the flag when limit * limit exceeds this
 template <typename T> __device__ __forceinline__ bool hot2(T x, T y) { return x * x + y * y > (T)FS_HOT_SQ; }

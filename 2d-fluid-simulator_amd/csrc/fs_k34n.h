@@ -202,7 +202,16 @@ __device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Kons
             if (PLAIN || ((fl[t] >> q) & 1u)) { OV.a[q] = of; OX.a[q] = ofx; OY.a[q] = ofy; }      // (PLAIN: rows past je have left the loop above)
         }
         if (lm.owner) {
-            if (SELF) raise_hot(hot, lv_hot1<T, N>(OV));                                   // one component per pass: conservative
+            if (SELF && lv_hot1<T, N>(OV)) {                                               // one component per pass: conservative - and rare
+                // FLUID cells raise word [3] (cleared by the next kernel that rewrites every fluid cell of this buffer with both components in
+                // sight: K2, K5+K6), carried non-fluid values the sticky word [0] (fs_device.h)
+                bool hf = false, hn = false;
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+                    if (hot1(OV.a[q])) { if (PLAIN || ((fl[t] >> q) & 1u)) hf = true; else hn = true; }
+                raise_hot(hot + 3, hf);
+                raise_hot(hot, hn);
+            }
             lv_store<T, N>(out + idx<C, T>(g, c, i0, j), OV);                              // every cell: result or carried value
             if (nw[t + 1]) {
                 lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), OX, nw[t + 1]);           // fluid: result, inflow/outflow: carried
@@ -232,10 +241,11 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_n(Grid g, Konst<T> k, i
 // of input; 2 cells x 4 rows: 18 B per cell.)
 // ------------------------------------------------------------------------------------------------
 template <int N, int RT, int DM, typename T>
-__global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot)
+__global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot, int clear3)
 {
     using R = LV<T, N>;
     constexpr int HL = 1, L = N - 1;
+    if (clear3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) hot[3] = 0u;      // every not-wall cell of fn is rewritten (fs_device.h "hot" word [3])
     int wx, ty, cg;
     if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
     const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
@@ -302,10 +312,11 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nb
 // writes RT rows of vn; w / |w| never touch HBM unless STORE_W.  One halo lane per side (the pass reaches 2 cells in x).
 // ------------------------------------------------------------------------------------------------
 template <int N, int RT, int DM, bool STORE_W, typename T>
-__global__ __launch_bounds__(256) void k_vort_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot)
+__global__ __launch_bounds__(256) void k_vort_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot, int clear3)
 {
     using R = LV<T, N>;
     constexpr int HL = 1, L = N - 1;
+    if (clear3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) hot[3] = 0u;      // every fluid cell of vn is rewritten (fs_device.h "hot" word [3])
     int wx, ty, cg;
     if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
     const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, int je, T li
 {
     // `gated`: the buffer's flag is authoritative for this limit (fs_device.h) - while it is down no cell can exceed it: done.
     // A fixed grid of gridDim.y row lanes keeps the common case a ~3 us launch; the rare full pass strides over the rows.
-    if (gated && (hot[0] | hot[1] | hot[2]) == 0u) return;      // ([1], [2]: raised by the op lists of k_velocity_bc_limit launches)
+    if (gated && (hot[0] | hot[1] | hot[2] | hot[3]) == 0u) return;      // ([1], [2]: raised by the op lists of k_velocity_bc_limit launches)
     const int i0 = (blockIdx.x * 256 + threadIdx.x) << 2;
     if (i0 >= g.X) return;
     for (int j = jb + blockIdx.y; j < je; j += gridDim.y) {
@@ -926,7 +926,7 @@ __device__ __forceinline__ void limit_pass_and_barrier(const Grid &g, int lb, in
 template <typename T>
 __global__ __launch_bounds__(256) void k_velocity_bc_limit(Grid g, BcOps ops, int jb, int je, int lb, int le, T lim, T *v, const T *bc_const, unsigned *hot, unsigned *sync, int parity)
 {
-    if ((hot[0] | hot[2 - parity]) != 0u) limit_pass_and_barrier<T>(g, lb, le, lim, v, hot, sync);
+    if ((hot[0] | hot[2 - parity] | hot[3]) != 0u) limit_pass_and_barrier<T>(g, lb, le, lim, v, hot, sync);      // ([3]: nobody raises it in this launch either)
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned *raise = hot + 1 + parity;
     if (n < ops.nsimple) {
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256) void k_velocity_bc_limit(Grid g, BcOps ops, in
 template <typename T>
 __global__ __launch_bounds__(256) void k_dye_bc_limit(Grid g, BcOps ops, int jb, int je, int lb, int le, T lim, T *v, unsigned *hot, unsigned *sync, T *dye, const T *bc_dye)
 {
-    if ((hot[0] | hot[1] | hot[2]) != 0u) limit_pass_and_barrier<T>(g, lb, le, lim, v, hot, sync);
+    if ((hot[0] | hot[1] | hot[2] | hot[3]) != 0u) limit_pass_and_barrier<T>(g, lb, le, lim, v, hot, sync);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= ops.nsimple) return;
     const int4 o = ops.simple[n];

@@ -74,8 +74,9 @@ class FluidSimulator:
         if not getattr(dev, "limit_deferral", False):
             return
         s = self._solver
-        bufs = [f for f in (getattr(getattr(s, "v", None), "current", None), getattr(getattr(s, "v", None), "next", None), getattr(s, "_v_spare", None)) if f is not None]
-        if any(dev.field_hot(f) for f in bufs):
+        target = getattr(getattr(s, "v", None), "current", None)      # the buffer limit_field is applied to at a step boundary - the others' flags do not
+        if target is not None and dev.field_hot(target):             # decide whether a pass runs (a K3+K4 output carries word [3] until it is rewritten)
+            bufs = [f for f in (target, getattr(getattr(s, "v", None), "next", None), getattr(s, "_v_spare", None)) if f is not None]
             dev.stop_limit_deferral(bufs)
             self._pending_after_step = self._limit_pending()
 

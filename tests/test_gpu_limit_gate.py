@@ -282,3 +282,44 @@ def test_a_run_that_went_hot_stops_deferring(graph, hip_lib, monkeypatch):
             assert np.array_equal(out[k], e, equal_nan=True), k
     finally:
         sim._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("vc", [5.0, None])
+def test_one_fast_component_does_not_keep_the_limit_pass_running(vc, hip_lib, monkeypatch):
+    """Round 4, flag word [3]: the fused K3+K4 pass sees one velocity component per wave and must raise at |u| > 7.04 although the limiter only acts
+    above a speed of 10.  With vorticity confinement the buffer limit_field looks at is written by a kernel that sees both components: its flag
+    stays down for a flow of (7.5, 0) - without it, K3+K4's output goes straight to limit_field and is judged conservatively.  Same fields as the
+    oracle either way."""
+    from fs.boundary_condition import create_scene_arrays
+    res = 64
+    const, mask, _ = create_scene_arrays(2, res)
+    monkeypatch.setenv("FS_LIMIT_DEFER", "1")
+    sim, ref = _pair(const, mask, "cip", vc, 0.05 / res, 1.0 / res)
+    try:
+        dev = sim._solver._bc.device
+        # (7.5, 0) in the fluid cells at least 6 cells away from anything that is not fluid: what K3+K4 carries on walls / inflow / outflow stays slow
+        # (those cells are judged per component as before: word [0])
+        far = mask == 0
+        for _ in range(6):
+            f = far.copy()
+            f[1:, :] &= far[:-1, :]; f[:-1, :] &= far[1:, :]; f[:, 1:] &= far[:, :-1]; f[:, :-1] &= far[:, 1:]
+            f[0, :] = f[-1, :] = False; f[:, 0] = f[:, -1] = False
+            far = f
+        assert far.sum() > 100
+        v0 = np.zeros(mask.shape + (2,), np.float32)
+        v0[far, 0] = 7.5
+        sim._solver.v.current.from_numpy(v0)
+        ref.v.current[...] = v0
+        assert not dev.field_hot(sim._solver.v.current)                  # speed 7.5: the upload's exact scan leaves the flag down
+        for _ in range(2):
+            sim.step()
+            ref.update()
+        hot = dev.field_hot(sim._solver.v.current)
+        assert hot == (vc is None), f"flag of the buffer limit_field reads: {hot}"
+        out = sim.field_to_numpy()
+        for k, e in ref.fields().items():
+            assert np.array_equal(out[k], e, equal_nan=True), k
+        speed = np.sqrt((out["v"].astype(np.float64) ** 2).sum(-1))
+        assert 7.04 < np.nanmax(np.abs(out["v"][..., 0])) and np.nanmax(speed) < 9.9      # the case this test is about
+    finally:
+        sim._solver._bc.device.close()
