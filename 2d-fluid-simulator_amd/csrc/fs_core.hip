@@ -1,4 +1,5 @@
-// fs_api.hip - C-ABI entry points (include/fs_hip.h): contexts, fields, scene upload, kernel launches.
+// fs_core.hip - C-ABI entry points (include/fs_hip.h): contexts, fields, scene upload, boundary kernels, pointwise passes, visualisation,
+// hipGraph capture, command tapes, profiling, box-rate probes.  Transport kernels: fs_transport.hip; pressure kernels: fs_pressure.hip.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -8,7 +9,7 @@
 #include <type_traits>
 #include <unordered_map>
 
-#include "fs_host.h"
+#include "fs_launch.h"
 
 namespace fs {
 
@@ -51,50 +52,12 @@ __global__ __launch_bounds__(256) static void k_verify_f64div(float d, double rd
 }
 
 // ---- launch helper: optional HIP-event pair around every launch (fs_prof_*) --------------------
-static hipEvent_t prof_event(fs_ctx *c)
+hipEvent_t prof_event(fs_ctx *c)
 {
     hipEvent_t e;
     if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); return e; }
     hipEventCreate(&e);
     return e;
-}
-
-// Every kernel launch of the library goes through here.  The callable captures its arguments BY VALUE: while a tape is being
-// recorded (fs_tape_begin) a copy is kept and re-issued by fs_tape_replay without going back through the caller.
-template <typename F>
-static int launch(fs_ctx *c, const char *name, F &&f)
-{
-    if (c->tape_rec) {
-        c->tape_rec->ops.emplace_back([f]() -> int {
-            f();
-            hipError_t e = hipGetLastError();
-            return e == hipSuccess ? FS_OK : hip_fail(e, "tape replay", __FILE__, __LINE__);
-        });
-        if (!c->tape_execute) return FS_OK;
-    }
-    const bool prof = c->prof_on && !c->capturing;
-    ProfRec rec{};
-    if (prof) {
-        auto it = c->prof_ids.find(name);
-        if (it == c->prof_ids.end()) {
-            it = c->prof_ids.emplace(name, (int)c->prof_names.size()).first;
-            c->prof_names.push_back(name);
-            c->prof_launches.push_back(0);
-            c->prof_ms.push_back(0.0);
-        }
-        rec.name_id = it->second;
-        rec.start = prof_event(c);
-        rec.stop = prof_event(c);
-        (void)hipEventRecord(rec.start, c->stream);
-    }
-    f();
-    if (prof) {
-        (void)hipEventRecord(rec.stop, c->stream);
-        c->prof_recs.push_back(rec);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, name, __FILE__, __LINE__);
-    return FS_OK;
 }
 
 // the same event pair for work that is not a single kernel launch (fs_comm.hip: the pack -> RCCL -> unpack chain of a ghost-row exchange),
@@ -140,27 +103,13 @@ static int prof_drain(fs_ctx *c)
     return FS_OK;
 }
 
-// Grids below 2 M cells have few waves per SIMD: a launch takes as long as ONE wave's chain of loads, stages and stores, and
-// tiles of half the height halve that chain (round 4, tools/r4_chain.py; env FS_SMALL_TILES=0: the big grids' tile heights everywhere)
-static inline bool small_tiles(const fs_ctx *c) { return c->small_tiles && (size_t)c->X * c->Y < c->small_cells; }
-
-// a launch over every row of a single-GPU grid (what may clear a buffer's "hot" word [3], fs_device.h)
-static inline int whole_grid(const fs_ctx *c, int jb, int je) { return c->halo == 0 && jb == 0 && je == c->rows ? 1 : 0; }
-
-static inline dim3 cells_grid(const fs_ctx *c, int jb, int je) { return dim3((c->X + 255) / 256, je - jb, 1); }
-
-// overlapped-wave tile kernels: nbx blocks of 4 waves x 62 quads across, nby tile rows, XCD-band 1-D launch
-struct OvGrid { int nbx, nby; dim3 grid; Grid g; int threads = 256; };    // threads: 64 x waves per workgroup
-enum { XCD_RBSOR = 1, XCD_VORT = 2, XCD_ADVECT = 4, XCD_NONADV = 8, XCD_GRAD = 16, XCD_JACOBI = 32, XCD_MARCH = 64 };   // XCD_MARCH: the row-marching passes - one strip row per XCD group, workgroups side by side
 // Compact list of the workgroups of a dense XCD-band launch that have anything to do (Grid::tiles), built once per geometry from the
 // host-side activity maps of the scene.  lanes = cells per lane (4: wave columns of 248 cells, 2: of 120), rt = rows per tile.
 // cls: 0 = every workgroup with work; 1 / 2 = those whose tiles see nothing but fluid within `reach` rows and the halo lanes ("plain":
 // no mask loads, no boundary views - their own kernel and register budget) / the others
 // `lanes` names the wave geometry: 4 = quads, 62 owner lanes (248 cells, 4 halo cells per side); 2 = pairs, 60 owner lanes (120 cells, 4 halo
 // cells); 3 = pairs, 62 owner lanes (124 cells, 2 halo cells)
-static inline int geo_cells(int lanes) { return lanes == 4 ? 4 : 2; }
-static inline int geo_owners(int lanes) { return lanes == 2 ? 60 : (lanes == 5 ? 58 : (lanes == 6 ? 56 : 62)); }   // 5 / 6: pairs with 3 / 4 halo lanes per side (the 6- / 8-sweep marching passes; no compact lists)
-static const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls = 0, int reach = 0, int wgw = 4, int jb = 0, int je = -1, int parent_rt = 0)
+const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, int group, int nbx, int nby, int cls, int reach, int wgw, int jb, int je, int parent_rt)
 {
     if (c->h_act4.empty() || nbx > 0xfff || nby > 0xffff || lanes > 4 || c->rows > 0xffff) return nullptr;      // (entry: class hints << 28 | by << 12 | bx)
     if (je < 0) je = c->rows;
@@ -245,82 +194,7 @@ static void tile_lists_free(fs_ctx *c)
     c->tile_lists.clear();
 }
 
-// XCD-band launch geometry of a tile kernel family (fs_march.h band_coords); `lanes`: cells per lane.  When the launch covers the whole
-// single-GPU grid, the workgroups without anything to do are left out (compact list, Grid::tiles).
-static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true, int cls = 0, int reach = 0, int wgw = 4, int parent_rt = 0)
-{
-    OvGrid o;
-    o.g = c->grid();
-    const int ow = geo_owners(lanes);
-    const int nu = c->X / geo_cells(lanes), waves = (nu + ow - 1) / ow, tiles = (je - jb + rt - 1) / rt;
-    const bool stacked = (c->stack_mask & family) != 0;    // the 4 waves of a workgroup: 4 tile rows of one wave column
-    o.threads = 64 * wgw;
-    o.nbx = stacked ? waves : (waves + wgw - 1) / wgw;
-    o.nby = stacked ? (tiles + wgw - 1) / wgw : tiles;
-    if (c->xcd_mask & family) {
-        // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords)
-        int xg = c->xcd_group;
-        for (int f = 0; f < 7; ++f) if ((family >> f) & 1) xg = c->xcd_group_fam[f] > 0 ? c->xcd_group_fam[f] : xg;
-        const int group = stacked ? std::max(1, xg / wgw) : xg;     // the same number of field rows per XCD group
-        const int groups = (o.nby + group - 1) / group;
-        const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && ((jb == 0 && je == c->rows) || (c->halo != 0 && cls == 0))
-                                         ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach, wgw, jb, je, parent_rt) : nullptr;
-        const bool inner = zgroups > 1 && (tl || (c->cg_inner_mask & family) != 0);
-        if (tl) { o.grid = dim3(8 * tl->per_xcd * zgroups, 1, 1); o.g.tiles = tl->d; }
-        else o.grid = inner ? dim3(8 * o.nbx * zgroups, group, (groups + 7) / 8) : dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
-        o.nby |= (group - 1) << 24;
-        if (inner) o.nby |= FS_CG_INNER;
-    } else { o.grid = dim3(o.nbx * o.nby, zgroups, 1); o.nbx = -o.nbx; }   // negative nbx = row-major decode
-    if (stacked) o.nby |= FS_STACKED;
-    return o;
-}
-static inline OvGrid ov_grid(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, bool allow_list = true)
-{ return ov_grid_lanes(c, jb, je, rt, zgroups, family, 4, allow_list); }
-template <int N>
-static OvGrid ov_grid_n(fs_ctx *c, int jb, int je, int rt) { return ov_grid_lanes(c, jb, je, rt, 1, XCD_RBSOR, N); }
-
-// Division-mode dispatch (fs_device.h DM_*): CALL(DM) is expanded for the modes a kernel family distinguishes.  f32 fields divide by their
-// loop-invariant divisors through the f64 multiplication (modes 4 / 5; FS_F64DIV=0: IEEE division, modes 0 / 1); power-of-two dx-derived
-// divisors by exact multiplication (bit 0).
-#define FS_F32_ONLY(dm, bits, CALL, MODE) if constexpr (std::is_same<T, float>::value) { if (((dm) & 7) == (bits)) { CALL(MODE); break; } }
-#define FS_DMC(dm, CALL)      /* modes 0 / 4 : no dx-derived divisor                */ \
-    do { FS_F32_ONLY(dm, 4, CALL, 4) CALL(0); } while (0)
-#define FS_DMX(dm, CALL)      /* modes 0 / 1 / 4 : dx-derived divisors only         */ \
-    do { if ((dm) & 1) { CALL(1); break; } FS_F32_ONLY(dm, 4, CALL, 4) CALL(0); } while (0)
-#define FS_DMA(dm, CALL)      /* modes 0 / 1 / 4 / 5 : both kinds                   */ \
-    do { FS_F32_ONLY(dm, 5, CALL, 5) FS_F32_ONLY(dm, 4, CALL, 4) if ((dm) & 1) { CALL(1); break; } CALL(0); } while (0)
-
-#define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, HV, T>), grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
-                               (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, list, nlist, zoff, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
-template <bool SW, bool HV, typename T>
-static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, int row_end, fs_field *pn, const fs_field *pc, const fs_field *src)
-{
-    // the general rows ride in front: `zoff` leading z slices of the same launch, one wave per listed row
-    const uint32_t *list = ctx->d_pairlist + (HV ? (size_t)ctx->nwx * ctx->rows : 0);
-    const int nlist = ctx->n_pairlist[HV ? 1 : 0];
-    const int per_slice = (int)(og.grid.x * og.grid.y), blocks = nlist, zoff = (blocks + per_slice - 1) / per_slice;      // one listed row per workgroup
-    const dim3 grid(og.grid.x, og.grid.y, og.grid.z + zoff);
-    if (rt == 1) FS_PAIR(1); else if (rt == 4) FS_PAIR(4); else if (rt == 2) FS_PAIR(2); else FS_PAIR(3);
-}
-
-template <bool SRC, typename T>
-static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
-{
-    // overlapped-wave register tiles of 1 - 4 rows (FS_JACOBI=21 .. 24).  Default (0): the source-pair
-    // form streams best with 1-row tiles at 8 waves/SIMD (76 vs 79 us), the v-reading form with 2-row tiles (89 vs 95 us)
-    const int v = ctx->jacobi_variant ? ctx->jacobi_variant : (SRC ? 21 : 24);      // (round 4, after the DPP diet: 4-row tiles for the v-reading form: 84.7 against 85.9-86.4 us)
-    const int rt = v == 24 ? 4 : (v == 21 ? 1 : (v == 23 ? 3 : 2));
-    const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
-    const int dm = SRC ? 0 : dm_const(ctx, k);           // the source-pair form divides nothing
-#define FS_JAC(DM) do { \
-        if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else if (rt == 3) hipLaunchKernelGGL((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
-    return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC); });
-}
-
-static int check_rows(const fs_ctx *c, int jb, int je)
+int check_rows(const fs_ctx *c, int jb, int je)
 {
     if (!(0 <= jb && jb <= je && je <= c->rows)) {
         set_error("row range outside the local slab");
@@ -329,7 +203,7 @@ static int check_rows(const fs_ctx *c, int jb, int je)
     return FS_OK;
 }
 
-static int check_field(const fs_ctx *c, const fs_field *f, int C, const char *what)
+int check_field(const fs_ctx *c, const fs_field *f, int C, const char *what)
 {
     if (!f || f->ctx != c || f->C != C) {
         set_error(std::string("field argument '") + what + "' is null, from another context, or has the wrong channel count");
@@ -338,25 +212,7 @@ static int check_field(const fs_ctx *c, const fs_field *f, int C, const char *wh
     return FS_OK;
 }
 
-#define FS_FIELD(f, C)                                             \
-    do {                                                           \
-        int rc__ = fs::check_field(ctx, f, C, #f);                 \
-        if (rc__) return rc__;                                     \
-    } while (0)
-#define FS_ROWS()                                                  \
-    do {                                                           \
-        int rc__ = fs::check_rows(ctx, row_begin, row_end);        \
-        if (rc__) return rc__;                                     \
-        if (!ctx->mask_set) { fs::set_error("mask not uploaded"); return FS_ERR_STATE; } \
-        if (row_begin == row_end) return FS_OK;                    \
-    } while (0)
-
-// dispatch on ctx dtype: BODY sees `T`
-#define FS_DISPATCH(ctx, ...)                                      \
-    if ((ctx)->dtype == 0) { using T = float; __VA_ARGS__ }        \
-    else { using T = double; __VA_ARGS__ }
-
-static int ensure_stage(fs_ctx *c, size_t bytes)
+int ensure_stage(fs_ctx *c, size_t bytes)
 {
     if (c->stage_bytes >= bytes) return FS_OK;
     if (c->d_stage) { FS_HIP(hipStreamSynchronize(c->stream)); FS_HIP(hipFree(c->d_stage)); c->d_stage = nullptr; c->stage_bytes = 0; }
@@ -666,52 +522,6 @@ static int build_bc_ops(fs_ctx *c, const uint8_t *mask)
 
 using namespace fs;
 
-// K3 + K4 in one pass (fs_k34n.h), velocity (C = 2, v = nullptr) and dye (C = 3): lane width / tile rows from FS_K34_N / FS_K34_RT
-// (default: 2 cells per lane, 4 rows; 4 cells per lane: 2 rows), compact two-part launch on large single-GPU grids
-template <int C, bool CLAMP>
-static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, double dt, double dx, fs_field *f_out, fs_field *gx_out, fs_field *gy_out,
-                      const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v, int full, int jb, int je)
-{
-    using T = float;
-    auto k = make_konst<T>(ctx, dt, dx, 1.0);
-    const int dm = dm_dx(ctx, k);
-    // geometry by grid size unless FS_K34_N / FS_K34_RT say otherwise (K3+K4 of the velocity, us):   2 cells x 4 rows   4 x 2   2 x 2
-    //   >= 8 M cells (two-part launch): bc5 res 4096 / bc5 res 2048 / bc2 res 3000                   307 / 103 / 258    325 / 106 / 267   - / 113 / 282
-    //   2 - 8 M cells: bc2 res 1600 / bc5 res 1024 (the boundary kernel of 2 x 4 holds 4 waves per SIMD)  90.7 / 26.5   81.6 / 27.8   90.3 / 26.4
-    //   smaller: bc2 res 800 / res 400 (workgroups of half the size)                                  28.2 / 14.5        26.6 / 13.7       24.8 / 12.9
-    const size_t cells = (size_t)ctx->X * ctx->rows;      // (this context's slab)
-    const int N = ctx->X % 4 != 0 ? 2 : (ctx->k34_n ? ctx->k34_n : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4));
-    // (below 1 M cells: 1-row tiles for the dye's three channels - a launch is one wave's chain there, fs_ctx::small_tiles; res 400: 17.6 against
-    //  17.1 k steps/s with the dye; the velocity's pass stays on 2 rows: 29.0 against 28.1 k)
-    const int RT = N == 4 ? 2 : (ctx->k34_rt ? ctx->k34_rt : (cells >= ((size_t)1 << 23) ? 4 : (small_tiles(ctx) && !full && C == 3 ? 1 : 2))), geo = N == 2 ? 3 : 4;
-#define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
-        (T *)f_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v ? (const T *)v->d : (const T *)nullptr, \
-        f_out->hot, (const uint8_t *)ctx->d_bcmap, full)
-#define FS_K34_24(DM) FS_K34(2, 4, DM, false)
-#define FS_K34_24P(DM) FS_K34(2, 4, DM, true)
-#define FS_K34_22(DM) FS_K34(2, 2, DM, false)
-#define FS_K34_22P(DM) FS_K34(2, 2, DM, true)
-#define FS_K34_42(DM) FS_K34(4, 2, DM, false)
-#define FS_K34_42P(DM) FS_K34(4, 2, DM, true)
-#define FS_K34_21(DM) FS_K34(2, 1, DM, false)
-#define FS_K34_ANY(SUF) do { if (N == 4) FS_DMX(dm, FS_K34_42##SUF); else if (RT == 4) FS_DMX(dm, FS_K34_24##SUF); else FS_DMX(dm, FS_K34_22##SUF); } while (0)
-    // Compact launch in two parts on large single-GPU grids (as fs_rbsor_pair): the workgroups that see nothing but fluid within
-    // reach run without mask loads, selects and conditional stores (PLAIN), the others the general tile
-    if (!full && RT != 1 && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
-        const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 1, 2, ctx->split_wgw);
-        const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 2, 2, ctx->split_wgw);
-        if (og.g.tiles && ogb.g.tiles) {
-            int rc = launch(ctx, name, [=] { FS_K34_ANY(P); });
-            if (rc) return rc;
-            { const OvGrid og = ogb; return launch(ctx, name_bnd, [=] { FS_K34_ANY(); }); }
-        }
-    }
-    // (the carrying pass visits every tile.  The per-wave plain hint of fs_rbsor_pair was tried here too: 78.8-79.2 against 77.4-78.8 us at bc2 res 1600 -
-    //  the kernel then holds four tile bodies instead of two)
-    const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, !full);
-    return launch(ctx, name, [=] { if (N == 2 && RT == 1) FS_DMX(dm, FS_K34_21); else FS_K34_ANY(); });
-}
-
 extern "C" {
 
 int fs_abi_version(void) { return FS_ABI_VERSION; }
@@ -760,17 +570,12 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6) c->rbpair_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8) c->rbpair_plain_rt = v; }
     if (const char *s = getenv("FS_SPLIT_WGW")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->split_wgw = v; }
-    if (const char *s = getenv("FS_RBMARCH")) c->use_rbmarch = atoi(s);
-    if (const char *s = getenv("FS_RBM_L")) { const int v = atoi(s); if (v >= 14 && v <= 254 && (v + 10) % 12 == 0) c->rbm_L = v; }
-    if (const char *s = getenv("FS_JM_L")) { const int v = atoi(s); if (v >= 2 && v <= 254 && v % 2 == 0) c->jm_L = v; }
-    if (const char *s = getenv("FS_JM_PF")) { const int v = atoi(s); if (v == 1 || v == 3) c->jm_pf = v; }
-    if (const char *s = getenv("FS_RBM_PF")) { const int v = atoi(s); if (v == 1 || v == 3) c->rbm_pf = v; }
     if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : (atoi(s) == 4 ? 4 : (atoi(s) == 1 ? 1 : 0));
     if (const char *s = getenv("FS_MAC_RT")) { const int v = atoi(s); c->mac_rt = v == 2 || v == 4 ? v : 0; }
     if (const char *s = getenv("FS_K34_N")) c->k34_n = atoi(s) == 4 ? 4 : (atoi(s) == 2 ? 2 : 0);
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
-    c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI | XCD_MARCH;
+    c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
     if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);
     c->stack_mask = XCD_RBSOR | XCD_ADVECT | XCD_GRAD;      // measured per family: K4 313 -> 301 us, K3 246 -> 243, RB-SOR 129 -> 127.5; the others lose 1 %
     if (const char *s = getenv("FS_STACK")) c->stack_mask = atoi(s);
@@ -810,8 +615,6 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_sync) hipFree(ctx->d_sync);
     if (ctx->d_bcmap) hipFree(ctx->d_bcmap);
     if (ctx->d_lazyflags) hipFree(ctx->d_lazyflags);
-    if (ctx->d_rbcode) hipFree(ctx->d_rbcode);
-    if (ctx->d_jcode) hipFree(ctx->d_jcode);
     if (ctx->d_pairlist) hipFree(ctx->d_pairlist);
     if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -896,19 +699,6 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     FS_HIP(hipMemsetAsync(ctx->d_bcmap, 0, (size_t)ctx->rows * ctx->Pm, ctx->stream));
     FS_HIP(hipMemsetAsync(ctx->d_lazyflags, 63, (size_t)std::max(ctx->nwx, 1) * ctx->rows, ctx->stream));
     rc = upload_global(ctx, ctx->d_bcmap, 1, 1, ctx->h_bcmap.data(), ctx->Pm);
-    if (rc == FS_OK) {       // the marching red-black pass reads ONE byte per cell: recipe bits 0-6 + "not fluid" (rows outside the domain: wall)
-        if (!ctx->d_rbcode) FS_HIP(hipMalloc(&ctx->d_rbcode, (size_t)ctx->rows * ctx->Pm));
-        FS_HIP(hipMemsetAsync(ctx->d_rbcode, 0x80, (size_t)ctx->rows * ctx->Pm, ctx->stream));
-        std::vector<uint8_t> rb((size_t)ctx->X * ctx->Y);
-        for (size_t q = 0; q < rb.size(); ++q) rb[q] = (uint8_t)((ctx->h_bcmap[q] & 0x7f) | (mask_xy[q] != 0 ? 0x80 : 0));
-        rc = upload_global(ctx, ctx->d_rbcode, 1, 1, rb.data(), ctx->Pm);
-        if (rc == FS_OK) {   // ... and the marching Jacobi passes recipe bits + "wall" (the sweep computes every cell that is not a wall)
-            if (!ctx->d_jcode) FS_HIP(hipMalloc(&ctx->d_jcode, (size_t)ctx->rows * ctx->Pm));
-            FS_HIP(hipMemsetAsync(ctx->d_jcode, 0x80, (size_t)ctx->rows * ctx->Pm, ctx->stream));
-            for (size_t q = 0; q < rb.size(); ++q) rb[q] = (uint8_t)((ctx->h_bcmap[q] & 0x7f) | (mask_xy[q] == 1 ? 0x80 : 0));
-            rc = upload_global(ctx, ctx->d_jcode, 1, 1, rb.data(), ctx->Pm);
-        }
-    }
     // activity of the scene per (wave column, row) for the compact launches: a cell is "deep wall" when it is a wall cell that no
     // boundary kernel writes - workgroups made of such cells only have nothing to do in any kernel
     // captured graphs and recorded tapes hold the device pointers of the lists (and the launch geometry of the old scene): a new mask
@@ -1231,430 +1021,6 @@ int fs_dye_bc_limit(fs_ctx *ctx, double limit, fs_field *v, fs_field *dye, int l
     })
 }
 
-// ---- transport -----------------------------------------------------------------------------------------
-#define FS_LAUNCH_CELLS(name, kern, ...)                                                                   \
-    return launch(ctx, name, [=] {                                                                         \
-        hipLaunchKernelGGL(kern, cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, __VA_ARGS__); \
-    });
-
-int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_field *vn, const fs_field *vc,
-                  const fs_field *pc, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_REQUIRE(scheme == FS_UPWIND || scheme == FS_KK, "unknown advection scheme");
-    FS_FIELD(vn, 2); FS_FIELD(vc, 2); FS_FIELD(pc, 1);
-    FS_REQUIRE(vn != vc, "vn must not alias vc");
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, re);
-        if (ctx->use_pairs) {
-            // lanes of 2 cells (fs_k34n.h k_mac_update_n), tiles of 4 rows on large f32 grids (KK at bc3 res 4096: 178 -> 162 us against the one-row quad
-            // form it replaces; f64: 424 -> 306 with 2-row tiles), 2 rows on small grids (more workgroups) and for f64 (registers)
-            const int rt = ctx->mac_rt ? ctx->mac_rt : (sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2);
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_NONADV, 3);
-            return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
-#define FS_K2MN(SS, RR, PP) hipLaunchKernelGGL((k_mac_update_n<SS, 2, RR, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-            (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot)
-#define FS_K2MN_UP4(DM) FS_K2MN(0, 4, DM)
-#define FS_K2MN_KK4(DM) FS_K2MN(1, 4, DM)
-#define FS_K2MN_UP2(DM) FS_K2MN(0, 2, DM)
-#define FS_K2MN_KK2(DM) FS_K2MN(1, 2, DM)
-                if (rt == 2) { if (scheme == FS_UPWIND) FS_DMA(dm_all(ctx, k), FS_K2MN_UP2); else FS_DMA(dm_all(ctx, k), FS_K2MN_KK2); }
-                else { if (scheme == FS_UPWIND) FS_DMA(dm_all(ctx, k), FS_K2MN_UP4); else FS_DMA(dm_all(ctx, k), FS_K2MN_KK4); }
-            });
-        }
-        if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_update_upwind", (k_mac_update<0, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot) }
-        else { FS_LAUNCH_CELLS("mac_update_kk", (k_mac_update<1, T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot) }
-    })
-}
-
-int fs_mac_dye(fs_ctx *ctx, int scheme, double dt, double dx, fs_field *dn, const fs_field *dc, const fs_field *vc,
-               int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_REQUIRE(scheme == FS_UPWIND || scheme == FS_KK, "unknown advection scheme");
-    FS_FIELD(dn, 3); FS_FIELD(dc, 3); FS_FIELD(vc, 2);
-    FS_REQUIRE(dn != dc, "dn must not alias dc");
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        if (scheme == FS_UPWIND) { FS_LAUNCH_CELLS("mac_dye_upwind", (k_mac_dye<0, T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d, (const T *)vc->d) }
-        else { FS_LAUNCH_CELLS("mac_dye_kk", (k_mac_dye<1, T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d, (const T *)vc->d) }
-    })
-}
-
-int fs_cip_set_grad(fs_ctx *ctx, double dx, fs_field *fx, fs_field *fy, const fs_field *f, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx && f, "null argument");
-    const int C = f->C;
-    FS_REQUIRE(C == 2 || C == 3, "set_grad needs a 2- or 3-channel field");
-    FS_FIELD(fx, C); FS_FIELD(fy, C); FS_FIELD(f, C);
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, 1.0, dx, 1.0);
-        if (C == 2) { FS_LAUNCH_CELLS("cip_set_grad", (k_cip_set_grad<2, T>), ctx->grid(), k, row_begin, (T *)fx->d, (T *)fy->d, (const T *)f->d) }
-        else { FS_LAUNCH_CELLS("cip_set_grad_c3", (k_cip_set_grad<3, T>), ctx->grid(), k, row_begin, (T *)fx->d, (T *)fy->d, (const T *)f->d) }
-    })
-}
-
-int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, const fs_field *fc, const fs_field *pc,
-                  int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(fn, 2); FS_FIELD(fc, 2); FS_FIELD(pc, 1);
-    FS_REQUIRE(fn != fc, "fn must not alias fc");
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, re);
-        if (ctx->use_pairs) {
-            // lanes of 2 cells, tiles of 4 rows (fs_k34n.h k_cip_nonadv_n), compact launch: 116 -> 102 us at bc5 res 4096 against the one-row quad form
-            // it replaces (2 rows: 112, 8 rows: 106-110)
-            // (small grids - fewer waves than SIMDs, a launch takes as long as one wave's chain: 2-row tiles, fs_ctx::small_tiles)
-            const bool small = small_tiles(ctx);
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3);
-            const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
-            return launch(ctx, "cip_nonadv", [=] {
-#define FS_K2N4(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
-#define FS_K2N2(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
-                if (small) FS_DMA(dm_all(ctx, k), FS_K2N2); else FS_DMA(dm_all(ctx, k), FS_K2N4);
-            });
-        }
-        if (k.p2) { FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<true, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot) }
-        FS_LAUNCH_CELLS("cip_nonadv", (k_cip_nonadv<false, T>), ctx->grid(), k, row_begin, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot)
-    })
-}
-
-int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn, const fs_field *dc, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(dn, 3); FS_FIELD(dc, 3);
-    FS_REQUIRE(dn != dc, "dn must not alias dc");
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, re);
-        if (ctx->use_pairs) {
-            // lanes of 2 cells, 4-row tiles (fs_k34n.h k_cip_nonadv_dye_n), compact launch: 141 -> 122-130 us at bc5 res 4096 against the one-row quad form
-            const bool small = small_tiles(ctx);       // (2-row tiles, see fs_cip_nonadv)
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3);
-            return launch(ctx, "cip_nonadv_dye", [=] {
-#define FS_K12N(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
-#define FS_K12N2(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
-                if (small) FS_DMA(dm_all(ctx, k), FS_K12N2); else FS_DMA(dm_all(ctx, k), FS_K12N);
-            });
-        }
-        FS_LAUNCH_CELLS("cip_nonadv_dye", (k_cip_nonadv_dye<T>), ctx->grid(), k, row_begin, (T *)dn->d, (const T *)dc->d)
-    })
-}
-
-#define FS_K3Q(CC, NC, PP) hipLaunchKernelGGL((k_cip_nonadv_grad_quad<CC, NC, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-            (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d)
-#define FS_K3(CC, PP, NAME) { FS_LAUNCH_CELLS(NAME, (k_cip_nonadv_grad<CC, PP, T>), ctx->grid(), k, row_begin, (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d) }
-int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, const fs_field *fxc, const fs_field *fyc,
-                       const fs_field *fc, const fs_field *fn, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx && fc, "null argument");
-    const int C = fc->C;
-    FS_REQUIRE(C == 2 || C == 3, "nonadv_grad needs 2- or 3-channel fields");
-    FS_FIELD(fxn, C); FS_FIELD(fyn, C); FS_FIELD(fxc, C); FS_FIELD(fyc, C); FS_FIELD(fc, C); FS_FIELD(fn, C);
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, 1.0, dx, 1.0);
-        if (ctx->use_march) {
-            const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, C == 2 ? 1 : 3, XCD_GRAD);
-            return launch(ctx, C == 2 ? "cip_nonadv_grad" : "cip_nonadv_grad_c3", [=] {
-#define FS_K3Q_V(DM) FS_K3Q(2, 2, DM)
-#define FS_K3Q_D(DM) FS_K3Q(3, 1, DM)
-                if (C == 2) FS_DMX(dm_dx(ctx, k), FS_K3Q_V); else FS_DMX(dm_dx(ctx, k), FS_K3Q_D);
-            });
-        }
-        if (C == 2 && k.p2) FS_K3(2, true, "cip_nonadv_grad")
-        else if (C == 2) FS_K3(2, false, "cip_nonadv_grad")
-        else if (k.p2) FS_K3(3, true, "cip_nonadv_grad_c3")
-        else FS_K3(3, false, "cip_nonadv_grad_c3")
-    })
-}
-
-#define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, false, T>), qgrid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-#define FS_K4D(PP) hipLaunchKernelGGL((k_cip_advect_dye<PP, false, T>), qgrid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-#define FS_K4N(CC, PP) hipLaunchKernelGGL((k_cip_advect<CC, PP, T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, \
-        (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
-                  const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx && fc, "null argument");
-    const int C = fc->C;
-    FS_REQUIRE(C == 2 || C == 3, "cip_advect needs 2- or 3-channel fields");
-    FS_FIELD(fn, C); FS_FIELD(fxn, C); FS_FIELD(fyn, C); FS_FIELD(fc, C); FS_FIELD(fxc, C); FS_FIELD(fyc, C); FS_FIELD(v, 2);
-    FS_REQUIRE(fn != fc && fxn != fxc && fyn != fyc, "outputs must not alias inputs");
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        const bool self = (v == fc);
-        const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, (C == 2 && !self) ? 2 : 1, XCD_ADVECT);   // C == 3: one pass over the channels
-        const dim3 qgrid = og.grid;
-        return launch(ctx, C == 2 ? "cip_advect" : "cip_advect_c3", [=] {
-            if (ctx->use_march) {
-#define FS_K4Q_SELF(DM) FS_K4Q(2, 2, true, DM)
-#define FS_K4Q_OTHER(DM) FS_K4Q(2, 1, false, DM)
-                if (C == 2 && self) FS_DMX(dm_dx(ctx, k), FS_K4Q_SELF);
-                else if (C == 2) FS_DMX(dm_dx(ctx, k), FS_K4Q_OTHER);
-                else FS_DMX(dm_dx(ctx, k), FS_K4D);
-            } else {
-                if (C == 2) { if (k.p2) FS_K4N(2, true); else FS_K4N(2, false); }
-                else { if (k.p2) FS_K4N(3, true); else FS_K4N(3, false); }
-            }
-        });
-    })
-}
-
-int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
-                              const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(fn, 3); FS_FIELD(fxn, 3); FS_FIELD(fyn, 3); FS_FIELD(fc, 3); FS_FIELD(fxc, 3); FS_FIELD(fyc, 3); FS_FIELD(v, 2);
-    FS_REQUIRE(fn != fc && fxn != fxc && fyn != fyc, "outputs must not alias inputs");
-    FS_REQUIRE(ctx->use_march, "needs X % 4 == 0 (use fs_cip_advect + fs_clamp_field)");
-    FS_ROWS();
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_ADVECT);
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        return launch(ctx, "cip_advect_c3_clamped", [=] {
-#define FS_K4DC(DM) hipLaunchKernelGGL((k_cip_advect_dye<DM, true, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-                                         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-            FS_DMX(dm_dx(ctx, k), FS_K4DC);
-        });
-    })
-}
-
-int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(dye, 3);
-    FS_ROWS();
-    if (!ctx->d_bc_dye) { set_error("bc_dye not uploaded"); return FS_ERR_STATE; }
-    if (ctx->ops_dye.lanes() == 0) return FS_OK;
-    FS_DISPATCH(ctx, {
-        return launch(ctx, "clamp_inflow", [=] {
-            hipLaunchKernelGGL(k_clamp_inflow<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
-                               ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T)low, (T)high, (T *)dye->d);
-        });
-    })
-}
-
-int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
-                       const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(v_out, 2); FS_FIELD(gx_out, 2); FS_FIELD(gy_out, 2); FS_FIELD(fn, 2); FS_FIELD(fc, 2); FS_FIELD(gxc, 2); FS_FIELD(gyc, 2);
-    FS_REQUIRE(v_out != fn && v_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
-    FS_REQUIRE(ctx->use_pairs, "the fused gradient+advection pass needs an even X (use the two-kernel form)");
-    FS_ROWS();
-    if (ctx->dtype != 0) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
-    return launch_k34<2, false>(ctx, "cip_grad_advect_rt", "cip_grad_advect_rt_bnd", dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, nullptr, full, row_begin, row_end);
-}
-
-// the dye: d_out <- advect(fn with the gradients K3 derives from fc -> fn) by v
-int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, fs_field *gx_out, fs_field *gy_out,
-                           const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v,
-                           int clamp01, int full, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(d_out, 3); FS_FIELD(gx_out, 3); FS_FIELD(gy_out, 3); FS_FIELD(fn, 3); FS_FIELD(fc, 3); FS_FIELD(gxc, 3); FS_FIELD(gyc, 3); FS_FIELD(v, 2);
-    FS_REQUIRE(d_out != fn && d_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
-    FS_REQUIRE(ctx->use_pairs, "the fused gradient+advection pass needs an even X (use the two-kernel form)");
-    FS_ROWS();
-    if (row_begin >= row_end) return FS_OK;
-    if (ctx->dtype != 0) { set_error("the fused dye pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
-    if (clamp01) return launch_k34<3, true>(ctx, "cip_grad_advect_dye", "cip_grad_advect_dye_bnd", dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, full, row_begin, row_end);
-    return launch_k34<3, false>(ctx, "cip_grad_advect_dye", "cip_grad_advect_dye_bnd", dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, full, row_begin, row_end);
-}
-
-// ---- vorticity confinement -------------------------------------------------------------------------------
-int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, const fs_field *vc, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1); FS_FIELD(vc, 2);
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, 1.0, dx, 1.0);
-        FS_LAUNCH_CELLS("vort_calc", (k_vort_calc<T>), ctx->grid(), k, row_begin, (T *)vort->d, (T *)vort_abs->d, (const T *)vc->d)
-    })
-}
-
-int fs_vort_add(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, const fs_field *vc, const fs_field *vort,
-                const fs_field *vort_abs, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(vn, 2); FS_FIELD(vc, 2); FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1);
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
-        FS_LAUNCH_CELLS("vort_add", (k_vort_add<T>), ctx->grid(), k, row_begin, (T *)vn->d, (const T *)vc->d, (const T *)vort->d, (const T *)vort_abs->d, vn->hot)
-    })
-}
-
-int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *vn, const fs_field *vc, fs_field *vort,
-                    fs_field *vort_abs, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(vn, 2); FS_FIELD(vc, 2);
-    FS_REQUIRE(vn != vc, "vn must not alias vc");
-    FS_REQUIRE((vort == nullptr) == (vort_abs == nullptr), "pass both vort and vort_abs or neither");
-    if (vort) { FS_FIELD(vort, 1); FS_FIELD(vort_abs, 1); }
-    FS_ROWS();
-    if (!ctx->use_pairs) {   // odd width: the unfused pair
-        if (!vort) { set_error("fused vorticity confinement needs an even X or explicit vort fields"); return FS_ERR_UNSUPPORTED; }
-        int rc = fs_vort_calc(ctx, dx, vort, vort_abs, vc, std::max(row_begin - 1, 0), std::min(row_end + 1, ctx->rows));
-        if (rc) return rc;
-        return fs_vort_add(ctx, dt, dx, weight, vn, vc, vort, vort_abs, row_begin, row_end);
-    }
-    // lanes of 2 cells (fs_k34n.h k_vort_n), 4-row tiles, compact launch: 100 -> 95 us at bc5 res 4096 against the quad form it replaces (6 / 8 rows:
-    // 102 / 103; f64 at bc3 res 4096: 251 -> 224)
-    const bool small = small_tiles(ctx) && !vort;      // (small grids: 2-row tiles, see fs_cip_nonadv)
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_VORT, 3);
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
-        const int dm = dm_dx(ctx, k);
-        T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
-        const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
-#define FS_VORTN(DM, ST) hipLaunchKernelGGL((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
-#define FS_VORTN_S(DM) FS_VORTN(DM, true)
-#define FS_VORTN_N(DM) FS_VORTN(DM, false)
-#define FS_VORTN_2(DM) hipLaunchKernelGGL((k_vort_n<2, 2, DM, false, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
-        return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORTN_S); else if (small) FS_DMX(dm, FS_VORTN_2); else FS_DMX(dm, FS_VORTN_N); });
-    })
-}
-
-// ---- pressure ------------------------------------------------------------------------------------------------
-int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_field *pc, const fs_field *vc, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(vc, 2);
-    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        if (ctx->use_march) return launch_jacobi<false, T>(ctx, "jacobi_sweep", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
-        FS_LAUNCH_CELLS("jacobi_sweep", (k_jacobi<false, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
-    })
-}
-
-int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
-    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, 1.0, 1.0, 1.0);
-        if (ctx->use_march) return launch_jacobi<true, T>(ctx, "jacobi_sweep_src", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
-        FS_LAUNCH_CELLS("jacobi_sweep_src", (k_jacobi<true, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
-    })
-}
-
-int fs_lazy_bc_ok(const fs_ctx *ctx, int *ok)
-{
-    FS_REQUIRE(ctx && ok, "null argument");
-    *ok = ctx->mask_set && ctx->lazy_ok && ctx->use_march && ctx->use_lazy ? 1 : 0;
-    return FS_OK;
-}
-
-// diagnostic: the per wave-tile-row flags of the lazy / two-sweep kernels (fs_march.h k_lazy_flags, k_pair_list), [wave column][local row]
-int fs_lazy_flags(fs_ctx *ctx, uint8_t *out, int capacity, int *wave_columns, int *rows, int *general_rows)
-{
-    FS_REQUIRE(ctx && wave_columns && rows && general_rows, "null argument");
-    FS_REQUIRE(ctx->mask_set && ctx->d_lazyflags, "no mask uploaded");
-    *wave_columns = ctx->nwx; *rows = ctx->rows; general_rows[0] = ctx->n_pairlist[0]; general_rows[1] = ctx->n_pairlist[1];
-    if (out) {
-        FS_REQUIRE(capacity >= ctx->nwx * ctx->rows, "buffer too small");
-        FS_HIP(hipMemcpyAsync(out, ctx->d_lazyflags, (size_t)ctx->nwx * ctx->rows, hipMemcpyDeviceToHost, ctx->stream));
-        FS_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    return FS_OK;
-}
-
-int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
-    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
-    FS_ROWS();
-    if (!(ctx->lazy_ok && ctx->use_march)) { set_error("this mask does not admit the lazy pressure boundary condition (fs_lazy_bc_ok)"); return FS_ERR_UNSUPPORTED; }
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_JACOBI);
-    FS_DISPATCH(ctx, {
-        return launch(ctx, "jacobi_sweep_lazy", [=] {
-            hipLaunchKernelGGL((k_jacobi_lazy<T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
-                               (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
-        });
-    })
-}
-
-// two lazily-bounded sweeps in one pass (fs_march.h k_jacobi_pair): pn <- sweep(sweep(pc)); pn's wall cells are read (the intermediate
-// buffer of the two-buffer rotation is pn itself)
-int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int mode, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
-    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
-    FS_REQUIRE(mode >= 0 && mode <= 3, "mode: bit 0 = swapped buffers, bit 1 = vertical recipes in the tile path");
-    FS_ROWS();
-    if (!(ctx->lazy_ok && ctx->use_march)) { set_error("this mask does not admit the lazy pressure boundary condition (fs_lazy_bc_ok)"); return FS_ERR_UNSUPPORTED; }
-    const int rt = (mode & 2) ? std::min(ctx->pair_rt, 2) : ctx->pair_rt;      // (the third tile path at 3 rows: 97 VGPRs, one wave per SIMD less)
-    const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_JACOBI, false);      // (dense: its general rows ride in leading z slices)
-    FS_DISPATCH(ctx, {
-        return launch(ctx, "jacobi_pair_lazy", [=] {
-            switch (mode) {
-            case 0: launch_pair<false, false, T>(ctx, og, rt, row_begin, row_end, pn, pc, src); break;
-            case 1: launch_pair<true, false, T>(ctx, og, rt, row_begin, row_end, pn, pc, src); break;
-            case 2: launch_pair<false, true, T>(ctx, og, rt, row_begin, row_end, pn, pc, src); break;
-            default: launch_pair<true, true, T>(ctx, og, rt, row_begin, row_end, pn, pc, src); break;
-            }
-        });
-    })
-}
-
-static inline dim3 rb_grid(const fs_ctx *c, int jb, int je) { return dim3(((c->X + 1) / 2 + 255) / 256, je - jb, 1); }
-
-int fs_rbsor_halfsweep(fs_ctx *ctx, double dt, double dx, double omega, int parity, fs_field *pn, const fs_field *pc,
-                       const fs_field *vc, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_REQUIRE(parity == 0 || parity == 1, "parity must be 0 or 1");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(vc, 2);
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-        return launch(ctx, parity ? "rbsor_odd" : "rbsor_even", [=] {
-            hipLaunchKernelGGL((k_rbsor<false, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
-                               row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
-        });
-    })
-}
-
-int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pn, const fs_field *pc, const fs_field *vc,
-                       int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(vc, 2);
-    FS_REQUIRE(pn != pc, "the fused iteration needs distinct p.next / p.current");
-    FS_ROWS();
-    if (!ctx->use_pairs) {
-        int rc = fs_rbsor_halfsweep(ctx, dt, dx, omega, 1, pn, pc, vc, std::max(row_begin - 1, 0), std::min(row_end + 1, ctx->rows));
-        if (rc) return rc;
-        return fs_rbsor_halfsweep(ctx, dt, dx, omega, 0, pn, pn, vc, row_begin, row_end);
-    }
-    // lanes of 2 cells, 4-row tiles (fs_k34n.h k_rbsor_iter_n): 119 -> 115 us at bc5 res 4096 against the 3-row quad tiles it replaces, f64 (bc3 res
-    // 4096) 318 -> 289; 2 / 6 rows: 129 / 115
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 3, false);
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-#define FS_RBN4(DM) hipLaunchKernelGGL((k_rbsor_iter_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-                               (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
-        return launch(ctx, "rbsor_iteration", [=] { FS_DMC(dm_const(ctx, k), FS_RBN4); });
-    })
-}
 
 // diagnostic: how many of ~2^28 dividends (see k_verify_f64div) does the f64-multiply division of f32 values get wrong for this divisor?
 int fs_selftest_f64div(fs_ctx *ctx, double divisor, int *mismatches)
@@ -1859,245 +1225,6 @@ int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps,
     if (b) hipFree(b);
     if (sink) hipFree(sink);
     if (e != hipSuccess) return hip_fail(e, "fs_box_rates", __FILE__, __LINE__);
-    return FS_OK;
-}
-
-// four lazily-bounded Jacobi sweeps in one pass (fs_jquad.h): pn[not wall] <- sweep^4(pc); both buffers hold raw sweep output
-int fs_jacobi_quad_ok(const fs_ctx *ctx, int *ok)
-{
-    FS_REQUIRE(ctx && ok, "null argument");
-    *ok = ctx->mask_set && ctx->jq_ok && ctx->use_march && ctx->use_lazy && ctx->dtype == 0 ? 1 : 0;
-    return FS_OK;
-}
-
-int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
-    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
-    FS_ROWS();
-    if (!(ctx->jq_ok && ctx->use_march && ctx->dtype == 0)) { set_error("this mask / precision does not admit the four-sweep Jacobi pass (fs_jacobi_quad_ok)"); return FS_ERR_UNSUPPORTED; }
-    using T = float;
-    const Grid gg = ctx->grid();
-    // lanes of 2 cells (116 VGPRs = 4 waves per SIMD at 4 rows; quads: 182 = 2 waves, 44.9 against 34.3 us per pass at bc2 res 1600)
-    const int rt = ctx->jquad_rt;
-#define FS_JQ(RT, PATH) hipLaunchKernelGGL((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
-                               (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
-    // plain and boundary workgroups as two compact launches (as fs_rbsor_pair) - on large grids: a second launch costs ~5 us, which a
-    // cache-resident grid does not earn back (bc2 res 1600: 18.1 + 21.3 against 34.6 us; bc5 res 4096: 81.4 + 49.8 against 137.5)
-    if ((ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw);
-        if (og.g.tiles && ogb.g.tiles) {
-            int rc = launch(ctx, "jacobi_quad_lazy", [=] { FS_JQ(4, 3); });
-            if (rc) return rc;
-            { const OvGrid og = ogb; return launch(ctx, "jacobi_quad_lazy_bnd", [=] { FS_JQ(4, 2); }); }
-        }
-    }
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 0, 4);      // (per-wave plain hints in the list, as fs_rbsor_pair)
-    return launch(ctx, "jacobi_quad_lazy", [=] {
-        if (rt == 2) FS_JQ(2, 2); else if (rt == 6) FS_JQ(6, 2); else if (rt == 8) FS_JQ(8, 2); else FS_JQ(4, 2);
-    });
-}
-
-// `sweeps` (4, 6 or 8) lazily-bounded Jacobi sweeps in one row-marching pass (fs_jmarch.h): pn[not wall] <- sweep^S(pc); the conditions of
-// the four-sweep pass (fs_jacobi_quad_ok).  Strip height: 12 m - 2 S rows (the 12-step loop body then runs whole), the tallest that still
-// gives every SIMD of the chip a few waves (FS_JM_L overrides).
-int fs_jacobi_march(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int sweeps, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
-    FS_REQUIRE(pn != pc, "Jacobi needs two distinct pressure fields");
-    FS_REQUIRE(sweeps == 4 || sweeps == 6 || sweeps == 8, "sweeps per pass: 4, 6 or 8");
-    FS_ROWS();
-    if (!(ctx->jq_ok && ctx->use_pairs && ctx->dtype == 0)) { set_error("this mask / precision does not admit the multi-sweep Jacobi passes (fs_jacobi_quad_ok)"); return FS_ERR_UNSUPPORTED; }
-    using T = float;
-    int L = ctx->jm_L;
-    if (L <= 0) {
-        const int ow = 64 - sweeps, cols = (ctx->X / 2 + ow - 1) / ow, rows = row_end - row_begin;
-        L = 12 - 2 * sweeps > 0 ? 12 - 2 * sweeps : 24 - 2 * sweeps;
-        while (L + 12 <= 254 && (long long)cols * (rows / (L + 12)) >= 2048) L += 12;       // at least ~2 waves per SIMD
-    }
-    const int pf = ctx->jm_pf;
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, L, 1, XCD_MARCH, sweeps == 4 ? 2 : (sweeps == 6 ? 5 : 6), true, 0);
-    const JmArgs a{(const uint8_t *)ctx->d_jcode, pn->d, pc->d, src->d};
-#define FS_JM_K(S, PF) hipLaunchKernelGGL((k_jacobi_march<2, S, PF, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, L, a)
-    return launch(ctx, "jacobi_march", [=] {
-        if (sweeps == 4) { if (pf == 3) FS_JM_K(4, 3); else FS_JM_K(4, 1); }
-        else if (sweeps == 6) { if (pf == 3) FS_JM_K(6, 3); else FS_JM_K(6, 1); }
-        else FS_JM_K(8, 1);            // (8 sweeps: the code-word ring of 12 rows holds S + 2 + PF = 11)
-    });
-}
-
-// the last two rounds of a lazily-bounded Jacobi run in one pass (fs_jquad.h k_jacobi_finish): from pc = raw iterate n-2,
-//   pc_out <- iterate n (not-wall cells) + K7(iterate n-2) (wall cells with a recipe);  pn <- iterate n-1 as K7 leaves it
-int fs_jacobi_finish(fs_ctx *ctx, fs_field *pc_out, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pc_out, 1); FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
-    FS_REQUIRE(pc_out != pc && pc_out != pn && pn != pc, "the finishing pass needs three distinct pressure fields");
-    FS_ROWS();
-    if (!(ctx->jq_ok && ctx->use_march && ctx->dtype == 0)) { set_error("this mask / precision does not admit the multi-sweep Jacobi passes (fs_jacobi_quad_ok)"); return FS_ERR_UNSUPPORTED; }
-    using T = float;
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2, true, 0, 2);      // (per-wave plain hints: two sweeps reach 2 rows)
-    return launch(ctx, "jacobi_finish", [=] {
-        hipLaunchKernelGGL((k_jacobi_finish<2, 4, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
-                           (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
-    });
-}
-
-int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok)
-{
-    FS_REQUIRE(ctx && ok, "null argument");
-    *ok = ctx->mask_set && ctx->rb_pair_ok && ctx->use_pairs && ctx->use_lazy ? 1 : 0;      // (f32 and, since round 4, f64)
-    return FS_OK;
-}
-
-// two red-black iterations + both pressure boundary passes in one pass (fs_rbpair.h): (pc_out, pn_out) <- the state two iterations of
-// fs/pressure_updater.py:86-96 leave in (p.current, p.next) when they start from (pc, pn)
-int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_out, fs_field *pn_out, const fs_field *pc, const fs_field *pn,
-                  const fs_field *vc, int full, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(pc_out, 1); FS_FIELD(pn_out, 1); FS_FIELD(pc, 1); FS_FIELD(pn, 1); FS_FIELD(vc, 2);
-    FS_REQUIRE(pc_out != pn_out && pc_out != pc && pc_out != pn && pn_out != pc && pn_out != pn && pc != pn, "the two-iteration pass needs four distinct pressure fields");
-    FS_ROWS();
-    if (!(ctx->rb_pair_ok && ctx->use_pairs)) {
-        set_error("this mask does not admit the two-iteration red-black pass (fs_rbsor_pair_ok)");
-        return FS_ERR_UNSUPPORTED;
-    }
-    const Grid gg = ctx->grid();
-    const int par0 = (gg.ybase + row_begin) & 1;
-    if (ctx->dtype == 1) {
-        // f64 (round 4; BASELINE configs[4]'s truth leg): the same body on double2 lanes.  A lane's window costs twice the registers, so the
-        // tiles are 2 rows high (230 VGPRs with both paths = 2 waves per SIMD; the plain part on 4-row tiles: 220) - against 2 x (K7 + single
-        // iteration) at 137 VGPRs that is still one pass over p and v instead of two.
-        using T = double;
-        auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-#define FS_RBPD_K(RT, PAR, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, 0, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-                               (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
-#define FS_RBPD(RT, PATH, FULL) do { if (par0) FS_RBPD_K(RT, 1, PATH, FULL); else FS_RBPD_K(RT, 0, PATH, FULL); } while (0)
-        if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && ctx->split_wgw == 1) {
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2, true, 1, 4, 1);
-            const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_RBSOR, 2, true, 2, 4, 1, 4);
-            if (og.g.tiles && ogb.g.tiles) {
-                int rc = launch(ctx, "rbsor_pair", [=] { FS_RBPD(4, 3, false); });
-                if (rc) return rc;
-                { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBPD(2, 2, false); }); }
-            }
-        }
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_RBSOR, 2, !full, 0, 4);
-        return launch(ctx, "rbsor_pair", [=] { if (full) FS_RBPD(2, 2, true); else FS_RBPD(2, 2, false); });
-    }
-    using T = float;
-    auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-    const int dm = dm_const(ctx, k);
-    // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 (FS_RBPAIR_RT=6: 6) rows per tile.  The carrying
-    // pass after an upload (full) is rare: one configuration.
-    // (grids below 1 M cells: 2-row tiles - fewer waves than SIMDs there, the pass takes as long as ONE wave's chain of loads and stages:
-    //  res 200 12.1 -> 9.2 us per launch, BASELINE configs[0] 53.3 -> 62.8 k steps/s; res 1600: 4 rows, 5602 against 5435 steps/s)
-    const int rt = full ? 4 : (ctx->rbpair_rt ? ctx->rbpair_rt : (small_tiles(ctx) ? 2 : 4));
-    if (!full && ctx->use_rbmarch) {
-        // the row-marching form (fs_rbmarch.h): strips of L rows, one wave column each, plain and boundary rows in one kernel; the compact
-        // list leaves out the strips of nothing but deep wall
-        const int L = ctx->rbm_L, pf = ctx->rbm_pf;
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, L, 1, XCD_MARCH, 2, true, 0);
-        const RbmArgs a{(const uint8_t *)ctx->d_rbcode, pc_out->d, pn_out->d, pc->d, pn->d, vc->d};
-#define FS_RBM_K(PF, PAR, DM) hipLaunchKernelGGL((k_rbsor_march<2, PF, PAR, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, L, a)
-#define FS_RBM_PAR(PF, DM) do { if (par0) FS_RBM_K(PF, 1, DM); else FS_RBM_K(PF, 0, DM); } while (0)
-#define FS_RBM_DM(PF) do { if (dm & DM_F64) FS_RBM_PAR(PF, 4); else FS_RBM_PAR(PF, 0); } while (0)
-        return launch(ctx, "rbsor_pair", [=] { if (pf == 1) FS_RBM_DM(1); else FS_RBM_DM(3); });
-    }
-#define FS_RBP_K(RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-                               (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
-#define FS_RBP_PAR(RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, PATH, FULL); else FS_RBP_K(RT, 0, DM, PATH, FULL); } while (0)
-#define FS_RBP_DM(RT, PATH) do { if (dm & DM_F64) FS_RBP_PAR(RT, 4, PATH, false); else FS_RBP_PAR(RT, 0, PATH, false); } while (0)
-    // Compact launch in two parts where the lists exist (single GPU, whole grid): the workgroups that see nothing but fluid within reach run
-    // the plain path as its own kernel (PATH 3: no mask loads, 126 VGPRs = 4 waves per SIMD), the others the kernel with both paths.
-    if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
-        // the plain part on tiles of 8 rows (round 4: 125 VGPRs, still 4 waves per SIMD, since the DPP shifts lost their init moves - 2 rows
-        // of window per output row instead of 3), the boundary part on tiles of 4 rows that lie in no plain 8-row tile; one wave per workgroup
-        const int prt = ctx->split_wgw == 1 && ctx->rbpair_plain_rt == 8 ? 8 : rt;
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw, prt);
-        if (og.g.tiles && ogb.g.tiles) {
-            int rc = launch(ctx, "rbsor_pair", [=] { if (prt == 8) FS_RBP_DM(8, 3); else FS_RBP_DM(4, 3); });      // (12-row tiles: 151 VGPRs = 3 waves, 188 against 177 us)
-            if (rc) return rc;
-            { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_DM(4, 2); }); }
-        }
-    }
-    // (one launch: the list's entries carry a per-wave "plain" hint - a wave that sees nothing but fluid within 4 rows skips its mask loads)
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, !full, 0, 4);
-    return launch(ctx, "rbsor_pair", [=] {
-        if (full) FS_RBP_PAR(4, 0, 2, true);
-        else if (rt == 6) FS_RBP_DM(6, 2);
-        else if (rt == 2) FS_RBP_DM(2, 2);
-        else FS_RBP_DM(4, 2);
-    });
-}
-
-int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, const fs_field *pc, const fs_field *src,
-                           int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_REQUIRE(parity == 0 || parity == 1, "parity must be 0 or 1");
-    FS_FIELD(pn, 1); FS_FIELD(pc, 1); FS_FIELD(src, 2);
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, 1.0, 1.0, 1.0, 0.0, omega);
-        return launch(ctx, parity ? "rbsor_odd_src" : "rbsor_even_src", [=] {
-            hipLaunchKernelGGL((k_rbsor<true, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
-                               row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
-        });
-    })
-}
-
-int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs_field *vc, int row_begin, int row_end)
-{
-    FS_REQUIRE(ctx, "ctx is null");
-    FS_FIELD(src, 2); FS_FIELD(vc, 2);
-    FS_REQUIRE(src != vc, "src must not alias vc");
-    FS_ROWS();
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        if (ctx->use_pairs && !getenv("FS_SRC_CELLS")) {
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_JACOBI, 3);      // (deep-wall workgroups skipped: nobody reads the source there)
-#define FS_PSN(DM) hipLaunchKernelGGL((k_poisson_source_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)src->d, (const T *)vc->d)
-            return launch(ctx, "poisson_source", [=] { FS_DMC(dm_const(ctx, k), FS_PSN); });
-        }
-        FS_LAUNCH_CELLS("poisson_source", (k_poisson_source<T>), ctx->grid(), k, row_begin, (T *)src->d, (const T *)vc->d)
-    })
-}
-
-int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, const fs_field *vc, double *sum_sq, double *count)
-{
-    FS_REQUIRE(ctx && sum_sq && count, "null argument");
-    FS_FIELD(p, 1); FS_FIELD(vc, 2);
-    FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "residual during graph capture / tape recording");
-    if (!ctx->mask_set) { set_error("mask not uploaded"); return FS_ERR_STATE; }
-    const int row_begin = ctx->halo, row_end = ctx->halo + ctx->nyl;
-    const dim3 grid((ctx->X + 255) / 256, (row_end - row_begin + RES_ROWS - 1) / RES_ROWS);
-    const size_t nblocks = (size_t)grid.x * grid.y;
-    if (nblocks > ctx->partial_cap) {
-        if (ctx->d_partial) { FS_HIP(hipStreamSynchronize(ctx->stream)); FS_HIP(hipFree(ctx->d_partial)); ctx->d_partial = nullptr; ctx->partial_cap = 0; }
-        FS_HIP(hipMalloc(&ctx->d_partial, nblocks * 2 * sizeof(double)));
-        ctx->partial_cap = nblocks;
-    }
-    int rc;
-    FS_DISPATCH(ctx, {
-        auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        rc = launch(ctx, "poisson_residual", [=] {
-            hipLaunchKernelGGL((k_residual<T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end,
-                               (const T *)p->d, (const T *)vc->d, ctx->d_partial);
-            hipLaunchKernelGGL((k_residual_final<double>), dim3(1), dim3(1024), 0, ctx->stream, (const double *)ctx->d_partial, (int)nblocks, ctx->d_acc);
-        });
-    })
-    if (rc) return rc;
-    double h[2];
-    FS_HIP(hipMemcpyAsync(h, ctx->d_acc, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(hipStreamSynchronize(ctx->stream));
-    *sum_sq = h[0];
-    *count = h[1];
     return FS_OK;
 }
 

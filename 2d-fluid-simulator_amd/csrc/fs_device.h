@@ -107,6 +107,30 @@ template <int DM, typename T>
 __device__ __forceinline__ T rdiv(T x, T d, double rd) { return (DM & DM_F64) ? f64div_guarded(x, d, rd) : x / d; }
 
 
+// ---- packed f32: the two cells of a lane as ONE operand --------------------------------------------------------------------
+// gfx950 issues v_pk_mul_f32 / v_pk_add_f32 (two IEEE f32 operations on an aligned register pair, each rounded like its scalar form) in
+// the slot of one scalar operation.  The tile kernels hold 2 consecutive x cells per lane and evaluate the same expression tree for
+// both: written on v2f the mul / add / sub chains pack; selects, DPP shifts and the f64-multiply divisions stay per half.  No
+// contraction (-ffp-contract=off), no reassociation: the bits are those of the scalar form (tests compare them at tolerance 0).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+template <typename V> struct VecOf;
+template <> struct VecOf<float> { using S = float; using D = double; };
+template <> struct VecOf<double> { using S = double; using D = double; };
+template <> struct VecOf<v2f> { using S = float; using D = v2d; };
+__device__ __forceinline__ double to_dbl(float x) { return (double)x; }
+__device__ __forceinline__ double to_dbl(double x) { return x; }
+__device__ __forceinline__ v2d to_dbl(v2f x) { return __builtin_convertvector(x, v2d); }
+// x < 0 ? a : b  per element (sign(0) = +1, fs/differentiation.py:12-14)
+__device__ __forceinline__ float sel_neg(float x, float a, float b) { return x < 0.0f ? a : b; }
+__device__ __forceinline__ double sel_neg(double x, double a, double b) { return x < 0.0 ? a : b; }
+__device__ __forceinline__ v2f sel_neg(v2f x, v2f a, v2f b) { v2f r; r.x = x.x < 0.0f ? a.x : b.x; r.y = x.y < 0.0f ? a.y : b.y; return r; }
+__device__ __forceinline__ v2f f64div(v2f x, v2d rd) { return __builtin_convertvector(__builtin_convertvector(x, v2d) * rd, v2f); }
+template <int DM> __device__ __forceinline__ v2f xdiv(v2f x, v2f d, v2f inv_d, v2d rd) { return (DM & DM_P2) ? x * inv_d : ((DM & DM_F64) ? f64div(x, rd) : x / d); }
+template <int DM> __device__ __forceinline__ v2f xdiv(v2f x, float d, float inv_d, double rd)
+{ return (DM & DM_P2) ? x * inv_d : ((DM & DM_F64) ? f64div(x, (v2d)rd) : x / d); }
+
 template <typename T> __device__ __forceinline__ T tmin(T a, T b);
 template <typename T> __device__ __forceinline__ T tmax(T a, T b);
 template <> __device__ __forceinline__ float tmin<float>(float a, float b) { return fminf(a, b); }

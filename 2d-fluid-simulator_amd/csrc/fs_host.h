@@ -15,8 +15,6 @@
 #include "fs_kernels.h"
 #include "fs_march.h"
 #include "fs_rbpair.h"
-#include "fs_rbmarch.h"
-#include "fs_jmarch.h"
 #include "fs_jquad.h"
 #include "fs_k34n.h"
 
@@ -71,11 +69,6 @@ struct fs_ctx {
     uint8_t *d_mask = nullptr;
     uint8_t *d_bcmap = nullptr;    // [rows][Pm] recipe byte of the pressure boundary condition per cell (fs_march.h k_jacobi_lazy)
     uint8_t *d_lazyflags = nullptr;   // [nwx][rows] tile needs the lazy evaluation
-    uint8_t *d_rbcode = nullptr;   // [rows][Pm] bits 0-6 of the recipe byte + bit 7 "mask != 0": the ONE byte plane of the marching red-black pass (fs_rbmarch.h)
-    uint8_t *d_jcode = nullptr;    // [rows][Pm] bits 0-6 of the recipe byte + bit 7 "wall" (mask == 1): the byte plane of the marching Jacobi passes (fs_jmarch.h)
-    int jm_L = 0, jm_pf = 1;       // env FS_JM_L (rows per strip; 0: by grid size), FS_JM_PF (1 / 3): strip height and prefetch distance of those passes
-    int use_rbmarch = 0;           // env FS_RBMARCH=1: the two-iteration red-black pass as a row-marching pipeline (fs_rbmarch.h) instead of register tiles (fs_rbpair.h)
-    int rbm_L = 38, rbm_pf = 3;    // env FS_RBM_L (12 m - 10: 14, 26, 38, 50, 62 ...), FS_RBM_PF (1 / 3): strip height and prefetch distance of the marching form
     std::vector<uint8_t> h_bcmap;  // host copy between build_bc_ops and the upload
     bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
     bool rb_pair_ok = false;                 // mask admits the two-iteration red-black pass (fs_rbpair.h; decided in build_bc_ops)

@@ -221,6 +221,179 @@ __device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Kons
     }
 }
 
+// ---- the same pass with the lane's two cells as ONE packed operand (f32, N = 2; fs_device.h v2f) ----------------------------------
+// Every mul / add / sub of K3 and of the CIP polynomial is the same expression for both cells of the lane: on v2f they issue as
+// v_pk_mul_f32 / v_pk_add_f32 (one slot for two IEEE operations); the upwind selects, the DPP shifts and the divisions that are not
+// multiplications stay per half.  Same expression tree, same rounding per element: bit-identical to the scalar form above (which
+// remains the form of N = 4 and of f64).
+__device__ __forceinline__ v2f pk(const LV<float, 2> &r) { v2f v; v.x = r.a[0]; v.y = r.a[1]; return v; }
+__device__ __forceinline__ LV<float, 2> unpk(v2f v) { LV<float, 2> r; r.a[0] = v.x; r.a[1] = v.y; return r; }
+__device__ __forceinline__ v2f east(v2f c, float r) { v2f v; v.x = c.y; v.y = r; return v; }      // the cells right of the lane's two
+__device__ __forceinline__ v2f west(float l, v2f c) { v2f v; v.x = l; v.y = c.x; return v; }      // ... left of them
+__device__ __forceinline__ v2f sel2(unsigned bits, v2f a, v2f b) { v2f r; r.x = (bits & 1u) ? a.x : b.x; r.y = (bits & 2u) ? a.y : b.y; return r; }
+// east(c, r) - west(l, c) = (c.y - l, r - c.x) as ONE packed add on the register pairs (c.x, c.y) and (l, r): the halves are picked by op_sel
+// and negated by neg_lo / neg_hi ((-c.x) + r has the bits of r - c.x: IEEE addition commutes).  Building the two shifted pairs costs a
+// v_mov each - hipcc does not fold a VGPR swizzle into the modifiers.
+__device__ __forceinline__ v2f ew_diff(v2f c, float l, float r)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    v2f z, o;
+    z.x = l; z.y = r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(o) : "v"(c), "v"(z));
+    return o;
+#else
+    return east(c, r) - west(l, c);
+#endif
+}
+
+template <int C, int c, int RT, int DM, bool PLAIN, bool CLAMP>
+__device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Konst<float> &k, int nbx, int nby, int jb, int je,
+                                                        float *out, float *gxo, float *gyo, const float *fn, const float *fc,
+                                                        const float *gxc, const float *gyc, const float *v, unsigned *hot, const uint8_t *bcmap, int full)
+{
+    using T = float;
+    constexpr int N = 2;
+    using R = LV<T, N>;
+    constexpr unsigned ALL = 3u;
+    constexpr int HL = 1;
+    constexpr bool SELF = C == 2;
+    int wx, ty, cg;
+    if (!tile_coords_nz<N, C, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
+    const LaneMapN<N> lm = PLAIN ? LaneMapN<N>{lm_in.i0, lm_in.owner, false, false} : lm_in;
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+
+    unsigned nw[RT + 2], fl[RT];
+    bool any_fl = PLAIN;
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        if (PLAIN) { nw[s] = ALL; if (s >= 1 && s <= RT) fl[s - 1] = j0 + s - 1 < je ? ALL : 0u; continue; }
+        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 1 + s));
+        nw[s] = lv_sel_nw<N>(m);
+        if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? lv_sel_fluid<N>(m) : 0u; any_fl |= fl[s - 1] != 0u; }
+    }
+    if (!PLAIN && !__any(any_fl)) {
+        // (no fluid cell in this wave's tile: carried values only - see cip_grad_advect_n_body)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int j = j0 + t;
+            if (j >= je) break;
+            unsigned touch = full ? ALL : nw[t + 1];
+            if (SELF && !full) touch |= lv_sel_bit7<N>(lv_bytes<N>(bcmap, g, i0, clampy(g, j)));
+            if (!__any(lm.owner && touch != 0u)) continue;
+            const R f = lv_field<C, T, N>(fc, g, c, i0, j);
+            if (lm.owner && touch) {
+                if (SELF) raise_hot(hot, lv_hot1<T, N>(f));
+                lv_store<T, N>(out + idx<C, T>(g, c, i0, j), f);
+                if (nw[t + 1]) {
+                    lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), lv_field<C, T, N>(gxc, g, c, i0, j), nw[t + 1]);
+                    lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), lv_field<C, T, N>(gyc, g, c, i0, j), nw[t + 1]);
+                }
+            }
+        }
+        return;
+    }
+
+    v2f Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        Nn[u] = pk(lv_field<C, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
+        Fc[u] = pk(lv_field<C, T, N>(fc, g, c, i0, clampy(g, j0 - 2 + u)));
+    }
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const int row = clampy(g, j0 - 1 + s);
+        GX[s] = pk(lv_field<C, T, N>(gxc, g, c, i0, row));
+        GY[s] = pk(lv_field<C, T, N>(gyc, g, c, i0, row));
+        if (SELF) {
+            if (c == 0) AY[s] = pk(lv_field<2, T, N>(fn, g, 1, i0, row)); else AX[s] = pk(lv_field<2, T, N>(fn, g, 0, i0, row));
+        } else {
+            AX[s] = pk(lv_field<2, T, N>(v, g, 0, i0, row));
+            AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
+        }
+    }
+    // ---- K3 on rows j0-1 .. j0+RT ----
+    // D = fn - fc per row, once: it is the first difference of sy two rows below AND - shifted one cell - of sx one row below
+    // ((nE - cE) of a lane's second cell is the next lane's first D: the same operation on the same operands)
+    v2f NX[RT + 2], NY[RT + 2], D[RT + 4];
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) D[u] = Nn[u] - Fc[u];
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const v2f n1 = Nn[s + 1], c1 = Fc[s + 1], d1 = D[s + 1];
+        const T nl = lv_left<T, N>(lm, unpk(n1)), cl = lv_left<T, N>(lm, unpk(c1)), dr = lv_right<T, N>(lm, unpk(d1));
+        v2f sx;
+        sx.x = (d1.y - nl) + cl;
+        sx.y = (dr - n1.x) + c1.x;
+        const v2f sy = (D[s + 2] - Nn[s]) + Fc[s];
+        const v2f ux = GX[s] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx), uy = GY[s] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx);
+        NX[s] = PLAIN ? ux : sel2(nw[s], ux, GX[s]);
+        NY[s] = PLAIN ? uy : sel2(nw[s], uy, GY[s]);
+    }
+    if (!PLAIN) {        // (a plain tile lies inside the fluid: no row of its window is outside the domain)
+        if (j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
+#pragma unroll
+        for (int s = 1; s < RT + 2; ++s)
+            if (j0 - 1 + s > g.jhi) { NX[s] = NX[s - 1]; NY[s] = NY[s - 1]; }
+    }
+    // ---- K4 on rows j0 .. j0+RT-1 ----
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        if (j >= je) break;
+        const v2f Nm = Nn[t + 1], Nc = Nn[t + 2], Np = Nn[t + 3];
+        const v2f VXm = SELF && c == 0 ? Nm : AX[t], VXr = SELF && c == 0 ? Nc : AX[t + 1], VXp = SELF && c == 0 ? Np : AX[t + 2];
+        const v2f VYm = SELF && c == 1 ? Nm : AY[t], VYr = SELF && c == 1 ? Nc : AY[t + 1], VYp = SELF && c == 1 ? Np : AY[t + 2];
+        const T vxl = lv_left<T, N>(lm, unpk(VXr)), vxr = lv_right<T, N>(lm, unpk(VXr));
+        const T vyl = lv_left<T, N>(lm, unpk(VYr)), vyr = lv_right<T, N>(lm, unpk(VYr));
+        const T fl0 = lv_left<T, N>(lm, unpk(Nm)), fr0 = lv_right<T, N>(lm, unpk(Nm));
+        const T fl1 = lv_left<T, N>(lm, unpk(Nc)), fr1 = lv_right<T, N>(lm, unpk(Nc));
+        const T fl2 = lv_left<T, N>(lm, unpk(Np)), fr2 = lv_right<T, N>(lm, unpk(Np));
+        const T fxl = lv_left<T, N>(lm, unpk(NX[t + 1])), fxr = lv_right<T, N>(lm, unpk(NX[t + 1]));
+        const T fyl = lv_left<T, N>(lm, unpk(NY[t + 1])), fyr = lv_right<T, N>(lm, unpk(NY[t + 1]));
+        const v2f vx = VXr, vy = VYr;
+        const v2f dxx = xdiv<DM>(0.5f * ew_diff(VXr, vxl, vxr), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>(0.5f * ew_diff(VYr, vyl, vyr), k.dx, k.inv_dx, k.r_dx);
+        const v2f dyx = xdiv<DM>(0.5f * (VXp - VXm), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>(0.5f * (VYp - VYm), k.dx, k.inv_dx, k.r_dx);
+        const v2f f00 = Nc;
+        const v2f f0m = sel_neg(vy, Np, Nm);
+        const v2f fm0 = sel_neg(vx, east(Nc, fr1), west(fl1, Nc));
+        const v2f fmm = sel_neg(vy, sel_neg(vx, east(Np, fr2), west(fl2, Np)), sel_neg(vx, east(Nm, fr0), west(fl0, Nm)));
+        const v2f fx00 = NX[t + 1], fxm0 = sel_neg(vx, east(NX[t + 1], fxr), west(fxl, NX[t + 1])), fx0m = sel_neg(vy, NX[t + 2], NX[t]);
+        const v2f fy00 = NY[t + 1], fy0m = sel_neg(vy, NY[t + 2], NY[t]), fym0 = sel_neg(vx, east(NY[t + 1], fyr), west(fyl, NY[t + 1]));
+        v2f of, ofx, ofy;
+        cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
+        if (CLAMP) { of.x = tmin(tmax(of.x, 0.0f), 1.0f); of.y = tmin(tmax(of.y, 0.0f), 1.0f); }
+        const R OV = unpk(PLAIN ? of : sel2(fl[t], of, Fc[t + 2])), OX = unpk(PLAIN ? ofx : sel2(fl[t], ofx, GX[t + 1])), OY = unpk(PLAIN ? ofy : sel2(fl[t], ofy, GY[t + 1]));
+        if (lm.owner) {
+            if (SELF && lv_hot1<T, N>(OV)) {
+                bool hf = false, hn = false;
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+                    if (hot1(OV.a[q])) { if (PLAIN || ((fl[t] >> q) & 1u)) hf = true; else hn = true; }
+                raise_hot(hot + 3, hf);
+                raise_hot(hot, hn);
+            }
+            lv_store<T, N>(out + idx<C, T>(g, c, i0, j), OV);
+            if (nw[t + 1]) {
+                lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), OX, nw[t + 1]);
+                lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), OY, nw[t + 1]);
+            }
+        }
+    }
+}
+
+#ifndef FS_K34_PK
+#define FS_K34_PK 1        // f32 lanes of 2 cells: the packed body (0: the scalar body; A/B)
+#endif
+template <int C, int c, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T>
+__device__ __forceinline__ void cip_grad_advect_dispatch(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+                                                         T *out, T *gxo, T *gyo, const T *fn, const T *fc,
+                                                         const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
+{
+    if constexpr (FS_K34_PK && N == 2 && sizeof(T) == 4) cip_grad_advect_pk_body<C, c, RT, DM, PLAIN, CLAMP>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    else cip_grad_advect_n_body<C, c, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+}
+
 // blockIdx.y (or, channel groups innermost / compact lists, the block index >> 3) % C = the channel of this workgroup
 template <int C, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T>
 __global__ __launch_bounds__(256) void k_cip_grad_advect_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
@@ -229,9 +402,9 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_n(Grid g, Konst<T> k, i
 {
     const int yy = (nbx >= 0 && (nby & FS_CG_INNER)) ? ((int)blockIdx.x >> 3) : (int)blockIdx.y;
     const int ch = yy % C;
-    if (ch == 0) cip_grad_advect_n_body<C, 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
-    else if (ch == 1) cip_grad_advect_n_body<C, 1, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
-    else if (C == 3) cip_grad_advect_n_body<C, C == 3 ? 2 : 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    if (ch == 0) cip_grad_advect_dispatch<C, 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    else if (ch == 1) cip_grad_advect_dispatch<C, 1, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    else if (C == 3) cip_grad_advect_dispatch<C, C == 3 ? 2 : 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -156,32 +156,34 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_grad(Grid g, Konst<T> k, int
 // _cip_advect for one cell and one channel, fs/solver.py:282-332, on already-gathered values:
 //   f00 = f[i,j], f0m = f[i,j_m], fm0 = f[i_m,j], fmm = f[i_m,j_m]  with the upwind cell (i_m, j_m) = (i - sign(u), j - sign(v));
 //   likewise the x- / y-gradient fields; (vx, vy) the advecting velocity, d?? its central differences.
-template <int DM, typename T>
-__device__ __forceinline__ void cip_point(const Konst<T> &k, T vx, T vy, T dxx, T dxy, T dyx, T dyy,
-                                          T f00, T f0m, T fm0, T fmm, T fx00, T fxm0, T fx0m, T fy00, T fy0m, T fym0,
-                                          T &out_f, T &out_fx, T &out_fy)
+// V: one cell (float / double) or the two cells of a lane as one packed operand (v2f, fs_device.h): the same expression tree per element.
+template <int DM, typename V, typename S>
+__device__ __forceinline__ void cip_point(const Konst<S> &k, V vx, V vy, V dxx, V dxy, V dyx, V dyy,
+                                          V f00, V f0m, V fm0, V fmm, V fx00, V fxm0, V fx0m, V fy00, V fy0m, V fym0,
+                                          V &out_f, V &out_fx, V &out_fy)
 {
-    const T is = vx < (T)0.0 ? (T)-1 : (T)1;   // sign(0) = +1, fs/differentiation.py:12-14
-    const T js = vy < (T)0.0 ? (T)-1 : (T)1;
-    const T i_s_denom = is * k.dx3_fold, j_s_denom = js * k.dx3_fold, is_dx = is * k.dx;
-    const T i_s_inv = is * k.inv_dx3_fold, j_s_inv = js * k.inv_dx3_fold, is_dx_inv = is * k.inv_dx;   // +-1 times the reciprocal: exact
-    const double i_s_r = (double)is * k.r_dx3_fold, j_s_r = (double)js * k.r_dx3_fold, is_dx_r = (double)is * k.r_dx;   // likewise (1 / (-d) = -(1 / d))
-    const T Xd = (-vx) * k.dt, Yd = (-vy) * k.dt;
-    const T tmp1 = ((f00 - f0m) - fm0) + fmm;
-    const T tmp2 = fm0 - f00;
-    const T tmp3 = f0m - f00;
-    const T a = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (T)2.0 * (-tmp2), i_s_denom, i_s_inv, i_s_r);
-    const T b = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (T)2.0 * (-tmp3), j_s_denom, j_s_inv, j_s_r);
-    const T cc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv, j_s_r);
-    const T d = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv, i_s_r);
-    const T e = xdiv<DM>((T)3.0 * tmp2 + (is * (fxm0 + (T)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold);
-    const T f = xdiv<DM>((T)3.0 * tmp3 + (js * (fy0m + (T)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold);
-    const T gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, is_dx_r);
+    using D = typename VecOf<V>::D;
+    const V is = sel_neg(vx, (V)(S)-1, (V)(S)1);   // sign(0) = +1, fs/differentiation.py:12-14
+    const V js = sel_neg(vy, (V)(S)-1, (V)(S)1);
+    const V i_s_denom = is * k.dx3_fold, j_s_denom = js * k.dx3_fold, is_dx = is * k.dx;
+    const V i_s_inv = is * k.inv_dx3_fold, j_s_inv = js * k.inv_dx3_fold, is_dx_inv = is * k.inv_dx;   // +-1 times the reciprocal: exact
+    const D i_s_r = to_dbl(is) * k.r_dx3_fold, j_s_r = to_dbl(js) * k.r_dx3_fold, is_dx_r = to_dbl(is) * k.r_dx;   // likewise (1 / (-d) = -(1 / d))
+    const V Xd = (-vx) * k.dt, Yd = (-vy) * k.dt;
+    const V tmp1 = ((f00 - f0m) - fm0) + fmm;
+    const V tmp2 = fm0 - f00;
+    const V tmp3 = f0m - f00;
+    const V a = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (S)2.0 * (-tmp2), i_s_denom, i_s_inv, i_s_r);
+    const V b = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (S)2.0 * (-tmp3), j_s_denom, j_s_inv, j_s_r);
+    const V cc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv, j_s_r);
+    const V d = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv, i_s_r);
+    const V e = xdiv<DM>((S)3.0 * tmp2 + (is * (fxm0 + (S)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold);
+    const V f = xdiv<DM>((S)3.0 * tmp3 + (js * (fy0m + (S)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold);
+    const V gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, is_dx_r);
     out_f = (((((a * Xd + cc * Yd) + e) * Xd + gq * Yd) + fx00) * Xd + (((b * Yd + d * Xd) + f) * Yd + fy00) * Yd) + f00;
-    const T Fx = ((((T)3.0 * a) * Xd + ((T)2.0 * cc) * Yd) + (T)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
-    const T Fy = ((((T)3.0 * b) * Yd + ((T)2.0 * d) * Xd) + (T)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;
-    out_fx = Fx - (k.dt * (Fx * dxx + Fy * dxy)) / (T)2.0;
-    out_fy = Fy - (k.dt * (Fx * dyx + Fy * dyy)) / (T)2.0;
+    const V Fx = ((((S)3.0 * a) * Xd + ((S)2.0 * cc) * Yd) + (S)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
+    const V Fy = ((((S)3.0 * b) * Yd + ((S)2.0 * d) * Xd) + (S)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;
+    out_fx = Fx - (k.dt * (Fx * dxx + Fy * dxy)) / (S)2.0;
+    out_fy = Fy - (k.dt * (Fx * dyx + Fy * dyy)) / (S)2.0;
 }
 
 // K4  _advection_phase / _cip_advect, fs/solver.py:267-332  (fluid cells; C channels advected by v), one cell per lane

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libfs_hip.so")     # FS_LIB: A/B builds (tools/)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -65,7 +65,6 @@ _PROTOS = {
     "fs_jacobi_pair_lazy": [_c_vp, _c_vp, _c_vp, _c_vp, _c_int] + _ROWS,
     "fs_jacobi_quad_ok": [_c_vp, _P(_c_int)],
     "fs_jacobi_quad_lazy": [_c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
-    "fs_jacobi_march": [_c_vp, _c_vp, _c_vp, _c_vp, _c_int] + _ROWS,
     "fs_jacobi_finish": [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_lazy_flags": [_c_vp, _c_vp, _c_int, _P(_c_int), _P(_c_int), _P(_c_int)],
     "fs_selftest_f64div": [_c_vp, _c_dbl, _P(_c_int)],

@@ -64,12 +64,6 @@ class JacobiPressureUpdater(PressureUpdater):
         self._quads = (self._pairs and n_iter >= 10 and os.environ.get("FS_JACOBI_QUADS", "1") == "1" and getattr(self._dev, "jacobi_quad_ok", False))
         if self._quads:
             self.form = "four sweeps per pass"
-        # S sweeps per pass as a row-marching pipeline (fs_jacobi_march, csrc/fs_jmarch.h) where the four-sweep pass is admitted: a strip of
-        # L rows costs L + 2 S rows of loads and of every sweep, a 4-row tile 12 and 10.  FS_JACOBI_MARCH = 0 / 4 / 6 / 8 (sweeps per pass).
-        want_m = os.environ.get("FS_JACOBI_MARCH", "0")
-        self._march = int(want_m) if (self._quads and want_m in ("4", "6", "8") and n_iter - 2 >= int(want_m)) else 0
-        if self._march:
-            self.form = f"{self._march} sweeps per pass, row-marching"
         if tentative and not self._pairs:
             self._precompute, self._src, self._lazy = False, None, False
         # The last two rounds - 2 x (boundary kernel + sweep), which leave both buffers as the reference does - in ONE pass into a third
@@ -85,11 +79,6 @@ class JacobiPressureUpdater(PressureUpdater):
         if self._quads and p.current.static_id == p.next.static_id:
             # four sweeps per pass (the pass writes not-wall cells only: the wall cells nothing writes must be equal in the two buffers,
             # Field.static_id); what does not fill a pass runs as single lazily-bounded sweeps
-            if self._march:
-                for _ in range(n_lazy // self._march):
-                    self._dev.jacobi_march(p.next, p.current, self._src, self._march)
-                    p.swap()
-                n_lazy %= self._march
             for _ in range(n_lazy // 4):
                 self._dev.jacobi_quad_lazy(p.next, p.current, self._src)
                 p.swap()

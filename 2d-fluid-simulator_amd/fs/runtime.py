@@ -702,10 +702,6 @@ class DeviceBase:
         """Four lazily-bounded sweeps in one pass, pn[not wall] <- sweep^4(pc) (csrc/fs_jquad.h)."""
         self._run("jacobi_quad_lazy", (pn._h, pc._h, src._h), reads=[(pc, 4), (src, 3)], writes=[pn])
 
-    def jacobi_march(self, pn, pc, src, sweeps):
-        """`sweeps` (4, 6, 8) lazily-bounded sweeps in one row-marching pass, pn[not wall] <- sweep^S(pc) (csrc/fs_jmarch.h)."""
-        self._run("jacobi_march", (pn._h, pc._h, src._h, int(sweeps)), reads=[(pc, sweeps), (src, sweeps - 1)], writes=[pn])
-
     def jacobi_finish(self, pc_out, pn, pc, src):
         """The last two (K7, sweep, swap) rounds of a lazily-bounded run in one pass (csrc/fs_jquad.h k_jacobi_finish): pc = raw iterate n-2;
         pc_out <- what the reference leaves in p.current, pn <- what it leaves in p.next."""

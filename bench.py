@@ -103,7 +103,7 @@ def algorithmic_bytes(mask, esize=4):
 
 def merge_parts(rep):
     """Kernels launched in two compact parts (the workgroups that see nothing but fluid, then the others: "<name>" + "<name>_bnd",
-    csrc/fs_api.hip tile_list) count as ONE launch of <name>."""
+    csrc/fs_core.hip tile_list) count as ONE launch of <name>."""
     for name in [n for n in rep if n.endswith("_bnd") and n[:-4] in rep]:
         (l0, m0), (_, m1) = rep[name[:-4]], rep[name]
         rep[name[:-4]] = (l0, m0 + m1)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 7
+#define FS_ABI_VERSION 8
 
 typedef struct fs_ctx fs_ctx;
 typedef struct fs_field fs_field;
@@ -221,11 +221,6 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
  * its target as seen from a cell whose value is used; otherwise FS_ERR_UNSUPPORTED - use fs_jacobi_pair_lazy / fs_jacobi_sweep_lazy.  */
 int fs_jacobi_quad_ok(const fs_ctx *ctx, int *ok);
 int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int row_begin, int row_end);
-/* `sweeps` = 4, 6 or 8 such sweeps in one ROW-MARCHING pass (csrc/fs_jmarch.h): a wave walks down a strip of rows with the sweeps as a
- * software pipeline, one row apart - a strip of L rows requests L + 2 S rows instead of 3 rows per output row, and every sweep runs
- * (L + 2 S) / L times per row instead of 2.5 times.  Same conditions (fs_jacobi_quad_ok), same bits as `sweeps` rounds of
- * fs/pressure_updater.py:56-66 on the not-wall cells of pn. */
-int fs_jacobi_march(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_field *src, int sweeps, int row_begin, int row_end);
 /* The LAST two rounds (K7, sweep, swap; K7, sweep, swap - fs/pressure_updater.py:56-66) of such a run in one pass: pc holds the raw iterate
  * n-2; pc_out (a third buffer) receives what the reference leaves in p.current (iterate n on the not-wall cells, K7(iterate n-2) on the wall
  * cells with a recipe), pn what it leaves in p.next (iterate n-1 with K7 applied).  Cells no kernel writes are not stored: they must be

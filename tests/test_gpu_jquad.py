@@ -8,12 +8,6 @@ from test_gpu_rbpair import thick_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _tile_form(monkeypatch):
-    """this file pins the register-tile form; the row-marching passes (the default where admitted) have tests/test_gpu_jmarch.py"""
-    monkeypatch.setenv("FS_JACOBI_MARCH", "0")
-
-
 def build(const, mask, n_iter, res=64, scheme="cip", vc=5.0):
     import fs
     from fs.boundary_condition import BoundaryCondition

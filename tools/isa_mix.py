@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction mix of the gfx950 kernels: tools/isa_mix.py [name-substring ...]   (device-only -S of csrc/fs_api.hip)"""
+"""Instruction mix of the gfx950 kernels: tools/isa_mix.py [name-substring ...]   (device-only -S of csrc/fs_transport.hip, fs_pressure.hip, fs_core.hip)"""
 import collections
 import os
 import re
@@ -11,10 +11,12 @@ CSRC = os.path.join(REPO, "2d-fluid-simulator_amd", "csrc")
 
 
 def main():
-    asm = "/tmp/fs_api_isa.s"
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w",
-                    "-I/opt/rocm/include", "--cuda-device-only", "-S", os.path.join(CSRC, "fs_api.hip"), "-o", asm], check=True)
-    lines = open(asm).read().split("\n")
+    lines = []
+    for tu in ("fs_transport", "fs_pressure", "fs_core"):
+        asm = f"/tmp/{tu}_isa.s"
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w",
+                        "-I/opt/rocm/include", "--cuda-device-only", "-S", os.path.join(CSRC, tu + ".hip"), "-o", asm], check=True)
+        lines += open(asm).read().split("\n")
     subs = sys.argv[1:] or ["k_rbsor_pair", "k_cip_grad_advect_n", "k_vort_n", "k_cip_nonadv_n", "k_jacobi_ov", "k_jacobi_quad", "k_limit_quad"]
     i = 0
     while i < len(lines):
