@@ -113,17 +113,27 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
 {
     if (c->h_act4.empty() || nbx > 0xfff || nby > 0xffff || lanes > 4 || c->rows > 0xffff) return nullptr;      // (entry: class hints << 28 | by << 12 | bx)
     if (je < 0) je = c->rows;
-    const uint32_t key0 = (uint32_t)lanes | ((uint32_t)rt << 4) | ((uint32_t)stacked << 12) | ((uint32_t)group << 16) | ((uint32_t)cls << 24) | ((uint32_t)reach << 26) | ((uint32_t)(wgw & 7) << 29);
     if (parent_rt == rt) parent_rt = 0;
     if (parent_rt && (wgw != 1 || parent_rt % rt != 0 || parent_rt > 64)) return nullptr;      // (a coarser plain tiling is defined for one-wave workgroups)
-    const std::pair<uint32_t, uint32_t> key(key0 ^ ((uint32_t)parent_rt << 5), ((uint32_t)jb << 16) | (uint32_t)je);      // slab launches cover varying row ranges: one list per range
+    const fs_ctx::TileKey key{{lanes, rt, stacked ? 1 : 0, group, cls, reach, wgw, parent_rt, jb, je}};      // (slab launches cover varying row ranges: one list per range)
     auto it = c->tile_lists.find(key);
     if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
     if (c->capturing || c->tape_rec) return nullptr;      // (building one synchronises the stream: not inside a capture - the dense grid then)
+    if (c->tile_lists.size() >= 512) return nullptr;      // (slab launches over ever new row ranges: the dense grid from here on, not one allocation per range)
     const std::vector<uint8_t> &act = lanes == 4 ? c->h_act4 : (lanes == 2 ? c->h_act2 : c->h_act2w);
     const int ow = geo_owners(lanes), waves = (c->X / geo_cells(lanes) + ow - 1) / ow, Y = c->rows;       // (activity maps are indexed by LOCAL row)
     std::vector<uint32_t> per[8];
     bool any_hint = false;
+    // no non-fluid cell (bit 1 of the activity byte: halo lanes included) in wave columns [wx0, wx1) within `reach` rows of rows [p0, p1) - and
+    // the whole box inside the domain: a wave column at the domain's first / last column clamps its halo lanes onto the edge cells, a row
+    // range that leaves the slab has rows nobody classified (the reference's scenes keep walls there; an uploaded mask need not)
+    auto plain_box = [&](int wx0, int wx1, int p0, int p1) -> bool {
+        if (wx0 <= 0 || wx1 >= waves || p0 - reach < 0 || p1 + reach > Y) return false;
+        for (int wx = wx0; wx < wx1; ++wx)
+            for (int j = p0 - reach; j < p1 + reach; ++j)
+                if (act[(size_t)wx * Y + j] & 2) return false;
+        return true;
+    };
     const int groups = (nby + group - 1) / group;
     // inside a group the workgroups are listed column by column: vertically adjacent workgroups, which re-read each other's halo rows, are
     // neighbours in dispatch order (bc5 res 4096: K3+K4 333 -> 319 us, the red-black pair 195 -> 191; FS_LIST_ROWMAJOR=1: row by row)
@@ -142,16 +152,26 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                     for (int wx = wx0; wx < wx1 && !any; ++wx)
                         for (int j = j0; j < j1; ++j)
                             if (act[(size_t)wx * Y + j] & 1) { any = true; break; }
-                    if (any && cls) {
+                    if (any && cls && cls != 3) {
                         // plain: no non-fluid cell (bit 1 of the activity byte; halo lanes included) within `reach` rows of the tile - or, for the
                         // boundary list of a launch whose plain part runs on tiles of parent_rt rows, of the parent tile this tile lies in
                         int p0 = j0, p1 = j1;
                         if (parent_rt) { p0 = jb + (j0 - jb) / parent_rt * parent_rt; p1 = std::min(je, p0 + parent_rt); }
-                        bool plain = true;
-                        for (int wx = wx0; wx < wx1 && plain; ++wx)
-                            for (int j = std::max(0, p0 - reach); j < std::min(Y, p1 + reach); ++j)
-                                if (act[(size_t)wx * Y + j] & 2) { plain = false; break; }
-                        any = plain == (cls == 1);
+                        any = plain_box(wx0, wx1, p0, p1) == (cls == 1);
+                    }
+                    if (cls == 3) {
+                        // a BOUNDARY tile (active, not plain) of the same tiling, or the tile above / below one: the rows the general kernel of a
+                        // two-part launch reads around its own tiles (fs_transport.hip fs_cip_step: K2 where K3 + K4 read its result from memory;
+                        // that launch stores one lane beyond the owner lanes on either side, which is as far as K3 + K4 look sideways).
+                        // One-wave workgroups only (stacked or not: the same tiling).
+                        any = false;
+                        if (wgw == 1)
+                            for (int ty = std::max(0, by - 1); ty <= std::min(nby - 1, by + 1) && !any; ++ty) {
+                                const int t0 = jb + ty * rt, t1 = std::min(je, t0 + rt);
+                                bool act_t = false;
+                                for (int j = t0; j < t1 && !act_t; ++j) act_t = (act[(size_t)bx * Y + j] & 1) != 0;
+                                any = act_t && !plain_box(bx, bx + 1, t0, t1);
+                            }
                     }
                     uint32_t hints = 0u;
                     if (any && !cls && reach > 0 && wgw <= 4) {
@@ -161,9 +181,7 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                             const int wx = stacked ? bx : bx * wgw + w;
                             const int t0 = jb + (stacked ? by * wgw + w : by) * rt, t1 = std::min(je, t0 + rt);
                             if (wx >= waves || t0 >= je) continue;
-                            bool plain = true;
-                            for (int j = std::max(0, t0 - reach); j < std::min(Y, t1 + reach) && plain; ++j)
-                                if (act[(size_t)wx * Y + j] & 2) plain = false;
+                            const bool plain = plain_box(wx, wx + 1, t0, t1);
                             if (plain) hints |= 1u << w;
                         }
                         any_hint = any_hint || hints != 0u;
@@ -561,6 +579,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_F64DIV")) c->use_f64div = atoi(s) != 0;
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
+    if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = atoi(s) != 0;
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <array>
 #include <cmath>
 #include <functional>
 #include <map>
@@ -121,6 +122,7 @@ struct fs_ctx {
     int mac_rt = 0;            // env FS_MAC_RT: rows per tile (2 / 4) of K2' (upwind / KK update); 0: by grid size and precision
     int k34_n = 0;             // env FS_K34_N: cells per lane (2 / 4) of the fused K3 + K4 pass (fs_k34n.h); 0: by grid size (fs_api.hip launch_k34)
     int k34_rt = 0;            // env FS_K34_RT: rows per register tile (2 / 4) of that pass at 2 cells per lane; 0: by grid size
+    bool fuse_k2 = true;       // env FS_FUSE_K2=0: fs_cip_step as its two calls, K2 then the fused K3 + K4 pass (A/B; the same observable results)
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
     int xcd_group_fam[7] = {0, 0, 0, 0, 0, 0, 1};   // ... of single kernel families (env FS_XCD_GROUP_FAM; 0: xcd_group)
@@ -137,7 +139,8 @@ struct fs_ctx {
                                              // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement (2-cell lanes) 97 -> 95, K2 (2-cell lanes) 105 -> 102, the plain Jacobi sweeps 87.2 -> 85.8 (reading v) / 75.5 -> 74.1 (source pair)
     std::vector<uint8_t> h_act4, h_act2, h_act2w;     // [wave column][local row]
     struct TileList { uint32_t *d = nullptr; int per_xcd = 0; };
-    std::map<std::pair<uint32_t, uint32_t>, TileList> tile_lists;     // key: (geometry, row range)
+    using TileKey = std::array<int, 10>;     // lanes, rows per tile, stacked, group, class, reach, waves per workgroup, parent tile rows, row range
+    std::map<TileKey, TileList> tile_lists;
 
     fs::Grid grid() const
     {

@@ -1,0 +1,145 @@
+// fs_k234.h - K2 + K3 + K4 of the CIP velocity step in ONE pass over HBM, for the tiles that see nothing but fluid.
+//
+// Reference: fs/solver.py:213-227 (_update_velocities): K2 _non_advection_phase :229-240 writes v.next from v.current and p, the buffers
+// stay, K3 _non_advection_phase_grad :242-261 and K4 _advection_phase :267-332 read v.next back on a 5 x 5 neighbourhood.  As kernels of
+// their own K2 moves 20 B per cell and the fused K3+K4 pass (fs_k34n.h) reads its 8 B per cell again: at res 4096 that is 540 MB of the
+// 2.7 GB a step moves.  Here K2 is evaluated where it is consumed:
+//
+//   * a workgroup is TWO waves on one tile of RT rows x 120 cells (lanes of 2 cells, 60 owner lanes + 2 halo lanes per side: K2 o K3 o K4
+//     reaches 3 cells) - wave c owns velocity component c, as in fs_k34n.h;
+//   * wave c evaluates K2 for ITS component on rows j0-2 .. j0+RT+1 from rows j0-3 .. j0+RT+2 of v.current and p (packed f32, fs_device.h
+//     v2f) and keeps the result in registers: the "Nn" window of the K3+K4 core;
+//   * K4 advects with BOTH components of the post-K2 velocity: rows j0-1 .. j0+RT of a wave's result go to LDS (6 KB per workgroup), one
+//     barrier, and the sibling wave reads them as its advecting component;
+//   * K3 + K4: the packed core of fs_k34n.h, unchanged.
+//
+// Same expression trees, same operation order, one rounding per operation: the bits of the three-kernel sequence (tests compare at
+// tolerance 0).  What is NOT the same is the content of the intermediate buffer: the post-K2 velocity of these tiles never reaches HBM.
+// Nothing reads it there - the reference's own sequence overwrites every fluid cell of that buffer (K2 of the next step, or the vorticity
+// confinement of this one) before anything looks at it - EXCEPT the boundary tiles of this same step, whose K3 + K4 (the general kernel of
+// fs_k34n.h) read it within 2 cells of their own rows.  The host therefore launches three parts (fs_transport.hip fs_cip_step):
+//   K2 (k_cip_nonadv_n, unchanged) over the tiles within one tile of a boundary tile - every not-wall cell that is not fluid lies in one;
+//   this kernel over the plain tiles; k_cip_grad_advect_n over the boundary tiles, on the same wave columns (HL = 2).
+// Plain tile: every cell within 2 rows and within the halo lanes is fluid and inside the domain (fs_core.hip tile_list) - K2's own reads
+// one cell further out take whatever the buffers hold there, as the reference's K2 does.
+#pragma once
+#include "fs_k34n.h"
+
+namespace fs {
+
+// The loads take a scalar row base + ONE 32-bit lane offset (the `saddr` form, fs_march.h load_row_quad).  hipcc selects that form only when it
+// sees the zero-extension of the offset in the basic block of the load; the two component bodies of this kernel are separate blocks and the
+// extension of a value computed in front of them is hoisted out - each load then pays a 64-bit VALU add.  An empty asm makes the offset opaque
+// inside the body, so the extension stays there.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_PIN_LANE_OFFSET(i) asm volatile("" : "+v"(i))
+#else
+#define FS_PIN_LANE_OFFSET(i) (void)(i)
+#endif
+
+template <int RT> struct K234State {
+    v2f Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2];
+};
+
+// K2 for component c of one wave: rows j0-2 .. j0+RT+1 (slot u <-> row j0-2+u), every cell not-wall by the launch's construction.
+//   fn = fc + ((-grad p) + (diff2_x(fc) + diff2_y(fc)) / re) * dt      fs/solver.py:234-239, 263-265
+template <int c, int RT, int DM>
+__device__ __forceinline__ void k234_nonadv(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0,
+                                            const float *fc, const float *pc, K234State<RT> &st)
+{
+    using T = float;
+    constexpr int N = 2;
+    v2f F[RT + 6];                               // rows j0-3 .. j0+RT+2
+    v2f P[RT + 6];                               // c == 0: rows j0-2 .. j0+RT+1 in slots 1 .. RT+4;  c == 1: rows j0-3 .. j0+RT+2
+#pragma unroll
+    for (int u = 0; u < RT + 6; ++u) {
+        const int row = clampy(g, j0 - 3 + u);
+        F[u] = pk(lv_field<2, T, N>(fc, g, c, i0, row));
+        if (c == 1 || (u >= 1 && u <= RT + 4)) P[u] = pk(lv_field<1, T, N>(pc, g, 0, i0, row));
+    }
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        const v2f fm = F[u], f1 = F[u + 1], fp = F[u + 2];
+        const T l = lv_left<T, N>(lm, unpk(f1)), r = lv_right<T, N>(lm, unpk(f1));
+        const v2f two_f = 2.0f * f1;
+        const v2f d2x = xdiv<DM>((east(f1, r) - two_f) + west(l, f1), k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+        const v2f d2y = xdiv<DM>((fp - two_f) + fm, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+        const v2f lap = d2x + d2y;
+        v2f dif;
+        dif.x = rdiv<DM>(lap.x, k.re, k.r_re);
+        dif.y = rdiv<DM>(lap.y, k.re, k.r_re);
+        v2f gp;
+        if (c == 0) {
+            const v2f p1 = P[u + 1];
+            const T pl = lv_left<T, N>(lm, unpk(p1)), pr = lv_right<T, N>(lm, unpk(p1));
+            gp = xdiv<DM>(0.5f * ew_diff(p1, pl, pr), k.dx, k.inv_dx, k.r_dx);
+        } else {
+            gp = xdiv<DM>(0.5f * (P[u + 2] - P[u]), k.dx, k.inv_dx, k.r_dx);
+        }
+        const v2f gg = (-gp) + dif;
+        st.Nn[u] = f1 + gg * k.dt;
+        st.Fc[u] = f1;
+    }
+}
+
+template <int c, int RT, int DM>
+__device__ __forceinline__ void k234_phase1(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0,
+                                            const float *fc, const float *pc, const float *gxc, const float *gyc, K234State<RT> &st, v2f (*xch)[64])
+{
+    using T = float;
+    constexpr int N = 2;
+    FS_PIN_LANE_OFFSET(i0);
+    // the old gradients of the tile: requested before K2 so that they are on their way while it runs
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const int row = clampy(g, j0 - 1 + s);
+        st.GX[s] = pk(lv_field<2, T, N>(gxc, g, c, i0, row));
+        st.GY[s] = pk(lv_field<2, T, N>(gyc, g, c, i0, row));
+    }
+    k234_nonadv<c, RT, DM>(g, k, lm, i0, j0, fc, pc, st);
+    // rows j0-1 .. j0+RT of this component: the sibling wave's advecting velocity
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) xch[c * (RT + 2) + s][lane] = st.Nn[s + 1];
+}
+
+template <int c, int RT, int DM>
+__device__ __forceinline__ void k234_phase2(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
+                                            float *out, float *gxo, float *gyo, unsigned *hot, const K234State<RT> &st, const v2f (*xch)[64])
+{
+    const int lane = threadIdx.x & 63;
+    v2f A[RT + 2];
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) A[s] = xch[(1 - c) * (RT + 2) + s][lane];
+    unsigned nw[RT + 2], fl[RT];
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) nw[s] = 3u;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) fl[t] = j0 + t < je ? 3u : 0u;
+    cip_k34_pk_core<2, c, RT, DM, true, false>(g, k, lm, i0, j0, je, nw, fl, st.Nn, st.Fc, st.GX, st.GY, A, A, out, gxo, gyo, hot);
+}
+
+// one workgroup = 2 waves = the two velocity components of ONE listed tile (compact launch only: Grid::tiles, one entry per tile)
+template <int RT, int DM>
+__global__ __launch_bounds__(128) void k_cip_step_plain(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
+                                                        float *out, float *gxo, float *gyo, const float *fc, const float *pc,
+                                                        const float *gxc, const float *gyc, unsigned *hot)
+{
+    constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
+    __shared__ v2f xch[2 * (RT + 2)][64];
+    int wx, ty, cg;
+    if (!band_coords<1>(g, nbx, nby, wx, ty, cg)) return;                        // (workgroup-uniform: both waves leave, or neither)
+    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
+    const int c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
+    const LaneMapN<N> lm{lm_in.i0, lm_in.owner, false, false};                  // (a plain tile holds no lane at the domain's first / last column)
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    K234State<RT> st;
+    if (c == 0) k234_phase1<0, RT, DM>(g, k, lm, i0, j0, fc, pc, gxc, gyc, st, xch);
+    else        k234_phase1<1, RT, DM>(g, k, lm, i0, j0, fc, pc, gxc, gyc, st, xch);
+    __syncthreads();
+    if (c == 0) k234_phase2<0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, xch);
+    else        k234_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, xch);
+}
+
+}  // namespace fs

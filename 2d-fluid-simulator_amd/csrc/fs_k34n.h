@@ -67,14 +67,15 @@ __device__ __forceinline__ bool tile_coords_nz(const Grid &g, int nbx, int nby_p
     return wave_x * OW < g.X / N && jb + tile_y * rt < je;
 }
 
-template <int C, int c, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T>
+template <int C, int c, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T, int HL = 1>
 __device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                        T *out, T *gxo, T *gyo, const T *fn, const T *fc,
                                                        const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
 {
     using R = LV<T, N>;
     constexpr unsigned ALL = (1u << N) - 1u;
-    constexpr int HL = 1;                        // the pass reaches 2 cells in x: ONE halo lane per side (62 owner lanes)
+    // HL: halo lanes per side.  The pass reaches 2 cells in x: ONE suffices (62 owner lanes); 2 (60 owners) where the launch shares its wave
+    // columns with the pass that evaluates K2 on the way (fs_k234.h: reach 3 cells)
     constexpr bool SELF = C == 2;                // the field advects itself
     int wx, ty, cg;
     if (!tile_coords_nz<N, C, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
@@ -246,7 +247,97 @@ __device__ __forceinline__ v2f ew_diff(v2f c, float l, float r)
 #endif
 }
 
+// K3 on rows j0-1 .. j0+RT and K4 on rows j0 .. j0+RT-1 of one wave's tile from its register window (packed): Nn / Fc rows j0-2 .. j0+RT+1 of
+// the field after / before K2, GX / GY rows j0-1 .. j0+RT of the old gradients, AX / AY the advecting velocity on those rows (C = 2: only
+// the component that is not the field's own is read).  Shared by the two-kernel form below and the pass that evaluates K2 on the way
+// (fs_k234.h).
 template <int C, int c, int RT, int DM, bool PLAIN, bool CLAMP>
+__device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
+                                                const unsigned (&nw)[RT + 2], const unsigned (&fl)[RT],
+                                                const v2f (&Nn)[RT + 4], const v2f (&Fc)[RT + 4], const v2f (&GX)[RT + 2], const v2f (&GY)[RT + 2],
+                                                const v2f (&AX)[RT + 2], const v2f (&AY)[RT + 2], float *out, float *gxo, float *gyo, unsigned *hot)
+{
+    using T = float;
+    constexpr int N = 2;
+    using R = LV<T, N>;
+    constexpr bool SELF = C == 2;
+    // K3 on rows j0-1 .. j0+RT (slot s) and K4 on rows j0 .. j0+RT-1 (t), interleaved: K4 of row t follows K3 of row t+2, the last gradient
+    // row it reads - a row of the old gradients and of fc is dead one step after its K3 (the register peak of this pass is K4's: ~30 live pairs).
+    // D = fn - fc per row, once: it is the first difference of sy two rows below AND - shifted one cell - of sx one row below
+    // ((nE - cE) of a lane's second cell is the next lane's first D: the same operation on the same operands)
+    v2f NX[RT + 2], NY[RT + 2], D[RT + 4];
+    D[0] = Nn[0] - Fc[0];
+    D[1] = Nn[1] - Fc[1];
+#pragma unroll
+    for (int t = -2; t < RT; ++t) {
+        const int s = t + 2;
+        {
+            D[s + 2] = Nn[s + 2] - Fc[s + 2];
+            const v2f n1 = Nn[s + 1], c1 = Fc[s + 1], d1 = D[s + 1];
+            const T nl = lv_left<T, N>(lm, unpk(n1)), cl = lv_left<T, N>(lm, unpk(c1)), dr = lv_right<T, N>(lm, unpk(d1));
+            v2f sx;
+            sx.x = (d1.y - nl) + cl;
+            sx.y = (dr - n1.x) + c1.x;
+            const v2f sy = (D[s + 2] - Nn[s]) + Fc[s];
+            const v2f ux = GX[s] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx), uy = GY[s] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx);
+            NX[s] = PLAIN ? ux : sel2(nw[s], ux, GX[s]);
+            NY[s] = PLAIN ? uy : sel2(nw[s], uy, GY[s]);
+            if (!PLAIN) {        // a slot that stands for a row outside the domain takes the K3 result of the edge row it clamps onto (wave-uniform;
+                                 // a plain tile lies inside the fluid: no row of its window is outside the domain)
+                if (s == 1 && j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
+                if (s >= 1 && j0 - 1 + s > g.jhi) { NX[s] = NX[s - 1]; NY[s] = NY[s - 1]; }
+            }
+        }
+        const int j = j0 + t;
+        if (t < 0 || j >= je) continue;
+        const v2f Nm = Nn[t + 1], Nc = Nn[t + 2], Np = Nn[t + 3];
+        const v2f VXm = SELF && c == 0 ? Nm : AX[t], VXr = SELF && c == 0 ? Nc : AX[t + 1], VXp = SELF && c == 0 ? Np : AX[t + 2];
+        const v2f VYm = SELF && c == 1 ? Nm : AY[t], VYr = SELF && c == 1 ? Nc : AY[t + 1], VYp = SELF && c == 1 ? Np : AY[t + 2];
+        const T vxl = lv_left<T, N>(lm, unpk(VXr)), vxr = lv_right<T, N>(lm, unpk(VXr));
+        const T vyl = lv_left<T, N>(lm, unpk(VYr)), vyr = lv_right<T, N>(lm, unpk(VYr));
+        const T fl0 = lv_left<T, N>(lm, unpk(Nm)), fr0 = lv_right<T, N>(lm, unpk(Nm));
+        const T fl1 = lv_left<T, N>(lm, unpk(Nc)), fr1 = lv_right<T, N>(lm, unpk(Nc));
+        const T fl2 = lv_left<T, N>(lm, unpk(Np)), fr2 = lv_right<T, N>(lm, unpk(Np));
+        const T fxl = lv_left<T, N>(lm, unpk(NX[t + 1])), fxr = lv_right<T, N>(lm, unpk(NX[t + 1]));
+        const T fyl = lv_left<T, N>(lm, unpk(NY[t + 1])), fyr = lv_right<T, N>(lm, unpk(NY[t + 1]));
+        const v2f vx = VXr, vy = VYr;
+        const v2f dxx = xdiv<DM>(0.5f * ew_diff(VXr, vxl, vxr), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>(0.5f * ew_diff(VYr, vyl, vyr), k.dx, k.inv_dx, k.r_dx);
+        const v2f dyx = xdiv<DM>(0.5f * (VXp - VXm), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>(0.5f * (VYp - VYm), k.dx, k.inv_dx, k.r_dx);
+        const v2f f00 = Nc;
+        const v2f f0m = sel_neg(vy, Np, Nm);
+        const v2f fm0 = sel_neg(vx, east(Nc, fr1), west(fl1, Nc));
+        const v2f fmm = sel_neg(vy, sel_neg(vx, east(Np, fr2), west(fl2, Np)), sel_neg(vx, east(Nm, fr0), west(fl0, Nm)));
+        const v2f fx00 = NX[t + 1], fxm0 = sel_neg(vx, east(NX[t + 1], fxr), west(fxl, NX[t + 1])), fx0m = sel_neg(vy, NX[t + 2], NX[t]);
+        const v2f fy00 = NY[t + 1], fy0m = sel_neg(vy, NY[t + 2], NY[t]), fym0 = sel_neg(vx, east(NY[t + 1], fyr), west(fyl, NY[t + 1]));
+        v2f of, ofx, ofy;
+        cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
+        if (CLAMP) { of.x = tmin(tmax(of.x, 0.0f), 1.0f); of.y = tmin(tmax(of.y, 0.0f), 1.0f); }
+        const R OV = unpk(PLAIN ? of : sel2(fl[t], of, Fc[t + 2])), OX = unpk(PLAIN ? ofx : sel2(fl[t], ofx, GX[t + 1])), OY = unpk(PLAIN ? ofy : sel2(fl[t], ofy, GY[t + 1]));
+        if (lm.owner) {
+            if (SELF && lv_hot1<T, N>(OV)) {
+                bool hf = false, hn = false;
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+                    if (hot1(OV.a[q])) { if (PLAIN || ((fl[t] >> q) & 1u)) hf = true; else hn = true; }
+                raise_hot(hot + 3, hf);
+                raise_hot(hot, hn);
+            }
+            if (PLAIN) {         // whole lanes: scalar row base + the lane offset of the loads
+                lv_store_row<C, T, N>(out, g, c, i0, j, OV);
+                lv_store_row<C, T, N>(gxo, g, c, i0, j, OX);
+                lv_store_row<C, T, N>(gyo, g, c, i0, j, OY);
+            } else {
+                lv_store<T, N>(out + idx<C, T>(g, c, i0, j), OV);
+                if (nw[t + 1]) {
+                    lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), OX, nw[t + 1]);
+                    lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), OY, nw[t + 1]);
+                }
+            }
+        }
+    }
+}
+
+template <int C, int c, int RT, int DM, bool PLAIN, bool CLAMP, int HL = 1>
 __device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Konst<float> &k, int nbx, int nby, int jb, int je,
                                                         float *out, float *gxo, float *gyo, const float *fn, const float *fc,
                                                         const float *gxc, const float *gyc, const float *v, unsigned *hot, const uint8_t *bcmap, int full)
@@ -255,7 +346,6 @@ __device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Kon
     constexpr int N = 2;
     using R = LV<T, N>;
     constexpr unsigned ALL = 3u;
-    constexpr int HL = 1;
     constexpr bool SELF = C == 2;
     int wx, ty, cg;
     if (!tile_coords_nz<N, C, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
@@ -312,99 +402,32 @@ __device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Kon
             AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
         }
     }
-    // ---- K3 on rows j0-1 .. j0+RT ----
-    // D = fn - fc per row, once: it is the first difference of sy two rows below AND - shifted one cell - of sx one row below
-    // ((nE - cE) of a lane's second cell is the next lane's first D: the same operation on the same operands)
-    v2f NX[RT + 2], NY[RT + 2], D[RT + 4];
-#pragma unroll
-    for (int u = 0; u < RT + 4; ++u) D[u] = Nn[u] - Fc[u];
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        const v2f n1 = Nn[s + 1], c1 = Fc[s + 1], d1 = D[s + 1];
-        const T nl = lv_left<T, N>(lm, unpk(n1)), cl = lv_left<T, N>(lm, unpk(c1)), dr = lv_right<T, N>(lm, unpk(d1));
-        v2f sx;
-        sx.x = (d1.y - nl) + cl;
-        sx.y = (dr - n1.x) + c1.x;
-        const v2f sy = (D[s + 2] - Nn[s]) + Fc[s];
-        const v2f ux = GX[s] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx), uy = GY[s] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx);
-        NX[s] = PLAIN ? ux : sel2(nw[s], ux, GX[s]);
-        NY[s] = PLAIN ? uy : sel2(nw[s], uy, GY[s]);
-    }
-    if (!PLAIN) {        // (a plain tile lies inside the fluid: no row of its window is outside the domain)
-        if (j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
-#pragma unroll
-        for (int s = 1; s < RT + 2; ++s)
-            if (j0 - 1 + s > g.jhi) { NX[s] = NX[s - 1]; NY[s] = NY[s - 1]; }
-    }
-    // ---- K4 on rows j0 .. j0+RT-1 ----
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const int j = j0 + t;
-        if (j >= je) break;
-        const v2f Nm = Nn[t + 1], Nc = Nn[t + 2], Np = Nn[t + 3];
-        const v2f VXm = SELF && c == 0 ? Nm : AX[t], VXr = SELF && c == 0 ? Nc : AX[t + 1], VXp = SELF && c == 0 ? Np : AX[t + 2];
-        const v2f VYm = SELF && c == 1 ? Nm : AY[t], VYr = SELF && c == 1 ? Nc : AY[t + 1], VYp = SELF && c == 1 ? Np : AY[t + 2];
-        const T vxl = lv_left<T, N>(lm, unpk(VXr)), vxr = lv_right<T, N>(lm, unpk(VXr));
-        const T vyl = lv_left<T, N>(lm, unpk(VYr)), vyr = lv_right<T, N>(lm, unpk(VYr));
-        const T fl0 = lv_left<T, N>(lm, unpk(Nm)), fr0 = lv_right<T, N>(lm, unpk(Nm));
-        const T fl1 = lv_left<T, N>(lm, unpk(Nc)), fr1 = lv_right<T, N>(lm, unpk(Nc));
-        const T fl2 = lv_left<T, N>(lm, unpk(Np)), fr2 = lv_right<T, N>(lm, unpk(Np));
-        const T fxl = lv_left<T, N>(lm, unpk(NX[t + 1])), fxr = lv_right<T, N>(lm, unpk(NX[t + 1]));
-        const T fyl = lv_left<T, N>(lm, unpk(NY[t + 1])), fyr = lv_right<T, N>(lm, unpk(NY[t + 1]));
-        const v2f vx = VXr, vy = VYr;
-        const v2f dxx = xdiv<DM>(0.5f * ew_diff(VXr, vxl, vxr), k.dx, k.inv_dx, k.r_dx), dxy = xdiv<DM>(0.5f * ew_diff(VYr, vyl, vyr), k.dx, k.inv_dx, k.r_dx);
-        const v2f dyx = xdiv<DM>(0.5f * (VXp - VXm), k.dx, k.inv_dx, k.r_dx), dyy = xdiv<DM>(0.5f * (VYp - VYm), k.dx, k.inv_dx, k.r_dx);
-        const v2f f00 = Nc;
-        const v2f f0m = sel_neg(vy, Np, Nm);
-        const v2f fm0 = sel_neg(vx, east(Nc, fr1), west(fl1, Nc));
-        const v2f fmm = sel_neg(vy, sel_neg(vx, east(Np, fr2), west(fl2, Np)), sel_neg(vx, east(Nm, fr0), west(fl0, Nm)));
-        const v2f fx00 = NX[t + 1], fxm0 = sel_neg(vx, east(NX[t + 1], fxr), west(fxl, NX[t + 1])), fx0m = sel_neg(vy, NX[t + 2], NX[t]);
-        const v2f fy00 = NY[t + 1], fy0m = sel_neg(vy, NY[t + 2], NY[t]), fym0 = sel_neg(vx, east(NY[t + 1], fyr), west(fyl, NY[t + 1]));
-        v2f of, ofx, ofy;
-        cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
-        if (CLAMP) { of.x = tmin(tmax(of.x, 0.0f), 1.0f); of.y = tmin(tmax(of.y, 0.0f), 1.0f); }
-        const R OV = unpk(PLAIN ? of : sel2(fl[t], of, Fc[t + 2])), OX = unpk(PLAIN ? ofx : sel2(fl[t], ofx, GX[t + 1])), OY = unpk(PLAIN ? ofy : sel2(fl[t], ofy, GY[t + 1]));
-        if (lm.owner) {
-            if (SELF && lv_hot1<T, N>(OV)) {
-                bool hf = false, hn = false;
-#pragma unroll
-                for (int q = 0; q < N; ++q)
-                    if (hot1(OV.a[q])) { if (PLAIN || ((fl[t] >> q) & 1u)) hf = true; else hn = true; }
-                raise_hot(hot + 3, hf);
-                raise_hot(hot, hn);
-            }
-            lv_store<T, N>(out + idx<C, T>(g, c, i0, j), OV);
-            if (nw[t + 1]) {
-                lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), OX, nw[t + 1]);
-                lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), OY, nw[t + 1]);
-            }
-        }
-    }
+    cip_k34_pk_core<C, c, RT, DM, PLAIN, CLAMP>(g, k, lm, i0, j0, je, nw, fl, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, hot);
 }
 
 #ifndef FS_K34_PK
 #define FS_K34_PK 1        // f32 lanes of 2 cells: the packed body (0: the scalar body; A/B)
 #endif
-template <int C, int c, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T>
+template <int C, int c, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T, int HL = 1>
 __device__ __forceinline__ void cip_grad_advect_dispatch(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
                                                          T *out, T *gxo, T *gyo, const T *fn, const T *fc,
                                                          const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
 {
-    if constexpr (FS_K34_PK && N == 2 && sizeof(T) == 4) cip_grad_advect_pk_body<C, c, RT, DM, PLAIN, CLAMP>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
-    else cip_grad_advect_n_body<C, c, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    if constexpr (FS_K34_PK && N == 2 && sizeof(T) == 4) cip_grad_advect_pk_body<C, c, RT, DM, PLAIN, CLAMP, HL>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    else cip_grad_advect_n_body<C, c, N, RT, DM, PLAIN, CLAMP, T, HL>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
 }
 
 // blockIdx.y (or, channel groups innermost / compact lists, the block index >> 3) % C = the channel of this workgroup
-template <int C, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T>
+template <int C, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T, int HL = 1>
 __global__ __launch_bounds__(256) void k_cip_grad_advect_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                            T *out, T *gxo, T *gyo, const T *fn, const T *fc,
                                                            const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
 {
     const int yy = (nbx >= 0 && (nby & FS_CG_INNER)) ? ((int)blockIdx.x >> 3) : (int)blockIdx.y;
     const int ch = yy % C;
-    if (ch == 0) cip_grad_advect_dispatch<C, 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
-    else if (ch == 1) cip_grad_advect_dispatch<C, 1, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
-    else if (C == 3) cip_grad_advect_dispatch<C, C == 3 ? 2 : 0, N, RT, DM, PLAIN, CLAMP, T>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    if (ch == 0) cip_grad_advect_dispatch<C, 0, N, RT, DM, PLAIN, CLAMP, T, HL>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    else if (ch == 1) cip_grad_advect_dispatch<C, 1, N, RT, DM, PLAIN, CLAMP, T, HL>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
+    else if (C == 3) cip_grad_advect_dispatch<C, C == 3 ? 2 : 0, N, RT, DM, PLAIN, CLAMP, T, HL>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,15 +436,21 @@ __global__ __launch_bounds__(256) void k_cip_grad_advect_n(Grid g, Konst<T> k, i
 // (The quad form with one row per tile, fs_march.h cip_nonadv_quad_tile, requests 9 16-byte rows per output row: 36 B per cell for 12 B
 // of input; 2 cells x 4 rows: 18 B per cell.)
 // ------------------------------------------------------------------------------------------------
-template <int N, int RT, int DM, typename T>
+// WIDE (HL = 2): the lane next to the owner lanes on either side stores too - the launch that feeds the boundary tiles of fs_cip_step
+// (fs_k234.h), whose K3 + K4 look one lane sideways; neighbouring wave columns then store the same values into the same cells.
+template <int N, int RT, int DM, typename T, int HL = 1, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot, int clear3)
 {
     using R = LV<T, N>;
-    constexpr int HL = 1, L = N - 1;
+    constexpr int L = N - 1;
     if (clear3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) hot[3] = 0u;      // every not-wall cell of fn is rewritten (fs_device.h "hot" word [3])
     int wx, ty, cg;
     if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
-    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    if (WIDE) {
+        const int lane = threadIdx.x & 63, q = wx * (64 - 2 * HL) - HL + lane;
+        lm.owner = lane >= 1 && lane < 63 && q >= 0 && q < g.X / N;
+    }
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[RT];
     bool any = false;

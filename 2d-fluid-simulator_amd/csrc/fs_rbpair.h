@@ -94,6 +94,24 @@ __device__ __forceinline__ void lv_store_sel(T *dst, const LV<T, N> &v, unsigned
         if (sel & (1u << c)) dst[c] = v.a[c];
 }
 
+// the whole lane into row j, channel c of a C-channel field: wave-uniform row base + the lane offset (the addressing of lv_field; rows must be wave-uniform)
+template <int C, typename T, int N>
+__device__ __forceinline__ void lv_store_row(T *f, const Grid &g, int c, int i0, int j, const LV<T, N> &v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Q = typename LVec<T, N>::type;
+    Q q;
+    if constexpr (N == 4) { q.x = v.a[0]; q.y = v.a[1]; q.z = v.a[2]; q.w = v.a[3]; }
+    else { q.x = v.a[0]; q.y = v.a[1]; }
+    // (the empty asm keeps the zero-extension of the lane offset in the basic block of the store - usually the body of `if (owner)`: hipcc selects
+    //  the scalar-base form only when it sees the extension there; hoisted out, every store pays a 64-bit VALU add and a register pair)
+    asm volatile("" : "+v"(i0));
+    *reinterpret_cast<__attribute__((address_space(1))) Q *>((fs_gptr)uniform64((uint64_t)(f + ((size_t)j * C + c) * g.P)) + (unsigned)i0 * (unsigned)sizeof(T)) = q;
+#else
+    lv_store_sel<T, N>(f + ((size_t)j * C + c) * g.P + i0, v, (1u << N) - 1u);
+#endif
+}
+
 // overlapped-wave column mapping for lanes of N cells: HL halo lanes on each side (default 4 / N = 4 cells: the reach of four radius-1 stages)
 template <int N> struct LaneMapN { int i0; bool owner, at_lo, at_hi; };
 template <int N, int HL = 4 / N>

@@ -1,6 +1,7 @@
 // fs_transport.hip - C-ABI entry points of the transport kernels: K2' (upwind / KK update), K0, K2, K3, K4 and the fused K3+K4 pass of the CIP
 // solvers, K10 - K13 of the dye, K5 / K6 / the fused vorticity confinement.
 #include "fs_launch.h"
+#include "fs_k234.h"
 
 using namespace fs;
 
@@ -267,6 +268,69 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
     FS_REQUIRE(ctx->use_pairs, "the fused gradient+advection pass needs an even X (use the two-kernel form)");
     FS_ROWS();
     if (ctx->dtype != 0) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
+    return launch_k34<2, false>(ctx, "cip_grad_advect_rt", "cip_grad_advect_rt_bnd", dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, nullptr, full, row_begin, row_end);
+}
+
+static bool cip_step_three_parts(const fs_ctx *ctx)
+{
+    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23));
+    return ctx->mask_set && ctx->fuse_k2 && big && ctx->halo == 0 && ctx->dtype == 0 && ctx->use_pairs && !ctx->k34_n && !ctx->k34_rt && !ctx->h_act2.empty() &&
+           (ctx->tile_list_mask & XCD_ADVECT) && (ctx->xcd_mask & XCD_ADVECT);
+}
+int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
+{
+    FS_REQUIRE(ctx && ok, "null argument");
+    *ok = cip_step_three_parts(ctx) ? 1 : 0;
+    return FS_OK;
+}
+
+// K2 + K3 + K4 of the velocity (fs/solver.py:213-227) as ONE call: fs_cip_nonadv(fn <- fc, pc) followed by fs_cip_grad_advect(v_out, gx_out,
+// gy_out <- fn, fc, gxc, gyc) - with the one difference that the fluid cells of fn that nothing reads before the next kernel rewrites them
+// are NOT stored where the three-part launch below applies (large single-GPU f32 grids; fs_k234.h): K2 runs as a kernel of its own only over
+// the tiles within one tile of a boundary tile, the plain tiles evaluate it in registers on the way to K3 + K4, the boundary tiles run the
+// general K3 + K4 kernel on the same wave columns.  fs_cip_step_ok: the static conditions of that form (the kernel names of a profile say what ran).
+int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
+                const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(v_out, 2); FS_FIELD(gx_out, 2); FS_FIELD(gy_out, 2); FS_FIELD(fn, 2); FS_FIELD(fc, 2); FS_FIELD(pc, 1); FS_FIELD(gxc, 2); FS_FIELD(gyc, 2);
+    FS_REQUIRE(v_out != fn && v_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
+    FS_REQUIRE(ctx->use_pairs, "the fused gradient+advection pass needs an even X (use the two-kernel form)");
+    FS_ROWS();
+    if (ctx->dtype != 0) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
+    using T = float;
+    constexpr int RT = 4;
+    if (cip_step_three_parts(ctx) && !full && row_begin == 0 && row_end == ctx->rows) {
+        const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 1, 2, 1);      // plain tiles: one entry per tile, two waves each
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 2, XCD_ADVECT, 2, true, 2, 2, 1);      // boundary tiles: one wave per tile and component
+        const OvGrid ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);      // K2: the boundary tiles and the tiles above / below them
+        if (ogp.g.tiles && ogb.g.tiles && ogk.g.tiles) {
+            auto k = make_konst<T>(ctx, dt, dx, re);
+            const int dm = dm_all(ctx, k);
+            int rc = launch(ctx, "cip_step_band", [=] {
+                const OvGrid og = ogk;
+#define FS_K2B(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, RT, DM, T, 2, true>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, 0)
+                FS_DMA(dm, FS_K2B);
+            });
+            if (rc) return rc;
+            rc = launch(ctx, "cip_step", [=] {
+                const OvGrid og = ogp;
+#define FS_K234(DM) hipLaunchKernelGGL((k_cip_step_plain<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
+                FS_DMA(dm, FS_K234);
+            });
+            if (rc) return rc;
+            const int dmx = dm_dx(ctx, k);
+            return launch(ctx, "cip_step_bnd", [=] {
+                const OvGrid og = ogb;
+#define FS_K34B(DM) hipLaunchKernelGGL((k_cip_grad_advect_n<2, 2, RT, DM, false, false, T, 2>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)nullptr, v_out->hot, (const uint8_t *)ctx->d_bcmap, 0)
+                FS_DMX(dmx, FS_K34B);
+            });
+        }
+    }
+    int rc = fs_cip_nonadv(ctx, dt, dx, re, fn, fc, pc, row_begin, row_end);
+    if (rc) return rc;
     return launch_k34<2, false>(ctx, "cip_grad_advect_rt", "cip_grad_advect_rt_bnd", dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, nullptr, full, row_begin, row_end);
 }
 

@@ -642,6 +642,17 @@ class DeviceBase:
         self._run("cip_grad_advect", (dt, dx, v_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, 1 if full else 0),
                   reads=[(fn, 2), (fc, 2), (gxc, 1), (gyc, 1)], writes=[gx_out, gy_out], full_writes=[v_out])
 
+    def cip_step(self, dt, dx, re, v_out, gx_out, gy_out, fn, fc, pc, gxc, gyc, full=False):
+        """K2 + K3 + K4 of the velocity as one call (fs/solver.py:213-227; include/fs_hip.h fs_cip_step): on large single-GPU f32 grids the
+        post-K2 velocity of the all-fluid tiles stays in registers (csrc/fs_k234.h) - fn then holds it only where something reads it.
+        Slabs, and devices without the entry point: the two calls."""
+        if self.nranks > 1 or not getattr(self, "has_cip_step", False):
+            self.cip_nonadv(dt, dx, re, fn, fc, pc)
+            self.cip_grad_advect(dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, full=full)
+            return
+        self._run("cip_step", (dt, dx, re, v_out._h, gx_out._h, gy_out._h, fn._h, fc._h, pc._h, gxc._h, gyc._h, 1 if full else 0),
+                  reads=[(fc, 3), (pc, 3), (gxc, 1), (gyc, 1)], writes=[gx_out, gy_out, fn], full_writes=[v_out])
+
     def cip_grad_advect_dye(self, dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=False, full=False):
         """K3 + K4 of the dye in one pass (csrc/fs_k34n.h k_cip_grad_advect_n<3>); clamp01 folds clamp_field(dye, 0, 1) into the store."""
         self._run("cip_grad_advect_dye", (dt, dx, d_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, v._h, 1 if clamp01 else 0, 1 if full else 0),
@@ -856,6 +867,16 @@ class Device(DeviceBase):
         ok = ctypes.c_int()
         _lib.call("fs_dye_bc_limit_ok", self._ctx, ctypes.byref(ok))
         return bool(ok.value)
+
+    has_cip_step = True      # fs_cip_step exists (include/fs_hip.h)
+
+    @property
+    def cip_step_fused(self):
+        """Whole-grid fs_cip_step calls evaluate K2 in registers on the all-fluid tiles: the post-K2 buffer then holds that velocity only where
+        something reads it (csrc/fs_k234.h)."""
+        ok = ctypes.c_int()
+        _lib.call("fs_cip_step_ok", self._ctx, ctypes.byref(ok))
+        return bool(ok.value) and self.nranks == 1
 
     @property
     def jacobi_quad_ok(self):

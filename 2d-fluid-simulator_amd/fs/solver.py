@@ -105,7 +105,7 @@ class CipMacSolver(Solver):
     """Two-phase CIP solver: non-advection phase (pressure gradient + diffusion, with the gradient fields
     updated alongside), then CIP advection of value and gradients (fs/solver.py:165-332)."""
 
-    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None, fused_transport=None):
+    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None, fused_transport=None, fused_k2=None):
         super().__init__(boundary_condition)
         self.dt = dt
         self.dx = dx
@@ -127,6 +127,8 @@ class CipMacSolver(Solver):
         self._fused_transport = (bool(fused_transport) and self.resolution[0] % 2 == 0 and self._dev.dtype == np.float32
                                  and os.environ.get("FS_MARCH", "1") != "0")      # (f64: 256 VGPRs per tile - the two-kernel form)
         self._v_spare = self._dev.alloc(2) if self._fused_transport else None
+        # ... and K2 in the same call (fs_cip_step; FS_FUSE_K2=0 / fused_k2=False: K2 as its own launch everywhere)
+        self._fused_k2 = self._fused_transport and (os.environ.get("FS_FUSE_K2", "1") == "1" if fused_k2 is None else bool(fused_k2)) and hasattr(self._dev, "cip_step")
 
     def _flow_step(self):
         self._bc.set_velocity_boundary_condition(self.v.current)
@@ -155,6 +157,17 @@ class CipMacSolver(Solver):
     def _update_velocities(self, v, vx, vy, p):
         grads = (vx.current, vx.next, vy.current, vy.next)
         fused34 = self._fused_transport and not any(f.user_data for f in grads)
+        if fused34 and self._fused_k2:
+            # K2 + K3 + K4 as one call (include/fs_hip.h fs_cip_step): on large single-GPU grids the tiles that see nothing but fluid evaluate
+            # K2 in registers on the way (csrc/fs_k234.h) - v.next then holds the post-K2 velocity only where something reads it before the
+            # reference's own sequence overwrites it (every fluid cell: this step's vorticity confinement, or the next step's K2)
+            full = self._v_spare.static_id != v.current.static_id
+            self._dev.cip_step(self.dt, self.dx, self.re, self._v_spare, vx.next, vy.next, v.next, v.current, p.current, vx.current, vy.current, full=full)
+            self._v_spare.static_id = v.current.static_id
+            v.current, self._v_spare = self._v_spare, v.current
+            vx.swap()
+            vy.swap()
+            return
         self._non_advection_phase(v.next, v.current, p.current)
         if fused34:
             # one pass instead of K3 + swap + K4 + swap.  End state as in the reference: v.current = advected velocity with the
@@ -188,8 +201,8 @@ class CipMacSolver(Solver):
 class DyeCipMacSolver(CipMacSolver):
     """CipMacSolver + CIP-advected dye with its own gradient fields (fs/solver.py:335-401)."""
 
-    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None, fused_transport=None):
-        super().__init__(boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement, fused_transport)
+    def __init__(self, boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement=None, fused_transport=None, fused_k2=None):
+        super().__init__(boundary_condition, pressure_updater, dt, dx, re, vorticity_confinement, fused_transport, fused_k2)
         res = boundary_condition.get_resolution()
         self.dye = DoubleBuffer(res, 3, self._dev)
         self.dyex = DoubleBuffer(res, 3, self._dev)

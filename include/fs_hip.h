@@ -138,6 +138,15 @@ int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn
 int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_field *gx_out, fs_field *gy_out,
                        const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc,
                        int full, int row_begin, int row_end);
+/* CipMacSolver._update_velocities (fs/solver.py:213-227) as ONE call: _non_advection_phase (:229-240; fn <- fc, pc on the not-wall cells)
+ * followed by the fused pass above.  Same results in v_out / gx_out / gy_out and in every cell of fn that anything reads before it is
+ * rewritten.  On large single-GPU f32 grids the post-K2 velocity of the tiles that see nothing but fluid is evaluated in registers on
+ * the way (csrc/fs_k234.h) and NOT stored: those fluid cells of fn keep their old content - which the reference's own sequence overwrites
+ * (K2 of the next step, or this step's vorticity confinement) before reading it.  fs_cip_step_ok: whether whole-grid calls take that form
+ * (f32, one GPU, >= 8 M cells, FS_FUSE_K2 != 0); otherwise the call is exactly fs_cip_nonadv + fs_cip_grad_advect.                 */
+int fs_cip_step_ok(const fs_ctx *ctx, int *ok);
+int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
+                const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end);
 /* The same for the dye (C = 3, advected by the velocity field v of the finished flow step; fs/solver.py:378-401 _update_dye without its
  * first kernel): K3 (_non_advection_phase_grad, :242-261) + K4 (_cip_advect, :267-332), d_out = a third dye buffer the caller rotates.
  * clamp01 != 0 folds clamp_field(dye, 0, 1) (:46-49) into the store of the advected cells; full as above.  f32 only.                   */
