@@ -573,6 +573,19 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e == hipSuccess) e = hipMalloc(&c->d_acc, 2 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_sync, 16 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_sync, 0, 16 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) {
+        // how many workgroups of the merged limit + boundary kernels THIS device holds at once (their rare path meets at a grid barrier: every
+        // workgroup must be resident - a partitioned or smaller part holds fewer than a whole MI355X): occupancy x compute units, half of it
+        // left to whatever else is resident (the tail of the kernel before)
+        hipDeviceProp_t prop;
+        int bv = 0, bd = 0;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) e = dtype == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&bv, k_velocity_bc_limit<float>, 256, 0)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&bv, k_velocity_bc_limit<double>, 256, 0);
+        if (e == hipSuccess) e = dtype == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&bd, k_dye_bc_limit<float>, 256, 0)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&bd, k_dye_bc_limit<double>, 256, 0);
+        if (e == hipSuccess) c->barrier_wgs = std::min(bv, bd) * prop.multiProcessorCount / 2;
+    }
     c->nwx = (nx / 4 + 61) / 62;
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
@@ -580,6 +593,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = atoi(s) != 0;
+    if (const char *s = getenv("FS_K234_CELLS")) { const long long v = atoll(s); if (v >= 0) c->k234_cells = (size_t)v; }
     if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
     if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
     if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
@@ -957,8 +971,8 @@ int fs_velocity_bc_limit_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
     const int wgs = (ctx->ops_vel.lanes() + 255) / 256;
-    // every workgroup resident: the grid barrier of the rare path
-    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && ctx->d_bc_const && wgs >= 1 && wgs <= 1024 ? 1 : 0;
+    // every workgroup resident (the grid barrier of the rare path): the launch has max(wgs, <= 64) workgroups, the device holds barrier_wgs at once
+    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && ctx->d_bc_const && wgs >= 1 && std::max(wgs, 64) <= ctx->barrier_wgs ? 1 : 0;
     return FS_OK;
 }
 
@@ -1018,7 +1032,7 @@ int fs_dye_bc_limit_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
     const int wgs = (ctx->ops_dye.lanes() + 255) / 256;
-    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && ctx->d_bc_dye && wgs >= 1 && wgs <= 1024 ? 1 : 0;
+    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && ctx->d_bc_dye && wgs >= 1 && std::max(wgs, 64) <= ctx->barrier_wgs ? 1 : 0;
     return FS_OK;
 }
 
@@ -1109,7 +1123,28 @@ __global__ __launch_bounds__(256) static void k_box_valu(float *sink, float a, f
     if (s == 1.2345f) sink[0] = s;
 }
 
-int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd)
+// the same chains on PACKED operands (v2f: v_pk_mul_f32 / v_pk_add_f32, two IEEE f32 operations per lane and instruction): what the packed bodies
+// of the transport kernels issue.  (Round 3 read "half rate" from tools/valu_rate.hip - whose scalar baseline the SLP vectoriser had packed as
+// well; built with the library's flags, -fno-slp-vectorize, the scalar loop above stays scalar and the comparison is what it says.)
+__global__ __launch_bounds__(256) static void k_box_valu_pk(float *sink, float a, float b, int iters)
+{
+    v2f x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { x[u].x = a + (float)(threadIdx.x + u); x[u].y = b + (float)(threadIdx.x + 2 * u); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = x[u] * a;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = x[u] + b;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += x[u].x + x[u].y;
+    if (s == 1.2345f) sink[0] = s;
+}
+
+// packed != 0: the packed chains (wave-instructions per second and SIMD, each doing two operations per lane)
+static int box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd, int packed)
 {
     FS_REQUIRE(ctx && ginstr_per_simd, "null argument");
     FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "fs_box_valu_rate during graph capture / tape recording");
@@ -1126,7 +1161,10 @@ int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd)
     int reps = 1;
     for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
         (void)hipEventRecord(e0, ctx->stream);
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_box_valu, dim3(cus * 4), dim3(256), 0, ctx->stream, sink, 1.0000001f, 1e-9f, iters);
+        for (int r = 0; r < reps; ++r) {
+            if (packed) hipLaunchKernelGGL(k_box_valu_pk, dim3(cus * 4), dim3(256), 0, ctx->stream, sink, 1.0000001f, 1e-9f, iters);
+            else hipLaunchKernelGGL(k_box_valu, dim3(cus * 4), dim3(256), 0, ctx->stream, sink, 1.0000001f, 1e-9f, iters);
+        }
         (void)hipEventRecord(e1, ctx->stream);
         e = hipEventSynchronize(e1);
         float ms = 0.f;
@@ -1143,6 +1181,8 @@ int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd)
     if (e != hipSuccess) return hip_fail(e, "fs_box_valu_rate", __FILE__, __LINE__);
     return FS_OK;
 }
+int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd) { return box_valu_rate(ctx, budget_ms, ginstr_per_simd, 0); }
+int fs_box_valu_pk_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd) { return box_valu_rate(ctx, budget_ms, ginstr_per_simd, 1); }
 
 // ... and both at once: a float4 copy with 176 f32 multiplies / adds per 16 bytes on the way - 5.5 lane-operations per byte moved, the instruction
 // density of K3+K4 (131 M wave-instructions for 1.5 GB).  The pure stream and the pure ALU loop above measured alike on boxes whose real kernels

@@ -93,6 +93,7 @@ struct fs_ctx {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     double *d_acc = nullptr;  // 2 doubles (residual)
+    int barrier_wgs = 0;          // workgroups of 256 threads of those kernels this device keeps resident at once, with headroom (fs_create): the bound of their grids
     unsigned *d_sync = nullptr;   // k_velocity_bc_limit / k_dye_bc_limit: arrive / depart counters of the grid barrier of their rare path [0, 1] (zero between launches)
     double *d_partial = nullptr;   // per-block partial (sum, count) pairs of the residual reduction
     size_t partial_cap = 0;        // pairs
@@ -122,6 +123,7 @@ struct fs_ctx {
     int mac_rt = 0;            // env FS_MAC_RT: rows per tile (2 / 4) of K2' (upwind / KK update); 0: by grid size and precision
     int k34_n = 0;             // env FS_K34_N: cells per lane (2 / 4) of the fused K3 + K4 pass (fs_k34n.h); 0: by grid size (fs_api.hip launch_k34)
     int k34_rt = 0;            // env FS_K34_RT: rows per register tile (2 / 4) of that pass at 2 cells per lane; 0: by grid size
+    size_t k234_cells = (size_t)1 << 23;      // env FS_K234_CELLS: the smallest grid on which fs_cip_step takes its three-part form
     bool fuse_k2 = true;       // env FS_FUSE_K2=0: fs_cip_step as its two calls, K2 then the fused K3 + K4 pass (A/B; the same observable results)
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)

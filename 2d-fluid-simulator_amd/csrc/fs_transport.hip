@@ -273,7 +273,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
 
 static bool cip_step_three_parts(const fs_ctx *ctx)
 {
-    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23));
+    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ctx->k234_cells);
     return ctx->mask_set && ctx->fuse_k2 && big && ctx->halo == 0 && ctx->dtype == 0 && ctx->use_pairs && !ctx->k34_n && !ctx->k34_rt && !ctx->h_act2.empty() &&
            (ctx->tile_list_mask & XCD_ADVECT) && (ctx->xcd_mask & XCD_ADVECT);
 }

@@ -106,6 +106,7 @@ _PROTOS = {
     "fs_field_hot": [_c_vp, _P(_c_int)],
     "fs_box_rates": [_c_vp, _c_sz, _c_dbl, _P(_c_dbl), _P(_c_dbl)],
     "fs_box_valu_rate": [_c_vp, _c_dbl, _P(_c_dbl)],
+    "fs_box_valu_pk_rate": [_c_vp, _c_dbl, _P(_c_dbl)],
     "fs_box_mixed_rate": [_c_vp, _c_sz, _c_dbl, _P(_c_dbl)],
     "fs_prof_enable": [_c_vp, _c_int],
     "fs_prof_reset": [_c_vp],

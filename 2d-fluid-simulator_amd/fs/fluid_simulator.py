@@ -69,8 +69,10 @@ class FluidSimulator:
         """Deferred limit passes are for runs that never need them.  Once a velocity buffer's flag is up (a speed above 9.95 - or one component above 7.04 - was stored; it stays
         up) the pass runs on every step, and as its own full-grid launch it is three times faster than inside a boundary launch at res 4096:
         looked at between launch sequences - at the start of run() / capture_period() and every 256 eager steps (one 12-byte download)."""
-        self._since_hot_check = 0
         dev = self._dev
+        if getattr(dev, "capturing", False):
+            return            # (a user capture of step() in progress: the look is a download - it waits for the next eager step)
+        self._since_hot_check = 0
         if not getattr(dev, "limit_deferral", False):
             return
         s = self._solver

@@ -941,9 +941,11 @@ class Device(DeviceBase):
     def capture(self, fn):
         """Run fn() once in stream-capture mode and return a graph id replayable with replay()."""
         _lib.call("fs_graph_begin", self._ctx)
+        self.capturing = True
         try:
             fn()
         finally:
+            self.capturing = False
             gid = ctypes.c_int(-1)
             _lib.call("fs_graph_end", self._ctx, ctypes.byref(gid))
         return gid.value
@@ -984,6 +986,8 @@ class Device(DeviceBase):
             tape["id"] = None
 
     def field_hot(self, f):
+        if getattr(self, "capturing", False):      # (a download: not inside a capture - the caller asks again later)
+            return False
         h = ctypes.c_int()
         _lib.call("fs_field_hot", f._h, ctypes.byref(h))
         return bool(h.value)
@@ -999,6 +1003,12 @@ class Device(DeviceBase):
         issue-bound kernels see it (include/fs_hip.h fs_box_valu_rate)."""
         r = ctypes.c_double()
         _lib.call("fs_box_valu_rate", self._ctx, float(budget_ms), ctypes.byref(r))
+        return r.value
+
+    def box_valu_pk_rate(self, budget_ms=10.0):
+        """The same for PACKED f32 instructions (v_pk_mul_f32 / v_pk_add_f32, two operations per lane): what the packed transport kernels issue."""
+        r = ctypes.c_double()
+        _lib.call("fs_box_valu_pk_rate", self._ctx, float(budget_ms), ctypes.byref(r))
         return r.value
 
     def box_mixed_rate(self, nbytes, budget_ms=100.0):

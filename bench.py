@@ -288,6 +288,8 @@ def main():
         box = {"read_GBps": round(rd, 1), "copy_GBps": round(cp, 1), "buffer_MB": 268.4, "note": "float4 read / copy measured in this run on this GPU before the timed region"}
         if hasattr(dev, "box_valu_rate"):      # what one SIMD of this box issues per second: the issue-bound K3+K4 pass is priced against it (roofline.valu_issue)
             box["valu_ginstr_per_simd"] = round(dev.box_valu_rate(10.0), 3)
+        if hasattr(dev, "box_valu_pk_rate"):   # ... and packed f32 instructions (two operations per lane each): the same rate means twice the arithmetic
+            box["valu_pk_ginstr_per_simd"] = round(dev.box_valu_pk_rate(10.0), 3)
         if hasattr(dev, "box_mixed_rate"):     # stream + ALU at once, 100 ms: the two pure probes measured alike on boxes whose kernels differed by 5-9 %
             box["mixed_GBps"] = round(dev.box_mixed_rate(2 * 8192 * 4096 * 4, 100.0), 1)
     for _ in range(args.warmup):

@@ -319,6 +319,9 @@ int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps,
 /* ... and the rate at which one SIMD issues independent f32 multiplies / adds at 4 waves per SIMD, in 1e9 wave-instructions per second
  * (no memory traffic): what the issue-bound K3+K4 pass is priced against (bench.py roofline.valu_issue). */
 int fs_box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd);
+/* The same chains on packed operands (v_pk_mul_f32 / v_pk_add_f32: two f32 operations per lane and instruction) - what the packed bodies of
+ * the transport kernels (csrc/fs_k34n.h, fs_k234.h) issue.  Wave-instructions per second and SIMD. */
+int fs_box_valu_pk_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd);
 /* ... and a float4 copy with 176 f32 multiplies / adds per 16 bytes on the way (5.5 lane-operations per byte moved: the instruction density of the K3+K4 pass): memory system and SIMDs loaded
  * together, in GB/s of read + written bytes. */
 int fs_box_mixed_rate(fs_ctx *ctx, size_t bytes, double budget_ms, double *GBps);
