@@ -646,6 +646,7 @@ int fs_destroy(fs_ctx *ctx)
     if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->d_acc) hipFree(ctx->d_acc);
     if (ctx->d_sync) hipFree(ctx->d_sync);
+    for (hipEvent_t ev : ctx->span_ev) if (ev) hipEventDestroy(ev);
     if (ctx->d_bcmap) hipFree(ctx->d_bcmap);
     if (ctx->d_lazyflags) hipFree(ctx->d_lazyflags);
     if (ctx->d_pairlist) hipFree(ctx->d_pairlist);
@@ -1482,6 +1483,29 @@ int fs_prof_enable(fs_ctx *ctx, int on)
     FS_REQUIRE(ctx, "ctx is null");
     int rc = prof_drain(ctx); if (rc) return rc;
     ctx->prof_on = on != 0;
+    return FS_OK;
+}
+
+// one HIP-event pair around whatever the caller queues in between (bench.py: a whole ping-pong of sweeps - launch boundaries included,
+// SURVEY.md 8d's "bytes / event time averaged over the sweeps"); independent of the per-launch profile
+int fs_span_begin(fs_ctx *ctx)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_REQUIRE(!ctx->capturing && !ctx->tape_rec, "fs_span_begin during graph capture / tape recording");
+    FS_HIP(hipSetDevice(ctx->device));
+    if (!ctx->span_ev[0]) { FS_HIP(hipEventCreate(&ctx->span_ev[0])); FS_HIP(hipEventCreate(&ctx->span_ev[1])); }
+    FS_HIP(hipEventRecord(ctx->span_ev[0], ctx->stream));
+    return FS_OK;
+}
+int fs_span_end(fs_ctx *ctx, double *ms)
+{
+    FS_REQUIRE(ctx && ms, "null argument");
+    FS_REQUIRE(ctx->span_ev[0], "fs_span_end without fs_span_begin");
+    FS_HIP(hipEventRecord(ctx->span_ev[1], ctx->stream));
+    FS_HIP(hipEventSynchronize(ctx->span_ev[1]));
+    float f = 0.f;
+    FS_HIP(hipEventElapsedTime(&f, ctx->span_ev[0], ctx->span_ev[1]));
+    *ms = f;
     return FS_OK;
 }
 

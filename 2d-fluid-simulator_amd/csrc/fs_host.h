@@ -112,6 +112,7 @@ struct fs_ctx {
     std::vector<hipEvent_t> prof_pool;
     std::vector<int> prof_launches;
     std::vector<double> prof_ms;
+    hipEvent_t span_ev[2] = {nullptr, nullptr};      // fs_span_begin / fs_span_end
     // comm
     fs::Comm *comm = nullptr;
     std::set<fs_field *> fields;  // live fields, released with the context

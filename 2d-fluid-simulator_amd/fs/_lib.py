@@ -109,6 +109,8 @@ _PROTOS = {
     "fs_box_valu_pk_rate": [_c_vp, _c_dbl, _P(_c_dbl)],
     "fs_box_mixed_rate": [_c_vp, _c_sz, _c_dbl, _P(_c_dbl)],
     "fs_prof_enable": [_c_vp, _c_int],
+    "fs_span_begin": [_c_vp],
+    "fs_span_end": [_c_vp, _P(_c_dbl)],
     "fs_prof_reset": [_c_vp],
     "fs_prof_count": [_c_vp, _P(_c_int)],
     "fs_prof_get": [_c_vp, _c_int, ctypes.c_char_p, _c_int, _P(_c_int), _P(_c_dbl)],

@@ -1024,6 +1024,15 @@ class Device(DeviceBase):
     def profile_reset(self):
         _lib.call("fs_prof_reset", self._ctx)
 
+    def span_begin(self):
+        """One HIP-event pair around everything queued until span_end() (which waits and returns the milliseconds)."""
+        _lib.call("fs_span_begin", self._ctx)
+
+    def span_end(self):
+        ms = ctypes.c_double()
+        _lib.call("fs_span_end", self._ctx, ctypes.byref(ms))
+        return ms.value
+
     def profile_report(self):
         """{kernel name: (launches, total_ms)} accumulated since the last reset."""
         n = ctypes.c_int()

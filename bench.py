@@ -76,6 +76,10 @@ def algorithmic_bytes(mask, esize=4):
         # fluid cells; old gradients read and new gradients written on not-wall cells.  The intermediate gradients the reference's two
         # kernels exchange through HBM (16 B/cell written + read back 3x3) never leave the registers.
         "cip_grad_advect_rt": n + nw * (2 * e + 2 * e) + fl * 2 * e + nw * (4 * e + 4 * e),
+        # K2 + K3 + K4 of the velocity as one logical launch (fs_cip_step, csrc/fs_k234.h: the all-fluid tiles evaluate K2 in registers; "cip_step"
+        # + "cip_step_bnd" + "cip_step_band"): mask; v.current, p and the old gradients read, the advected velocity and the new gradients
+        # written - 52 B per not-wall cell.  The post-K2 velocity is no algorithmic byte any more: it reaches HBM only around the boundary tiles.
+        "cip_step": n + nw * (2 * e + e + 4 * e) + nw * (2 * e + 4 * e),
         # the same fusion for the dye (k_cip_grad_advect_n<3>): 3 channels + the advecting velocity on fluid cells
         "cip_grad_advect_dye": n + nw * (3 * e + 3 * e) + fl * (3 * e + 2 * e) + nw * (6 * e + 6 * e),
         "vort_calc": n + fl * (2 * e + 2 * e),                           # v -> w, |w|
@@ -102,12 +106,14 @@ def algorithmic_bytes(mask, esize=4):
 
 
 def merge_parts(rep):
-    """Kernels launched in two compact parts (the workgroups that see nothing but fluid, then the others: "<name>" + "<name>_bnd",
-    csrc/fs_core.hip tile_list) count as ONE launch of <name>."""
-    for name in [n for n in rep if n.endswith("_bnd") and n[:-4] in rep]:
-        (l0, m0), (_, m1) = rep[name[:-4]], rep[name]
-        rep[name[:-4]] = (l0, m0 + m1)
-        del rep[name]
+    """Kernels launched in compact parts (the workgroups that see nothing but fluid, then the others: "<name>" + "<name>_bnd", csrc/fs_core.hip
+    tile_list; fs_cip_step also "<name>_band": K2 over the rows its boundary tiles read) count as ONE launch of <name>."""
+    for suffix in ("_bnd", "_band"):
+        for name in [n for n in rep if n.endswith(suffix) and n[:-len(suffix)] in rep]:
+            base = name[:-len(suffix)]
+            (l0, m0), (_, m1) = rep[base], rep[name]
+            rep[base] = (l0, m0 + m1)
+            del rep[name]
     return rep
 
 
@@ -406,11 +412,22 @@ def main():
     residual = {"rms": float(np.sqrt(r_sum / max(r_cnt, 1.0))), "cells": int(r_cnt)}
     abytes, counts = algorithmic_bytes(mask, esize)
     # HBM bytes per launch from rocprofv3 PMC passes of this same workload (tools/profile.sh -> profiles/*.json), if present
-    pmc_traffic, traffic_source = {}, None
+    pmc_traffic, pmc_valu, traffic_source = {}, {}, None
     pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_file) and (res, args.bc, args.scheme, args.dye, args.dtype) == (4096, 5, "cip", False, "f32") and world == 1:
-        pmc_traffic = json.load(open(pmc_file)).get("bytes_per_launch", {})
-        traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this workload (tools/profile.sh), NOT measured in this run"
+        # counters of ANOTHER run of this workload: quoted only when they were taken on the very library this process loaded (tools/profile.sh stamps
+        # the file with the library's sha256); a kernel edited since then gives `traffic: null`, not a number that no longer belongs to it
+        import hashlib
+        pm = json.load(open(pmc_file))
+        lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+        if pm.get("lib_sha256") == lib_sha:
+            pmc_traffic = pm.get("bytes_per_launch", {})
+            pmc_valu = pm.get("valu_wave_insts_per_launch", {})
+            traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this workload on this build of libfs_hip.so (sha256 " + lib_sha[:16] +
+                              ", tools/profile.sh), NOT measured in this run")
+        else:
+            traffic_source = ("stale: profiles/pmc_traffic.json was taken on another build of libfs_hip.so (" + str(pm.get("lib_sha256"))[:16] + " != " + lib_sha[:16] +
+                              "); re-run tools/profile.sh")
     merge_parts(rep)
     frac_rows = dev.nyl / dev.ny
     kernels = {}
@@ -474,14 +491,28 @@ def main():
                     dev.jacobi_quad_lazy(pa, pb, src)
         rj = merge_parts(dev.profile_report())
         dev.profile(False)
+        # SURVEY.md 8d's definition - bytes / HIP-event time averaged over >= 200 consecutive sweeps: ONE event pair around the whole ping-pong
+        # (launch boundaries between dependent sweeps included, no per-launch event records in between); the per-launch brackets above stay
+        # next to it as `per_launch_*`
+        span = {}
+        if hasattr(dev, "span_begin"):
+            for name, fn in (("jacobi_sweep", lambda a, b: dev.jacobi_sweep(dt, dx, a, b, v)), ("jacobi_sweep_src", lambda a, b: dev.jacobi_sweep_src(a, b, src))):
+                fn(pb, pa); fn(pa, pb)
+                dev.span_begin()
+                for _ in range(args.sweeps // 2):
+                    fn(pb, pa); fn(pa, pb)
+                span[name] = dev.span_end() / (2 * (args.sweeps // 2)) * 1e-3        # seconds per sweep
 
         def leg(name, label):
             n_, ms_ = rj[name]
-            avg_s = max(dev.allgather_scalars(ms_ / n_ * 1e-3))     # slowest slab
+            per_launch_s = max(dev.allgather_scalars(ms_ / n_ * 1e-3))     # slowest slab
+            avg_s = max(dev.allgather_scalars(span[name])) if name in span else per_launch_s
             slab_bytes = abytes[name] * frac_rows                     # PER DEVICE: this slab's share of the grid against ONE GPU's peak
             gbs = slab_bytes / avg_s / 1e9
             return {"kernel": label, "sweeps": n_, "avg_us": round(avg_s * 1e6, 2), "alg_MB": round(slab_bytes / 1e6, 2),
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "timing": "one HIP-event pair around the whole ping-pong of sweeps (span / sweeps)" if name in span else "mean of per-launch HIP-event brackets",
+                    "per_launch_avg_us": round(per_launch_s * 1e6, 2), "per_launch_frac": round(slab_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
                     "frac_of_box_copy": round(gbs / box["copy_GBps"], 4) if box else None,
                     "per": "device" if world > 1 else "grid", "traffic": pmc_traffic.get(name)}
         # The graded kernel first: the literal sweep that reads v like the reference (S = 8 B of source per cell).  Then the two build-side
@@ -542,9 +573,9 @@ def main():
     }
     if dominant:
         kd = kernels[dominant]
-        if dominant == "cip_grad_advect_rt":
-            # what the reference's two launches (K3: 49 B/cell, K4: 49 B/cell) would have moved for the same result
-            unfused = (abytes["cip_nonadv_grad"] + abytes["cip_advect"]) * frac_rows
+        if dominant in ("cip_grad_advect_rt", "cip_step"):
+            # what the reference's launches (K3: 49 B/cell, K4: 49 B/cell; cip_step: + K2's 21) would have moved for the same result
+            unfused = (abytes["cip_nonadv_grad"] + abytes["cip_advect"] + (abytes["cip_nonadv"] if dominant == "cip_step" else 0)) * frac_rows
             kd["unfused_equiv_MB"] = round(unfused / 1e6, 2)
             kd["unfused_equiv_frac"] = round(unfused / (kd["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         if dominant == "jacobi_pair_lazy":
@@ -560,19 +591,21 @@ def main():
                 "two Jacobi sweeps (and both pressure boundary passes) per launch, the first sweep's rows in registers: `frac` counts what "
                 "ONE pass has to move (p in, source pair in, p out); the reference's 2 x (K7 + sweep) move twice that"
                 if dominant == "jacobi_pair_lazy" else
-                "fused gradient-update + advection pass: `frac` counts the bytes the fused kernel has to move "
-                "(mask 1 + 32 read + 24 written = 57 B per fluid cell); the reference's two kernels move 98 B per fluid cell for the same result")
+                ("K2 + K3 + K4 of the velocity as one logical launch (three parts, csrc/fs_k234.h): `frac` counts the bytes the step has to move through "
+                 "them (mask 1 + 28 read + 24 written = 53 B per fluid cell); the reference's three kernels move 119 B per fluid cell for the same result"
+                 if dominant == "cip_step" else
+                 "fused gradient-update + advection pass: `frac` counts the bytes the fused kernel has to move "
+                 "(mask 1 + 32 read + 24 written = 57 B per fluid cell); the reference's two kernels move 98 B per fluid cell for the same result"))
             out["roofline"]["unfused_equiv_frac"] = kd["unfused_equiv_frac"]
-        if dominant == "cip_grad_advect_rt" and pmc_traffic and box and box.get("valu_ginstr_per_simd"):
-            # what actually bounds this kernel: its plain part is issue-stalled 60 % of the wave time.  SQ_INSTS_VALU of one launch on the headline
-            # grid (plain + boundary part: 103.25 M + 27.55 M wave-instructions, profiles/r4_sq_wave_cycles.txt) against what one SIMD of THIS box
-            # issues per second (box.valu_ginstr_per_simd, measured in this run): the time the launch needs for issuing alone
-            winst = 130.8e6
+        if dominant in pmc_valu and box and box.get("valu_ginstr_per_simd"):
+            # how much of the kernel's time the issue of its VALU instructions alone accounts for: SQ_INSTS_VALU of one launch of this workload on
+            # this build (profiles/pmc_traffic.json, stamped) / 1024 SIMDs / what one SIMD of THIS box issues per second (measured in this run;
+            # packed f32 instructions issue at the same rate, box.valu_pk_ginstr_per_simd)
+            winst = float(pmc_valu[dominant])
             issue_us = winst / 1024.0 / (box["valu_ginstr_per_simd"] * 1e9) * 1e6
             out["roofline"]["valu_issue"] = {"wave_insts_per_launch": winst, "per_simd": round(winst / 1024.0), "box_ginstr_per_simd": box["valu_ginstr_per_simd"],
                                              "issue_us": round(issue_us, 1), "frac_of_kernel_time": round(issue_us / kd["avg_us"], 3),
-                                             "note": "f32 VALU wave-instructions of one launch (PMC, profiles/r4_sq_wave_cycles.txt) / 1024 SIMDs / the box's measured issue rate: "
-                                                     "the kernel is bound by instruction issue (bit-exact CIP arithmetic without FMA contraction), not by HBM"}
+                                             "note": "VALU wave-instructions of one launch (PMC, stamped file) / 1024 SIMDs / the box's measured issue rate"}
     if jac:
         out["poisson_jacobi_sweep"] = jac
     out["kernels"] = kernels

@@ -328,6 +328,10 @@ int fs_box_mixed_rate(fs_ctx *ctx, size_t bytes, double budget_ms, double *GBps)
 
 /* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) --------------- */
 int fs_prof_enable(fs_ctx *ctx, int on);          /* record an event pair around every launch      */
+/* One HIP-event pair on the context's stream around whatever is queued between the two calls (launch boundaries included); fs_span_end waits
+ * for it and returns the milliseconds.  Independent of the per-launch profile. */
+int fs_span_begin(fs_ctx *ctx);
+int fs_span_end(fs_ctx *ctx, double *ms);
 int fs_prof_reset(fs_ctx *ctx);
 int fs_prof_count(fs_ctx *ctx, int *n);           /* number of distinct kernels seen (syncs)       */
 int fs_prof_get(fs_ctx *ctx, int idx, char *name, int name_cap, int *launches, double *total_ms);

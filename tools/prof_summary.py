@@ -22,9 +22,9 @@ for sub in ("pmc_fetch", "pmc_write"):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             full[short(r["Kernel_Name"])][r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # kernels launched in two compact parts per logical launch (workgroups that see nothing but fluid / the others: two instantiations)
-SPLIT = {"k_cip_grad_advect_rt", "k_cip_grad_advect_dye", "k_rbsor_pair", "k_jacobi_quad"}
+SPLIT = {"k_cip_grad_advect_dye", "k_rbsor_pair", "k_jacobi_quad"} | ({"k_cip_grad_advect_rt"} if "k_cip_step_plain" not in stats else set())
 import json
-traffic = {}
+traffic, by_short = {}, {}
 NAMES = {"k_rbsor_pair": "rbsor_pair", "k_jacobi_quad": "jacobi_quad_lazy", "k_cip_grad_advect_dye": "cip_grad_advect_dye", "k_mac_update_n": "mac_update_kk",
          "k_cip_grad_advect_rt": "cip_grad_advect_rt", "k_cip_advect_quad": "cip_advect", "k_rbsor_iter_n": "rbsor_iteration", "k_cip_nonadv_grad_quad": "cip_nonadv_grad",
          "k_cip_nonadv_n": "cip_nonadv", "k_vort_n": "vort_confine", "k_limit": "limit_field", "k_limit_quad": "limit_field",
@@ -44,8 +44,10 @@ for k, (calls, tot) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     wr_mb = None if wr is None else wr * 1024 / 1e6
     hr = None if hit is None or miss is None or hit + miss == 0 else 100 * hit / (hit + miss)
     bw = None if fe_mb is None or wr_mb is None else (fe_mb + wr_mb) * 1e6 / (avg * 1e-6) / 1e9
-    if fe_mb is not None and wr_mb is not None and k in NAMES:
-        traffic[NAMES[k]] = int((fe_mb + wr_mb) * 1e6)
+    if fe_mb is not None and wr_mb is not None:
+        by_short[k] = int((fe_mb + wr_mb) * 1e6)
+        if k in NAMES:
+            traffic[NAMES[k]] = by_short[k]
     f = lambda x, w, p=1: (f"{x:{w}.{p}f}" if x is not None else " " * (w - 1) + "-")
     print(f"{k:28s} {calls:6d} {avg:9.2f} {f(fe_mb,13)} {f(wr_mb,9)} {f(hr,7)} {f(bw,9,0)}")
 
@@ -61,6 +63,26 @@ for form, key in (("V", "jacobi_sweep"), ("SRC", "jacobi_sweep_src")):
     wr = [v for n, fo, v in rows if n == "WRITE_SIZE" and fo == form]
     if fe and wr:
         traffic[key] = int((2 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024)
+# fs_cip_step = three kernels per logical launch (csrc/fs_k234.h): K2 over the boundary tiles' rows, the all-fluid tiles, the boundary tiles
+parts3 = ("k_cip_step_plain", "k_cip_grad_advect_rt", "k_cip_nonadv_n")
+if all(k in by_short for k in parts3):
+    traffic["cip_step"] = sum(by_short[k] for k in parts3)
+    traffic["cip_step_parts"] = {k: by_short[k] for k in parts3}
+    traffic.pop("cip_grad_advect_rt", None); traffic.pop("cip_nonadv", None)
+# VALU wave-instructions per launch (SQ_INSTS_VALU pass), per kernel and for the logical launches
+valu = collections.defaultdict(list)
+for f in glob.glob(os.path.join(out, "pmc_valu", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "SQ_INSTS_VALU":
+            valu[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+valu_per_launch = {k: sum(v) / len(v) for k, v in valu.items() if v}
+if all(k in valu_per_launch for k in parts3):
+    valu_per_launch["cip_step"] = sum(valu_per_launch[k] for k in parts3)
+# the stamp: these numbers belong to ONE build of the library - bench.py quotes them only when the library it loaded has this hash
+import hashlib
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2d-fluid-simulator_amd", "csrc", "libfs_hip.so")
+sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
 json.dump({"note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from rocprofv3 --pmc passes (gfx950 FETCH_SIZE correction x2), "
-                   "workload bc5 res4096 cip+vc, see tools/profile.sh", "bytes_per_launch": traffic},
+                   "workload bc5 res4096 cip+vc, see tools/profile.sh; valu_wave_insts_per_launch = SQ_INSTS_VALU of the same workload",
+           "lib_sha256": sha, "bytes_per_launch": traffic, "valu_wave_insts_per_launch": {k: int(v) for k, v in valu_per_launch.items()}},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (gpurun -- 'bash tools/profile.sh <tag>'): rocprofv3 kernel-trace stats + PMC passes for bench.py.
 # Outputs land in gpurun_out/prof_<tag>/; copy the summaries you want judged into profiles/.
 set -u
-TAG=${1:-r3}
+TAG=${1:-r5}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -10,6 +10,7 @@ ARGS="bench.py --steps 20 --warmup 10 --no-cpu --no-graph --sweeps 40"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python3 $ARGS > /dev/null 2> $OUT/pmc_write.err
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_valu -o p -- python3 $ARGS > /dev/null 2> $OUT/pmc_valu.err
 find $OUT -name "*.csv" | head -20
 python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
