@@ -399,6 +399,22 @@ int fs_halo_exchange_begin(fs_ctx *ctx, fs_field *const *fields, int nfields, in
 int fs_halo_exchange_begin_partial(fs_ctx *ctx, fs_field *const *fields, const int *valid_rows, int nfields, int depth)
 { return begin(ctx, fields, valid_rows, nfields, depth, false); }
 
+// Where the exchanges of this context run from now on: 0 - in line on the compute stream (the default), 1 - on the communication stream (what
+// lets them overlap with kernels; FS_OVERLAP=1 sets it at fs_comm_init).  Both give the same bits.  bench.py times both on the first
+// steps of an N > 1 run and keeps the faster.  Not while an exchange is in flight or a tape is being recorded.
+int fs_comm_set_overlap(fs_ctx *ctx, int on)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    Comm *cm = ctx->comm;
+    if (!cm) { set_error("fs_comm_set_overlap without fs_comm_init"); return FS_ERR_COMM; }
+    FS_REQUIRE(!cm->in_flight && !ctx->tape_rec && !ctx->capturing, "fs_comm_set_overlap while an exchange is in flight / a tape is being recorded");
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    FS_HIP(hipStreamSynchronize(cm->stream));
+    cm->own_stream = on != 0;
+    cm->marked = false;
+    return FS_OK;
+}
+
 // Optional, before begin(): fix the point of the compute stream the exchange depends on NOW, so that kernels launched between
 // mark() and begin() (the interior rows) are already running while the host is still issuing the exchange.
 int fs_halo_exchange_mark(fs_ctx *ctx)

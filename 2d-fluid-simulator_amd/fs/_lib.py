@@ -91,6 +91,7 @@ _PROTOS = {
     "fs_halo_exchange_begin": [_c_vp, _P(_c_vp), _c_int, _c_int],
     "fs_halo_exchange_begin_partial": [_c_vp, _P(_c_vp), _P(_c_int), _c_int, _c_int],
     "fs_halo_exchange_wait": [_c_vp],
+    "fs_comm_set_overlap": [_c_vp, _c_int],
     "fs_halo_exchange_mark": [_c_vp],
     "fs_comm_loopback": [_c_vp, _c_int],
     "fs_allreduce_sum": [_c_vp, _P(_c_dbl), _c_int],

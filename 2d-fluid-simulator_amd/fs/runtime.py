@@ -16,6 +16,7 @@ numpy/gloo stand-in to check the slab logic without a GPU); `Device` binds it to
 import ctypes
 import itertools
 import os
+import time
 import weakref
 
 import numpy as np
@@ -251,6 +252,16 @@ class DeviceBase:
     def exchange_wait(self):
         self._p_exchange_wait()
 
+    def set_overlap(self, on):
+        """Exchanges behind the interior rows of the kernel that needs them, on the communication stream (True), or in line on the compute
+        stream (False).  Same bits either way; every rank must choose the same (bench.py decides from max-over-ranks timings).  Tapes recorded
+        before the switch belong to the old setting."""
+        self.overlap = self.overlap_stream = bool(on) and self.nranks > 1
+        self._p_set_overlap(self.overlap_stream)
+
+    def _p_set_overlap(self, on):                   # backends without a communication stream: the flags above are all there is
+        pass
+
     def _p_exchange_begin(self, handles, depth):    # backends without an asynchronous primitive: blocking
         self._p_exchange_many(handles, depth)
 
@@ -446,6 +457,45 @@ class DeviceBase:
         finally:
             self._oplog = None
             self.overlap = saved_overlap
+
+    def choose_exchange_mode(self, step_fn, record_tries=20, trial_steps=120, margin=0.02):
+        """N > 1: record the period of step_fn() and replay it for ~trial_steps steps with the exchanges in line on the compute stream, then on
+        the communication stream; keep the faster (max-over-ranks time; the communication stream must win by more than `margin`) and return
+        (tape of the chosen mode or None, report).  Collective: every rank times both modes and sees the same max-over-ranks numbers, so every
+        rank chooses alike.  Same bits in both modes; the caller counts the steps through step_fn, the replayed trial steps are in the report."""
+        trial, tapes, last, replayed = {}, {}, None, 0
+        for mode in (False, True):
+            self.set_overlap(mode)
+            tp = self.tape_period(step_fn, nsteps=2, tries=record_tries)
+            if tp is None:
+                continue
+            reps = max(1, trial_steps // tp["nsteps"])
+            sync = getattr(self, "sync", lambda: None)
+            sync()
+            self._p_max_over_ranks([0.0])               # every rank has arrived
+            t0 = time.perf_counter()
+            self.replay_tape(tp, reps)
+            sync()
+            el = float(self._p_max_over_ranks([time.perf_counter() - t0])[0])
+            replayed += reps * tp["nsteps"]
+            trial[mode] = el / (reps * tp["nsteps"])
+            tapes[mode], last = tp, mode
+        if not trial:
+            self.set_overlap(False)
+            return None, {"chosen": "in line (compute stream)", "replayed_steps": 0, "note": "no steady period found in either mode"}
+        chosen = True in trial and (False not in trial or trial[True] < (1.0 - margin) * trial[False])
+        report = {"in_line_us_per_step": round(trial[False] * 1e6, 2) if False in trial else None,
+                  "overlapped_us_per_step": round(trial[True] * 1e6, 2) if True in trial else None,
+                  "trial_steps_per_mode": trial_steps, "replayed_steps": replayed,
+                  "chosen": "overlapped (communication stream)" if chosen else "in line (compute stream)",
+                  "rule": f"max-over-ranks time of the replayed period in each mode; the communication stream is taken when it wins by more than {margin:.0%}"}
+        for mode, tp in tapes.items():
+            if mode != chosen or chosen != last:
+                self.free_tape(tp)
+        if chosen == last:
+            return tapes[chosen], report
+        self.set_overlap(chosen)        # the other mode was recorded last: back, and the period once more (a tape belongs to the setting it was recorded under)
+        return self.tape_period(step_fn, nsteps=2, tries=record_tries), report
 
     @staticmethod
     def hoist_exchanges(log):
@@ -786,6 +836,7 @@ class Device(DeviceBase):
         self._ctx = ctx
         self._graphs = []
         if nranks > 1 or (os.environ.get("FS_TEST_COMM") == "1" and bcast is not None):   # FS_TEST_COMM: 1-rank communicator (debug)
+            self._has_comm = True
             uid = None
             if rank == 0:
                 buf = ctypes.create_string_buffer(128)
@@ -902,6 +953,10 @@ class Device(DeviceBase):
 
     def _p_exchange_mark(self):
         _lib.call("fs_halo_exchange_mark", self._ctx)
+
+    def _p_set_overlap(self, on):
+        if getattr(self, "_has_comm", False):
+            _lib.call("fs_comm_set_overlap", self._ctx, 1 if on else 0)
 
     def _p_max_over_ranks(self, values):
         if self.nranks == 1:

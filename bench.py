@@ -302,10 +302,19 @@ def main():
         sim.step()
     graph = tape = glong = None
     launch = "eager (python per step)"
-    settle = 40                        # untimed steps reserved for finding / capturing the replayable period; what the search does not
-    later = 0                          # use is stepped AFTER the timed region, so every mode and every N takes the same total
+    # Untimed steps reserved for finding / capturing the replayable period and - N > 1 - for choosing the exchange mode: what a run does not
+    # use of the budget is stepped AFTER the timed region, so every mode and every N takes the same total (state_checksum is comparable).
+    #   N > 1, FS_OVERLAP unset: the exchanges of a slab step can run in line on the compute stream or on the communication stream behind the
+    #   interior rows of the kernel that needs them - same bits, and which one is faster depends on the links (in loop-back the in-line form wins
+    #   by 15 %; on xGMI a transfer is ~40 us of a ~100 us step).  So the run measures: the period is recorded and replayed for TRIAL steps in
+    #   each mode, the max-over-ranks times decide (every rank sees the same numbers), a tie within 2 % keeps the simpler in-line form, and the
+    #   tape of the chosen mode is the one the timed region replays.  Both timings go into exchange_model.
+    SETTLE, TRIAL = 40, 120
+    settle = 3 * SETTLE + 2 * TRIAL
+    later = 0
+    exchange_trial = None
     if world == 1 and not args.force_dist and not args.no_graph:
-        done = sim.capture_period(budget=settle)       # one period of the buffer rotation (2 or 6 steps) as a hipGraph
+        done = sim.capture_period(budget=SETTLE)       # one period of the buffer rotation (2 or 6 steps) as a hipGraph
         later = settle - done
         if sim._graph is not None:
             graph, gperiod = sim._graph[1], sim._graph[2]
@@ -317,7 +326,15 @@ def main():
         def counted():
             sim.step()
             done[0] += 1
-        tape = dev.tape_period(counted, nsteps=2, tries=settle // 2)      # returns AT the start of a period: replay must follow directly
+
+        def record():
+            return dev.tape_period(counted, nsteps=2, tries=SETTLE // 2)      # returns AT the start of a period: replay must follow directly
+        auto = "FS_OVERLAP" not in os.environ and hasattr(dev, "set_overlap") and world > 1
+        if auto:
+            tape, exchange_trial = dev.choose_exchange_mode(counted, record_tries=SETTLE // 2, trial_steps=TRIAL)
+            done[0] += exchange_trial["replayed_steps"]
+        else:
+            tape = record()
         later = settle - done[0]
         if tape is not None:
             launch = f"tape replay of {tape['nsteps']}-step periods ({len(tape['ops'])} operations, C++ loop)"
@@ -459,7 +476,8 @@ def main():
             "compute_us_per_step": round(sum(v["avg_us"] * v["launches_per_step"] for v in compute.values()), 2),
             "longest_kernel": longest, "longest_kernel_us": compute[longest]["avg_us"] if longest else None,
             "coverable_us_per_step": round(min(ex["avg_us"], compute[longest]["avg_us"]) * ex["launches_per_step"], 2) if longest else 0.0,
-            "overlap": "on (FS_OVERLAP=1)" if dev.overlap_stream else "off (in line on the compute stream)",
+            "overlap": "on (communication stream)" if dev.overlap_stream else "off (in line on the compute stream)",
+            "trial": exchange_trial,
             "reading": "an exchange on the communication stream can hide at most min(chain, longest kernel) per exchange, and costs two more strip "
                        "launches and three stream hand-offs (~8 us each, DESIGN.md 6): worth it when coverable_us_per_step exceeds ~25 us x exchanges_per_step"}
 
@@ -495,7 +513,7 @@ def main():
         # (launch boundaries between dependent sweeps included, no per-launch event records in between); the per-launch brackets above stay
         # next to it as `per_launch_*`
         span = {}
-        if hasattr(dev, "span_begin"):
+        if hasattr(dev, "span_begin") and world == 1:      # (slabs: the ghost-row exchanges between sweeps would be inside the span - the per-launch brackets there)
             for name, fn in (("jacobi_sweep", lambda a, b: dev.jacobi_sweep(dt, dx, a, b, v)), ("jacobi_sweep_src", lambda a, b: dev.jacobi_sweep_src(a, b, src))):
                 fn(pb, pa); fn(pa, pb)
                 dev.span_begin()
@@ -564,6 +582,7 @@ def main():
         "state_checksum": checksum,
         "poisson_residual": residual,
         "exchange_model": exchange_model,
+        "exchange_mode_trial": exchange_trial,
         "halo_exchanges_per_step": None if world == 1 else {
             "grouped_launches": round(dev.n_exchanges / max(total_steps, 1), 2),
             "fields": round(dev.n_exchanged_fields / max(total_steps, 1), 2),

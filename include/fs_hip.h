@@ -286,6 +286,9 @@ int fs_halo_exchange_begin_partial(fs_ctx *ctx, fs_field *const *fields, const i
 int fs_halo_exchange_wait(fs_ctx *ctx);
 /* Optional, before begin(): the exchange will depend on the compute stream as of NOW - kernels launched between mark() and
  * begin() (same restrictions as above) are already running while the host still issues the exchange.                     */
+/* Exchanges in line on the compute stream (0, default) or on the communication stream (1: overlappable; FS_OVERLAP=1 at fs_comm_init).  Same
+ * bits either way; a tape recorded under one setting is replayed under it. */
+int fs_comm_set_overlap(fs_ctx *ctx, int on);
 int fs_halo_exchange_mark(fs_ctx *ctx);
 /* Loop-back self-test on a 1-rank communicator: the rank is its own lower and upper neighbour, so afterwards
  * lower ghost rows == first owned rows and upper ghost rows == last owned rows (single-GPU check of the RCCL leg).

@@ -65,6 +65,10 @@ def test_bench_as_n_ranks_matches_single_rank(world, halo, single):
     assert d["halo_exchanges_per_step"]["grouped_launches"] > 0
     assert d["roofline"]["frac"] > 0 and d["poisson_jacobi_sweep"]["frac"] > 0
     assert "cpu_baseline" not in d and single["value"] > 0
+    # the run timed its period with the exchanges in line and on the communication stream and kept one of the two (same bits: the checksum above)
+    tr = d["exchange_mode_trial"]
+    assert tr and tr["in_line_us_per_step"] > 0 and tr["overlapped_us_per_step"] > 0 and tr["chosen"].split()[0] in ("in", "overlapped"), tr
+    assert single["exchange_mode_trial"] is None
 
 
 def test_bench_gpus_2_as_one_command(single):

@@ -38,6 +38,7 @@ def _device_cls():
                 os.dup2(saved, 1)
                 os.close(saved)
             _lib.call("fs_comm_loopback", ctx, 1)
+            self._has_comm = True
 
         def _p_max_over_ranks(self, values):
             return list(values)
@@ -110,3 +111,40 @@ def test_tape_replay_equals_eager(res, halo, scheme, updater, hip_lib):
     for k in eager:
         assert np.array_equal(taped[k], eager[k], equal_nan=True), (k, steps, nops, period)
     assert float(np.nanmax(np.abs(eager["p"]))) > 0
+
+
+def test_the_run_chooses_its_exchange_mode(hip_lib):
+    """bench.py's N > 1 start (DeviceBase.choose_exchange_mode): the period is recorded and replayed in line and on the communication stream,
+    the faster mode stays - in loop-back, where the RCCL kernel competes with the compute kernels for the same CUs, that is the in-line form -
+    and the state afterwards is the state of eager stepping through the same number of steps."""
+    import fs
+    from fs.boundary_condition import BoundaryCondition, create_scene_arrays
+    res, halo = 1024, 16
+    const, mask, _ = create_scene_arrays(5, res)
+    dt, dx = 0.05 / res, 1.0 / res
+
+    def build():
+        dev = _device_cls()(mask.shape[0], mask.shape[1], halo, False)
+        bc = BoundaryCondition(const, mask, device=dev)
+        solver = fs.CipMacSolver(bc, fs.RedBlackSorPressureUpdater(bc, dt, dx, 1.3, 2), dt, dx, 1e6, fs.VorticityConfinement(bc, dt, dx, 5.0))
+        return dev, solver
+    dev, solver = build()
+    done = [0]
+
+    def counted():
+        solver.update()
+        done[0] += 1
+    tape, rep = dev.choose_exchange_mode(counted, record_tries=20, trial_steps=48)
+    assert tape is not None and rep["in_line_us_per_step"] and rep["overlapped_us_per_step"], rep
+    assert rep["chosen"].startswith("in line"), rep          # (loop-back: measured 119 against 139 us per step at the headline size)
+    assert not dev.overlap and not dev.overlap_stream
+    dev.replay_tape(tape, 2)
+    steps = done[0] + rep["replayed_steps"] + 2 * tape["nsteps"]
+    got = {n: getattr(solver, n).current.local_window() for n in ("v", "p", "vx", "vy")}
+    dev.close()
+    dev2, solver2 = build()
+    for _ in range(steps):
+        solver2.update()
+    for n, a in got.items():
+        assert np.array_equal(a, getattr(solver2, n).current.local_window(), equal_nan=True), n
+    dev2.close()
