@@ -601,7 +601,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_SMALL_TILES")) c->small_tiles = atoi(s) != 0;
     if (const char *s = getenv("FS_SMALL_CELLS")) c->small_cells = (size_t)atoll(s);
     if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6) c->rbpair_rt = v; }
-    if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8) c->rbpair_plain_rt = v; }
+    if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8 || v == 16) c->rbpair_plain_rt = v; }
     if (const char *s = getenv("FS_SPLIT_WGW")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->split_wgw = v; }
     if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : (atoi(s) == 4 ? 4 : (atoi(s) == 1 ? 1 : 0));
     if (const char *s = getenv("FS_MAC_RT")) { const int v = atoi(s); c->mac_rt = v == 2 || v == 4 ? v : 0; }

@@ -80,7 +80,7 @@ struct fs_ctx {
     bool small_tiles = true;                 // 2-row tiles on grids below 2 M cells (env FS_SMALL_TILES=0)
     size_t small_cells = (size_t)1 << 21;    // ... that threshold (env FS_SMALL_CELLS): res 800 +4.7 %, res 1024 (2 M cells) +0.3 %
     int rbpair_rt = 0;                       // rows per tile of that pass (env FS_RBPAIR_RT = 2, 4, 6; 0: 2 below 1 M cells, else 4)
-    int rbpair_plain_rt = 8;                 // env FS_RBPAIR_PLAIN_RT = 4 / 8: rows per tile of the pair pass's PLAIN part (two-part launch, one-wave workgroups)
+    int rbpair_plain_rt = 16;                // env FS_RBPAIR_PLAIN_RT = 4 / 8 / 16: rows per tile of the pair pass's PLAIN part (two-part launch; 16: two stacked waves per workgroup, fs_rbpair.h)
     int split_wgw = 1;                       // env FS_SPLIT_WGW = 1 / 2 / 4: waves per workgroup of the two-part launches - the plain / boundary classification is per workgroup
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters

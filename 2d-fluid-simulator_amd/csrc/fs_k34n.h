@@ -419,7 +419,8 @@ __device__ __forceinline__ void cip_grad_advect_dispatch(const Grid &g, const Ko
 
 // blockIdx.y (or, channel groups innermost / compact lists, the block index >> 3) % C = the channel of this workgroup
 template <int C, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T, int HL = 1>
-__global__ __launch_bounds__(256) void k_cip_grad_advect_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+// (4 waves per SIMD: the packed general body of 2 x 4 tiles comes out at 131 VGPRs unbounded - 3 waves; held to 128 it spills 12 bytes)
+__global__ __launch_bounds__(256, 4) void k_cip_grad_advect_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                            T *out, T *gxo, T *gyo, const T *fn, const T *fc,
                                                            const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
 {

@@ -278,11 +278,20 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
         // the plain part on tiles of 8 rows (round 4: 125 VGPRs, still 4 waves per SIMD, since the DPP shifts lost their init moves - 2 rows
         // of window per output row instead of 3), the boundary part on tiles of 4 rows that lie in no plain 8-row tile; one wave per workgroup
-        const int prt = ctx->split_wgw == 1 && ctx->rbpair_plain_rt == 8 ? 8 : rt;
+        // (round 5: the plain part as workgroups of TWO stacked waves on tiles of 16 rows that exchange their edge rows through LDS instead of
+        //  recomputing them - rbsor_pair_stack_tile, FS_RBPAIR_PLAIN_RT=16, the default)
+        const int prt = ctx->split_wgw == 1 && ctx->rbpair_plain_rt >= 8 ? ctx->rbpair_plain_rt : rt;
         const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
         const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw, prt);
         if (og.g.tiles && ogb.g.tiles) {
-            int rc = launch(ctx, "rbsor_pair", [=] { if (prt == 8) FS_RBP_DM(8, 3); else FS_RBP_DM(4, 3); });      // (12-row tiles: 151 VGPRs = 3 waves, 188 against 177 us)
+#define FS_RBS_K(PAR, DM) hipLaunchKernelGGL((k_rbsor_pair_stack<2, 8, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+                               (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
+#define FS_RBS_PAR(DM) do { if (par0) FS_RBS_K(1, DM); else FS_RBS_K(0, DM); } while (0)
+            int rc = launch(ctx, "rbsor_pair", [=] {
+                if (prt == 16) { if (dm & DM_F64) FS_RBS_PAR(4); else FS_RBS_PAR(0); }
+                else if (prt == 8) FS_RBP_DM(8, 3);
+                else FS_RBP_DM(4, 3);      // (12-row tiles: 151 VGPRs = 3 waves, 188 against 177 us)
+            });
             if (rc) return rc;
             { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_DM(4, 2); }); }
         }

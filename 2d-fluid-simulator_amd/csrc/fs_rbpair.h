@@ -281,6 +281,118 @@ __device__ __forceinline__ void rbsor_pair_tile(const Grid &g, const Konst<T> &k
 #undef FS_ROW
 }
 
+// ---- plain tiles, two stacked waves per workgroup (round 5) ------------------------------------------------------------------------------
+// The shrinking window of rbsor_pair_tile requests RT + 8 rows for RT: two rows per output row at RT = 8, and the L2 gives back only part of
+// what neighbouring tiles request twice (PMC: 1.3 x the algorithmic bytes on the plain part, which runs at the chip's copy rate on what it
+// really moves).  Here a workgroup is TWO waves on a tile of 2 RT rows: the lower wave owns rows j0 .. j0+RT-1 and keeps the shrinking halo
+// of 4 rows BELOW, the upper wave owns rows j0+RT .. j0+2RT-1, holds its window upside down (rbsor_pair_tile MIRROR) and keeps the halo ABOVE.
+// Towards each other they do not shrink: each loads ONE raw row of the partner (window row RT + 4) for the first half sweep, and after each of
+// the first three half sweeps hands its edge row (window row RT + 3) to the partner through LDS (3 x 1 KiB, one barrier each).  Per 2 RT = 16
+// output rows: 26 row requests per plane instead of 32, 38 instead of 44 relaxed rows per wave - and the same expression per cell, so the
+// same bits.  Plain tiles only (the host lists them per 2 RT rows; the boundary tiles keep the general kernel).
+template <int N, int RT, int PAR0, int DM, bool MIRROR, typename T>
+__device__ __forceinline__ void rbsor_pair_stack_tile(const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm_in, int i0, int j0,
+                                                      T *C, T *D, const T *A, const T *B, const T *v, typename LVec<T, N>::type (*xch)[2][64], int slot)
+{
+    constexpr int W = RT + 5;                  // window rows: 0 .. 3 the outer halo, 4 .. RT+3 the wave's own rows, RT+4 the partner's edge row
+    constexpr int UP = MIRROR ? -1 : 1;
+    constexpr int PARW = MIRROR ? PAR0 + 1 : PAR0;
+#define FS_ROW(w) (MIRROR ? j0 + RT + 3 - (w) : j0 - 4 + (w))
+    using R = LV<T, N>;
+    using Q = typename LVec<T, N>::type;
+    constexpr unsigned ALL = (1u << N) - 1u;
+    const LaneMapN<N> lm{lm_in.i0, lm_in.owner, false, false};
+    const int lane = threadIdx.x & 63;
+    R PA[W], VX[W], VY[W], PB[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int j = clampy(g, FS_ROW(w));
+        PA[w] = lv_field<1, T, N>(A, g, 0, i0, j);
+        VX[w] = lv_field<2, T, N>(v, g, 0, i0, j);
+        VY[w] = lv_field<2, T, N>(v, g, 1, i0, j);
+        if (w >= 1 && w <= W - 2) PB[w] = lv_field<1, T, N>(B, g, 0, i0, j);
+    }
+    R S2[W], S3[W];
+#pragma unroll
+    for (int w = 1; w <= W - 2; ++w) {
+        const T xl = lv_left<T, N>(lm, VX[w]), xr = lv_right<T, N>(lm, VX[w]);
+        const T yl = lv_left<T, N>(lm, VY[w]), yr = lv_right<T, N>(lm, VY[w]);
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const T xE = c == N - 1 ? xr : VX[w].a[c == N - 1 ? c : c + 1], xW = c == 0 ? xl : VX[w].a[c == 0 ? 0 : c - 1];
+            const T yE = c == N - 1 ? yr : VY[w].a[c == N - 1 ? c : c + 1], yW = c == 0 ? yl : VY[w].a[c == 0 ? 0 : c - 1];
+            source_from<DM>(k, xE, xW, yE, yW, VX[w + UP].a[c], VX[w - UP].a[c], VY[w + UP].a[c], VY[w - UP].a[c], S2[w].a[c], S3[w].a[c]);
+        }
+    }
+    auto put = [&](int e, const R &r) { Q q; q.x = r.a[0]; q.y = r.a[1]; xch[e][slot][lane] = q; };
+    auto get = [&](int e) { const Q q = xch[e][1 - slot][lane]; R r; r.a[0] = q.x; r.a[1] = q.y; return r; };
+    // stage 1: odd pass of iteration 1 on rows 1 .. W-2:  B[odd] <- A   (a plain tile: view(A) = A)
+#pragma unroll
+    for (int w = 1; w <= W - 2; ++w) {
+        if ((PARW + w) & 1) rbp_relax<1, 1>(k, lm, ALL, PA[w - UP], PA[w], PA[w + UP], S2[w], S3[w], PB[w]);
+        else                rbp_relax<0, 1>(k, lm, ALL, PA[w - UP], PA[w], PA[w + UP], S2[w], S3[w], PB[w]);
+    }
+    put(0, PB[W - 2]);
+    __syncthreads();
+    PB[W - 1] = get(0);
+    // stage 2: even pass of iteration 1 on rows 2 .. W-2, in place on B
+    R P2[W];
+#pragma unroll
+    for (int w = 2; w <= W - 2; ++w) {
+        P2[w] = PB[w];
+        if ((PARW + w) & 1) rbp_relax<1, 0>(k, lm, ALL, PB[w - UP], PB[w], PB[w + UP], S2[w], S3[w], P2[w]);
+        else                rbp_relax<0, 0>(k, lm, ALL, PB[w - UP], PB[w], PB[w + UP], S2[w], S3[w], P2[w]);
+    }
+    put(1, P2[W - 2]);
+    __syncthreads();
+    P2[W - 1] = get(1);
+    // stage 3: odd pass of iteration 2 on rows 3 .. W-2:  A[odd] <- B'
+    R P3[W];
+#pragma unroll
+    for (int w = 3; w <= W - 2; ++w) {
+        P3[w] = PA[w];
+        if ((PARW + w) & 1) rbp_relax<1, 1>(k, lm, ALL, P2[w - UP], P2[w], P2[w + UP], S2[w], S3[w], P3[w]);
+        else                rbp_relax<0, 1>(k, lm, ALL, P2[w - UP], P2[w], P2[w + UP], S2[w], S3[w], P3[w]);
+    }
+    put(2, P3[W - 2]);
+    __syncthreads();
+    P3[W - 1] = get(2);
+    // stage 4: even pass of iteration 2 on the wave's own rows 4 .. W-2
+    R P4[W];
+#pragma unroll
+    for (int w = 4; w <= W - 2; ++w) {
+        P4[w] = P3[w];
+        if ((PARW + w) & 1) rbp_relax<1, 0>(k, lm, ALL, P3[w - UP], P3[w], P3[w + UP], S2[w], S3[w], P4[w]);
+        else                rbp_relax<0, 0>(k, lm, ALL, P3[w - UP], P3[w], P3[w + UP], S2[w], S3[w], P4[w]);
+    }
+    if (lm.owner) {
+#pragma unroll
+        for (int w = 4; w <= W - 2; ++w) {
+            lv_store_row<1, T, N>(C, g, 0, i0, FS_ROW(w), P4[w]);
+            lv_store_row<1, T, N>(D, g, 0, i0, FS_ROW(w), P2[w]);
+        }
+    }
+#undef FS_ROW
+}
+
+// one workgroup = 2 waves = one listed tile of 2 RT rows (compact launch only)
+template <int N, int RT, int PAR0, int DM, typename T>
+// (5 waves per SIMD: 97 VGPRs unbounded - one over; held to 96 nothing spills)
+__global__ __launch_bounds__(128, 5) void k_rbsor_pair_stack(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *C, T *D, const T *A, const T *B, const T *v)
+{
+    static_assert(RT % 2 == 0, "the row parity of a tile is a launch constant only for even tile heights");
+    __shared__ typename LVec<T, N>::type xch[3][2][64];
+    constexpr int OW = 64 - 2 * (4 / N);
+    int wx, ty, cg;
+    if (!band_coords<1>(g, nbx, nby, wx, ty, cg)) return;                       // (workgroup-uniform)
+    if (!(wx * OW < g.X / N && jb + ty * 2 * RT < je)) return;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const LaneMapN<N> lm = lane_map_n<N>(g, wx);
+    const int j0 = jb + ty * 2 * RT;
+    if (w == 0) rbsor_pair_stack_tile<N, RT, PAR0, DM, false, T>(g, k, lm, lm.i0, j0, C, D, A, B, v, xch, 0);
+    else        rbsor_pair_stack_tile<N, RT, PAR0, DM, true, T>(g, k, lm, lm.i0, j0 + RT, C, D, A, B, v, xch, 1);
+}
+
 // PATH: 2 - classify the tile here (mask loads) and take the plain or the boundary path; 3 - the plain path without looking (compact launch
 // of the workgroups the host found to be plain: its own kernel, so its own register budget - 126 VGPRs = 4 waves per SIMD, where the
 // boundary path with its recipe bytes and views needs 156); 0 / 1 - classify and run only the plain / only the boundary tiles (A/B).
