@@ -136,8 +136,8 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
     };
     const int groups = (nby + group - 1) / group;
     // inside a group the workgroups are listed column by column: vertically adjacent workgroups, which re-read each other's halo rows, are
-    // neighbours in dispatch order (bc5 res 4096: K3+K4 333 -> 319 us, the red-black pair 195 -> 191; FS_LIST_ROWMAJOR=1: row by row)
-    const bool col_major = getenv("FS_LIST_ROWMAJOR") == nullptr;
+    // neighbours in dispatch order (bc5 res 4096: K3+K4 333 -> 319 us, the red-black pair 195 -> 191 against row by row)
+    constexpr bool col_major = true;
     for (int xcd = 0; xcd < 8; ++xcd)
         for (int lg = 0; lg * 8 + xcd < groups; ++lg)
             for (int o = 0; o < group * nbx; ++o) {
@@ -370,7 +370,7 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
         }
         if (kept.size() == 1) {        // the common case: one assignment, no hazard -> a flat 16-byte record
             h_simple.push_back(record(ops[kept[0]]));
-        } else if (kept.size() == 2 && !getenv("FS_BC_NOPAIRS")) {      // a chain of two: two flat records side by side (BcOps::pair)
+        } else if (kept.size() == 2) {      // a chain of two: two flat records side by side (BcOps::pair)
             h_pair.push_back(record(ops[kept[0]]));
             h_pair.push_back(record(ops[kept[1]]));
         } else if (!kept.empty()) {
@@ -392,13 +392,6 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
         pos = end;
     }
     h_begin.push_back((int)h_kind.size());
-    if (getenv("FS_BC_STATS")) {        // (debug: how long the serial chains of this op list are)
-        std::map<int, int> hist;
-        for (size_t k = 0; k + 1 < h_begin.size(); ++k) hist[h_begin[k + 1] - h_begin[k]]++;
-        fprintf(stderr, "fs: bc op list: %zu simple, %zu chains of two, %zu longer chains:", h_simple.size(), h_pair.size() / 2, h_rlo.size());
-        for (auto &kv : hist) fprintf(stderr, " %dx len %d", kv.second, kv.first);
-        fprintf(stderr, "\n");
-    }
     out.ncomp = (int)h_rlo.size();
     out.nops = (int)h_kind.size();
     // Stream-ordered like every other memory operation of a context: its stream is non-blocking, so work on the null stream
@@ -593,31 +586,12 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = atoi(s) != 0;
-    if (const char *s = getenv("FS_K234_CELLS")) { const long long v = atoll(s); if (v >= 0) c->k234_cells = (size_t)v; }
-    if (const char *s = getenv("FS_LAZY_BC")) c->use_lazy = atoi(s) != 0;
-    if (const char *s = getenv("FS_PAIR_RT")) { const int v = atoi(s); if (v >= 1 && v <= 4) c->pair_rt = v; }
-    if (const char *s = getenv("FS_JQUAD_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6 || v == 8) c->jquad_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
-    if (const char *s = getenv("FS_SMALL_TILES")) c->small_tiles = atoi(s) != 0;
     if (const char *s = getenv("FS_SMALL_CELLS")) c->small_cells = (size_t)atoll(s);
-    if (const char *s = getenv("FS_RBPAIR_RT")) { const int v = atoi(s); if (v == 2 || v == 4 || v == 6) c->rbpair_rt = v; }
     if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8 || v == 16) c->rbpair_plain_rt = v; }
-    if (const char *s = getenv("FS_SPLIT_WGW")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->split_wgw = v; }
-    if (const char *s = getenv("FS_K34_RT")) c->k34_rt = atoi(s) == 2 ? 2 : (atoi(s) == 4 ? 4 : (atoi(s) == 1 ? 1 : 0));
-    if (const char *s = getenv("FS_MAC_RT")) { const int v = atoi(s); c->mac_rt = v == 2 || v == 4 ? v : 0; }
-    if (const char *s = getenv("FS_K34_N")) c->k34_n = atoi(s) == 4 ? 4 : (atoi(s) == 2 ? 2 : 0);
     if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
     if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
-    c->xcd_mask = XCD_RBSOR | XCD_VORT | XCD_ADVECT | XCD_NONADV | XCD_GRAD | XCD_JACOBI;
-    if (const char *s = getenv("FS_XCD")) c->xcd_mask = atoi(s);
     c->stack_mask = XCD_RBSOR | XCD_ADVECT | XCD_GRAD;      // measured per family: K4 313 -> 301 us, K3 246 -> 243, RB-SOR 129 -> 127.5; the others lose 1 %
-    if (const char *s = getenv("FS_STACK")) c->stack_mask = atoi(s);
-    if (const char *s = getenv("FS_CG_INNER")) c->cg_inner_mask = atoi(s);
-    if (const char *s = getenv("FS_XCD_GROUP")) { int v = atoi(s); if (v >= 1 && v <= 128) c->xcd_group = v; }
-    if (const char *s = getenv("FS_XCD_GROUP_FAM")) {      // "bit:rows,bit:rows": tile rows per XCD group of single kernel families (XCD_* bit numbers 0 .. 5)
-        int f, v, n = 0;
-        while (sscanf(s, "%d:%d%n", &f, &v, &n) == 2) { if (f >= 0 && f < 7 && v >= 1 && v <= 128) c->xcd_group_fam[f] = v; s += n; if (*s == ',') ++s; else break; }
-    }
     c->use_pairs = c->use_march && nx % 2 == 0;   // the kernels on lanes of 2 cells (fs_k34n.h, fs_rbpair.h, fs_jquad.h): any even width, i.e. any `res`
     if (nx % 4 != 0) c->use_march = false;        // quads need 16-byte aligned rows
     *out = c;

@@ -71,20 +71,15 @@ struct fs_ctx {
     uint8_t *d_bcmap = nullptr;    // [rows][Pm] recipe byte of the pressure boundary condition per cell (fs_march.h k_jacobi_lazy)
     uint8_t *d_lazyflags = nullptr;   // [nwx][rows] tile needs the lazy evaluation
     std::vector<uint8_t> h_bcmap;  // host copy between build_bc_ops and the upload
-    bool lazy_ok = false, use_lazy = true;   // mask admits the lazy pressure BC / env FS_LAZY_BC=0 switches it off
+    bool lazy_ok = false;                    // mask admits the lazy pressure BC
     bool rb_pair_ok = false;                 // mask admits the two-iteration red-black pass (fs_rbpair.h; decided in build_bc_ops)
     bool jq_ok = false;                      // mask admits the four-sweep Jacobi pass (fs_jquad.h)
-    int jquad_rt = 4;                        // its tile height (env FS_JQUAD_RT = 2, 4, 6, 8)
     int rbpair_split = 1;                    // plain and boundary workgroups of that pass (and of the four-sweep Jacobi pass) as two compact
                                              // launches: env FS_RBPAIR_SPLIT = 0 never, 1 on grids of 8 M cells or more, 2 always
-    bool small_tiles = true;                 // 2-row tiles on grids below 2 M cells (env FS_SMALL_TILES=0)
-    size_t small_cells = (size_t)1 << 21;    // ... that threshold (env FS_SMALL_CELLS): res 800 +4.7 %, res 1024 (2 M cells) +0.3 %
-    int rbpair_rt = 0;                       // rows per tile of that pass (env FS_RBPAIR_RT = 2, 4, 6; 0: 2 below 1 M cells, else 4)
+    size_t small_cells = (size_t)1 << 21;    // 2-row tiles on grids below this many cells (env FS_SMALL_CELLS; 0: never): res 800 +4.7 %, res 1024 (2 M cells) +0.3 %
     int rbpair_plain_rt = 16;                // env FS_RBPAIR_PLAIN_RT = 4 / 8 / 16: rows per tile of the pair pass's PLAIN part (two-part launch; 16: two stacked waves per workgroup, fs_rbpair.h)
-    int split_wgw = 1;                       // env FS_SPLIT_WGW = 1 / 2 / 4: waves per workgroup of the two-part launches - the plain / boundary classification is per workgroup
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
-    int pair_rt = 3;                         // rows per tile of the two-sweep kernel (env FS_PAIR_RT = 1 .. 4; 3: within 2 % of the best of 2 / 3 / 4 from res 1024 to 4096)
     int nwx = 0;                   // wave columns of 62 quads across a row
     void *d_bc_const = nullptr, *d_bc_dye = nullptr;
     bool mask_set = false, bc_incomplete = false;
@@ -121,17 +116,9 @@ struct fs_ctx {
     bool use_march = true;
     bool use_pairs = true;     // lanes of 2 cells: even widths (every `res`); use_march: the quad kernels, X % 4 == 0
     bool use_f64div = true;    // env FS_F64DIV=0: IEEE division for the loop-invariant divisors of f32 runs (A/B; the results are the same)
-    int mac_rt = 0;            // env FS_MAC_RT: rows per tile (2 / 4) of K2' (upwind / KK update); 0: by grid size and precision
-    int k34_n = 0;             // env FS_K34_N: cells per lane (2 / 4) of the fused K3 + K4 pass (fs_k34n.h); 0: by grid size (fs_api.hip launch_k34)
-    int k34_rt = 0;            // env FS_K34_RT: rows per register tile (2 / 4) of that pass at 2 cells per lane; 0: by grid size
-    size_t k234_cells = (size_t)1 << 23;      // env FS_K234_CELLS: the smallest grid on which fs_cip_step takes its three-part form
     bool fuse_k2 = true;       // env FS_FUSE_K2=0: fs_cip_step as its two calls, K2 then the fused K3 + K4 pass (A/B; the same observable results)
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
-    int xcd_group = 8;  // tile rows per XCD group (env FS_XCD_GROUP)
-    int xcd_group_fam[7] = {0, 0, 0, 0, 0, 0, 1};   // ... of single kernel families (env FS_XCD_GROUP_FAM; 0: xcd_group)
-    int xcd_mask = 0;   // env FS_XCD: bit per kernel family that uses the XCD-group block mapping (see ov_grid)
-    int stack_mask = 0;       // env FS_STACK: kernel families (XCD_* bits) launched with stacked workgroups
-    int cg_inner_mask = 0;    // env FS_CG_INNER: kernel families whose channel-group passes over one tile are consecutive workgroups of one XCD
+    int stack_mask = 0;       // kernel families (XCD_* bits) launched with stacked workgroups (fs_create)
     bool pack_halo = true;    // env FS_PACK_HALO=0: one ncclSend/ncclRecv per field instead of one packed message per neighbour
     int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default, 21 / 22 / 23 / 24 = overlapped-wave tiles of 1 - 4 rows
 

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 4) void k_cip_grad_advect_n(Grid g, Konst<T> k
                                                            T *out, T *gxo, T *gyo, const T *fn, const T *fc,
                                                            const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
 {
-    const int yy = (nbx >= 0 && (nby & FS_CG_INNER)) ? ((int)blockIdx.x >> 3) : (int)blockIdx.y;
+    const int yy = (nby & FS_CG_INNER) ? ((int)blockIdx.x >> 3) : (int)blockIdx.y;
     const int ch = yy % C;
     if (ch == 0) cip_grad_advect_dispatch<C, 0, N, RT, DM, PLAIN, CLAMP, T, HL>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
     else if (ch == 1) cip_grad_advect_dispatch<C, 1, N, RT, DM, PLAIN, CLAMP, T, HL>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);

@@ -54,8 +54,8 @@ inline int launch(fs_ctx *c, const char *name, F &&f)
 }
 
 // Grids below 2 M cells have few waves per SIMD: a launch takes as long as ONE wave's chain of loads, stages and stores, and
-// tiles of half the height halve that chain (round 4, tools/r4_chain.py; env FS_SMALL_TILES=0: the big grids' tile heights everywhere)
-static inline bool small_tiles(const fs_ctx *c) { return c->small_tiles && (size_t)c->X * c->Y < c->small_cells; }
+// tiles of half the height halve that chain (round 4, tools/r4_chain.py; env FS_SMALL_CELLS=0: the big grids' tile heights everywhere)
+static inline bool small_tiles(const fs_ctx *c) { return (size_t)c->X * c->Y < c->small_cells; }
 
 // a launch over every row of a single-GPU grid (what may clear a buffer's "hot" word [3], fs_device.h)
 static inline int whole_grid(const fs_ctx *c, int jb, int je) { return c->halo == 0 && jb == 0 && je == c->rows ? 1 : 0; }
@@ -87,20 +87,20 @@ static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroup
     o.threads = 64 * wgw;
     o.nbx = stacked ? waves : (waves + wgw - 1) / wgw;
     o.nby = stacked ? (tiles + wgw - 1) / wgw : tiles;
-    if (c->xcd_mask & family) {
-        // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords)
-        int xg = c->xcd_group;
-        for (int f = 0; f < 7; ++f) if ((family >> f) & 1) xg = c->xcd_group_fam[f] > 0 ? c->xcd_group_fam[f] : xg;
+    {
+        // (8 * block columns, rows per XCD group * channel groups, groups per XCD): decoded without a division (fs_march.h band_coords).  Groups of
+        // 8 tile rows per XCD measured best for every family (2 / 4 / 16 / 32 / per-family sizes: rounds 2 - 4)
+        constexpr int xg = 8;
         const int group = stacked ? std::max(1, xg / wgw) : xg;     // the same number of field rows per XCD group
         const int groups = (o.nby + group - 1) / group;
         const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && ((jb == 0 && je == c->rows) || (c->halo != 0 && cls == 0))
                                          ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach, wgw, jb, je, parent_rt) : nullptr;
-        const bool inner = zgroups > 1 && (tl || (c->cg_inner_mask & family) != 0);
+        const bool inner = zgroups > 1 && tl;
         if (tl) { o.grid = dim3(8 * tl->per_xcd * zgroups, 1, 1); o.g.tiles = tl->d; }
-        else o.grid = inner ? dim3(8 * o.nbx * zgroups, group, (groups + 7) / 8) : dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
+        else o.grid = dim3(8 * o.nbx, group * zgroups, (groups + 7) / 8);
         o.nby |= (group - 1) << 24;
         if (inner) o.nby |= FS_CG_INNER;
-    } else { o.grid = dim3(o.nbx * o.nby, zgroups, 1); o.nbx = -o.nbx; }   // negative nbx = row-major decode
+    }
     if (stacked) o.nby |= FS_STACKED;
     return o;
 }

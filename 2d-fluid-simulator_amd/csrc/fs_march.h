@@ -176,13 +176,6 @@ __device__ __forceinline__ bool band_coords(const Grid &g, int nbx, int nby_pack
         return e != 0xffffffffu;
     }
     const int nby = nby_packed & 0x3fffff, FS_XCD_GROUP = (nby_packed >> 24) + 1;   // group size rides in the top byte, bit 23 = stacked, bit 22 = channel groups innermost
-    if (nbx < 0) {   // plain row-major decode (FS_XCD=0: rows of one tile row spread over the XCDs): grid = (nbx * nby, ZG)
-        nbx = -nbx;
-        by = blockIdx.x / nbx;
-        bx = blockIdx.x - by * nbx;
-        cg = blockIdx.y;
-        return by < nby;
-    }
     const int xcd = blockIdx.x & 7;
     int ly;
     if (ZG > 1 && (nby_packed & FS_CG_INNER)) {

@@ -14,7 +14,7 @@ static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, in
     const int nlist = ctx->n_pairlist[HV ? 1 : 0];
     const int per_slice = (int)(og.grid.x * og.grid.y), blocks = nlist, zoff = (blocks + per_slice - 1) / per_slice;      // one listed row per workgroup
     const dim3 grid(og.grid.x, og.grid.y, og.grid.z + zoff);
-    if (rt == 1) FS_PAIR(1); else if (rt == 4) FS_PAIR(4); else if (rt == 2) FS_PAIR(2); else FS_PAIR(3);
+    if (rt == 2) FS_PAIR(2); else FS_PAIR(3);
 }
 
 template <bool SRC, typename T>
@@ -65,7 +65,7 @@ int fs_jacobi_sweep_src(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
 int fs_lazy_bc_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
-    *ok = ctx->mask_set && ctx->lazy_ok && ctx->use_march && ctx->use_lazy ? 1 : 0;
+    *ok = ctx->mask_set && ctx->lazy_ok && ctx->use_march ? 1 : 0;
     return FS_OK;
 }
 
@@ -109,7 +109,7 @@ int fs_jacobi_pair_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     FS_REQUIRE(mode >= 0 && mode <= 3, "mode: bit 0 = swapped buffers, bit 1 = vertical recipes in the tile path");
     FS_ROWS();
     if (!(ctx->lazy_ok && ctx->use_march)) { set_error("this mask does not admit the lazy pressure boundary condition (fs_lazy_bc_ok)"); return FS_ERR_UNSUPPORTED; }
-    const int rt = (mode & 2) ? std::min(ctx->pair_rt, 2) : ctx->pair_rt;      // (the third tile path at 3 rows: 97 VGPRs, one wave per SIMD less)
+    const int rt = (mode & 2) ? 2 : 3;      // rows per tile: 3 is within 2 % of the best of 2 / 3 / 4 from res 1024 to 4096 (the third tile path at 3 rows: 97 VGPRs, one wave per SIMD less)
     const OvGrid og = ov_grid(ctx, row_begin, row_end, rt, 1, XCD_JACOBI, false);      // (dense: its general rows ride in leading z slices)
     FS_DISPATCH(ctx, {
         return launch(ctx, "jacobi_pair_lazy", [=] {
@@ -168,7 +168,7 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
 int fs_jacobi_quad_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
-    *ok = ctx->mask_set && ctx->jq_ok && ctx->use_march && ctx->use_lazy && ctx->dtype == 0 ? 1 : 0;
+    *ok = ctx->mask_set && ctx->jq_ok && ctx->use_march && ctx->dtype == 0 ? 1 : 0;
     return FS_OK;
 }
 
@@ -181,14 +181,14 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     if (!(ctx->jq_ok && ctx->use_march && ctx->dtype == 0)) { set_error("this mask / precision does not admit the four-sweep Jacobi pass (fs_jacobi_quad_ok)"); return FS_ERR_UNSUPPORTED; }
     using T = float;
     // lanes of 2 cells (116 VGPRs = 4 waves per SIMD at 4 rows; quads: 182 = 2 waves, 44.9 against 34.3 us per pass at bc2 res 1600)
-    const int rt = ctx->jquad_rt;
+    constexpr int rt = 4;
 #define FS_JQ(RT, PATH) hipLaunchKernelGGL((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
     // plain and boundary workgroups as two compact launches (as fs_rbsor_pair) - on large grids: a second launch costs ~5 us, which a
     // cache-resident grid does not earn back (bc2 res 1600: 18.1 + 21.3 against 34.6 us; bc5 res 4096: 81.4 + 49.8 against 137.5)
-    if ((ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw);
+    if ((ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4, 1);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, 1);
         if (og.g.tiles && ogb.g.tiles) {
             int rc = launch(ctx, "jacobi_quad_lazy", [=] { FS_JQ(4, 3); });
             if (rc) return rc;
@@ -197,7 +197,7 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     }
     const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 0, 4);      // (per-wave plain hints in the list, as fs_rbsor_pair)
     return launch(ctx, "jacobi_quad_lazy", [=] {
-        if (rt == 2) FS_JQ(2, 2); else if (rt == 6) FS_JQ(6, 2); else if (rt == 8) FS_JQ(8, 2); else FS_JQ(4, 2);
+        FS_JQ(4, 2);
     });
 }
 
@@ -221,7 +221,7 @@ int fs_jacobi_finish(fs_ctx *ctx, fs_field *pc_out, fs_field *pn, const fs_field
 int fs_rbsor_pair_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
-    *ok = ctx->mask_set && ctx->rb_pair_ok && ctx->use_pairs && ctx->use_lazy ? 1 : 0;      // (f32 and, since round 4, f64)
+    *ok = ctx->mask_set && ctx->rb_pair_ok && ctx->use_pairs ? 1 : 0;      // (f32 and, since round 4, f64)
     return FS_OK;
 }
 
@@ -249,7 +249,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
 #define FS_RBPD_K(RT, PAR, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, 0, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBPD(RT, PATH, FULL) do { if (par0) FS_RBPD_K(RT, 1, PATH, FULL); else FS_RBPD_K(RT, 0, PATH, FULL); } while (0)
-        if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && ctx->split_wgw == 1) {
+        if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2, true, 1, 4, 1);
             const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_RBSOR, 2, true, 2, 4, 1, 4);
             if (og.g.tiles && ogb.g.tiles) {
@@ -264,11 +264,11 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     using T = float;
     auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
     const int dm = dm_const(ctx, k);
-    // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 (FS_RBPAIR_RT=6: 6) rows per tile.  The carrying
+    // lanes of 2 cells (8-byte loads: 126 - 156 VGPRs where quads need 223 - 248), RT = 4 rows per tile (6: 210-254 us, window registers).  The carrying
     // pass after an upload (full) is rare: one configuration.
     // (grids below 1 M cells: 2-row tiles - fewer waves than SIMDs there, the pass takes as long as ONE wave's chain of loads and stages:
     //  res 200 12.1 -> 9.2 us per launch, BASELINE configs[0] 53.3 -> 62.8 k steps/s; res 1600: 4 rows, 5602 against 5435 steps/s)
-    const int rt = full ? 4 : (ctx->rbpair_rt ? ctx->rbpair_rt : (small_tiles(ctx) ? 2 : 4));
+    const int rt = full || !small_tiles(ctx) ? 4 : 2;
 #define FS_RBP_K(RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBP_PAR(RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, PATH, FULL); else FS_RBP_K(RT, 0, DM, PATH, FULL); } while (0)
@@ -280,9 +280,9 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
         // of window per output row instead of 3), the boundary part on tiles of 4 rows that lie in no plain 8-row tile; one wave per workgroup
         // (round 5: the plain part as workgroups of TWO stacked waves on tiles of 16 rows that exchange their edge rows through LDS instead of
         //  recomputing them - rbsor_pair_stack_tile, FS_RBPAIR_PLAIN_RT=16, the default)
-        const int prt = ctx->split_wgw == 1 && ctx->rbpair_plain_rt >= 8 ? ctx->rbpair_plain_rt : rt;
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, ctx->split_wgw);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, ctx->split_wgw, prt);
+        const int prt = ctx->rbpair_plain_rt >= 8 ? ctx->rbpair_plain_rt : rt;
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, 1);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, 1, prt);
         if (og.g.tiles && ogb.g.tiles) {
 #define FS_RBS_K(PAR, DM) hipLaunchKernelGGL((k_rbsor_pair_stack<2, 8, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
@@ -300,7 +300,6 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, !full, 0, 4);
     return launch(ctx, "rbsor_pair", [=] {
         if (full) FS_RBP_PAR(4, 0, 2, true);
-        else if (rt == 6) FS_RBP_DM(6, 2);
         else if (rt == 2) FS_RBP_DM(2, 2);
         else FS_RBP_DM(4, 2);
     });

@@ -5,8 +5,8 @@
 
 using namespace fs;
 
-// K3 + K4 in one pass (fs_k34n.h), velocity (C = 2, v = nullptr) and dye (C = 3): lane width / tile rows from FS_K34_N / FS_K34_RT
-// (default: 2 cells per lane, 4 rows; 4 cells per lane: 2 rows), compact two-part launch on large single-GPU grids
+// K3 + K4 in one pass (fs_k34n.h), velocity (C = 2, v = nullptr) and dye (C = 3): lane width / tile rows by grid size
+// (2 cells per lane x 4 rows; 4 cells per lane: 2 rows), compact two-part launch on large single-GPU grids
 template <int C, bool CLAMP>
 static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, double dt, double dx, fs_field *f_out, fs_field *gx_out, fs_field *gy_out,
                       const fs_field *fn, const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v, int full, int jb, int je)
@@ -14,15 +14,15 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     using T = float;
     auto k = make_konst<T>(ctx, dt, dx, 1.0);
     const int dm = dm_dx(ctx, k);
-    // geometry by grid size unless FS_K34_N / FS_K34_RT say otherwise (K3+K4 of the velocity, us):   2 cells x 4 rows   4 x 2   2 x 2
+    // geometry by grid size (K3+K4 of the velocity, us):   2 cells x 4 rows   4 x 2   2 x 2
     //   >= 8 M cells (two-part launch): bc5 res 4096 / bc5 res 2048 / bc2 res 3000                   307 / 103 / 258    325 / 106 / 267   - / 113 / 282
     //   2 - 8 M cells: bc2 res 1600 / bc5 res 1024 (the boundary kernel of 2 x 4 holds 4 waves per SIMD)  90.7 / 26.5   81.6 / 27.8   90.3 / 26.4
     //   smaller: bc2 res 800 / res 400 (workgroups of half the size)                                  28.2 / 14.5        26.6 / 13.7       24.8 / 12.9
     const size_t cells = (size_t)ctx->X * ctx->rows;      // (this context's slab)
-    const int N = ctx->X % 4 != 0 ? 2 : (ctx->k34_n ? ctx->k34_n : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4));
+    const int N = ctx->X % 4 != 0 ? 2 : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4);
     // (below 1 M cells: 1-row tiles for the dye's three channels - a launch is one wave's chain there, fs_ctx::small_tiles; res 400: 17.6 against
     //  17.1 k steps/s with the dye; the velocity's pass stays on 2 rows: 29.0 against 28.1 k)
-    const int RT = N == 4 ? 2 : (ctx->k34_rt ? ctx->k34_rt : (cells >= ((size_t)1 << 23) ? 4 : (small_tiles(ctx) && !full && C == 3 ? 1 : 2))), geo = N == 2 ? 3 : 4;
+    const int RT = N == 4 ? 2 : (cells >= ((size_t)1 << 23) ? 4 : (small_tiles(ctx) && !full && C == 3 ? 1 : 2)), geo = N == 2 ? 3 : 4;
 #define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
         (T *)f_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v ? (const T *)v->d : (const T *)nullptr, \
         f_out->hot, (const uint8_t *)ctx->d_bcmap, full)
@@ -37,8 +37,8 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     // Compact launch in two parts on large single-GPU grids (as fs_rbsor_pair): the workgroups that see nothing but fluid within
     // reach run without mask loads, selects and conditional stores (PLAIN), the others the general tile
     if (!full && RT != 1 && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
-        const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 1, 2, ctx->split_wgw);
-        const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 2, 2, ctx->split_wgw);
+        const OvGrid og = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 1, 2, 1);
+        const OvGrid ogb = ov_grid_lanes(ctx, jb, je, RT, C, XCD_ADVECT, geo, true, 2, 2, 1);
         if (og.g.tiles && ogb.g.tiles) {
             int rc = launch(ctx, name, [=] { FS_K34_ANY(P); });
             if (rc) return rc;
@@ -66,7 +66,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
         if (ctx->use_pairs) {
             // lanes of 2 cells (fs_k34n.h k_mac_update_n), tiles of 4 rows on large f32 grids (KK at bc3 res 4096: 178 -> 162 us against the one-row quad
             // form it replaces; f64: 424 -> 306 with 2-row tiles), 2 rows on small grids (more workgroups) and for f64 (registers)
-            const int rt = ctx->mac_rt ? ctx->mac_rt : (sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2);
+            const int rt = sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2;
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_NONADV, 3);
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
 #define FS_K2MN(SS, RR, PP) hipLaunchKernelGGL((k_mac_update_n<SS, 2, RR, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
@@ -273,9 +273,8 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
 
 static bool cip_step_three_parts(const fs_ctx *ctx)
 {
-    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ctx->k234_cells);
-    return ctx->mask_set && ctx->fuse_k2 && big && ctx->halo == 0 && ctx->dtype == 0 && ctx->use_pairs && !ctx->k34_n && !ctx->k34_rt && !ctx->h_act2.empty() &&
-           (ctx->tile_list_mask & XCD_ADVECT) && (ctx->xcd_mask & XCD_ADVECT);
+    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23));      // (mid grids - res 800 - 1600, cache resident - gain nothing from it: 5689 against 5642 steps/s at bc2 res 1600)
+    return ctx->mask_set && ctx->fuse_k2 && big && ctx->halo == 0 && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
 }
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
 {

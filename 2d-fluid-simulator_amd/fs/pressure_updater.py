@@ -68,7 +68,7 @@ class JacobiPressureUpdater(PressureUpdater):
             self._precompute, self._src, self._lazy = False, None, False
         # The last two rounds - 2 x (boundary kernel + sweep), which leave both buffers as the reference does - in ONE pass into a third
         # buffer (fs_jacobi_finish; bc2 res 1600: 47 -> 25 us of a 585 us step).  Single GPU, masks that admit the four-sweep pass.
-        self._finish = self._quads and self._dev.nranks == 1 and os.environ.get("FS_JACOBI_FINISH", "1") == "1"
+        self._finish = self._quads and self._dev.nranks == 1
         self._spare = (self._dev.alloc(1),) if self._finish else None      # (a tuple, like RedBlackSorPressureUpdater's: FluidSimulator._signature)
 
     def update(self, p, v_current):

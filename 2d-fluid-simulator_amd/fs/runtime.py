@@ -206,9 +206,9 @@ class DeviceBase:
         self.partial = os.environ.get("FS_PARTIAL_HALO", "1") != "0"     # send only the ghost rows beyond a field's validity
         # "refresh everything": when an exchange is due anyway, every ghost-read field below full depth travels with it (see _run).
         # Loop-back, middle slab of the 8-way cut of bc5 res 4096, halo 16: 1.0 -> 0.67 grouped exchanges per step, 141.8 -> 133.0 us per
-        # step (compute alone 116); the price is +47 % bytes per step and neighbour (4.05 instead of 2.77 MB) - FS_EXCHANGE_ALL=0 for a
+        # step (compute alone 116); the price is +47 % bytes per step and neighbour (4.05 instead of 2.77 MB) - exchange_all = False for a
         # link-bound node.
-        self.exchange_all = os.environ.get("FS_EXCHANGE_ALL", "1") == "1"
+        self.exchange_all = True
         self.clamp_deferral = False
         self.limit_deferral = False   # set by upload_scene: limit_field may ride with the next step's velocity boundary kernel (limit_field below)
 

@@ -213,7 +213,7 @@ class DyeCipMacSolver(CipMacSolver):
         # written.  Holds for device-initialised buffers; user-uploaded dye data falls back to the full-grid clamp.
         self._fused_clamp = self.resolution[0] % 4 == 0 and os.environ.get("FS_MARCH", "1") != "0"
         # K3 + K4 of the dye in one pass as well (f32; a third dye buffer rotates like the velocity's): 355 + 459 us -> one launch
-        self._fused_dye = (self._fused_transport and self._dev.dtype == np.float32 and os.environ.get("FS_FUSE_DYE", "1") == "1")
+        self._fused_dye = (self._fused_transport and self._dev.dtype == np.float32)
         self._dye_spare = self._dev.alloc(3) if self._fused_dye else None
 
     def update(self):

@@ -1,9 +1,8 @@
 """Every selectable launch variant of the fast paths (env knobs read at fs_create) produces the same bits as the
 one-cell-per-lane kernels (FS_MARCH=0), which the small-size tests pin against the oracle and the golden vectors:
-  FS_JACOBI   22 / 24 / 21 = overlapped-wave register tiles of 2 / 4 / 1 rows, 30 = LDS halo tile
-  FS_XCD      bit mask of the kernels launched in XCD-grouped block order (0 = all row-major, 63 = all grouped, default);
-  FS_XCD_GROUP = tile rows per XCD group (1..128, default 8)
-  FS_STACK    bit mask of the kernels whose workgroups are 4 stacked tile rows of one wave column instead of 4 wave columns of one row
+  FS_JACOBI   22 / 24 / 21 = overlapped-wave register tiles of 2 / 4 / 1 rows
+  FS_SMALL_CELLS, FS_TILE_LIST, FS_RBPAIR_SPLIT, FS_RBPAIR_PLAIN_RT, FS_FUSE_K2: tile heights by grid size, compact launch lists, two- / three-part launches
+(the block-order and tile-height A/B switches of rounds 2 - 4 are constants since round 5: DESIGN.md section 9)
 Grid 2*res x res with res = 520: several waves per row, a ragged last wave, row count not a multiple of any tile."""
 import numpy as np
 import pytest
@@ -17,8 +16,7 @@ def _run(monkeypatch, env, what):
     import fs
     from fs.boundary_condition import BoundaryCondition, create_scene_arrays
     from fs.runtime import Device
-    for k in ("FS_MARCH", "FS_JACOBI", "FS_XCD", "FS_XCD_GROUP", "FS_STACK", "FS_SMALL_TILES", "FS_SMALL_CELLS", "FS_RBPAIR_RT", "FS_RBPAIR_SPLIT",
-              "FS_RBPAIR_PLAIN_RT", "FS_BC_NOPAIRS", "FS_K34_RT", "FS_TILE_LIST", "FS_SPLIT_WGW"):
+    for k in ("FS_MARCH", "FS_JACOBI", "FS_SMALL_CELLS", "FS_RBPAIR_SPLIT", "FS_RBPAIR_PLAIN_RT", "FS_TILE_LIST", "FS_FUSE_K2"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -51,7 +49,7 @@ def _run(monkeypatch, env, what):
     return out
 
 
-@pytest.mark.parametrize("variant", ["22", "24", "21", "30"])
+@pytest.mark.parametrize("variant", ["22", "24", "21", "23"])
 def test_jacobi_tile_variants(variant, hip_lib, monkeypatch):
     ref = _run(monkeypatch, {"FS_MARCH": "0"}, "jacobi")
     got = _run(monkeypatch, {"FS_JACOBI": variant}, "jacobi")
@@ -59,27 +57,15 @@ def test_jacobi_tile_variants(variant, hip_lib, monkeypatch):
         assert np.array_equal(got[k], ref[k], equal_nan=True), (variant, k)
 
 
-@pytest.mark.parametrize("env", [{"FS_XCD": "0"}, {"FS_XCD": "21"}, {"FS_XCD_GROUP": "1"}, {"FS_XCD_GROUP": "3"},
-                                 {"FS_XCD_GROUP": "16"}, {"FS_XCD_GROUP": "128"}, {"FS_STACK": "63"}, {"FS_STACK": "63", "FS_XCD": "0"},
-                                 {"FS_STACK": "21", "FS_XCD_GROUP": "3"}],
-                         ids=lambda e: "-".join(f"{k[3:]}{v}" for k, v in e.items()))
-def test_block_order_variants(env, hip_lib, monkeypatch):
-    ref = _run(monkeypatch, {"FS_MARCH": "0"}, "step")
-    got = _run(monkeypatch, env, "step")
-    for k in ref:
-        assert np.array_equal(got[k], ref[k], equal_nan=True), (env, k)
-    assert float(np.abs(ref["p"]).max()) > 0
-
-
-@pytest.mark.parametrize("env", [{"FS_SMALL_TILES": "0"}, {"FS_SMALL_CELLS": "0"}, {"FS_RBPAIR_RT": "4"}, {"FS_RBPAIR_RT": "6"}, {"FS_BC_NOPAIRS": "1"},
-                                 {"FS_K34_RT": "1"}, {"FS_K34_RT": "4"}, {"FS_TILE_LIST": "0"},
-                                 {"FS_RBPAIR_SPLIT": "2"}, {"FS_RBPAIR_SPLIT": "2", "FS_SMALL_TILES": "0"}, {"FS_RBPAIR_SPLIT": "2", "FS_RBPAIR_PLAIN_RT": "4"},
-                                 {"FS_RBPAIR_SPLIT": "2", "FS_SPLIT_WGW": "4"}],
+@pytest.mark.parametrize("env", [{"FS_SMALL_CELLS": "0"}, {"FS_TILE_LIST": "0"},
+                                 {"FS_RBPAIR_SPLIT": "2"}, {"FS_RBPAIR_SPLIT": "2", "FS_SMALL_CELLS": "0"}, {"FS_RBPAIR_SPLIT": "2", "FS_RBPAIR_PLAIN_RT": "4"},
+                                 {"FS_RBPAIR_SPLIT": "2", "FS_RBPAIR_PLAIN_RT": "8"}, {"FS_RBPAIR_SPLIT": "2", "FS_FUSE_K2": "0"}],
                          ids=lambda e: "-".join(f"{k[3:]}{v}" for k, v in e.items()))
 def test_round4_tile_height_and_list_variants(env, hip_lib, monkeypatch):
-    """Round 4: tile heights by grid size (this grid, 0.54 M cells, takes the small-grid heights by default), flat op-list pairs, the per-wave
-    plain hints of the launch lists (FS_TILE_LIST=0: dense launches without them), the two-part launches with the mirrored 8-row plain tiles
-    of the pair pass forced onto a small grid: the same bits as the one-cell-per-lane kernels."""
+    """Tile heights by grid size (this grid, 0.54 M cells, takes the small-grid heights by default), the per-wave plain hints of the launch
+    lists (FS_TILE_LIST=0: dense launches without them), the two- and three-part launches forced onto a small grid - the pair pass's plain part
+    as two stacked waves per 16-row tile (default), on mirrored 8-row tiles, on 4-row tiles; fs_cip_step with K2 in registers (default) and
+    as its own launch: the same bits as the one-cell-per-lane kernels."""
     ref = _run(monkeypatch, {"FS_MARCH": "0"}, "step")
     got = _run(monkeypatch, env, "step")
     for k in ref:
