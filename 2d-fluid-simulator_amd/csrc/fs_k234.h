@@ -59,26 +59,8 @@ __device__ __forceinline__ void k234_nonadv(const Grid &g, const Konst<float> &k
     }
 #pragma unroll
     for (int u = 0; u < RT + 4; ++u) {
-        const v2f fm = F[u], f1 = F[u + 1], fp = F[u + 2];
-        const T l = lv_left<T, N>(lm, unpk(f1)), r = lv_right<T, N>(lm, unpk(f1));
-        const v2f two_f = 2.0f * f1;
-        const v2f d2x = xdiv<DM>((east(f1, r) - two_f) + west(l, f1), k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-        const v2f d2y = xdiv<DM>((fp - two_f) + fm, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-        const v2f lap = d2x + d2y;
-        v2f dif;
-        dif.x = rdiv<DM>(lap.x, k.re, k.r_re);
-        dif.y = rdiv<DM>(lap.y, k.re, k.r_re);
-        v2f gp;
-        if (c == 0) {
-            const v2f p1 = P[u + 1];
-            const T pl = lv_left<T, N>(lm, unpk(p1)), pr = lv_right<T, N>(lm, unpk(p1));
-            gp = xdiv<DM>(0.5f * ew_diff(p1, pl, pr), k.dx, k.inv_dx, k.r_dx);
-        } else {
-            gp = xdiv<DM>(0.5f * (P[u + 2] - P[u]), k.dx, k.inv_dx, k.r_dx);
-        }
-        const v2f gg = (-gp) + dif;
-        st.Nn[u] = f1 + gg * k.dt;
-        st.Fc[u] = f1;
+        st.Nn[u] = nonadv_pk_row<c, DM>(k, lm, F[u], F[u + 1], F[u + 2], P[u + 1], P[c == 0 ? u + 1 : u], P[c == 0 ? u + 1 : u + 2]);
+        st.Fc[u] = F[u + 1];
     }
 }
 

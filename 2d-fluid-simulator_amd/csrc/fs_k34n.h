@@ -431,6 +431,30 @@ __global__ __launch_bounds__(256, 4) void k_cip_grad_advect_n(Grid g, Konst<T> k
     else if (C == 3) cip_grad_advect_dispatch<C, C == 3 ? 2 : 0, N, RT, DM, PLAIN, CLAMP, T, HL>(g, k, nbx, nby, jb, je, out, gxo, gyo, fn, fc, gxc, gyc, v, hot, bcmap, full);
 }
 
+// K2 for one row of one component on packed operands (fs/solver.py:234-239, 263-265): f1 the row, fm / fp the rows below / above, and for the
+// pressure gradient the row of p (c == 0: x-difference) or the rows of p below / above (c == 1).  The division by Re stays per half.
+template <int c, int DM>
+__device__ __forceinline__ v2f nonadv_pk_row(const Konst<float> &k, const LaneMapN<2> &lm, v2f fm, v2f f1, v2f fp, v2f p1, v2f pm, v2f pp)
+{
+    const float l = lv_left<float, 2>(lm, unpk(f1)), r = lv_right<float, 2>(lm, unpk(f1));
+    const v2f two_f = 2.0f * f1;
+    const v2f d2x = xdiv<DM>((east(f1, r) - two_f) + west(l, f1), k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+    const v2f d2y = xdiv<DM>((fp - two_f) + fm, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+    const v2f lap = d2x + d2y;
+    v2f dif;
+    dif.x = rdiv<DM>(lap.x, k.re, k.r_re);
+    dif.y = rdiv<DM>(lap.y, k.re, k.r_re);
+    v2f gp;
+    if (c == 0) {
+        const float pl = lv_left<float, 2>(lm, unpk(p1)), pr = lv_right<float, 2>(lm, unpk(p1));
+        gp = xdiv<DM>(0.5f * ew_diff(p1, pl, pr), k.dx, k.inv_dx, k.r_dx);
+    } else {
+        gp = xdiv<DM>(0.5f * (pp - pm), k.dx, k.inv_dx, k.r_dx);
+    }
+    const v2f gg = (-gp) + dif;
+    return f1 + gg * k.dt;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2  CipMacSolver._non_advection_phase (fs/solver.py:229-240, 263-265) on lanes of N cells, tiles of RT rows: rows j0-1 .. j0+RT of v
 // (2 planes) and p are requested up front; not-wall cells get  fn = fc + ((-grad p) + lap(fc)/re) * dt.   One halo lane per side.
@@ -468,6 +492,23 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nb
         F[0][u] = lv_field<2, T, N>(fc, g, 0, i0, row);
         F[1][u] = lv_field<2, T, N>(fc, g, 1, i0, row);
         P[u] = lv_field<1, T, N>(pc, g, 0, i0, row);
+    }
+    if constexpr (FS_K34_PK && N == 2 && sizeof(T) == 4) {      // the lane's two cells as one packed operand (fs_device.h v2f): same expression, same bits
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int j = j0 + t;
+            if (j >= je) break;
+            const v2f p1 = pk(P[t + 1]), pm = pk(P[t]), pp = pk(P[t + 2]);
+            const R O0 = unpk(nonadv_pk_row<0, DM>(k, lm, pk(F[0][t]), pk(F[0][t + 1]), pk(F[0][t + 2]), p1, pm, pp));
+            const R O1 = unpk(nonadv_pk_row<1, DM>(k, lm, pk(F[1][t]), pk(F[1][t + 1]), pk(F[1][t + 2]), p1, pm, pp));
+            if (lm.owner && nw[t]) {
+#pragma unroll
+                for (int q = 0; q < N; ++q) raise_hot(hot, ((nw[t] >> q) & 1u) && hot2(O0.a[q], O1.a[q]));
+                lv_store_sel<T, N>(fn + idx<2, T>(g, 0, i0, j), O0, nw[t]);
+                lv_store_sel<T, N>(fn + idx<2, T>(g, 1, i0, j), O1, nw[t]);
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
