@@ -199,7 +199,7 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
         if (hipMalloc(&tl.d, h.size() * sizeof(uint32_t)) == hipSuccess &&
             hipMemcpyAsync(tl.d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
             hipStreamSynchronize(c->stream) == hipSuccess)
-            tl.per_xcd = (int)K;
+            { tl.per_xcd = (int)K; tl.count = (int)total; }
         else { if (tl.d) hipFree(tl.d); tl.d = nullptr; }
     }
     auto &slot = c->tile_lists[key] = tl;

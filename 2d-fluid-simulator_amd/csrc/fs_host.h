@@ -128,7 +128,7 @@ struct fs_ctx {
     int tile_list_mask = 1 | 2 | 4 | 8 | 32;              // env FS_TILE_LIST: kernel families (XCD_* bits) launched compactly.  Measured at bc5 res 4096:
                                              // K3+K4 363 -> 346 us, red-black pair 215 -> 192, vorticity confinement (2-cell lanes) 97 -> 95, K2 (2-cell lanes) 105 -> 102, the plain Jacobi sweeps 87.2 -> 85.8 (reading v) / 75.5 -> 74.1 (source pair)
     std::vector<uint8_t> h_act4, h_act2, h_act2w;     // [wave column][local row]
-    struct TileList { uint32_t *d = nullptr; int per_xcd = 0; };
+    struct TileList { uint32_t *d = nullptr; int per_xcd = 0; int count = 0; };      // count: listed workgroups (without the padding)
     using TileKey = std::array<int, 10>;     // lanes, rows per tile, stacked, group, class, reach, waves per workgroup, parent tile rows, row range
     std::map<TileKey, TileList> tile_lists;
 

@@ -19,7 +19,9 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     //   2 - 8 M cells: bc2 res 1600 / bc5 res 1024 (the boundary kernel of 2 x 4 holds 4 waves per SIMD)  90.7 / 26.5   81.6 / 27.8   90.3 / 26.4
     //   smaller: bc2 res 800 / res 400 (workgroups of half the size)                                  28.2 / 14.5        26.6 / 13.7       24.8 / 12.9
     const size_t cells = (size_t)ctx->X * ctx->rows;      // (this context's slab)
-    const int N = ctx->X % 4 != 0 ? 2 : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4);
+    // (round 5, packed bodies: the dye's three channels on pairs everywhere - bc2 res 1600: 141 against 184 us on quads; the velocity's two stay on
+    //  quads from 2 M to 8 M cells: 79 against 92 (2 x 2) / 101 (2 x 4) us)
+    const int N = ctx->X % 4 != 0 || C == 3 ? 2 : (cells >= ((size_t)1 << 23) || cells < ((size_t)1 << 21) ? 2 : 4);
     // (below 1 M cells: 1-row tiles for the dye's three channels - a launch is one wave's chain there, fs_ctx::small_tiles; res 400: 17.6 against
     //  17.1 k steps/s with the dye; the velocity's pass stays on 2 rows: 29.0 against 28.1 k)
     const int RT = N == 4 ? 2 : (cells >= ((size_t)1 << 23) ? 4 : (small_tiles(ctx) && !full && C == 3 ? 1 : 2)), geo = N == 2 ? 3 : 4;
@@ -280,6 +282,25 @@ int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
     *ok = cip_step_three_parts(ctx) ? 1 : 0;
+    return FS_OK;
+}
+
+// diagnostic (bench.py: the algorithmic bytes of each part): how many tiles of tile_rows x tile_cells cells each of the three parts of a whole-grid
+// fs_cip_step launch covers - the all-fluid tiles, the boundary tiles, the tiles K2 runs over as a kernel of its own (0 0 0: not this form)
+int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *tile_rows, int *tile_cells)
+{
+    FS_REQUIRE(ctx && plain && boundary && band && tile_rows && tile_cells, "null argument");
+    *plain = *boundary = *band = 0; *tile_rows = 4; *tile_cells = 120;
+    if (!cip_step_three_parts(ctx) || ctx->capturing || ctx->tape_rec) return FS_OK;
+    const OvGrid ogp = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 1, 2, 1);
+    const OvGrid ogb = ov_grid_lanes(ctx, 0, ctx->rows, 4, 2, XCD_ADVECT, 2, true, 2, 2, 1);
+    const OvGrid ogk = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 3, 2, 1);
+    for (const auto &kv : ctx->tile_lists) {
+        if (!kv.second.d) continue;
+        if (kv.second.d == ogp.g.tiles) *plain = kv.second.count;
+        if (kv.second.d == ogb.g.tiles) *boundary = kv.second.count;
+        if (kv.second.d == ogk.g.tiles) *band = kv.second.count;
+    }
     return FS_OK;
 }
 

@@ -929,6 +929,13 @@ class Device(DeviceBase):
         _lib.call("fs_cip_step_ok", self._ctx, ctypes.byref(ok))
         return bool(ok.value) and self.nranks == 1
 
+    def cip_step_tiles(self):
+        """(all-fluid tiles, boundary tiles, tiles of the stand-alone K2 launch, rows per tile, cells per tile row) of a whole-grid fs_cip_step
+        launch in its three-part form (zeros otherwise) - bench.py prices each part against the bytes of its own tiles."""
+        v = [ctypes.c_int() for _ in range(5)]
+        _lib.call("fs_cip_step_tiles", self._ctx, *[ctypes.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
     @property
     def jacobi_quad_ok(self):
         """The mask admits the four-sweep Jacobi pass (single GPU)."""

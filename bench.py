@@ -105,12 +105,15 @@ def algorithmic_bytes(mask, esize=4):
     }, {"cells": n, "fluid": fl, "not_wall": nw}
 
 
-def merge_parts(rep):
+def merge_parts(rep, parts=None):
     """Kernels launched in compact parts (the workgroups that see nothing but fluid, then the others: "<name>" + "<name>_bnd", csrc/fs_core.hip
-    tile_list; fs_cip_step also "<name>_band": K2 over the rows its boundary tiles read) count as ONE launch of <name>."""
+    tile_list; fs_cip_step also "<name>_band": K2 over the rows its boundary tiles read) count as ONE launch of <name>; `parts` (optional dict)
+    receives the unmerged (launches, ms) of every part of such a launch."""
     for suffix in ("_bnd", "_band"):
         for name in [n for n in rep if n.endswith(suffix) and n[:-len(suffix)] in rep]:
             base = name[:-len(suffix)]
+            if parts is not None:
+                parts.setdefault(base, {"plain": rep[base]})[suffix[1:]] = rep[name]
             (l0, m0), (_, m1) = rep[base], rep[name]
             rep[base] = (l0, m0 + m1)
             del rep[name]
@@ -445,7 +448,8 @@ def main():
         else:
             traffic_source = ("stale: profiles/pmc_traffic.json was taken on another build of libfs_hip.so (" + str(pm.get("lib_sha256"))[:16] + " != " + lib_sha[:16] +
                               "); re-run tools/profile.sh")
-    merge_parts(rep)
+    parts = {}
+    merge_parts(rep, parts)
     frac_rows = dev.nyl / dev.ny
     kernels = {}
     for name, (launches, ms) in rep.items():
@@ -460,7 +464,19 @@ def main():
             entry["frac"] = round(entry["GBps"] / HBM_PEAK_GBS, 4)
             if box:
                 entry["frac_of_box_copy"] = round(entry["GBps"] / box["copy_GBps"], 4)
+        if name in parts:        # the unmerged parts of a multi-part launch (per-launch HIP-event brackets of each)
+            entry["parts_us"] = {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in parts[name].items()}
         kernels[name] = entry
+    # fs_cip_step in its three-part form: the part over the all-fluid tiles (k_cip_step_plain) priced against the bytes of ITS tiles - 52 B per cell
+    # (v.current 8 + p 4 + old gradients 16 read, advected velocity 8 + new gradients 16 written; it reads no mask)
+    if "cip_step" in kernels and "cip_step" in parts and hasattr(dev, "cip_step_tiles") and world == 1:
+        n_plain, n_bnd, n_band, t_rows, t_cells = dev.cip_step_tiles()
+        if n_plain > 0:
+            pl_us = kernels["cip_step"]["parts_us"]["plain"]
+            pl_bytes = n_plain * t_rows * t_cells * 13 * esize
+            kernels["cip_step"]["plain_part"] = {"kernel": "k_cip_step_plain", "tiles": n_plain, "boundary_tiles": n_bnd, "stand_alone_K2_tiles": n_band,
+                                                 "cells": n_plain * t_rows * t_cells, "alg_MB": round(pl_bytes / 1e6, 2), "avg_us": pl_us,
+                                                 "GBps": round(pl_bytes / (pl_us * 1e-6) / 1e9, 1), "frac": round(pl_bytes / (pl_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
     dominant = max((k for k in kernels if "GBps" in kernels[k]), key=lambda k: kernels[k]["share"] * 1.0, default=None)
     # slab runs: what an exchange costs in line (pack -> grouped RCCL send / recv -> unpack, one HIP-event span on the stream it is queued
     # on) against the longest kernel that could cover it if the exchange ran on the communication stream (FS_OVERLAP=1): the model the
@@ -605,6 +621,17 @@ def main():
                            "frac": round(kd["GBps"] / HBM_PEAK_GBS, 4), "frac_of_box_copy": kd.get("frac_of_box_copy"),
                            "traffic": pmc_traffic.get(dominant), "traffic_source": traffic_source,
                            "alg_bytes_per_launch": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"]}
+        if dominant == "cip_step" and "plain_part" in kd:
+            # the dominant KERNEL of the step is the part of fs_cip_step over the all-fluid tiles: its own bytes over its own duration; the logical
+            # launch (three kernels: + the boundary tiles + K2 over their rows) stays next to it
+            pp = kd["plain_part"]
+            out["roofline"].update({"kernel": "cip_step / k_cip_step_plain (K2 + K3 + K4 over the all-fluid tiles)", "achieved": pp["GBps"], "frac": pp["frac"],
+                                    "frac_of_box_copy": round(pp["GBps"] / box["copy_GBps"], 4) if box else None,
+                                    "traffic": (pmc_traffic.get("cip_step_parts") or {}).get("k_cip_step_plain"),
+                                    "alg_bytes_per_launch": int(pp["alg_MB"] * 1e6), "avg_us": pp["avg_us"],
+                                    "logical_launch": {"kernels": "k_cip_step_plain + k_cip_grad_advect_n (boundary tiles) + k_cip_nonadv_n (K2 over their rows)",
+                                                       "alg_bytes": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"], "frac": round(kd["GBps"] / HBM_PEAK_GBS, 4),
+                                                       "traffic": pmc_traffic.get(dominant), "parts_us": kd.get("parts_us")}})
         if "unfused_equiv_frac" in kd:
             out["roofline"]["note"] = (
                 "two Jacobi sweeps (and both pressure boundary passes) per launch, the first sweep's rows in registers: `frac` counts what "
@@ -620,10 +647,11 @@ def main():
             # how much of the kernel's time the issue of its VALU instructions alone accounts for: SQ_INSTS_VALU of one launch of this workload on
             # this build (profiles/pmc_traffic.json, stamped) / 1024 SIMDs / what one SIMD of THIS box issues per second (measured in this run;
             # packed f32 instructions issue at the same rate, box.valu_pk_ginstr_per_simd)
-            winst = float(pmc_valu[dominant])
+            plain = dominant == "cip_step" and "plain_part" in kd and "k_cip_step_plain" in pmc_valu
+            winst = float(pmc_valu["k_cip_step_plain" if plain else dominant])
             issue_us = winst / 1024.0 / (box["valu_ginstr_per_simd"] * 1e9) * 1e6
             out["roofline"]["valu_issue"] = {"wave_insts_per_launch": winst, "per_simd": round(winst / 1024.0), "box_ginstr_per_simd": box["valu_ginstr_per_simd"],
-                                             "issue_us": round(issue_us, 1), "frac_of_kernel_time": round(issue_us / kd["avg_us"], 3),
+                                             "issue_us": round(issue_us, 1), "frac_of_kernel_time": round(issue_us / (kd["plain_part"]["avg_us"] if plain else kd["avg_us"]), 3),
                                              "note": "VALU wave-instructions of one launch (PMC, stamped file) / 1024 SIMDs / the box's measured issue rate"}
     if jac:
         out["poisson_jacobi_sweep"] = jac

@@ -145,6 +145,9 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
  * (K2 of the next step, or this step's vorticity confinement) before reading it.  fs_cip_step_ok: whether whole-grid calls take that form
  * (f32, one GPU, >= 8 M cells, FS_FUSE_K2 != 0); otherwise the call is exactly fs_cip_nonadv + fs_cip_grad_advect.                 */
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok);
+/* diagnostic: the tiles (tile_rows x tile_cells cells each) of the three parts of a whole-grid fs_cip_step launch - all-fluid tiles, boundary
+ * tiles, tiles K2 runs over as a kernel of its own; 0 0 0 where the call takes the two-call form. */
+int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *tile_rows, int *tile_cells);
 int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
                 const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end);
 /* The same for the dye (C = 3, advected by the velocity field v of the finished flow step; fs/solver.py:378-401 _update_dye without its

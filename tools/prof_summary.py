@@ -69,6 +69,11 @@ if all(k in by_short for k in parts3):
     traffic["cip_step"] = sum(by_short[k] for k in parts3)
     traffic["cip_step_parts"] = {k: by_short[k] for k in parts3}
     traffic.pop("cip_grad_advect_rt", None); traffic.pop("cip_nonadv", None)
+# fs_rbsor_pair: the all-fluid tiles as stacked two-wave workgroups (k_rbsor_pair_stack) + the boundary tiles (k_rbsor_pair)
+parts2 = ("k_rbsor_pair_stack", "k_rbsor_pair")
+if all(k in by_short for k in parts2):
+    traffic["rbsor_pair"] = sum(by_short[k] for k in parts2)
+    traffic["rbsor_pair_parts"] = {k: by_short[k] for k in parts2}
 # VALU wave-instructions per launch (SQ_INSTS_VALU pass), per kernel and for the logical launches
 valu = collections.defaultdict(list)
 for f in glob.glob(os.path.join(out, "pmc_valu", "**", "*counter_collection.csv"), recursive=True):
@@ -78,6 +83,8 @@ for f in glob.glob(os.path.join(out, "pmc_valu", "**", "*counter_collection.csv"
 valu_per_launch = {k: sum(v) / len(v) for k, v in valu.items() if v}
 if all(k in valu_per_launch for k in parts3):
     valu_per_launch["cip_step"] = sum(valu_per_launch[k] for k in parts3)
+if all(k in valu_per_launch for k in parts2):
+    valu_per_launch["rbsor_pair"] = sum(valu_per_launch[k] for k in parts2)
 # the stamp: these numbers belong to ONE build of the library - bench.py quotes them only when the library it loaded has this hash
 import hashlib
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2d-fluid-simulator_amd", "csrc", "libfs_hip.so")

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run ON THE GPU BOX, ONE lease (gpurun -- 'bash tools/r5_lease.sh'): everything profiles/r5_* is made of - the box's own read / copy rate,
+# one bench.py JSON per BASELINE configuration (+ the reference's default resolution with and without dye, the mid grids), rocprofv3 kernel
+# stats + PMC traffic + VALU counts (stamped with the library's hash) + SQ wave-cycle split of the headline run, the loop-back slab step.
+# Output: gpurun_out/r5/...; tools/r5_collect.sh (run locally afterwards) assembles profiles/r5_* from it.
+set -u
+OUT=gpurun_out/r5; mkdir -p $OUT gpurun_out/bench_r5; export TMPDIR=/tmp
+tools/membw.bin > $OUT/membw.txt 2>&1
+bash tools/bench_configs.sh r5 > $OUT/bench_configs.log 2>&1
+run() { name=$1; shift; python3 bench.py "$@" > gpurun_out/bench_r5/$name.json 2> gpurun_out/bench_r5/$name.err; }
+run res400_bc2_cip_vc      --bc 2 --res 400 --steps 6000 --warmup 100 --sweeps 0 --no-cpu
+run res400_bc2_cip_vc_dye  --bc 2 --res 400 --dye --steps 6000 --warmup 100 --sweeps 0 --no-cpu
+run res800_bc2_cip_vc      --bc 2 --res 800 --steps 3000 --warmup 60 --sweeps 0 --no-cpu
+run res1600_bc2_cip_vc     --bc 2 --res 1600 --steps 1200 --warmup 60 --sweeps 0 --no-cpu
+run res1600_bc2_cip_vc_dye --bc 2 --res 1600 --dye --steps 600 --warmup 60 --sweeps 0 --no-cpu
+bash tools/profile.sh r5 > $OUT/profile.log 2>&1
+EXTRA_PMC="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" bash tools/r3_pmc.sh r5 > $OUT/pmc.log 2>&1
+{ echo "== defaults (halo 20, pair on)"; timeout 600 python3 tools/overlap_bench.py 16 20 2>&1 | tail -8; } > $OUT/loopback.txt 2>&1
+tools/membw.bin > $OUT/membw_after.txt 2>&1
+ls gpurun_out/bench_r5 gpurun_out/prof_r5 gpurun_out/pmc_r5 > $OUT/files.txt 2>&1
+tail -8 $OUT/bench_configs.log
