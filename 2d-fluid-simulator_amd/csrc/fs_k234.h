@@ -23,6 +23,8 @@
 // Plain tile: every cell within 2 rows and within the halo lanes is fluid and inside the domain (fs_core.hip tile_list) - K2's own reads
 // one cell further out take whatever the buffers hold there, as the reference's K2 does.
 #pragma once
+#include <type_traits>
+
 #include "fs_k34n.h"
 
 namespace fs {
@@ -122,6 +124,61 @@ __global__ __launch_bounds__(128) void k_cip_step_plain(Grid g, Konst<float> k, 
     __syncthreads();
     if (c == 0) k234_phase2<0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, xch);
     else        k234_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, xch);
+}
+
+// ---- the dye: K12 + K3 + K4 (fs/solver.py:385-401 _update_dye) over the all-fluid tiles -----------------------------------------------
+// K12 (_non_advection_phase_dye :378-383: dn = dc + (lap(dc) / re) dt, no pressure term) of one channel needs nothing from the others, and
+// the advecting velocity is the finished flow step's - read from memory: one wave per tile and channel, no exchange.  The three-part
+// launch of fs_cip_step_dye is the velocity's (fs_transport.hip): K12 as a kernel over the boundary tiles' rows, this kernel, the general K3 + K4.
+template <int RT, int DM, bool CLAMP>
+__global__ __launch_bounds__(64) void k_cip_dye_plain(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
+                                                      float *out, float *gxo, float *gyo, const float *fc, const float *gxc, const float *gyc, const float *v)
+{
+    using T = float;
+    constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
+    int wx, ty, cg;
+    if (!band_coords<3>(g, nbx, nby, wx, ty, cg)) return;
+    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
+    const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
+    const LaneMapN<N> lm{lm_in.i0, lm_in.owner, false, false};
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    auto body = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        v2f F[RT + 6], Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
+#pragma unroll
+        for (int u = 0; u < RT + 6; ++u) F[u] = pk(lv_field<3, T, N>(fc, g, c, i0, clampy(g, j0 - 3 + u)));
+#pragma unroll
+        for (int s = 0; s < RT + 2; ++s) {
+            const int row = clampy(g, j0 - 1 + s);
+            GX[s] = pk(lv_field<3, T, N>(gxc, g, c, i0, row));
+            GY[s] = pk(lv_field<3, T, N>(gyc, g, c, i0, row));
+            AX[s] = pk(lv_field<2, T, N>(v, g, 0, i0, row));
+            AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
+        }
+#pragma unroll
+        for (int u = 0; u < RT + 4; ++u) {
+            const v2f fm = F[u], f1 = F[u + 1], fp = F[u + 2];
+            const T l = lv_left<T, N>(lm, unpk(f1)), r = lv_right<T, N>(lm, unpk(f1));
+            const v2f two_f = 2.0f * f1;
+            const v2f d2x = xdiv<DM>((east(f1, r) - two_f) + west(l, f1), k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const v2f d2y = xdiv<DM>((fp - two_f) + fm, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const v2f lap = d2x + d2y;
+            v2f dif;
+            dif.x = rdiv<DM>(lap.x, k.re, k.r_re);
+            dif.y = rdiv<DM>(lap.y, k.re, k.r_re);
+            Nn[u] = f1 + dif * k.dt;
+            Fc[u] = f1;
+        }
+        unsigned nw[RT + 2], fl[RT];
+#pragma unroll
+        for (int s = 0; s < RT + 2; ++s) nw[s] = 3u;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) fl[t] = j0 + t < je ? 3u : 0u;
+        cip_k34_pk_core<3, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, nw, fl, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
+    };
+    if (cg == 0) body(std::integral_constant<int, 0>{});
+    else if (cg == 1) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 2>{});
 }
 
 }  // namespace fs

@@ -874,14 +874,18 @@ __global__ __launch_bounds__(256) void k_poisson_source_n(Grid g, Konst<T> k, in
 // K12  DyeCipMacSolver._non_advection_phase_dye (fs/solver.py:378-383) on lanes of N cells, tiles of RT rows: dn = dc + (lap(dc)/re) dt on
 // not-wall cells, the three channels one after the other.  One halo lane per side.
 // ------------------------------------------------------------------------------------------------
-template <int N, int RT, int DM, typename T>
+template <int N, int RT, int DM, typename T, int HL = 1, bool WIDE = false>      // (HL, WIDE: as k_cip_nonadv_n)
 __global__ __launch_bounds__(256) void k_cip_nonadv_dye_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
 {
     using R = LV<T, N>;
-    constexpr int HL = 1, L = N - 1;
+    constexpr int L = N - 1;
     int wx, ty, cg;
     if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
-    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    if (WIDE) {
+        const int lane = threadIdx.x & 63, q = wx * (64 - 2 * HL) - HL + lane;
+        lm.owner = lane >= 1 && lane < 63 && q >= 0 && q < g.X / N;
+    }
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[RT];
     bool any = false;

@@ -370,6 +370,49 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
     return launch_k34<3, false>(ctx, "cip_grad_advect_dye", "cip_grad_advect_dye_bnd", dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, full, row_begin, row_end);
 }
 
+// K12 + K3 + K4 of the dye (fs/solver.py:385-401 _update_dye) as ONE call: fs_cip_nonadv_dye(fn <- fc) followed by fs_cip_grad_advect_dye - with the
+// three-part launch of fs_cip_step where that applies (same conditions, fs_cip_step_ok): K12 as a kernel only over the boundary tiles' rows, the
+// all-fluid tiles evaluate it in registers (fs_k234.h k_cip_dye_plain), the boundary tiles run the general K3 + K4 kernel.  The fluid cells
+// of fn that nothing reads before the next K12 rewrites them are then not stored.
+int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
+                    const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v, int clamp01, int full, int row_begin, int row_end)
+{
+    FS_REQUIRE(ctx, "ctx is null");
+    FS_FIELD(d_out, 3); FS_FIELD(gx_out, 3); FS_FIELD(gy_out, 3); FS_FIELD(fn, 3); FS_FIELD(fc, 3); FS_FIELD(gxc, 3); FS_FIELD(gyc, 3); FS_FIELD(v, 2);
+    FS_REQUIRE(d_out != fn && d_out != fc && gx_out != gxc && gy_out != gyc && fn != fc, "outputs must not alias inputs");
+    FS_REQUIRE(ctx->use_pairs, "the fused gradient+advection pass needs an even X (use the two-kernel form)");
+    FS_ROWS();
+    if (ctx->dtype != 0) { set_error("the fused dye pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
+    using T = float;
+    constexpr int RT = 4;
+    if (cip_step_three_parts(ctx) && !full && row_begin == 0 && row_end == ctx->rows) {
+        const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 1, 2, 1);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 2, 2, 1);
+        const OvGrid ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);
+        if (ogp.g.tiles && ogb.g.tiles && ogk.g.tiles) {
+            auto k = make_konst<T>(ctx, dt, dx, re);
+            const int dm = dm_all(ctx, k), dmx = dm_dx(ctx, k);
+#define FS_K12B(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, RT, DM, T, 2, true>), ogk.grid, dim3(64), 0, ctx->stream, ogk.g, k, ogk.nbx, ogk.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d)
+#define FS_KD(DM, CL) hipLaunchKernelGGL((k_cip_dye_plain<RT, DM, CL>), ogp.grid, dim3(64), 0, ctx->stream, ogp.g, k, ogp.nbx, ogp.nby, row_begin, row_end, \
+        (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
+#define FS_KD_C(DM) FS_KD(DM, true)
+#define FS_KD_N(DM) FS_KD(DM, false)
+#define FS_K34DB(DM, CL) hipLaunchKernelGGL((k_cip_grad_advect_n<3, 2, RT, DM, false, CL, T, 2>), ogb.grid, dim3(64), 0, ctx->stream, ogb.g, k, ogb.nbx, ogb.nby, row_begin, row_end, \
+        (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, d_out->hot, (const uint8_t *)ctx->d_bcmap, 0)
+#define FS_K34DB_C(DM) FS_K34DB(DM, true)
+#define FS_K34DB_N(DM) FS_K34DB(DM, false)
+            int rc = launch(ctx, "cip_step_dye_band", [=] { FS_DMA(dm, FS_K12B); });
+            if (rc) return rc;
+            rc = launch(ctx, "cip_step_dye", [=] { if (clamp01) FS_DMA(dm, FS_KD_C); else FS_DMA(dm, FS_KD_N); });
+            if (rc) return rc;
+            return launch(ctx, "cip_step_dye_bnd", [=] { if (clamp01) FS_DMX(dmx, FS_K34DB_C); else FS_DMX(dmx, FS_K34DB_N); });
+        }
+    }
+    int rc = fs_cip_nonadv_dye(ctx, dt, dx, re, fn, fc, row_begin, row_end);
+    if (rc) return rc;
+    return fs_cip_grad_advect_dye(ctx, dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01, full, row_begin, row_end);
+}
+
 // ---- vorticity confinement -------------------------------------------------------------------------------
 int fs_vort_calc(fs_ctx *ctx, double dx, fs_field *vort, fs_field *vort_abs, const fs_field *vc, int row_begin, int row_end)
 {

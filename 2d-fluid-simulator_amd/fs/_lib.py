@@ -54,6 +54,7 @@ _PROTOS = {
     "fs_cip_step_ok": [_c_vp, _P(_c_int)],
     "fs_cip_step_tiles": [_c_vp] + [_P(_c_int)] * 5,
     "fs_cip_step": [_c_vp, _c_dbl, _c_dbl, _c_dbl] + [_c_vp] * 8 + [_c_int] + _ROWS,
+    "fs_cip_step_dye": [_c_vp, _c_dbl, _c_dbl, _c_dbl] + [_c_vp] * 8 + [_c_int, _c_int] + _ROWS,
     "fs_cip_grad_advect_dye": [_c_vp, _c_dbl, _c_dbl] + [_c_vp] * 8 + [_c_int, _c_int] + _ROWS,
     "fs_vort_calc": [_c_vp, _c_dbl, _c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_vort_add": [_c_vp, _c_dbl, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp, _c_vp] + _ROWS,

@@ -703,6 +703,15 @@ class DeviceBase:
         self._run("cip_step", (dt, dx, re, v_out._h, gx_out._h, gy_out._h, fn._h, fc._h, pc._h, gxc._h, gyc._h, 1 if full else 0),
                   reads=[(fc, 3), (pc, 3), (gxc, 1), (gyc, 1)], writes=[gx_out, gy_out, fn], full_writes=[v_out])
 
+    def cip_step_dye(self, dt, dx, re, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=False, full=False):
+        """K12 + K3 + K4 of the dye as one call (fs/solver.py:385-401; include/fs_hip.h fs_cip_step_dye); slabs / other devices: the two calls."""
+        if self.nranks > 1 or not getattr(self, "has_cip_step", False):
+            self.cip_nonadv_dye(dt, dx, re, fn, fc)
+            self.cip_grad_advect_dye(dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=clamp01, full=full)
+            return
+        self._run("cip_step_dye", (dt, dx, re, d_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, v._h, 1 if clamp01 else 0, 1 if full else 0),
+                  reads=[(fc, 3), (gxc, 1), (gyc, 1), (v, 1)], writes=[gx_out, gy_out, fn], full_writes=[d_out])
+
     def cip_grad_advect_dye(self, dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=False, full=False):
         """K3 + K4 of the dye in one pass (csrc/fs_k34n.h k_cip_grad_advect_n<3>); clamp01 folds clamp_field(dye, 0, 1) into the store."""
         self._run("cip_grad_advect_dye", (dt, dx, d_out._h, gx_out._h, gy_out._h, fn._h, fc._h, gxc._h, gyc._h, v._h, 1 if clamp01 else 0, 1 if full else 0),

@@ -235,8 +235,20 @@ class DyeCipMacSolver(CipMacSolver):
         self._dev.cip_nonadv_dye(self.dt, self.dx, self.re, dn, dc)
 
     def _update_dye(self, dye, dyex, dyey, v, clamp=False):
+        fused = self._fused_dye and not any(f.user_data for f in (dyex.current, dyex.next, dyey.current, dyey.next))
+        if fused and self._fused_k2:
+            # K12 + K3 + K4 as one call (fs_cip_step_dye): as the velocity's fs_cip_step - dye.next holds the dye after its non-advection phase only
+            # where something reads it before the next step's K12 rewrites it
+            full = self._dye_spare.static_id != dye.current.static_id
+            self._dev.cip_step_dye(self.dt, self.dx, self.re, self._dye_spare, dyex.next, dyey.next, dye.next, dye.current,
+                                   dyex.current, dyey.current, v.current, clamp01=clamp, full=full)
+            self._dye_spare.static_id = dye.current.static_id
+            dye.current, self._dye_spare = self._dye_spare, dye.current
+            dyex.swap()
+            dyey.swap()
+            return
         self._non_advection_phase_dye(dye.next, dye.current)
-        if self._fused_dye and not any(f.user_data for f in (dyex.current, dyex.next, dyey.current, dyey.next)):
+        if fused:
             # one pass instead of K3 + swap + K4 + swap.  End state as in the reference: dye.current = advected dye with the previous
             # values on non-fluid cells, dye.next = the dye after its non-advection phase, dyex / dyey.current = new gradients (.next: dead)
             full = self._dye_spare.static_id != dye.current.static_id

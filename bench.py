@@ -80,6 +80,8 @@ def algorithmic_bytes(mask, esize=4):
         # + "cip_step_bnd" + "cip_step_band"): mask; v.current, p and the old gradients read, the advected velocity and the new gradients
         # written - 52 B per not-wall cell.  The post-K2 velocity is no algorithmic byte any more: it reaches HBM only around the boundary tiles.
         "cip_step": n + nw * (2 * e + e + 4 * e) + nw * (2 * e + 4 * e),
+        # ... and K12 + K3 + K4 of the dye (fs_cip_step_dye): 3 channels + their old gradients read, the advecting velocity on fluid cells, results written
+        "cip_step_dye": n + nw * (3 * e + 6 * e) + fl * 2 * e + nw * (3 * e + 6 * e),
         # the same fusion for the dye (k_cip_grad_advect_n<3>): 3 channels + the advecting velocity on fluid cells
         "cip_grad_advect_dye": n + nw * (3 * e + 3 * e) + fl * (3 * e + 2 * e) + nw * (6 * e + 6 * e),
         "vort_calc": n + fl * (2 * e + 2 * e),                           # v -> w, |w|

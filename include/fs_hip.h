@@ -145,6 +145,10 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
  * (K2 of the next step, or this step's vorticity confinement) before reading it.  fs_cip_step_ok: whether whole-grid calls take that form
  * (f32, one GPU, >= 8 M cells, FS_FUSE_K2 != 0); otherwise the call is exactly fs_cip_nonadv + fs_cip_grad_advect.                 */
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok);
+/* The same for the dye: DyeCipMacSolver._update_dye (fs/solver.py:385-401) as ONE call = fs_cip_nonadv_dye(fn <- fc) + fs_cip_grad_advect_dye, with
+ * K12 evaluated in registers on the all-fluid tiles under the conditions of fs_cip_step_ok (csrc/fs_k234.h k_cip_dye_plain). */
+int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
+                    const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v, int clamp01, int full, int row_begin, int row_end);
 /* diagnostic: the tiles (tile_rows x tile_cells cells each) of the three parts of a whole-grid fs_cip_step launch - all-fluid tiles, boundary
  * tiles, tiles K2 runs over as a kernel of its own; 0 0 0 where the call takes the two-call form. */
 int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *tile_rows, int *tile_cells);

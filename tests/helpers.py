@@ -55,3 +55,18 @@ def dead_buffers(solver):
     if getattr(solver, "_fused_dye", False):
         dead |= {"dyex.next", "dyey.next"}
     return dead
+
+
+def fluid_dead_buffers(solver):
+    """Internal buffers whose FLUID cells are unobservable (and not reproduced) while their other cells are: where fs_cip_step / fs_cip_step_dye run
+    in their three-part form (large single-GPU f32 grids; csrc/fs_k234.h) the post-K2 / post-K12 field of the all-fluid tiles stays in registers.
+    v.next is that buffer only without vorticity confinement (with it, v.next is the advected velocity, fully written)."""
+    dev = solver._bc.device
+    if not (getattr(solver, "_fused_k2", False) and getattr(dev, "cip_step_fused", False)):
+        return set()
+    out = set()
+    if getattr(solver, "vorticity_confinement", None) is None:
+        out.add("v.next")
+    if getattr(solver, "_fused_dye", False):
+        out.add("dye.next")
+    return out

@@ -155,3 +155,35 @@ def test_hipgraph_replay_of_the_three_part_step(hip_lib, monkeypatch):
     finally:
         a._solver._bc.device.close()
         b._solver._bc.device.close()
+
+
+@pytest.mark.parametrize("bc,res,steps", [(2, 512, 6), (5, 512, 5), (1, 400, 6)])
+def test_dye_trajectory_against_the_oracle(bc, res, steps, hip_lib, monkeypatch):
+    """fs_cip_step_dye: K12 in registers on the all-fluid tiles of the dye's step (k_cip_dye_plain), one wave per tile and channel."""
+    import fs
+    from oracle import oracle as O
+    monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")
+    dt, dx, re = 0.05 / res, 1.0 / res, 1.0e6
+    fs.runtime.init(gpu=0, dtype="f32")
+    sim = fs.DyeFluidSimulator.create(bc, res, dt, dx, re, 5.0, "cip")
+    try:
+        dev = sim._solver._bc.device
+        assert sim._solver._fused_k2 and sim._solver._fused_dye and dev.cip_step_fused
+        const, mask, dye = _scene(bc, res)
+        ref = O.make_simulator(const, mask, dye, scheme="cip", dt=dt, dx=dx, re=re, vor_eps=5.0)
+        dev.profile(True)
+        for _ in range(steps):
+            sim.step()
+            ref.update()
+        rep = dev.profile_report()
+        assert "cip_step_dye" in rep and "cip_step_dye_bnd" in rep and "cip_nonadv_dye" not in rep, sorted(rep)
+        out = sim.field_to_numpy()
+        for k, e in ref.fields().items():
+            assert np.array_equal(out[k], e), k
+        s = sim._solver
+        for name in ("dyex", "dyey"):
+            assert np.array_equal(getattr(s, name).current.to_numpy(), getattr(ref, name).current), name
+        a, e = s.dye.next.to_numpy(), ref.dye.next
+        assert np.array_equal(a[mask != 0], e[mask != 0])
+    finally:
+        sim._solver._bc.device.close()

@@ -67,7 +67,7 @@ def test_fast_paths_equal_reference_literal_kernels(cfg, steps, hip_lib):
         for _ in range(steps):
             fast.step()
             ref.step()
-        from helpers import dead_buffers
+        from helpers import dead_buffers, fluid_dead_buffers
         pmax = 0.0
         for name in ("v", "p", "vx", "vy", "dye", "dyex", "dyey"):          # one buffer at a time: res 8192 fields are 1 GB each
             for which in ("current", "next"):
@@ -76,6 +76,9 @@ def test_fast_paths_equal_reference_literal_kernels(cfg, steps, hip_lib):
                     continue
                 a = getattr(getattr(fast._solver, name), which).to_numpy()
                 b = getattr(getattr(ref._solver, name), which).to_numpy()
+                if k in fluid_dead_buffers(fast._solver):          # (the all-fluid tiles keep the intermediate field in registers: helpers.py)
+                    keep = fast._solver._bc.mask != 0
+                    a, b = a[keep], b[keep]
                 assert np.array_equal(a, b, equal_nan=True), f"{k}: rel-L2 {rel_l2(a, b):.3e}"
                 if k == "p.current":
                     pmax = float(np.abs(a).max())
