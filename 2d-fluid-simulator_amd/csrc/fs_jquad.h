@@ -34,14 +34,22 @@ __device__ __forceinline__ LV<T, N> jq_row(const LaneMapN<N> &lm, unsigned compu
                                            const LV<T, N> &s2, const LV<T, N> &s3)
 {
     const T pl = lv_left<T, N>(lm, ctr), pr = lv_right<T, N>(lm, ctr);
-    LV<T, N> o;
+    if constexpr (N == 2 && sizeof(T) == 4) {
+        // the lane's two cells as one packed operand (fs_device.h v2f): predict_p's five additions and its multiplication pair up; pE + pW of both
+        // cells is ONE v_pk_add_f32 on (c.x, c.y) and (left, right) (ew_sum; the second cell adds in the other order - the same bits)
+        const v2f c2 = pk(ctr);
+        const v2f val = (0.25f * ((ew_sum(c2, pl, pr) + pk(p)) + pk(m)) + pk(s2)) - pk(s3);
+        return unpk(sel2(computed, val, c2));
+    } else {
+        LV<T, N> o;
 #pragma unroll
-    for (int c = 0; c < N; ++c) {
-        const T pE = c == N - 1 ? pr : ctr.a[c == N - 1 ? c : c + 1], pW = c == 0 ? pl : ctr.a[c == 0 ? 0 : c - 1];
-        const T val = predict_from(pE, pW, p.a[c], m.a[c], s2.a[c], s3.a[c]);
-        o.a[c] = (computed & (1u << c)) ? val : ctr.a[c];
+        for (int c = 0; c < N; ++c) {
+            const T pE = c == N - 1 ? pr : ctr.a[c == N - 1 ? c : c + 1], pW = c == 0 ? pl : ctr.a[c == 0 ? 0 : c - 1];
+            const T val = predict_from(pE, pW, p.a[c], m.a[c], s2.a[c], s3.a[c]);
+            o.a[c] = (computed & (1u << c)) ? val : ctr.a[c];
+        }
+        return o;
     }
-    return o;
 }
 
 template <int N, int RT, bool BND, typename T>

@@ -227,26 +227,7 @@ __device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Kons
 // v_pk_mul_f32 / v_pk_add_f32 (one slot for two IEEE operations); the upwind selects, the DPP shifts and the divisions that are not
 // multiplications stay per half.  Same expression tree, same rounding per element: bit-identical to the scalar form above (which
 // remains the form of N = 4 and of f64).
-__device__ __forceinline__ v2f pk(const LV<float, 2> &r) { v2f v; v.x = r.a[0]; v.y = r.a[1]; return v; }
-__device__ __forceinline__ LV<float, 2> unpk(v2f v) { LV<float, 2> r; r.a[0] = v.x; r.a[1] = v.y; return r; }
-__device__ __forceinline__ v2f east(v2f c, float r) { v2f v; v.x = c.y; v.y = r; return v; }      // the cells right of the lane's two
-__device__ __forceinline__ v2f west(float l, v2f c) { v2f v; v.x = l; v.y = c.x; return v; }      // ... left of them
-__device__ __forceinline__ v2f sel2(unsigned bits, v2f a, v2f b) { v2f r; r.x = (bits & 1u) ? a.x : b.x; r.y = (bits & 2u) ? a.y : b.y; return r; }
-// east(c, r) - west(l, c) = (c.y - l, r - c.x) as ONE packed add on the register pairs (c.x, c.y) and (l, r): the halves are picked by op_sel
-// and negated by neg_lo / neg_hi ((-c.x) + r has the bits of r - c.x: IEEE addition commutes).  Building the two shifted pairs costs a
-// v_mov each - hipcc does not fold a VGPR swizzle into the modifiers.
-__device__ __forceinline__ v2f ew_diff(v2f c, float l, float r)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    v2f z, o;
-    z.x = l; z.y = r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(o) : "v"(c), "v"(z));
-    return o;
-#else
-    return east(c, r) - west(l, c);
-#endif
-}
-
+// (pk / unpk / east / west / sel2 / ew_diff: fs_rbpair.h, next to LV)
 // K3 on rows j0-1 .. j0+RT and K4 on rows j0 .. j0+RT-1 of one wave's tile from its register window (packed): Nn / Fc rows j0-2 .. j0+RT+1 of
 // the field after / before K2, GX / GY rows j0-1 .. j0+RT of the old gradients, AX / AY the advecting velocity on those rows (C = 2: only
 // the component that is not the field's own is read).  Shared by the two-kernel form below and the pass that evaluates K2 on the way

@@ -112,6 +112,40 @@ __device__ __forceinline__ void lv_store_row(T *f, const Grid &g, int c, int i0,
 #endif
 }
 
+// ---- the two cells of a lane as one packed operand (fs_device.h v2f) ----------------------------------------------------------------------
+__device__ __forceinline__ v2f pk(const LV<float, 2> &r) { v2f v; v.x = r.a[0]; v.y = r.a[1]; return v; }
+__device__ __forceinline__ LV<float, 2> unpk(v2f v) { LV<float, 2> r; r.a[0] = v.x; r.a[1] = v.y; return r; }
+__device__ __forceinline__ v2f east(v2f c, float r) { v2f v; v.x = c.y; v.y = r; return v; }      // the cells right of the lane's two
+__device__ __forceinline__ v2f west(float l, v2f c) { v2f v; v.x = l; v.y = c.x; return v; }      // ... left of them
+__device__ __forceinline__ v2f sel2(unsigned bits, v2f a, v2f b) { v2f r; r.x = (bits & 1u) ? a.x : b.x; r.y = (bits & 2u) ? a.y : b.y; return r; }
+// east(c, r) - west(l, c) = (c.y - l, r - c.x) as ONE packed add on the register pairs (c.x, c.y) and (l, r): the halves are picked by op_sel
+// and negated by neg_lo / neg_hi ((-c.x) + r has the bits of r - c.x: IEEE addition commutes).  Building the two shifted pairs costs a
+// v_mov each - hipcc does not fold a VGPR swizzle into the modifiers.
+__device__ __forceinline__ v2f ew_diff(v2f c, float l, float r)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    v2f z, o;
+    z.x = l; z.y = r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(o) : "v"(c), "v"(z));
+    return o;
+#else
+    return east(c, r) - west(l, c);
+#endif
+}
+
+// east(c, r) + west(l, c) = (c.y + l, c.x + r) the same way (the second half adds in the other order: IEEE addition commutes)
+__device__ __forceinline__ v2f ew_sum(v2f c, float l, float r)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    v2f z, o;
+    z.x = l; z.y = r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(o) : "v"(c), "v"(z));
+    return o;
+#else
+    return east(c, r) + west(l, c);
+#endif
+}
+
 // overlapped-wave column mapping for lanes of N cells: HL halo lanes on each side (default 4 / N = 4 cells: the reach of four radius-1 stages)
 template <int N> struct LaneMapN { int i0; bool owner, at_lo, at_hi; };
 template <int N, int HL = 4 / N>

@@ -67,7 +67,7 @@ def one_case(seed, max_cells, debug=False):
     dx = 1.0 / res
     dt = float(rng.choice([0.05 / res, 0.2 / res, 1e-4]))
     re = float(rng.choice([1.0, 100.0, 1e6, 1e8]))
-    os.environ["FS_FUSE_TRANSPORT"] = "1" if rng.random() < 0.2 else "0"
+    os.environ["FS_FUSE_TRANSPORT"] = "1" if rng.random() < float(os.environ.get("FUZZ_FUSE_P", "0.2")) else "0"      # FUZZ_FUSE_P=1: every CIP case through the fused passes
     os.environ["FS_RBSOR_PAIR"] = "0" if rng.random() < 0.3 else "1"
     desc = (f"seed {seed}: {X}x{Y} {np.dtype(dtype).name} {scheme} vc={vc} {updater} dye={with_dye} res={res:g} dt={dt:g} re={re:g} "
             f"fuse={os.environ['FS_FUSE_TRANSPORT']} pair={os.environ['FS_RBSOR_PAIR']}")
