@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Historical: the two variant libraries were built by editing launch_k34's geometry line - `const int N = 2;`, RT = 4 from 2 M cells - and are not kept.)
 # Run ON THE GPU BOX: K3+K4 on mid grids - quads x 2 rows (scalar) against pairs x 2 / x 4 rows (packed): tools/ab/lib_n2.so, lib_n2rt4.so
 set -u
 A=$PWD/2d-fluid-simulator_amd/csrc/libfs_hip.so; B=$PWD/tools/ab/lib_n2.so; C=$PWD/tools/ab/lib_n2rt4.so

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (tools/ab/lib_pk0.so = the library built with EXTRA=-DFS_K34_PK=0, the scalar bodies; not kept in the tree.)
 # Run ON THE GPU BOX: parity of the packed K3+K4 body, then interleaved A/B against the scalar build (tools/ab/lib_pk0.so)
 set -u
 mkdir -p gpurun_out

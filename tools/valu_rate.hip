@@ -1,5 +1,7 @@
 // valu_rate.hip - how many f32 VALU wave-instructions does one SIMD of this GPU issue per cycle?  (tool, not product)
-//   hipcc -O3 -ffp-contract=off --offload-arch=gfx950 tools/valu_rate.hip -o gpurun_out/valu_rate && gpurun_out/valu_rate
+//   hipcc -O3 -fno-slp-vectorize -ffp-contract=off --offload-arch=gfx950 tools/valu_rate.hip -o gpurun_out/valu_rate && gpurun_out/valu_rate
+// (-fno-slp-vectorize matters: without it the vectoriser packs the "scalar" loop as well - round 3's "packed issues at half rate" was that artefact;
+//  the library's own probes k_box_valu / k_box_valu_pk, built with its flags, are what bench.py reports: profiles/r5_valu_rate.txt)
 // Chains of independent multiplies / adds (no FMA contraction), scalar f32 and packed (float2: v_pk_mul_f32 / v_pk_add_f32), at
 // 1 .. 8 waves per SIMD.  Prints wave-instructions per SIMD per cycle (clock from hipDeviceProp) and the equivalent TFLOP/s.
 #include <hip/hip_runtime.h>
