@@ -162,6 +162,9 @@ __device__ __forceinline__ void cip_point(const Konst<S> &k, V vx, V vy, V dxx, 
                                           V f00, V f0m, V fm0, V fmm, V fx00, V fxm0, V fx0m, V fy00, V fy0m, V fym0,
                                           V &out_f, V &out_fx, V &out_fy)
 {
+#if defined(FS_CONTRACT_CIP)       // opt-in build flavour (EXTRA=-DFS_CONTRACT_CIP): FMA contraction inside the CIP polynomial - NOT bit-exact, never the default;
+#pragma clang fp contract(fast)    // built once to price bit-exactness (tools/r5_contract.sh)
+#endif
     using D = typename VecOf<V>::D;
     const V is = sel_neg(vx, (V)(S)-1, (V)(S)1);   // sign(0) = +1, fs/differentiation.py:12-14
     const V js = sel_neg(vy, (V)(S)-1, (V)(S)1);
