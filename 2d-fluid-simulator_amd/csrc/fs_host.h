@@ -120,7 +120,7 @@ struct fs_ctx {
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int stack_mask = 0;       // kernel families (XCD_* bits) launched with stacked workgroups (fs_create)
     bool pack_halo = true;    // env FS_PACK_HALO=0: one ncclSend/ncclRecv per field instead of one packed message per neighbour
-    int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default, 21 / 22 / 23 / 24 = overlapped-wave tiles of 1 - 4 rows
+    int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default (the literal f32 sweep: packed pairs, fs_jquad.h k_jacobi_ov2), 21 / 22 / 23 / 24 = quad tiles of 1 - 4 rows
 
     // compact launches (fs_device.h Grid::tiles): per-cell activity of the scene on the host (bit 0: some cell of wave column wx - 248
     // cells - in row j is not deep wall, bit 1: the same for the 120-cell wave columns of the 2-cell-lane kernels), and the lists built from

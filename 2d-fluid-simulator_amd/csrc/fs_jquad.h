@@ -94,6 +94,82 @@ __device__ __forceinline__ void jacobi_quad_tile(const Grid &g, const LaneMapN<N
 #undef FS_NW
 }
 
+// ------------------------------------------------------------------------------------------------
+// K8J, the literal sweep (reads p and v like fs/pressure_updater.py:62-66) on lanes of 2 cells, packed (round 5): the source term's four
+// differences, its products and sums and predict_p's additions pair up (fs_device.h v2f; sxx / sxy and pE + pW as ONE packed add each,
+// ew_diff / ew_sum); the division by 8 dt stays per half.  Tiles of RT rows, one halo lane per side (62 owner lanes = 124 cells).  Same
+// expression per cell as k_jacobi_ov - same bits; the quad form holds 4 cells per lane, whose inner x-neighbours are an unaligned register
+// pair and do not pack.  f32 only.
+// ------------------------------------------------------------------------------------------------
+template <int RT, int DM, bool PLAIN>
+__device__ __forceinline__ void jacobi_ov2_tile(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm_in, int i0, int j0, int je, const unsigned (&nw)[RT],
+                                                float *pn, const float *pc, const float *vc)
+{
+    using T = float;
+    constexpr int N = 2;
+    const LaneMapN<N> lm = PLAIN ? LaneMapN<N>{lm_in.i0, lm_in.owner, false, false} : lm_in;      // (a plain tile holds no lane at the domain's first / last column)
+    v2f P[RT + 2], VX[RT + 2], VY[RT + 2];
+#pragma unroll
+    for (int u = 0; u < RT + 2; ++u) {
+        const int row = clampy(g, j0 - 1 + u);
+        P[u] = pk(lv_field<1, T, N>(pc, g, 0, i0, row));
+        VX[u] = pk(lv_field<2, T, N>(vc, g, 0, i0, row));
+        VY[u] = pk(lv_field<2, T, N>(vc, g, 1, i0, row));
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        if (j >= je) break;
+        const v2f xc = VX[t + 1], yc = VY[t + 1], pcur = P[t + 1];
+        const T xl = lv_left<T, N>(lm, unpk(xc)), xr = lv_right<T, N>(lm, unpk(xc));
+        const T yl = lv_left<T, N>(lm, unpk(yc)), yr = lv_right<T, N>(lm, unpk(yc));
+        const T pl = lv_left<T, N>(lm, unpk(pcur)), pr = lv_right<T, N>(lm, unpk(pcur));
+        // fs_march.h source_from: s2 = ((sxx sxx + syy syy) + syx sxy) / 8,  s3 = (dx (sxx + syy)) / (8 dt)
+        const v2f sxx = ew_diff(xc, xl, xr), sxy = ew_diff(yc, yl, yr), syx = VX[t + 2] - VX[t], syy = VY[t + 2] - VY[t];
+        const v2f s2 = ((sxx * sxx + syy * syy) + (syx * sxy)) / 8.0f;
+        const v2f s3n = k.dx * (sxx + syy);
+        v2f s3;
+        s3.x = cdiv<DM>(s3n.x, k.eight_dt, k.r_eight_dt);
+        s3.y = cdiv<DM>(s3n.y, k.eight_dt, k.r_eight_dt);
+        // predict_from: (0.25 (((pE + pW) + pN) + pS) + s2) - s3
+        const v2f val = (0.25f * ((ew_sum(pcur, pl, pr) + P[t + 2]) + P[t]) + s2) - s3;
+        if (lm.owner) {
+            if (PLAIN) lv_store_row<1, T, N>(pn, g, 0, i0, j, unpk(val));
+            else if (nw[t]) lv_store_sel<T, N>(pn + idx<1, T>(g, 0, i0, j), unpk(val), nw[t]);
+        }
+    }
+}
+
+// the list's per-wave hint (fs_core.hip tile_list, reach 1): nothing but fluid in and around the wave's tile - no mask loads, whole-lane stores
+template <int RT, int DM>
+__global__ __launch_bounds__(256) void k_jacobi_ov2(Grid g, Konst<float> k, int nbx, int nby, int jb, int je, float *pn, const float *pc, const float *vc)
+{
+    constexpr int N = 2, HL = 1, OW = 64 - 2 * HL;
+    int bx, by, cg;
+    unsigned cls = 0u;
+    if (!band_coords<1>(g, nbx, nby, bx, by, cg, 0, &cls)) return;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwv = blockDim.x >> 6;
+    const int wx = (nby & FS_STACKED) ? bx : bx * nwv + w, ty = (nby & FS_STACKED) ? by * nwv + w : by;
+    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    unsigned nw[RT];
+    if ((cls >> w) & 1u) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) nw[t] = 3u;
+        jacobi_ov2_tile<RT, DM, true>(g, k, lm, i0, j0, je, nw, pn, pc, vc);
+        return;
+    }
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        nw[t] = j0 + t < je ? lv_sel_not_wall<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
+        any = any || (lm.owner && nw[t] != 0u);
+    }
+    if (!__any(any)) return;
+    jacobi_ov2_tile<RT, DM, false>(g, k, lm, i0, j0, je, nw, pn, pc, vc);
+}
+
 // PATH 2: classify the tile here (mask loads); 3: the host listed this workgroup as plain - nothing but fluid within reach (fs_api.hip
 // tile_list): the plain path without looking, as its own kernel with its own (small) register budget
 template <int N, int RT, int PATH, typename T>

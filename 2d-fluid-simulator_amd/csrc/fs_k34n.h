@@ -55,17 +55,7 @@ template <typename T, int N> __device__ __forceinline__ bool lv_hot1(const LV<T,
 }
 template <typename T, int N> __device__ __forceinline__ void lv_store(T *dst, const LV<T, N> &v) { lv_store_sel<T, N>(dst, v, (1u << N) - 1u); }
 
-template <int N, int ZG, int HL>
-__device__ __forceinline__ bool tile_coords_nz(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg)
-{
-    constexpr int OW = 64 - 2 * HL;
-    int bx, by;
-    if (!band_coords<ZG>(g, nbx, nby_packed, bx, by, cg)) return false;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-    if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
-    else { wave_x = bx * nw + w; tile_y = by; }
-    return wave_x * OW < g.X / N && jb + tile_y * rt < je;
-}
+// (tile_coords_nz: fs_rbpair.h)
 
 template <int C, int c, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T, int HL = 1>
 __device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,

@@ -23,6 +23,16 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
     // overlapped-wave register tiles of 1 - 4 rows (FS_JACOBI=21 .. 24).  Default (0): the source-pair
     // form streams best with 1-row tiles at 8 waves/SIMD (76 vs 79 us), the v-reading form with 2-row tiles (89 vs 95 us)
     const int v = ctx->jacobi_variant ? ctx->jacobi_variant : (SRC ? 21 : 24);      // (round 4, after the DPP diet: 4-row tiles for the v-reading form: 84.7 against 85.9-86.4 us)
+    if constexpr (!SRC && std::is_same<T, float>::value) {
+        // default (FS_JACOBI unset): the literal sweep on packed lanes of 2 cells, 4-row tiles, per-wave plain hints in the launch list (fs_jquad.h
+        // k_jacobi_ov2; round 5: 74.5-75.6 against 81.6 us for the quad form below - 8-row tiles 86, 2-row tiles 84, without the hints 79-80)
+        if (ctx->jacobi_variant == 0 && ctx->use_pairs) {
+            const OvGrid og = ov_grid_lanes(ctx, jb, je, 4, 1, XCD_JACOBI, 3, true, 0, 1);      // (reach 1: the hints)
+            const int dm = dm_const(ctx, k);
+#define FS_JAC2(DM) hipLaunchKernelGGL((k_jacobi_ov2<4, DM>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs)
+            return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC2); });
+        }
+    }
     const int rt = v == 24 ? 4 : (v == 21 ? 1 : (v == 23 ? 3 : 2));
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
     const int dm = SRC ? 0 : dm_const(ctx, k);           // the source-pair form divides nothing

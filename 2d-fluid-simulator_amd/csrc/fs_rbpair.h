@@ -182,6 +182,19 @@ __device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_pa
     return wave_x * OW < g.X / N && jb + tile_y * rt < je;
 }
 
+// the same for kernels with ZG channel groups and HL halo lanes per side (fs_k34n.h, fs_k234.h, fs_jquad.h k_jacobi_ov2)
+template <int N, int ZG, int HL>
+__device__ __forceinline__ bool tile_coords_nz(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg)
+{
+    constexpr int OW = 64 - 2 * HL;
+    int bx, by;
+    if (!band_coords<ZG>(g, nbx, nby_packed, bx, by, cg)) return false;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+    if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
+    else { wave_x = bx * nw + w; tile_y = by; }
+    return wave_x * OW < g.X / N && jb + tile_y * rt < je;
+}
+
 // one row of the buffer as K7 would leave it, from raw rows m / c / n = rows j-1 / j / j+1 and the recipe bytes of row j (whole wave)
 template <typename T, int N>
 __device__ __forceinline__ LV<T, N> lv_bc_row(const LaneMapN<N> &lm, const LV<T, N> &m, const LV<T, N> &c, const LV<T, N> &n, uint32_t code)

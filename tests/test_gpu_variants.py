@@ -49,10 +49,11 @@ def _run(monkeypatch, env, what):
     return out
 
 
-@pytest.mark.parametrize("variant", ["22", "24", "21", "23"])
+@pytest.mark.parametrize("variant", ["default", "22", "24", "21", "23"])
 def test_jacobi_tile_variants(variant, hip_lib, monkeypatch):
+    """default: the literal sweep on packed lanes of 2 cells with per-wave plain hints (k_jacobi_ov2); 21 - 24: the quad tiles of 1 - 4 rows"""
     ref = _run(monkeypatch, {"FS_MARCH": "0"}, "jacobi")
-    got = _run(monkeypatch, {"FS_JACOBI": variant}, "jacobi")
+    got = _run(monkeypatch, {} if variant == "default" else {"FS_JACOBI": variant}, "jacobi")
     for k in ref:
         assert np.array_equal(got[k], ref[k], equal_nan=True), (variant, k)
 
