@@ -526,26 +526,20 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nb
 // A lane computes w for RT+2 rows of its cells from RT+4 rows of v, takes the x-neighbours of |w| from the adjacent lanes (DPP) and
 // writes RT rows of vn; w / |w| never touch HBM unless STORE_W.  One halo lane per side (the pass reaches 2 cells in x).
 // ------------------------------------------------------------------------------------------------
-template <int N, int RT, int DM, bool STORE_W, typename T>
-__global__ __launch_bounds__(256) void k_vort_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot, int clear3)
+// PLAIN: the launch list says this wave sees nothing but fluid within reach (per-wave hint, fs_core.hip tile_list): no mask loads before the
+// window is requested, constant selectors, no lane at the domain's first / last column (round 5: the mask round trip in front of the loads was
+// what the literal Jacobi sweep lost 8 % to)
+template <int N, int RT, int DM, bool STORE_W, bool PLAIN, typename T>
+__device__ __forceinline__ void vort_n_tile(const Grid &g, const Konst<T> &k, const LaneMapN<N> &lm_in, int i0, int j0, int je, const unsigned (&fl_in)[RT + 2],
+                                            T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot)
 {
     using R = LV<T, N>;
-    constexpr int HL = 1, L = N - 1;
-    if (clear3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) hot[3] = 0u;      // every fluid cell of vn is rewritten (fs_device.h "hot" word [3])
-    int wx, ty, cg;
-    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
-    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
-    const int i0 = lm.i0, j0 = jb + ty * RT;
-
-    unsigned fl[RT + 2];   // fluid selectors of rows j0-1 .. j0+RT (clamped rows repeat)
-    bool any = false;
+    constexpr int L = N - 1;
+    constexpr unsigned ALL = (1u << N) - 1u;
+    const LaneMapN<N> lm = PLAIN ? LaneMapN<N>{lm_in.i0, lm_in.owner, false, false} : lm_in;
+    unsigned fl[RT + 2];
 #pragma unroll
-    for (int r = 0; r < RT + 2; ++r) {
-        fl[r] = lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 1 + r)));
-        if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
-    }
-    if (!__any(any)) return;
-
+    for (int r = 0; r < RT + 2; ++r) fl[r] = PLAIN ? ALL : fl_in[r];
     R VX[RT + 4], VY[RT + 4];   // rows j0-2 .. j0+RT+1
 #pragma unroll
     for (int r = 0; r < RT + 4; ++r) {
@@ -606,6 +600,36 @@ __global__ __launch_bounds__(256) void k_vort_n(Grid g, Konst<T> k, int nbx, int
             lv_store_sel<T, N>(vn + idx<2, T>(g, 1, i0, j), oy, f);
         }
     }
+}
+
+template <int N, int RT, int DM, bool STORE_W, typename T>
+__global__ __launch_bounds__(256) void k_vort_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, T *vort, T *vort_abs, unsigned *hot, int clear3)
+{
+    constexpr int HL = 1, OW = 64 - 2 * HL;
+    if (clear3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) hot[3] = 0u;      // every fluid cell of vn is rewritten (fs_device.h "hot" word [3])
+    int bx, by, cg;
+    unsigned cls = 0u;
+    if (!band_coords<1>(g, nbx, nby, bx, by, cg, 0, &cls)) return;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwv = blockDim.x >> 6;
+    const int wx = (nby & FS_STACKED) ? bx : bx * nwv + w, ty = (nby & FS_STACKED) ? by * nwv + w : by;
+    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    unsigned fl[RT + 2];   // fluid selectors of rows j0-1 .. j0+RT (clamped rows repeat)
+    if ((cls >> w) & 1u) {
+#pragma unroll
+        for (int r = 0; r < RT + 2; ++r) fl[r] = (1u << N) - 1u;
+        vort_n_tile<N, RT, DM, STORE_W, true, T>(g, k, lm, i0, j0, je, fl, vn, vc, vort, vort_abs, hot);
+        return;
+    }
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < RT + 2; ++r) {
+        fl[r] = lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 1 + r)));
+        if (r >= 1 && r <= RT && j0 - 1 + r < je) any |= fl[r] != 0u;
+    }
+    if (!__any(any)) return;
+    vort_n_tile<N, RT, DM, STORE_W, false, T>(g, k, lm, i0, j0, je, fl, vn, vc, vort, vort_abs, hot);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -455,7 +455,7 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
     // lanes of 2 cells (fs_k34n.h k_vort_n), 4-row tiles, compact launch: 100 -> 95 us at bc5 res 4096 against the quad form it replaces (6 / 8 rows:
     // 102 / 103; f64 at bc3 res 4096: 251 -> 224)
     const bool small = small_tiles(ctx) && !vort;      // (small grids: 2-row tiles, see fs_cip_nonadv)
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_VORT, 3);
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_VORT, 3, true, 0, 2);      // (reach 2: per-wave plain hints in the list)
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, weight);
         const int dm = dm_dx(ctx, k);
