@@ -440,8 +440,9 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nb
     using R = LV<T, N>;
     constexpr int L = N - 1;
     if (clear3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) hot[3] = 0u;      // every not-wall cell of fn is rewritten (fs_device.h "hot" word [3])
-    int wx, ty, cg;
-    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    int wx, ty;
+    bool plain;
+    if (!tile_coords_hint<N, HL>(g, nbx, nby, jb, je, RT, wx, ty, plain)) return;
     LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
     if (WIDE) {
         const int lane = threadIdx.x & 63, q = wx * (64 - 2 * HL) - HL + lane;
@@ -449,13 +450,18 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nb
     }
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[RT];
-    bool any = false;
+    if (plain) {                                    // (the list's hint: all fluid - the window is requested without waiting for the masks)
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        nw[t] = j0 + t < je ? lv_sel_nw<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
-        any = any || (lm.owner && nw[t] != 0u);
+        for (int t = 0; t < RT; ++t) nw[t] = j0 + t < je ? (1u << N) - 1u : 0u;
+    } else {
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            nw[t] = j0 + t < je ? lv_sel_nw<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
+            any = any || (lm.owner && nw[t] != 0u);
+        }
+        if (!__any(any)) return;
     }
-    if (!__any(any)) return;
     R F[2][RT + 2], P[RT + 2];
 #pragma unroll
     for (int u = 0; u < RT + 2; ++u) {
@@ -642,18 +648,24 @@ __global__ __launch_bounds__(256) void k_mac_update_n(Grid g, Konst<T> k, int nb
     using Rw = LV<T, N>;
     constexpr int R = SCHEME == 0 ? 1 : 2;          // stencil radius
     constexpr int HL = 1, L = N - 1;
-    int wx, ty, cg;
-    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    int wx, ty;
+    bool plain;
+    if (!tile_coords_hint<N, HL>(g, nbx, nby, jb, je, RT, wx, ty, plain)) return;
     const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned fl[RT];
-    bool any = false;
+    if (plain) {                                    // (the list's hint: all fluid - the window is requested without waiting for the masks)
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        fl[t] = j0 + t < je ? lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
-        any = any || (lm.owner && fl[t] != 0u);
+        for (int t = 0; t < RT; ++t) fl[t] = j0 + t < je ? (1u << N) - 1u : 0u;
+    } else {
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            fl[t] = j0 + t < je ? lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
+            any = any || (lm.owner && fl[t] != 0u);
+        }
+        if (!__any(any)) return;
     }
-    if (!__any(any)) return;
     Rw V[2][RT + 2 * R], P[RT + 2];                 // slot u of V <-> row j0 - R + u, slot u of P <-> row j0 - 1 + u
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -874,8 +886,9 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_dye_n(Grid g, Konst<T> k, in
 {
     using R = LV<T, N>;
     constexpr int L = N - 1;
-    int wx, ty, cg;
-    if (!tile_coords_nz<N, 1, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    int wx, ty;
+    bool plain;
+    if (!tile_coords_hint<N, HL>(g, nbx, nby, jb, je, RT, wx, ty, plain)) return;
     LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
     if (WIDE) {
         const int lane = threadIdx.x & 63, q = wx * (64 - 2 * HL) - HL + lane;
@@ -883,13 +896,18 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_dye_n(Grid g, Konst<T> k, in
     }
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[RT];
-    bool any = false;
+    if (plain) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        nw[t] = j0 + t < je ? lv_sel_nw<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
-        any = any || (lm.owner && nw[t] != 0u);
+        for (int t = 0; t < RT; ++t) nw[t] = j0 + t < je ? (1u << N) - 1u : 0u;
+    } else {
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            nw[t] = j0 + t < je ? lv_sel_nw<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 + t))) : 0u;
+            any = any || (lm.owner && nw[t] != 0u);
+        }
+        if (!__any(any)) return;
     }
-    if (!__any(any)) return;
     R D[3][RT + 2];
 #pragma unroll
     for (int c = 0; c < 3; ++c)

@@ -69,7 +69,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
             // lanes of 2 cells (fs_k34n.h k_mac_update_n), tiles of 4 rows on large f32 grids (KK at bc3 res 4096: 178 -> 162 us against the one-row quad
             // form it replaces; f64: 424 -> 306 with 2-row tiles), 2 rows on small grids (more workgroups) and for f64 (registers)
             const int rt = sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2;
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_NONADV, 3);
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_NONADV, 3, true, 0, 2);      // (reach: per-wave plain hints in the list)
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
 #define FS_K2MN(SS, RR, PP) hipLaunchKernelGGL((k_mac_update_n<SS, 2, RR, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
             (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot)
@@ -129,7 +129,7 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
             // it replaces (2 rows: 112, 8 rows: 106-110)
             // (small grids - fewer waves than SIMDs, a launch takes as long as one wave's chain: 2-row tiles, fs_ctx::small_tiles)
             const bool small = small_tiles(ctx);
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3);
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3, true, 0, 1);      // (reach 1: per-wave plain hints)
             const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
             return launch(ctx, "cip_nonadv", [=] {
 #define FS_K2N4(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
@@ -153,7 +153,7 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
         if (ctx->use_pairs) {
             // lanes of 2 cells, 4-row tiles (fs_k34n.h k_cip_nonadv_dye_n), compact launch: 141 -> 122-130 us at bc5 res 4096 against the one-row quad form
             const bool small = small_tiles(ctx);       // (2-row tiles, see fs_cip_nonadv)
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3);
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3, true, 0, 1);
             return launch(ctx, "cip_nonadv_dye", [=] {
 #define FS_K12N(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
 #define FS_K12N2(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
