@@ -186,6 +186,12 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                         }
                         any_hint = any_hint || hints != 0u;
                     }
+                    if (any && cls == 2 && wgw == 1) {
+                        // boundary list of a multi-part launch (one-wave workgroups): bit 1 of the hint = "a fluid cell in the tile's own rows, halo lanes
+                        // included" - the general kernels then request their window without waiting for the masks that would tell them so
+                        for (int j = j0; j < j1; ++j)
+                            if (act[(size_t)bx * Y + j] & 4) { hints |= 2u; break; }
+                    }
                     if (any) per[xcd].push_back((hints << 28) | ((uint32_t)by << 12) | (uint32_t)bx);
                 }
             }
@@ -731,7 +737,7 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
                 for (int lr = 0; lr < R; ++lr) {
                     const int j = g0 + lr;
                     if (j < 0 || j >= Y) { a[lr] |= 2; if (h) h[lr] |= 2; continue; }
-                    const uint8_t nf = m[j] != 0 ? 2 : 0;
+                    const uint8_t nf = m[j] != 0 ? 2 : 4;            // bit 1: a cell that is not fluid, bit 2: a fluid cell - both with the halo lanes of the neighbouring column
                     a[lr] |= (uint8_t)((m[j] != 1) | (b[j] != 0)) | nf;
                     if (h) h[lr] |= nf;
                 }

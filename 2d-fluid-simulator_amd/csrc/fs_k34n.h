@@ -319,7 +319,11 @@ __device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Kon
     constexpr unsigned ALL = 3u;
     constexpr bool SELF = C == 2;
     int wx, ty, cg;
-    if (!tile_coords_nz<N, C, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg)) return;
+    unsigned cls = 0u;
+    if (!tile_coords_nz<N, C, HL>(g, nbx, nby, jb, je, RT, wx, ty, cg, PLAIN ? nullptr : &cls)) return;
+    // boundary list of a multi-part launch (one-wave workgroups): bit 1 of the entry's hint = the host saw a fluid cell in the tile's own rows
+    // (fs_core.hip tile_list) - the window is then requested WITH the masks instead of behind the test that needs them
+    const bool bnd_fluid = !PLAIN && !full && (blockDim.x >> 6) == 1 && (cls & 2u) != 0u;
     const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
     const LaneMapN<N> lm = PLAIN ? LaneMapN<N>{lm_in.i0, lm_in.owner, false, false} : lm_in;
     const int i0 = lm.i0, j0 = jb + ty * RT;
@@ -333,7 +337,7 @@ __device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Kon
         nw[s] = lv_sel_nw<N>(m);
         if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? lv_sel_fluid<N>(m) : 0u; any_fl |= fl[s - 1] != 0u; }
     }
-    if (!PLAIN && !__any(any_fl)) {
+    if (!PLAIN && !bnd_fluid && !__any(any_fl)) {
         // (no fluid cell in this wave's tile: carried values only - see cip_grad_advect_n_body)
 #pragma unroll
         for (int t = 0; t < RT; ++t) {

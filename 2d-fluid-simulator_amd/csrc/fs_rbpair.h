@@ -168,8 +168,9 @@ template <typename T, int N> __device__ __forceinline__ T lv_right(const LaneMap
 { const T r = lane_next(v.a[0]); return m.at_hi ? v.a[N - 1] : r; }
 
 // plain_hint (optional): the host's list says this wave sees nothing but fluid within the kernel's reach (band_coords cls)
+// bnd_fluid (optional; one-wave workgroups of a boundary list): the host saw a fluid cell in the tile's own rows (bit 1 of the entry's hint)
 template <int N>
-__device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, bool *plain_hint = nullptr)
+__device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, bool *plain_hint = nullptr, bool *bnd_fluid = nullptr)
 {
     constexpr int OW = 64 - 2 * (4 / N);
     int bx, by, cg;
@@ -177,6 +178,7 @@ __device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_pa
     if (!band_coords<1>(g, nbx, nby_packed, bx, by, cg, 0, plain_hint ? &cls : nullptr)) return false;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     if (plain_hint) *plain_hint = ((cls >> w) & 1u) != 0u;
+    if (bnd_fluid) *bnd_fluid = nw == 1 && (cls & 2u) != 0u;
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }
     return wave_x * OW < g.X / N && jb + tile_y * rt < je;
@@ -184,11 +186,11 @@ __device__ __forceinline__ bool tile_coords_n(const Grid &g, int nbx, int nby_pa
 
 // the same for kernels with ZG channel groups and HL halo lanes per side (fs_k34n.h, fs_k234.h, fs_jquad.h k_jacobi_ov2)
 template <int N, int ZG, int HL>
-__device__ __forceinline__ bool tile_coords_nz(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg)
+__device__ __forceinline__ bool tile_coords_nz(const Grid &g, int nbx, int nby_packed, int jb, int je, int rt, int &wave_x, int &tile_y, int &cg, unsigned *cls = nullptr)
 {
     constexpr int OW = 64 - 2 * HL;
     int bx, by;
-    if (!band_coords<ZG>(g, nbx, nby_packed, bx, by, cg)) return false;
+    if (!band_coords<ZG>(g, nbx, nby_packed, bx, by, cg, 0, cls)) return false;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     if (nby_packed & FS_STACKED) { wave_x = bx; tile_y = by * nw + w; }
     else { wave_x = bx * nw + w; tile_y = by; }
@@ -466,15 +468,20 @@ __device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k
 {
     constexpr int W = RT + 8;
     int wx, ty;
-    bool hint = false;
-    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty, PATH == 2 && !FULL ? &hint : nullptr)) return;
+    bool hint = false, bnd_fluid = false;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty, PATH == 2 && !FULL ? &hint : nullptr, PATH == 2 && !FULL ? &bnd_fluid : nullptr)) return;
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned fl[W];
     // plain: the host listed this workgroup (PATH 3) / this wave (hint) as seeing nothing but fluid within reach (fs_api.hip tile_list) - or the
     // masks say so.  ONE instance of each path in the kernel.
     bool plain = PATH == 3 || hint;
-    if (!plain) {
+    if (!plain && bnd_fluid) {
+        // boundary list of the two-part launch, and the host saw fluid in the tile's own rows: not plain, something to store - the masks are
+        // requested with the window instead of in front of it
+#pragma unroll
+        for (int w = 0; w < W; ++w) fl[w] = lv_sel_fluid<N>(lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 4 + w)));
+    } else if (!plain) {
         bool own_fluid = false, all_fluid = true;
 #pragma unroll
         for (int w = 0; w < W; ++w) {
