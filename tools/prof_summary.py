@@ -69,6 +69,9 @@ if all(k in by_short for k in parts3):
     traffic["cip_step"] = sum(by_short[k] for k in parts3)
     traffic["cip_step_parts"] = {k: by_short[k] for k in parts3}
     traffic.pop("cip_grad_advect_rt", None); traffic.pop("cip_nonadv", None)
+# the literal Jacobi sweep is its own kernel since round 5 (packed lanes of 2 cells, fs_jquad.h k_jacobi_ov2); k_jacobi_ov is then the source-pair form only
+if "k_jacobi_ov2" in by_short:
+    traffic["jacobi_sweep"] = by_short["k_jacobi_ov2"]
 # fs_rbsor_pair: the all-fluid tiles as stacked two-wave workgroups (k_rbsor_pair_stack) + the boundary tiles (k_rbsor_pair)
 parts2 = ("k_rbsor_pair_stack", "k_rbsor_pair")
 if all(k in by_short for k in parts2):
