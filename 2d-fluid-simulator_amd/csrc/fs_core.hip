@@ -196,7 +196,27 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                 }
             }
     size_t K = 0, total = 0;
-    for (auto &v : per) { K = std::max(K, v.size()); total += v.size(); }
+    for (auto &v : per) total += v.size();
+    if (c->tile_balance && total >= 64) {
+        // The geometry deals a class of tiles unevenly (bc5 res 4096: the boundary tiles of the red-black pair 1003 .. 1365 per XCD) and a compact
+        // launch lasts as long as its fullest XCD.  An entry names its tile, so any XCD may run it: the surplus of an XCD - the END of its list, whole
+        // runs of vertically adjacent tiles - goes to the end of the emptiest lists.  Those tiles read their halo rows through another L2; they are
+        // a few per cent of the list.
+        const size_t target = (total + 7) / 8;
+        for (int d = 0; d < 8; ++d)
+            while (per[d].size() > target) {
+                int r = 0;
+                for (int x = 1; x < 8; ++x) if (per[x].size() < per[r].size()) r = x;
+                if (per[r].size() >= target) break;
+                const size_t n = std::min(per[d].size() - target, target - per[r].size());
+                per[r].insert(per[r].end(), per[d].end() - n, per[d].end());
+                per[d].resize(per[d].size() - n);
+            }
+    }
+    for (auto &v : per) K = std::max(K, v.size());
+    if (getenv("FS_TILE_LIST_DEBUG"))      // how evenly the geometry deals a class of tiles to the 8 XCDs (a compact launch takes max-per-XCD rounds)
+        fprintf(stderr, "tile_list lanes=%d rt=%d cls=%d reach=%d wgw=%d parent=%d: %zu entries, per XCD %zu %zu %zu %zu %zu %zu %zu %zu\n", lanes, rt, cls, reach, wgw, parent_rt,
+                total, per[0].size(), per[1].size(), per[2].size(), per[3].size(), per[4].size(), per[5].size(), per[6].size(), per[7].size());
     fs_ctx::TileList tl;
     if (K > 0 && (cls || any_hint || total < (size_t)nbx * nby)) {        // (nothing to skip, no hint to give: the dense grid needs no list)
         std::vector<uint32_t> h(K * 8, 0xffffffffu);
@@ -590,8 +610,9 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_F64DIV")) c->use_f64div = atoi(s) != 0;
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
+    if (const char *s = getenv("FS_TILE_BALANCE")) c->tile_balance = atoi(s) != 0;
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
-    if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = atoi(s) != 0;
+    if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = std::max(0, std::min(2, atoi(s)));
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_SMALL_CELLS")) c->small_cells = (size_t)atoll(s);
     if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8 || v == 16) c->rbpair_plain_rt = v; }

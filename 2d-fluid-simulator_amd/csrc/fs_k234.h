@@ -126,6 +126,117 @@ __global__ __launch_bounds__(128) void k_cip_step_plain(Grid g, Konst<float> k, 
     else        k234_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, xch);
 }
 
+// ---- the boundary tiles of the same call -------------------------------------------------------------------------------------------------
+// Same two waves per tile, with the masks: K2 is the reference's on every not-wall cell of the window (clamped rows, clamped edge lanes - the
+// lane map and row function of k_cip_nonadv_n), a WALL cell takes the value the intermediate buffer holds (nothing writes it in this step;
+// the load is predicated on the lanes that have one), and a slot that stands for a row outside the domain takes the slot of the edge row it
+// clamps onto.  The window then is, bit for bit, what the general K3 + K4 kernel (fs_k34n.h) reads from memory behind a K2 launch - without
+// that launch and without the 8 B per cell it wrote and the 14 rows per wave that were read back.  Stored from K2: the not-wall cells of
+// the tile's own rows that are not fluid (inflow / outflow: the reference's buffer keeps them, and a later step may look at them as stale
+// data); the fluid cells are dead as on the plain tiles.  K3 + K4: the packed core with its selectors.
+template <int c, int RT, int DM>
+__device__ __forceinline__ void k234_bnd_phase1(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
+                                                float *fn, const float *fc, const float *pc, const float *gxc, const float *gyc, unsigned *hot_fn,
+                                                K234State<RT> &st, unsigned (&nwk)[RT + 4], unsigned (&fl)[RT], v2f (*xch)[64])
+{
+    using T = float;
+    constexpr int N = 2;
+    FS_PIN_LANE_OFFSET(i0);
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + u));
+        nwk[u] = lv_sel_nw<N>(m);
+        if (u >= 2 && u < RT + 2) fl[u - 2] = j0 + u - 2 < je ? lv_sel_fluid<N>(m) : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const int row = clampy(g, j0 - 1 + s);
+        st.GX[s] = pk(lv_field<2, T, N>(gxc, g, c, i0, row));
+        st.GY[s] = pk(lv_field<2, T, N>(gyc, g, c, i0, row));
+    }
+    v2f F[RT + 6], P[RT + 6];
+#pragma unroll
+    for (int u = 0; u < RT + 6; ++u) {
+        const int row = clampy(g, j0 - 3 + u);
+        F[u] = pk(lv_field<2, T, N>(fc, g, c, i0, row));
+        if (c == 1 || (u >= 1 && u <= RT + 4)) P[u] = pk(lv_field<1, T, N>(pc, g, 0, i0, row));
+    }
+    // what the buffer holds on wall cells
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        st.Nn[u] = v2f{0.0f, 0.0f};
+        if (nwk[u] != 3u) st.Nn[u] = pk(lv_field<2, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
+    }
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        const v2f n = nonadv_pk_row<c, DM>(k, lm, F[u], F[u + 1], F[u + 2], P[u + 1], P[c == 0 ? u + 1 : u], P[c == 0 ? u + 1 : u + 2]);
+        st.Nn[u] = sel2(nwk[u], n, st.Nn[u]);
+        st.Fc[u] = F[u + 1];
+    }
+    // slots of rows outside the domain (wave-uniform): K2 of the edge row, which was evaluated from ITS neighbours
+#pragma unroll
+    for (int u = RT + 2; u >= 0; --u) if (j0 - 2 + u < g.jlo) st.Nn[u] = st.Nn[u + 1];
+#pragma unroll
+    for (int u = 1; u < RT + 4; ++u) if (j0 - 2 + u > g.jhi) st.Nn[u] = st.Nn[u - 1];
+    // K2's own output where it outlives the step
+    if (lm.owner) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const unsigned sel = nwk[t + 2] & ~fl[t] & 3u;
+            if (j0 + t < je && sel) {
+                const LV<T, N> O = unpk(st.Nn[t + 2]);
+#pragma unroll
+                for (int q = 0; q < N; ++q) raise_hot(hot_fn, ((sel >> q) & 1u) && hot1(O.a[q]));
+                lv_store_sel<T, N>(fn + idx<2, T>(g, c, i0, j0 + t), O, sel);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) xch[c * (RT + 2) + s][lane] = st.Nn[s + 1];
+}
+
+template <int c, int RT, int DM>
+__device__ __forceinline__ void k234_bnd_phase2(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
+                                                float *out, float *gxo, float *gyo, unsigned *hot, const K234State<RT> &st,
+                                                const unsigned (&nwk)[RT + 4], const unsigned (&fl)[RT], const v2f (*xch)[64])
+{
+    const int lane = threadIdx.x & 63;
+    v2f A[RT + 2];
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) A[s] = xch[(1 - c) * (RT + 2) + s][lane];
+    unsigned nw[RT + 2];
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) nw[s] = nwk[s + 1];
+    cip_k34_pk_core<2, c, RT, DM, false, false>(g, k, lm, i0, j0, je, nw, fl, st.Nn, st.Fc, st.GX, st.GY, A, A, out, gxo, gyo, hot);
+}
+
+// one workgroup = 2 waves = the two velocity components of ONE listed boundary tile (compact launch, class 2 list with one entry per tile)
+#ifndef FS_K234_BND_WAVES
+#define FS_K234_BND_WAVES 3
+#endif
+template <int RT, int DM>
+__global__ __launch_bounds__(128, FS_K234_BND_WAVES) void k_cip_step_bnd(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
+                                                      float *out, float *gxo, float *gyo, float *fn, const float *fc, const float *pc,
+                                                      const float *gxc, const float *gyc, unsigned *hot, unsigned *hot_fn)
+{
+    constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
+    __shared__ v2f xch[2 * (RT + 2)][64];
+    int wx, ty, cg;
+    if (!band_coords<1>(g, nbx, nby, wx, ty, cg)) return;
+    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
+    const int c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm.i0, j0 = jb + ty * RT;
+    K234State<RT> st;
+    unsigned nwk[RT + 4], fl[RT];
+    if (c == 0) k234_bnd_phase1<0, RT, DM>(g, k, lm, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwk, fl, xch);
+    else        k234_bnd_phase1<1, RT, DM>(g, k, lm, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwk, fl, xch);
+    __syncthreads();
+    if (c == 0) k234_bnd_phase2<0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, nwk, fl, xch);
+    else        k234_bnd_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, nwk, fl, xch);
+}
+
 // ---- the dye: K12 + K3 + K4 (fs/solver.py:385-401 _update_dye) over the all-fluid tiles -----------------------------------------------
 // K12 (_non_advection_phase_dye :378-383: dn = dc + (lap(dc) / re) dt, no pressure term) of one channel needs nothing from the others, and
 // the advecting velocity is the finished flow step's - read from memory: one wave per tile and channel, no exchange.  The three-part

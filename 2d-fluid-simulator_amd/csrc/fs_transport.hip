@@ -276,7 +276,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
 static bool cip_step_three_parts(const fs_ctx *ctx)
 {
     const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23));      // (mid grids - res 800 - 1600, cache resident - gain nothing from it: 5689 against 5642 steps/s at bc2 res 1600)
-    return ctx->mask_set && ctx->fuse_k2 && big && ctx->halo == 0 && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
+    return ctx->mask_set && ctx->fuse_k2 != 0 && big && ctx->halo == 0 && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
 }
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
 {
@@ -294,12 +294,13 @@ int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *ti
     if (!cip_step_three_parts(ctx) || ctx->capturing || ctx->tape_rec) return FS_OK;
     const OvGrid ogp = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 1, 2, 1);
     const OvGrid ogb = ov_grid_lanes(ctx, 0, ctx->rows, 4, 2, XCD_ADVECT, 2, true, 2, 2, 1);
-    const OvGrid ogk = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 3, 2, 1);
+    OvGrid ogk{};
+    if (ctx->fuse_k2 == 1) ogk = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 3, 2, 1);      // (2: K2 in registers on every tile - no such part)
     for (const auto &kv : ctx->tile_lists) {
         if (!kv.second.d) continue;
         if (kv.second.d == ogp.g.tiles) *plain = kv.second.count;
         if (kv.second.d == ogb.g.tiles) *boundary = kv.second.count;
-        if (kv.second.d == ogk.g.tiles) *band = kv.second.count;
+        if (ctx->fuse_k2 == 1 && kv.second.d == ogk.g.tiles) *band = kv.second.count;
     }
     return FS_OK;
 }
@@ -322,23 +323,38 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
     constexpr int RT = 4;
     if (cip_step_three_parts(ctx) && !full && row_begin == 0 && row_end == ctx->rows) {
         const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 1, 2, 1);      // plain tiles: one entry per tile, two waves each
+        auto k = make_konst<T>(ctx, dt, dx, re);
+        const int dm = dm_all(ctx, k);
+#define FS_K234(DM) hipLaunchKernelGGL((k_cip_step_plain<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
+        if (ctx->fuse_k2 == 2) {
+            // two parts: K2 in registers on the boundary tiles as well (fs_k234.h k_cip_step_bnd)
+#ifndef FS_K234_BND_RT
+#define FS_K234_BND_RT 4
+#endif
+            constexpr int RB = FS_K234_BND_RT;
+            const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RB, 1, XCD_ADVECT, 2, true, 2, 2, 1, RT);  // boundary tiles: one entry per tile, two waves each
+            if (ogp.g.tiles && ogb.g.tiles) {
+                int rc = launch(ctx, "cip_step", [=] { const OvGrid og = ogp; FS_DMA(dm, FS_K234); });
+                if (rc) return rc;
+                return launch(ctx, "cip_step_bnd", [=] {
+                    const OvGrid og = ogb;
+#define FS_K234B(DM) hipLaunchKernelGGL((k_cip_step_bnd<RB, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
+                    FS_DMA(dm, FS_K234B);
+                });
+            }
+        } else {
         const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 2, XCD_ADVECT, 2, true, 2, 2, 1);      // boundary tiles: one wave per tile and component
         const OvGrid ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);      // K2: the boundary tiles and the tiles above / below them
         if (ogp.g.tiles && ogb.g.tiles && ogk.g.tiles) {
-            auto k = make_konst<T>(ctx, dt, dx, re);
-            const int dm = dm_all(ctx, k);
             int rc = launch(ctx, "cip_step_band", [=] {
                 const OvGrid og = ogk;
 #define FS_K2B(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, RT, DM, T, 2, true>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, 0)
                 FS_DMA(dm, FS_K2B);
             });
             if (rc) return rc;
-            rc = launch(ctx, "cip_step", [=] {
-                const OvGrid og = ogp;
-#define FS_K234(DM) hipLaunchKernelGGL((k_cip_step_plain<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
-                FS_DMA(dm, FS_K234);
-            });
+            rc = launch(ctx, "cip_step", [=] { const OvGrid og = ogp; FS_DMA(dm, FS_K234); });
             if (rc) return rc;
             const int dmx = dm_dx(ctx, k);
             return launch(ctx, "cip_step_bnd", [=] {
@@ -347,6 +363,7 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
         (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)nullptr, v_out->hot, (const uint8_t *)ctx->d_bcmap, 0)
                 FS_DMX(dmx, FS_K34B);
             });
+        }
         }
     }
     int rc = fs_cip_nonadv(ctx, dt, dx, re, fn, fc, pc, row_begin, row_end);

@@ -53,11 +53,14 @@ def _build(case):
     return const, mask, res, case[-1]
 
 
+# FS_FUSE_K2: 2 (default) - K2 in registers on every tile, two launches; 1 - as a kernel over the boundary tiles' rows, three launches
+@pytest.mark.parametrize("mode", [2, 1])
 @pytest.mark.parametrize("case", CASES)
-def test_one_call_equals_the_two_calls(case, hip_lib, monkeypatch):
+def test_one_call_equals_the_two_calls(case, mode, hip_lib, monkeypatch):
     import fs
     from fs.boundary_condition import BoundaryCondition
-    monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")          # the three-part launch on a grid of any size
+    monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")          # the multi-part launch on a grid of any size
+    monkeypatch.setenv("FS_FUSE_K2", str(mode))
     const, mask, res, needs_register_tiles = _build(case)
     fs.runtime.init(gpu=0, dtype="f32")
     bc = BoundaryCondition(const, mask)
@@ -85,7 +88,7 @@ def test_one_call_equals_the_two_calls(case, hip_lib, monkeypatch):
             kernels = set(dev.profile_report())
             dev.profile(False)
             if form == "one":
-                assert {"cip_step", "cip_step_bnd", "cip_step_band"} <= kernels, kernels
+                assert {"cip_step", "cip_step_bnd"} <= kernels and ("cip_step_band" in kernels) == (mode == 1), kernels
             res_[form] = {n: f.to_numpy() for n, f in zip(names, (out, gxo, gyo, fn))}
         for n in ("out", "gxo", "gyo"):
             assert np.array_equal(res_["one"][n], res_["two"][n], equal_nan=True), n
@@ -100,11 +103,13 @@ def test_one_call_equals_the_two_calls(case, hip_lib, monkeypatch):
         dev.close()
 
 
-@pytest.mark.parametrize("bc,res,vc,steps", [(2, 512, 5.0, 8), (2, 512, None, 8), (1, 400, 5.0, 8), (5, 512, 5.0, 6), (3, 512, None, 6)])
-def test_trajectory_against_the_oracle(bc, res, vc, steps, hip_lib, monkeypatch):
+@pytest.mark.parametrize("bc,res,vc,steps,mode", [(2, 512, 5.0, 8, 2), (2, 512, None, 8, 2), (1, 400, 5.0, 8, 2), (5, 512, 5.0, 6, 2), (3, 512, None, 6, 2),
+                                                  (4, 512, 5.0, 6, 2), (5, 512, 5.0, 6, 1), (2, 512, None, 6, 1)])
+def test_trajectory_against_the_oracle(bc, res, vc, steps, mode, hip_lib, monkeypatch):
     import fs
     from oracle import oracle as O
     monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")
+    monkeypatch.setenv("FS_FUSE_K2", str(mode))
     dt, dx, re = 0.05 / res, 1.0 / res, 1.0e6
     fs.runtime.init(gpu=0, dtype="f32")
     sim = fs.FluidSimulator.create(bc, res, dt, dx, re, vc, "cip")
