@@ -241,6 +241,21 @@ __global__ __launch_bounds__(128, FS_K234_BND_WAVES) void k_cip_step_bnd(Grid g,
 // K12 (_non_advection_phase_dye :378-383: dn = dc + (lap(dc) / re) dt, no pressure term) of one channel needs nothing from the others, and
 // the advecting velocity is the finished flow step's - read from memory: one wave per tile and channel, no exchange.  The three-part
 // launch of fs_cip_step_dye is the velocity's (fs_transport.hip): K12 as a kernel over the boundary tiles' rows, this kernel, the general K3 + K4.
+// K12 for one row of one channel on packed operands: dn = dc + (lap(dc) / re) dt
+template <int DM>
+__device__ __forceinline__ v2f nonadv_dye_pk_row(const Konst<float> &k, const LaneMapN<2> &lm, v2f fm, v2f f1, v2f fp)
+{
+    const float l = lv_left<float, 2>(lm, unpk(f1)), r = lv_right<float, 2>(lm, unpk(f1));
+    const v2f two_f = 2.0f * f1;
+    const v2f d2x = xdiv<DM>((east(f1, r) - two_f) + west(l, f1), k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+    const v2f d2y = xdiv<DM>((fp - two_f) + fm, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+    const v2f lap = d2x + d2y;
+    v2f dif;
+    dif.x = rdiv<DM>(lap.x, k.re, k.r_re);
+    dif.y = rdiv<DM>(lap.y, k.re, k.r_re);
+    return f1 + dif * k.dt;
+}
+
 template <int RT, int DM, bool CLAMP>
 __global__ __launch_bounds__(64) void k_cip_dye_plain(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
                                                       float *out, float *gxo, float *gyo, const float *fc, const float *gxc, const float *gyc, const float *v)
@@ -268,17 +283,8 @@ __global__ __launch_bounds__(64) void k_cip_dye_plain(Grid g, Konst<float> k, in
         }
 #pragma unroll
         for (int u = 0; u < RT + 4; ++u) {
-            const v2f fm = F[u], f1 = F[u + 1], fp = F[u + 2];
-            const T l = lv_left<T, N>(lm, unpk(f1)), r = lv_right<T, N>(lm, unpk(f1));
-            const v2f two_f = 2.0f * f1;
-            const v2f d2x = xdiv<DM>((east(f1, r) - two_f) + west(l, f1), k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-            const v2f d2y = xdiv<DM>((fp - two_f) + fm, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
-            const v2f lap = d2x + d2y;
-            v2f dif;
-            dif.x = rdiv<DM>(lap.x, k.re, k.r_re);
-            dif.y = rdiv<DM>(lap.y, k.re, k.r_re);
-            Nn[u] = f1 + dif * k.dt;
-            Fc[u] = f1;
+            Nn[u] = nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]);
+            Fc[u] = F[u + 1];
         }
         unsigned nw[RT + 2], fl[RT];
 #pragma unroll
@@ -286,6 +292,70 @@ __global__ __launch_bounds__(64) void k_cip_dye_plain(Grid g, Konst<float> k, in
 #pragma unroll
         for (int t = 0; t < RT; ++t) fl[t] = j0 + t < je ? 3u : 0u;
         cip_k34_pk_core<3, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, nw, fl, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
+    };
+    if (cg == 0) body(std::integral_constant<int, 0>{});
+    else if (cg == 1) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 2>{});
+}
+
+// ... and the boundary tiles of the dye's call: k_cip_step_bnd without the exchange (masks, K12 of the reference on the not-wall cells of the
+// window, what the buffer holds on wall cells, edge-row slots; the not-wall cells that are not fluid are stored)
+template <int RT, int DM, bool CLAMP>
+__global__ __launch_bounds__(64) void k_cip_dye_bnd(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
+                                                    float *out, float *gxo, float *gyo, float *fn, const float *fc, const float *gxc, const float *gyc, const float *v)
+{
+    using T = float;
+    constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
+    int wx, ty, cg;
+    if (!band_coords<3>(g, nbx, nby, wx, ty, cg)) return;
+    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
+    const int j0 = jb + ty * RT;
+    auto body = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        int i0 = lm.i0;
+        FS_PIN_LANE_OFFSET(i0);
+        unsigned nwk[RT + 4], nw[RT + 2], fl[RT];
+#pragma unroll
+        for (int u = 0; u < RT + 4; ++u) {
+            const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + u));
+            nwk[u] = lv_sel_nw<N>(m);
+            if (u >= 1 && u < RT + 3) nw[u - 1] = nwk[u];
+            if (u >= 2 && u < RT + 2) fl[u - 2] = j0 + u - 2 < je ? lv_sel_fluid<N>(m) : 0u;
+        }
+        v2f F[RT + 6], Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
+#pragma unroll
+        for (int u = 0; u < RT + 6; ++u) F[u] = pk(lv_field<3, T, N>(fc, g, c, i0, clampy(g, j0 - 3 + u)));
+#pragma unroll
+        for (int s = 0; s < RT + 2; ++s) {
+            const int row = clampy(g, j0 - 1 + s);
+            GX[s] = pk(lv_field<3, T, N>(gxc, g, c, i0, row));
+            GY[s] = pk(lv_field<3, T, N>(gyc, g, c, i0, row));
+            AX[s] = pk(lv_field<2, T, N>(v, g, 0, i0, row));
+            AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
+        }
+#pragma unroll
+        for (int u = 0; u < RT + 4; ++u) {
+            Nn[u] = v2f{0.0f, 0.0f};
+            if (nwk[u] != 3u) Nn[u] = pk(lv_field<3, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
+        }
+#pragma unroll
+        for (int u = 0; u < RT + 4; ++u) {
+            Nn[u] = sel2(nwk[u], nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]), Nn[u]);
+            Fc[u] = F[u + 1];
+        }
+#pragma unroll
+        for (int u = RT + 2; u >= 0; --u) if (j0 - 2 + u < g.jlo) Nn[u] = Nn[u + 1];
+#pragma unroll
+        for (int u = 1; u < RT + 4; ++u) if (j0 - 2 + u > g.jhi) Nn[u] = Nn[u - 1];
+        if (lm.owner) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const unsigned sel = nwk[t + 2] & ~fl[t] & 3u;
+                if (j0 + t < je && sel) lv_store_sel<T, N>(fn + idx<3, T>(g, c, i0, j0 + t), unpk(Nn[t + 2]), sel);
+            }
+        }
+        cip_k34_pk_core<3, c, RT, DM, false, CLAMP>(g, k, lm, i0, j0, je, nw, fl, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
     };
     if (cg == 0) body(std::integral_constant<int, 0>{});
     else if (cg == 1) body(std::integral_constant<int, 1>{});

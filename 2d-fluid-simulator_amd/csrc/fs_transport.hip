@@ -405,8 +405,9 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
     if (cip_step_three_parts(ctx) && !full && row_begin == 0 && row_end == ctx->rows) {
         const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 1, 2, 1);
         const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 2, 2, 1);
-        const OvGrid ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);
-        if (ogp.g.tiles && ogb.g.tiles && ogk.g.tiles) {
+        OvGrid ogk{};
+        if (ctx->fuse_k2 == 1) ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);
+        if (ogp.g.tiles && ogb.g.tiles && (ogk.g.tiles || ctx->fuse_k2 == 2)) {
             auto k = make_konst<T>(ctx, dt, dx, re);
             const int dm = dm_all(ctx, k), dmx = dm_dx(ctx, k);
 #define FS_K12B(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, RT, DM, T, 2, true>), ogk.grid, dim3(64), 0, ctx->stream, ogk.g, k, ogk.nbx, ogk.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d)
@@ -418,10 +419,16 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
         (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, d_out->hot, (const uint8_t *)ctx->d_bcmap, 0)
 #define FS_K34DB_C(DM) FS_K34DB(DM, true)
 #define FS_K34DB_N(DM) FS_K34DB(DM, false)
-            int rc = launch(ctx, "cip_step_dye_band", [=] { FS_DMA(dm, FS_K12B); });
+#define FS_KDB(DM, CL) hipLaunchKernelGGL((k_cip_dye_bnd<RT, DM, CL>), ogb.grid, dim3(64), 0, ctx->stream, ogb.g, k, ogb.nbx, ogb.nby, row_begin, row_end, \
+        (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
+#define FS_KDB_C(DM) FS_KDB(DM, true)
+#define FS_KDB_N(DM) FS_KDB(DM, false)
+            int rc = FS_OK;
+            if (ctx->fuse_k2 == 1) rc = launch(ctx, "cip_step_dye_band", [=] { FS_DMA(dm, FS_K12B); });
             if (rc) return rc;
             rc = launch(ctx, "cip_step_dye", [=] { if (clamp01) FS_DMA(dm, FS_KD_C); else FS_DMA(dm, FS_KD_N); });
             if (rc) return rc;
+            if (ctx->fuse_k2 == 2) return launch(ctx, "cip_step_dye_bnd", [=] { if (clamp01) FS_DMA(dm, FS_KDB_C); else FS_DMA(dm, FS_KDB_N); });      // (K12 in registers there too)
             return launch(ctx, "cip_step_dye_bnd", [=] { if (clamp01) FS_DMX(dmx, FS_K34DB_C); else FS_DMX(dmx, FS_K34DB_N); });
         }
     }

@@ -162,12 +162,13 @@ def test_hipgraph_replay_of_the_three_part_step(hip_lib, monkeypatch):
         b._solver._bc.device.close()
 
 
-@pytest.mark.parametrize("bc,res,steps", [(2, 512, 6), (5, 512, 5), (1, 400, 6)])
-def test_dye_trajectory_against_the_oracle(bc, res, steps, hip_lib, monkeypatch):
+@pytest.mark.parametrize("bc,res,steps,mode", [(2, 512, 6, 2), (5, 512, 5, 2), (1, 400, 6, 2), (3, 512, 5, 2), (4, 512, 5, 2), (5, 512, 5, 1)])
+def test_dye_trajectory_against_the_oracle(bc, res, steps, mode, hip_lib, monkeypatch):
     """fs_cip_step_dye: K12 in registers on the all-fluid tiles of the dye's step (k_cip_dye_plain), one wave per tile and channel."""
     import fs
     from oracle import oracle as O
     monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")
+    monkeypatch.setenv("FS_FUSE_K2", str(mode))
     dt, dx, re = 0.05 / res, 1.0 / res, 1.0e6
     fs.runtime.init(gpu=0, dtype="f32")
     sim = fs.DyeFluidSimulator.create(bc, res, dt, dx, re, 5.0, "cip")
@@ -181,7 +182,7 @@ def test_dye_trajectory_against_the_oracle(bc, res, steps, hip_lib, monkeypatch)
             sim.step()
             ref.update()
         rep = dev.profile_report()
-        assert "cip_step_dye" in rep and "cip_step_dye_bnd" in rep and "cip_nonadv_dye" not in rep, sorted(rep)
+        assert "cip_step_dye" in rep and "cip_step_dye_bnd" in rep and "cip_nonadv_dye" not in rep and ("cip_step_dye_band" in rep) == (mode == 1), sorted(rep)
         out = sim.field_to_numpy()
         for k, e in ref.fields().items():
             assert np.array_equal(out[k], e), k
