@@ -95,12 +95,7 @@ __device__ __forceinline__ void k234_phase2(const Grid &g, const Konst<float> &k
     v2f A[RT + 2];
 #pragma unroll
     for (int s = 0; s < RT + 2; ++s) A[s] = xch[(1 - c) * (RT + 2) + s][lane];
-    unsigned nw[RT + 2], fl[RT];
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) nw[s] = 3u;
-#pragma unroll
-    for (int t = 0; t < RT; ++t) fl[t] = j0 + t < je ? 3u : 0u;
-    cip_k34_pk_core<2, c, RT, DM, true, false>(g, k, lm, i0, j0, je, nw, fl, st.Nn, st.Fc, st.GX, st.GY, A, A, out, gxo, gyo, hot);
+    cip_k34_pk_core<2, c, RT, DM, true, false>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, st.Nn, st.Fc, st.GX, st.GY, A, A, out, gxo, gyo, hot);
 }
 
 // one workgroup = 2 waves = the two velocity components of ONE listed tile (compact launch only: Grid::tiles, one entry per tile)
@@ -137,17 +132,20 @@ __global__ __launch_bounds__(128) void k_cip_step_plain(Grid g, Konst<float> k, 
 template <int c, int RT, int DM>
 __device__ __forceinline__ void k234_bnd_phase1(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
                                                 float *fn, const float *fc, const float *pc, const float *gxc, const float *gyc, unsigned *hot_fn,
-                                                K234State<RT> &st, unsigned (&nwk)[RT + 4], unsigned (&fl)[RT], v2f (*xch)[64])
+                                                K234State<RT> &st, unsigned &nwbits, unsigned &flbits, v2f (*xch)[64])
 {
     using T = float;
     constexpr int N = 2;
     FS_PIN_LANE_OFFSET(i0);
+    // the masks of the window: bits 2u, 2u+1 of nwbits = not-wall bits of row j0-2+u; bits 2t, 2t+1 of flbits = fluid bits of row j0+t
+    nwbits = 0u; flbits = 0u;
 #pragma unroll
     for (int u = 0; u < RT + 4; ++u) {
         const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + u));
-        nwk[u] = lv_sel_nw<N>(m);
-        if (u >= 2 && u < RT + 2) fl[u - 2] = j0 + u - 2 < je ? lv_sel_fluid<N>(m) : 0u;
+        nwbits |= lv_sel_nw<N>(m) << (2 * u);
+        if (u >= 2 && u < RT + 2 && j0 + u - 2 < je) flbits |= lv_sel_fluid<N>(m) << (2 * (u - 2));
     }
+#define FS_NWK(u) ((nwbits >> (2 * (u))) & 3u)
 #pragma unroll
     for (int s = 0; s < RT + 2; ++s) {
         const int row = clampy(g, j0 - 1 + s);
@@ -165,12 +163,12 @@ __device__ __forceinline__ void k234_bnd_phase1(const Grid &g, const Konst<float
 #pragma unroll
     for (int u = 0; u < RT + 4; ++u) {
         st.Nn[u] = v2f{0.0f, 0.0f};
-        if (nwk[u] != 3u) st.Nn[u] = pk(lv_field<2, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
+        if (FS_NWK(u) != 3u) st.Nn[u] = pk(lv_field<2, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
     }
 #pragma unroll
     for (int u = 0; u < RT + 4; ++u) {
         const v2f n = nonadv_pk_row<c, DM>(k, lm, F[u], F[u + 1], F[u + 2], P[u + 1], P[c == 0 ? u + 1 : u], P[c == 0 ? u + 1 : u + 2]);
-        st.Nn[u] = sel2(nwk[u], n, st.Nn[u]);
+        st.Nn[u] = sel2(FS_NWK(u), n, st.Nn[u]);
         st.Fc[u] = F[u + 1];
     }
     // slots of rows outside the domain (wave-uniform): K2 of the edge row, which was evaluated from ITS neighbours
@@ -182,7 +180,7 @@ __device__ __forceinline__ void k234_bnd_phase1(const Grid &g, const Konst<float
     if (lm.owner) {
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            const unsigned sel = nwk[t + 2] & ~fl[t] & 3u;
+            const unsigned sel = FS_NWK(t + 2) & ~(flbits >> (2 * t)) & 3u;
             if (j0 + t < je && sel) {
                 const LV<T, N> O = unpk(st.Nn[t + 2]);
 #pragma unroll
@@ -194,21 +192,19 @@ __device__ __forceinline__ void k234_bnd_phase1(const Grid &g, const Konst<float
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int s = 0; s < RT + 2; ++s) xch[c * (RT + 2) + s][lane] = st.Nn[s + 1];
+#undef FS_NWK
 }
 
 template <int c, int RT, int DM>
 __device__ __forceinline__ void k234_bnd_phase2(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
                                                 float *out, float *gxo, float *gyo, unsigned *hot, const K234State<RT> &st,
-                                                const unsigned (&nwk)[RT + 4], const unsigned (&fl)[RT], const v2f (*xch)[64])
+                                                unsigned nwbits, unsigned flbits, const v2f (*xch)[64])
 {
     const int lane = threadIdx.x & 63;
     v2f A[RT + 2];
 #pragma unroll
     for (int s = 0; s < RT + 2; ++s) A[s] = xch[(1 - c) * (RT + 2) + s][lane];
-    unsigned nw[RT + 2];
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) nw[s] = nwk[s + 1];
-    cip_k34_pk_core<2, c, RT, DM, false, false>(g, k, lm, i0, j0, je, nw, fl, st.Nn, st.Fc, st.GX, st.GY, A, A, out, gxo, gyo, hot);
+    cip_k34_pk_core<2, c, RT, DM, false, false>(g, k, lm, i0, j0, je, MaskPacked{nwbits >> 2, flbits}, st.Nn, st.Fc, st.GX, st.GY, A, A, out, gxo, gyo, hot);
 }
 
 // one workgroup = 2 waves = the two velocity components of ONE listed boundary tile (compact launch, class 2 list with one entry per tile)
@@ -229,12 +225,12 @@ __global__ __launch_bounds__(128, FS_K234_BND_WAVES) void k_cip_step_bnd(Grid g,
     const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     K234State<RT> st;
-    unsigned nwk[RT + 4], fl[RT];
-    if (c == 0) k234_bnd_phase1<0, RT, DM>(g, k, lm, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwk, fl, xch);
-    else        k234_bnd_phase1<1, RT, DM>(g, k, lm, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwk, fl, xch);
+    unsigned nwbits, flbits;
+    if (c == 0) k234_bnd_phase1<0, RT, DM>(g, k, lm, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, xch);
+    else        k234_bnd_phase1<1, RT, DM>(g, k, lm, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, xch);
     __syncthreads();
-    if (c == 0) k234_bnd_phase2<0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, nwk, fl, xch);
-    else        k234_bnd_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, nwk, fl, xch);
+    if (c == 0) k234_bnd_phase2<0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, nwbits, flbits, xch);
+    else        k234_bnd_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, nwbits, flbits, xch);
 }
 
 // ---- the dye: K12 + K3 + K4 (fs/solver.py:385-401 _update_dye) over the all-fluid tiles -----------------------------------------------
@@ -286,12 +282,7 @@ __global__ __launch_bounds__(64) void k_cip_dye_plain(Grid g, Konst<float> k, in
             Nn[u] = nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]);
             Fc[u] = F[u + 1];
         }
-        unsigned nw[RT + 2], fl[RT];
-#pragma unroll
-        for (int s = 0; s < RT + 2; ++s) nw[s] = 3u;
-#pragma unroll
-        for (int t = 0; t < RT; ++t) fl[t] = j0 + t < je ? 3u : 0u;
-        cip_k34_pk_core<3, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, nw, fl, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
+        cip_k34_pk_core<3, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
     };
     if (cg == 0) body(std::integral_constant<int, 0>{});
     else if (cg == 1) body(std::integral_constant<int, 1>{});
@@ -315,14 +306,14 @@ __global__ __launch_bounds__(64) void k_cip_dye_bnd(Grid g, Konst<float> k, int 
         constexpr int c = decltype(cc)::value;
         int i0 = lm.i0;
         FS_PIN_LANE_OFFSET(i0);
-        unsigned nwk[RT + 4], nw[RT + 2], fl[RT];
+        unsigned nwbits = 0u, flbits = 0u;      // (as k234_bnd_phase1)
 #pragma unroll
         for (int u = 0; u < RT + 4; ++u) {
             const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + u));
-            nwk[u] = lv_sel_nw<N>(m);
-            if (u >= 1 && u < RT + 3) nw[u - 1] = nwk[u];
-            if (u >= 2 && u < RT + 2) fl[u - 2] = j0 + u - 2 < je ? lv_sel_fluid<N>(m) : 0u;
+            nwbits |= lv_sel_nw<N>(m) << (2 * u);
+            if (u >= 2 && u < RT + 2 && j0 + u - 2 < je) flbits |= lv_sel_fluid<N>(m) << (2 * (u - 2));
         }
+#define FS_NWK(u) ((nwbits >> (2 * (u))) & 3u)
         v2f F[RT + 6], Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
 #pragma unroll
         for (int u = 0; u < RT + 6; ++u) F[u] = pk(lv_field<3, T, N>(fc, g, c, i0, clampy(g, j0 - 3 + u)));
@@ -337,11 +328,11 @@ __global__ __launch_bounds__(64) void k_cip_dye_bnd(Grid g, Konst<float> k, int 
 #pragma unroll
         for (int u = 0; u < RT + 4; ++u) {
             Nn[u] = v2f{0.0f, 0.0f};
-            if (nwk[u] != 3u) Nn[u] = pk(lv_field<3, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
+            if (FS_NWK(u) != 3u) Nn[u] = pk(lv_field<3, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
         }
 #pragma unroll
         for (int u = 0; u < RT + 4; ++u) {
-            Nn[u] = sel2(nwk[u], nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]), Nn[u]);
+            Nn[u] = sel2(FS_NWK(u), nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]), Nn[u]);
             Fc[u] = F[u + 1];
         }
 #pragma unroll
@@ -351,11 +342,12 @@ __global__ __launch_bounds__(64) void k_cip_dye_bnd(Grid g, Konst<float> k, int 
         if (lm.owner) {
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-                const unsigned sel = nwk[t + 2] & ~fl[t] & 3u;
+                const unsigned sel = FS_NWK(t + 2) & ~(flbits >> (2 * t)) & 3u;
                 if (j0 + t < je && sel) lv_store_sel<T, N>(fn + idx<3, T>(g, c, i0, j0 + t), unpk(Nn[t + 2]), sel);
             }
         }
-        cip_k34_pk_core<3, c, RT, DM, false, CLAMP>(g, k, lm, i0, j0, je, nw, fl, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
+        cip_k34_pk_core<3, c, RT, DM, false, CLAMP>(g, k, lm, i0, j0, je, MaskPacked{nwbits >> 2, flbits}, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
+#undef FS_NWK
     };
     if (cg == 0) body(std::integral_constant<int, 0>{});
     else if (cg == 1) body(std::integral_constant<int, 1>{});

@@ -222,9 +222,21 @@ __device__ __forceinline__ void cip_grad_advect_n_body(const Grid &g, const Kons
 // the field after / before K2, GX / GY rows j0-1 .. j0+RT of the old gradients, AX / AY the advecting velocity on those rows (C = 2: only
 // the component that is not the field's own is read).  Shared by the two-kernel form below and the pass that evaluates K2 on the way
 // (fs_k234.h).
-template <int C, int c, int RT, int DM, bool PLAIN, bool CLAMP>
-__device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
-                                                const unsigned (&nw)[RT + 2], const unsigned (&fl)[RT],
+// selectors of a tile's window for the packed core: nw(s) = not-wall bits of row j0-1+s (s = 0 .. RT+1), fl(t) = fluid bits of row j0+t, both
+// 2 bits per lane.  Packed: all rows in one word each (one register per row cost the general bodies 8 - 12 VGPRs: the dye's spilled 28 - 52 bytes);
+// Plain: constants.
+struct MaskPacked {
+    unsigned nwbits, flbits;        // bits 2s, 2s+1: nw(s);  bits 2t, 2t+1: fl(t)
+    __device__ __forceinline__ unsigned nw(int s) const { return (nwbits >> (2 * s)) & 3u; }
+    __device__ __forceinline__ unsigned fl(int t) const { return (flbits >> (2 * t)) & 3u; }
+};
+struct MaskPlain {
+    int rows;                       // own rows below je
+    __device__ __forceinline__ unsigned nw(int) const { return 3u; }
+    __device__ __forceinline__ unsigned fl(int t) const { return t < rows ? 3u : 0u; }
+};
+template <int C, int c, int RT, int DM, bool PLAIN, bool CLAMP, typename MK>
+__device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je, const MK &mk,
                                                 const v2f (&Nn)[RT + 4], const v2f (&Fc)[RT + 4], const v2f (&GX)[RT + 2], const v2f (&GY)[RT + 2],
                                                 const v2f (&AX)[RT + 2], const v2f (&AY)[RT + 2], float *out, float *gxo, float *gyo, unsigned *hot)
 {
@@ -251,8 +263,8 @@ __device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float
             sx.y = (dr - n1.x) + c1.x;
             const v2f sy = (D[s + 2] - Nn[s]) + Fc[s];
             const v2f ux = GX[s] + xdiv<DM>(sx, k.two_dx, k.inv_two_dx, k.r_two_dx), uy = GY[s] + xdiv<DM>(sy, k.two_dx, k.inv_two_dx, k.r_two_dx);
-            NX[s] = PLAIN ? ux : sel2(nw[s], ux, GX[s]);
-            NY[s] = PLAIN ? uy : sel2(nw[s], uy, GY[s]);
+            NX[s] = PLAIN ? ux : sel2(mk.nw(s), ux, GX[s]);
+            NY[s] = PLAIN ? uy : sel2(mk.nw(s), uy, GY[s]);
             if (!PLAIN) {        // a slot that stands for a row outside the domain takes the K3 result of the edge row it clamps onto (wave-uniform;
                                  // a plain tile lies inside the fluid: no row of its window is outside the domain)
                 if (s == 1 && j0 - 1 < g.jlo) { NX[0] = NX[1]; NY[0] = NY[1]; }
@@ -283,13 +295,13 @@ __device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float
         v2f of, ofx, ofy;
         cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
         if (CLAMP) { of.x = tmin(tmax(of.x, 0.0f), 1.0f); of.y = tmin(tmax(of.y, 0.0f), 1.0f); }
-        const R OV = unpk(PLAIN ? of : sel2(fl[t], of, Fc[t + 2])), OX = unpk(PLAIN ? ofx : sel2(fl[t], ofx, GX[t + 1])), OY = unpk(PLAIN ? ofy : sel2(fl[t], ofy, GY[t + 1]));
+        const R OV = unpk(PLAIN ? of : sel2(mk.fl(t), of, Fc[t + 2])), OX = unpk(PLAIN ? ofx : sel2(mk.fl(t), ofx, GX[t + 1])), OY = unpk(PLAIN ? ofy : sel2(mk.fl(t), ofy, GY[t + 1]));
         if (lm.owner) {
             if (SELF && lv_hot1<T, N>(OV)) {
                 bool hf = false, hn = false;
 #pragma unroll
                 for (int q = 0; q < N; ++q)
-                    if (hot1(OV.a[q])) { if (PLAIN || ((fl[t] >> q) & 1u)) hf = true; else hn = true; }
+                    if (hot1(OV.a[q])) { if (PLAIN || ((mk.fl(t) >> q) & 1u)) hf = true; else hn = true; }
                 raise_hot(hot + 3, hf);
                 raise_hot(hot, hn);
             }
@@ -299,9 +311,9 @@ __device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float
                 lv_store_row<C, T, N>(gyo, g, c, i0, j, OY);
             } else {
                 lv_store<T, N>(out + idx<C, T>(g, c, i0, j), OV);
-                if (nw[t + 1]) {
-                    lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), OX, nw[t + 1]);
-                    lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), OY, nw[t + 1]);
+                if (mk.nw(t + 1)) {
+                    lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), OX, mk.nw(t + 1));
+                    lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), OY, mk.nw(t + 1));
                 }
             }
         }
@@ -328,31 +340,33 @@ __device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Kon
     const LaneMapN<N> lm = PLAIN ? LaneMapN<N>{lm_in.i0, lm_in.owner, false, false} : lm_in;
     const int i0 = lm.i0, j0 = jb + ty * RT;
 
-    unsigned nw[RT + 2], fl[RT];
-    bool any_fl = PLAIN;
+    // the masks of the window in one word each (MaskPacked: bits 2s, 2s+1 of nwbits = not-wall bits of row j0-1+s, of flbits = fluid bits of row j0+t)
+    unsigned nwbits = 0u, flbits = 0u;
+    if (!PLAIN) {
 #pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        if (PLAIN) { nw[s] = ALL; if (s >= 1 && s <= RT) fl[s - 1] = j0 + s - 1 < je ? ALL : 0u; continue; }
-        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 1 + s));
-        nw[s] = lv_sel_nw<N>(m);
-        if (s >= 1 && s <= RT) { fl[s - 1] = j0 + s - 1 < je ? lv_sel_fluid<N>(m) : 0u; any_fl |= fl[s - 1] != 0u; }
+        for (int s = 0; s < RT + 2; ++s) {
+            const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 1 + s));
+            nwbits |= lv_sel_nw<N>(m) << (2 * s);
+            if (s >= 1 && s <= RT && j0 + s - 1 < je) flbits |= lv_sel_fluid<N>(m) << (2 * (s - 1));
+        }
     }
-    if (!PLAIN && !bnd_fluid && !__any(any_fl)) {
+    const MaskPacked mk{nwbits, flbits};
+    if (!PLAIN && !bnd_fluid && !__any(flbits != 0u)) {
         // (no fluid cell in this wave's tile: carried values only - see cip_grad_advect_n_body)
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const int j = j0 + t;
             if (j >= je) break;
-            unsigned touch = full ? ALL : nw[t + 1];
+            unsigned touch = full ? ALL : mk.nw(t + 1);
             if (SELF && !full) touch |= lv_sel_bit7<N>(lv_bytes<N>(bcmap, g, i0, clampy(g, j)));
             if (!__any(lm.owner && touch != 0u)) continue;
             const R f = lv_field<C, T, N>(fc, g, c, i0, j);
             if (lm.owner && touch) {
                 if (SELF) raise_hot(hot, lv_hot1<T, N>(f));
                 lv_store<T, N>(out + idx<C, T>(g, c, i0, j), f);
-                if (nw[t + 1]) {
-                    lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), lv_field<C, T, N>(gxc, g, c, i0, j), nw[t + 1]);
-                    lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), lv_field<C, T, N>(gyc, g, c, i0, j), nw[t + 1]);
+                if (mk.nw(t + 1)) {
+                    lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), lv_field<C, T, N>(gxc, g, c, i0, j), mk.nw(t + 1));
+                    lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), lv_field<C, T, N>(gyc, g, c, i0, j), mk.nw(t + 1));
                 }
             }
         }
@@ -377,7 +391,8 @@ __device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Kon
             AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
         }
     }
-    cip_k34_pk_core<C, c, RT, DM, PLAIN, CLAMP>(g, k, lm, i0, j0, je, nw, fl, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, hot);
+    if constexpr (PLAIN) cip_k34_pk_core<C, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, hot);
+    else cip_k34_pk_core<C, c, RT, DM, false, CLAMP>(g, k, lm, i0, j0, je, mk, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, hot);
 }
 
 #ifndef FS_K34_PK
@@ -395,7 +410,10 @@ __device__ __forceinline__ void cip_grad_advect_dispatch(const Grid &g, const Ko
 // blockIdx.y (or, channel groups innermost / compact lists, the block index >> 3) % C = the channel of this workgroup
 template <int C, int N, int RT, int DM, bool PLAIN, bool CLAMP, typename T, int HL = 1>
 // (4 waves per SIMD: the packed general body of 2 x 4 tiles comes out at 131 VGPRs unbounded - 3 waves; held to 128 it spills 12 bytes)
-__global__ __launch_bounds__(256, 4) void k_cip_grad_advect_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
+#ifndef FS_K34_DYE_WAVES
+#define FS_K34_DYE_WAVES 4
+#endif
+__global__ __launch_bounds__(256, C == 3 ? FS_K34_DYE_WAVES : 4) void k_cip_grad_advect_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je,
                                                            T *out, T *gxo, T *gyo, const T *fn, const T *fc,
                                                            const T *gxc, const T *gyc, const T *v, unsigned *hot, const uint8_t *bcmap, int full)
 {

@@ -76,9 +76,9 @@ def algorithmic_bytes(mask, esize=4):
         # fluid cells; old gradients read and new gradients written on not-wall cells.  The intermediate gradients the reference's two
         # kernels exchange through HBM (16 B/cell written + read back 3x3) never leave the registers.
         "cip_grad_advect_rt": n + nw * (2 * e + 2 * e) + fl * 2 * e + nw * (4 * e + 4 * e),
-        # K2 + K3 + K4 of the velocity as one logical launch (fs_cip_step, csrc/fs_k234.h: the all-fluid tiles evaluate K2 in registers; "cip_step"
-        # + "cip_step_bnd" + "cip_step_band"): mask; v.current, p and the old gradients read, the advected velocity and the new gradients
-        # written - 52 B per not-wall cell.  The post-K2 velocity is no algorithmic byte any more: it reaches HBM only around the boundary tiles.
+        # K2 + K3 + K4 of the velocity as one logical launch (fs_cip_step, csrc/fs_k234.h: K2 is evaluated in registers; "cip_step" over the all-fluid
+        # tiles + "cip_step_bnd" over the others): mask; v.current, p and the old gradients read, the advected velocity and the new gradients
+        # written - 52 B per not-wall cell.  The post-K2 velocity is no algorithmic byte any more: it reaches HBM only on inflow / outflow cells.
         "cip_step": n + nw * (2 * e + e + 4 * e) + nw * (2 * e + 4 * e),
         # ... and K12 + K3 + K4 of the dye (fs_cip_step_dye): 3 channels + their old gradients read, the advecting velocity on fluid cells, results written
         "cip_step_dye": n + nw * (3 * e + 6 * e) + fl * 2 * e + nw * (3 * e + 6 * e),
@@ -469,7 +469,7 @@ def main():
         if name in parts:        # the unmerged parts of a multi-part launch (per-launch HIP-event brackets of each)
             entry["parts_us"] = {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in parts[name].items()}
         kernels[name] = entry
-    # fs_cip_step in its three-part form: the part over the all-fluid tiles (k_cip_step_plain) priced against the bytes of ITS tiles - 52 B per cell
+    # fs_cip_step in its multi-part form: the part over the all-fluid tiles (k_cip_step_plain) priced against the bytes of ITS tiles - 52 B per cell
     # (v.current 8 + p 4 + old gradients 16 read, advected velocity 8 + new gradients 16 written; it reads no mask)
     if "cip_step" in kernels and "cip_step" in parts and hasattr(dev, "cip_step_tiles") and world == 1:
         n_plain, n_bnd, n_band, t_rows, t_cells = dev.cip_step_tiles()
@@ -625,13 +625,14 @@ def main():
                            "alg_bytes_per_launch": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"]}
         if dominant == "cip_step" and "plain_part" in kd:
             # the dominant KERNEL of the step is the part of fs_cip_step over the all-fluid tiles: its own bytes over its own duration; the logical
-            # launch (three kernels: + the boundary tiles + K2 over their rows) stays next to it
+            # launch (+ the kernel over the boundary tiles; FS_FUSE_K2=1: + K2 over their rows) stays next to it
             pp = kd["plain_part"]
             out["roofline"].update({"kernel": "cip_step / k_cip_step_plain (K2 + K3 + K4 over the all-fluid tiles)", "achieved": pp["GBps"], "frac": pp["frac"],
                                     "frac_of_box_copy": round(pp["GBps"] / box["copy_GBps"], 4) if box else None,
                                     "traffic": (pmc_traffic.get("cip_step_parts") or {}).get("k_cip_step_plain"),
                                     "alg_bytes_per_launch": int(pp["alg_MB"] * 1e6), "avg_us": pp["avg_us"],
-                                    "logical_launch": {"kernels": "k_cip_step_plain + k_cip_grad_advect_n (boundary tiles) + k_cip_nonadv_n (K2 over their rows)",
+                                    "logical_launch": {"kernels": "k_cip_step_plain + k_cip_step_bnd (boundary tiles)" if pp.get("stand_alone_K2_tiles", 0) == 0 else
+                                                                  "k_cip_step_plain + k_cip_grad_advect_n (boundary tiles) + k_cip_nonadv_n (K2 over their rows)",
                                                        "alg_bytes": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"], "frac": round(kd["GBps"] / HBM_PEAK_GBS, 4),
                                                        "traffic": pmc_traffic.get(dominant), "parts_us": kd.get("parts_us")}})
         if "unfused_equiv_frac" in kd:
@@ -639,7 +640,7 @@ def main():
                 "two Jacobi sweeps (and both pressure boundary passes) per launch, the first sweep's rows in registers: `frac` counts what "
                 "ONE pass has to move (p in, source pair in, p out); the reference's 2 x (K7 + sweep) move twice that"
                 if dominant == "jacobi_pair_lazy" else
-                ("K2 + K3 + K4 of the velocity as one logical launch (three parts, csrc/fs_k234.h): `frac` counts the bytes the step has to move through "
+                ("K2 + K3 + K4 of the velocity as one logical launch (all-fluid tiles + boundary tiles, csrc/fs_k234.h): `frac` counts the bytes the step has to move through "
                  "them (mask 1 + 28 read + 24 written = 53 B per fluid cell); the reference's three kernels move 119 B per fluid cell for the same result"
                  if dominant == "cip_step" else
                  "fused gradient-update + advection pass: `frac` counts the bytes the fused kernel has to move "
