@@ -275,7 +275,10 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
 
 static bool cip_step_three_parts(const fs_ctx *ctx)
 {
-    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23));      // (mid grids - res 800 - 1600, cache resident - gain nothing from it: 5689 against 5642 steps/s at bc2 res 1600)
+    // From 2.6 M cells (round 5, two-part form: bc2 res 1600 5 630 -> 6 195 steps/s, with dye 2 737 -> 3 435; res 1200 56 against 58.5 us; res 800, on its
+    // 2-row tiles, 37.6 against 35.3 us the other way).  The three-part form (FS_FUSE_K2=1) paid for its K2 launch below 8 M cells.
+    const size_t cells = (size_t)ctx->X * ctx->Y, from = ctx->fuse_k2 == 2 ? (size_t)5 << 19 : (size_t)1 << 23;
+    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && cells >= from);
     return ctx->mask_set && ctx->fuse_k2 != 0 && big && ctx->halo == 0 && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
 }
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
