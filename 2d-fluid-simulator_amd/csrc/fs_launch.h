@@ -77,7 +77,8 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
 
 // XCD-band launch geometry of a tile kernel family (fs_march.h band_coords); `lanes`: cells per lane.  When the launch covers the whole
 // single-GPU grid, the workgroups without anything to do are left out (compact list, Grid::tiles).
-static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true, int cls = 0, int reach = 0, int wgw = 4, int parent_rt = 0)
+static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroups, int family, int lanes, bool allow_list = true, int cls = 0, int reach = 0, int wgw = 4, int parent_rt = 0,
+                                   bool slab_classes = false)      // slab_classes: plain / boundary lists (cls 1 / 2) for a row range of a slab too (fs_cip_step)
 {
     OvGrid o;
     o.g = c->grid();
@@ -93,7 +94,7 @@ static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroup
         constexpr int xg = 8;
         const int group = stacked ? std::max(1, xg / wgw) : xg;     // the same number of field rows per XCD group
         const int groups = (o.nby + group - 1) / group;
-        const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && ((jb == 0 && je == c->rows) || (c->halo != 0 && cls == 0))
+        const fs_ctx::TileList *tl = allow_list && (c->tile_list_mask & family) && ((jb == 0 && je == c->rows) || (c->halo != 0 && (cls == 0 || slab_classes)))
                                          ? tile_list(c, lanes, rt, stacked, group, o.nbx, o.nby, cls, reach, wgw, jb, je, parent_rt) : nullptr;
         const bool inner = zgroups > 1 && tl;
         if (tl) { o.grid = dim3(8 * tl->per_xcd * zgroups, 1, 1); o.g.tiles = tl->d; }

@@ -279,7 +279,7 @@ static bool cip_step_three_parts(const fs_ctx *ctx)
     // 2-row tiles, 37.6 against 35.3 us the other way).  The three-part form (FS_FUSE_K2=1) paid for its K2 launch below 8 M cells.
     const size_t cells = (size_t)ctx->X * ctx->Y, from = ctx->fuse_k2 == 2 ? (size_t)5 << 19 : (size_t)1 << 23;
     const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && cells >= from);
-    return ctx->mask_set && ctx->fuse_k2 != 0 && big && ctx->halo == 0 && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
+    return ctx->mask_set && ctx->fuse_k2 != 0 && big && (ctx->halo == 0 || ctx->fuse_k2 == 2) && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
 }
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
 {
@@ -324,25 +324,24 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
     if (ctx->dtype != 0) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
     using T = float;
     constexpr int RT = 4;
-    if (cip_step_three_parts(ctx) && !full && row_begin == 0 && row_end == ctx->rows) {
-        const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 1, 2, 1);      // plain tiles: one entry per tile, two waves each
+    // (a slab - halo != 0, the two-part form only: any row range; K2 is then evaluated for the rows within 2 of the range from rows within 3 of it, which the
+    //  caller keeps valid - fs/runtime.py cip_step - where the two calls would read what an earlier K2 launch left in fn.  Single GPU: the whole grid.)
+    const bool slab = ctx->halo != 0;
+    if (cip_step_three_parts(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
+        const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 1, 2, 1, 0, slab);      // plain tiles: one entry per tile, two waves each
         auto k = make_konst<T>(ctx, dt, dx, re);
         const int dm = dm_all(ctx, k);
 #define FS_K234(DM) hipLaunchKernelGGL((k_cip_step_plain<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
         if (ctx->fuse_k2 == 2) {
             // two parts: K2 in registers on the boundary tiles as well (fs_k234.h k_cip_step_bnd)
-#ifndef FS_K234_BND_RT
-#define FS_K234_BND_RT 4
-#endif
-            constexpr int RB = FS_K234_BND_RT;
-            const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RB, 1, XCD_ADVECT, 2, true, 2, 2, 1, RT);  // boundary tiles: one entry per tile, two waves each
+            const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 2, 2, 1, 0, slab);  // boundary tiles: one entry per tile, two waves each
             if (ogp.g.tiles && ogb.g.tiles) {
                 int rc = launch(ctx, "cip_step", [=] { const OvGrid og = ogp; FS_DMA(dm, FS_K234); });
                 if (rc) return rc;
                 return launch(ctx, "cip_step_bnd", [=] {
                     const OvGrid og = ogb;
-#define FS_K234B(DM) hipLaunchKernelGGL((k_cip_step_bnd<RB, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K234B(DM) hipLaunchKernelGGL((k_cip_step_bnd<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
                     FS_DMA(dm, FS_K234B);
                 });
@@ -369,7 +368,8 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
         }
         }
     }
-    int rc = fs_cip_nonadv(ctx, dt, dx, re, fn, fc, pc, row_begin, row_end);
+    // (a slab: K2 also on the 2 rows either side that K3 + K4 read - the call's contract there, see above)
+    int rc = fs_cip_nonadv(ctx, dt, dx, re, fn, fc, pc, slab ? std::max(row_begin - 2, 0) : row_begin, slab ? std::min(row_end + 2, ctx->rows) : row_end);
     if (rc) return rc;
     return launch_k34<2, false>(ctx, "cip_grad_advect_rt", "cip_grad_advect_rt_bnd", dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, nullptr, full, row_begin, row_end);
 }
@@ -405,9 +405,10 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
     if (ctx->dtype != 0) { set_error("the fused dye pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
     using T = float;
     constexpr int RT = 4;
-    if (cip_step_three_parts(ctx) && !full && row_begin == 0 && row_end == ctx->rows) {
-        const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 1, 2, 1);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 2, 2, 1);
+    const bool slab = ctx->halo != 0;      // (as fs_cip_step)
+    if (cip_step_three_parts(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
+        const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 1, 2, 1, 0, slab);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 2, 2, 1, 0, slab);
         OvGrid ogk{};
         if (ctx->fuse_k2 == 1) ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);
         if (ogp.g.tiles && ogb.g.tiles && (ogk.g.tiles || ctx->fuse_k2 == 2)) {
@@ -435,7 +436,7 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
             return launch(ctx, "cip_step_dye_bnd", [=] { if (clamp01) FS_DMX(dmx, FS_K34DB_C); else FS_DMX(dmx, FS_K34DB_N); });
         }
     }
-    int rc = fs_cip_nonadv_dye(ctx, dt, dx, re, fn, fc, row_begin, row_end);
+    int rc = fs_cip_nonadv_dye(ctx, dt, dx, re, fn, fc, slab ? std::max(row_begin - 2, 0) : row_begin, slab ? std::min(row_end + 2, ctx->rows) : row_end);
     if (rc) return rc;
     return fs_cip_grad_advect_dye(ctx, dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01, full, row_begin, row_end);
 }

@@ -695,8 +695,10 @@ class DeviceBase:
     def cip_step(self, dt, dx, re, v_out, gx_out, gy_out, fn, fc, pc, gxc, gyc, full=False):
         """K2 + K3 + K4 of the velocity as one call (fs/solver.py:213-227; include/fs_hip.h fs_cip_step): on large single-GPU f32 grids the
         post-K2 velocity of the all-fluid tiles stays in registers (csrc/fs_k234.h) - fn then holds it only where something reads it.
-        Slabs, and devices without the entry point: the two calls."""
-        if self.nranks > 1 or not getattr(self, "has_cip_step", False):
+        Slabs: the same call on the row range K3 + K4 run on, where the library evaluates K2 in registers there too (cip_step_fused; the call then
+        computes K2 for the rows within 2 of the range from rows within 3 of it - the radii below), else the two calls; devices without the entry
+        point: the two calls."""
+        if not getattr(self, "has_cip_step", False) or (self.nranks > 1 and (self.halo < 3 or not self.cip_step_fused)):
             self.cip_nonadv(dt, dx, re, fn, fc, pc)
             self.cip_grad_advect(dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, full=full)
             return
@@ -704,8 +706,8 @@ class DeviceBase:
                   reads=[(fc, 3), (pc, 3), (gxc, 1), (gyc, 1)], writes=[gx_out, gy_out, fn], full_writes=[v_out])
 
     def cip_step_dye(self, dt, dx, re, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=False, full=False):
-        """K12 + K3 + K4 of the dye as one call (fs/solver.py:385-401; include/fs_hip.h fs_cip_step_dye); slabs / other devices: the two calls."""
-        if self.nranks > 1 or not getattr(self, "has_cip_step", False):
+        """K12 + K3 + K4 of the dye as one call (fs/solver.py:385-401; include/fs_hip.h fs_cip_step_dye); slabs as cip_step, other devices: the two calls."""
+        if not getattr(self, "has_cip_step", False) or (self.nranks > 1 and (self.halo < 3 or not self.cip_step_fused)):
             self.cip_nonadv_dye(dt, dx, re, fn, fc)
             self.cip_grad_advect_dye(dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, clamp01=clamp01, full=full)
             return
@@ -932,11 +934,11 @@ class Device(DeviceBase):
 
     @property
     def cip_step_fused(self):
-        """Whole-grid fs_cip_step calls evaluate K2 in registers on the all-fluid tiles: the post-K2 buffer then holds that velocity only where
-        something reads it (csrc/fs_k234.h)."""
+        """fs_cip_step calls (whole grid; on a slab: any row range) evaluate K2 in registers: the post-K2 buffer then holds that velocity only on
+        the inflow / outflow cells (csrc/fs_k234.h)."""
         ok = ctypes.c_int()
         _lib.call("fs_cip_step_ok", self._ctx, ctypes.byref(ok))
-        return bool(ok.value) and self.nranks == 1
+        return bool(ok.value)
 
     def cip_step_tiles(self):
         """(all-fluid tiles, boundary tiles, tiles of the stand-alone K2 launch, rows per tile, cells per tile row) of a whole-grid fs_cip_step

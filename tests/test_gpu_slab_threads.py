@@ -144,6 +144,21 @@ def test_slabs_on_one_gpu_are_bit_identical(fname, world, halo, hip_lib):
         assert results[0][1] <= 6.0
 
 
+@pytest.mark.parametrize("fname,world,halo", [c for c in CASES if "_cip_" in c[0] and "f64" not in c[0]])
+def test_slabs_with_k2_in_registers(fname, world, halo, hip_lib, monkeypatch):
+    """fs_cip_step / fs_cip_step_dye on slabs evaluate K2 in registers as on the single-GPU grid (csrc/fs_k234.h; halo >= 3: the call reads 3 rows
+    beyond its range) - forced onto the small golden scenes, where a slab's row ranges are a few rows and most tiles are boundary tiles."""
+    monkeypatch.setenv("FS_RBPAIR_SPLIT", "2")
+    g = np.load(os.path.join(GOLDEN, fname))
+    cfg = traj_config(g)
+    results = _run_slabs(g, cfg, world, halo)
+    names = ["v", "p", "dye"]
+    for step in cfg["snaps"]:
+        for k in range(len(results[0][0][step])):
+            full = np.concatenate([results[r][0][step][k] for r in range(world)], axis=1)
+            assert np.array_equal(full, g[f"step{step}.{names[k]}"]), f"{fname} step {step} {names[k]}"
+
+
 @pytest.mark.parametrize("bc,res,scheme,vc,updater,world,halo", [
     (5, 1024, "cip", 5.0, ("rbsor", 1.3, 2), 8, 8),      # configs[2]'s physics, the 8-slab cut of the scaling run
     (5, 4096, "cip", 5.0, ("rbsor", 1.3, 2), 8, 8),      # configs[2] itself, as the driver's --gpus 8 run cuts it

@@ -49,7 +49,7 @@ class LoopbackSlab(Device):
 
 
 def main():
-    res, world, rank = 4096, 8, 3
+    res, world, rank = 4096, int(os.environ.get("OB_WORLD", "8")), int(os.environ.get("OB_RANK", "3"))      # (OB_WORLD=2 OB_RANK=1: the upper half)
     const, mask, _ = create_scene_arrays(5, res)
     dt, dx = 0.05 / res, 1.0 / res
     modes = os.environ.get("OB_MODES", "none,blocking-commstream,blocking,overlap,tape").split(",")
