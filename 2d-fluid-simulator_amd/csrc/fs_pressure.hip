@@ -291,8 +291,9 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
         // (round 5: the plain part as workgroups of TWO stacked waves on tiles of 16 rows that exchange their edge rows through LDS instead of
         //  recomputing them - rbsor_pair_stack_tile, FS_RBPAIR_PLAIN_RT=16, the default)
         const int prt = ctx->rbpair_plain_rt >= 8 ? ctx->rbpair_plain_rt : rt;
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, 1);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, 1, prt);
+        const bool slab = ctx->halo != 0;      // (a slab's row ranges too: lists per range, fs_core.hip tile_list)
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, 1, 0, slab);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, 1, prt, slab);
         if (og.g.tiles && ogb.g.tiles) {
 #define FS_RBS_K(PAR, DM) hipLaunchKernelGGL((k_rbsor_pair_stack<2, 8, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
