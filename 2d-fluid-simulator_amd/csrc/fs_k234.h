@@ -16,10 +16,9 @@
 // Same expression trees, same operation order, one rounding per operation: the bits of the three-kernel sequence (tests compare at
 // tolerance 0).  What is NOT the same is the content of the intermediate buffer: the post-K2 velocity of these tiles never reaches HBM.
 // Nothing reads it there - the reference's own sequence overwrites every fluid cell of that buffer (K2 of the next step, or the vorticity
-// confinement of this one) before anything looks at it - EXCEPT the boundary tiles of this same step, whose K3 + K4 (the general kernel of
-// fs_k34n.h) read it within 2 cells of their own rows.  The host therefore launches three parts (fs_transport.hip fs_cip_step):
-//   K2 (k_cip_nonadv_n, unchanged) over the tiles within one tile of a boundary tile - every not-wall cell that is not fluid lies in one;
-//   this kernel over the plain tiles; k_cip_grad_advect_n over the boundary tiles, on the same wave columns (HL = 2).
+// confinement of this one) before anything looks at it.  The tiles that are NOT all fluid take the same route with the masks
+// (k_cip_step_bnd below; the host launches the two kernels over the two classes of its tile lists, fs_transport.hip fs_cip_step).  Until late
+// in round 5 they ran the general K3 + K4 kernel of fs_k34n.h behind a K2 launch over their rows (FS_FUSE_K2=1: that three-part form).
 // Plain tile: every cell within 2 rows and within the halo lanes is fluid and inside the domain (fs_core.hip tile_list) - K2's own reads
 // one cell further out take whatever the buffers hold there, as the reference's K2 does.
 #pragma once
@@ -235,8 +234,8 @@ __global__ __launch_bounds__(128, FS_K234_BND_WAVES) void k_cip_step_bnd(Grid g,
 
 // ---- the dye: K12 + K3 + K4 (fs/solver.py:385-401 _update_dye) over the all-fluid tiles -----------------------------------------------
 // K12 (_non_advection_phase_dye :378-383: dn = dc + (lap(dc) / re) dt, no pressure term) of one channel needs nothing from the others, and
-// the advecting velocity is the finished flow step's - read from memory: one wave per tile and channel, no exchange.  The three-part
-// launch of fs_cip_step_dye is the velocity's (fs_transport.hip): K12 as a kernel over the boundary tiles' rows, this kernel, the general K3 + K4.
+// the advecting velocity is the finished flow step's - read from memory: one wave per tile and channel, no exchange.  The launch of
+// fs_cip_step_dye is the velocity's (fs_transport.hip): this kernel over the all-fluid tiles, k_cip_dye_bnd over the others.
 // K12 for one row of one channel on packed operands: dn = dc + (lap(dc) / re) dt
 template <int DM>
 __device__ __forceinline__ v2f nonadv_dye_pk_row(const Konst<float> &k, const LaneMapN<2> &lm, v2f fm, v2f f1, v2f fp)

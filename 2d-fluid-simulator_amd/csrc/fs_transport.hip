@@ -273,7 +273,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
     return launch_k34<2, false>(ctx, "cip_grad_advect_rt", "cip_grad_advect_rt_bnd", dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, nullptr, full, row_begin, row_end);
 }
 
-static bool cip_step_three_parts(const fs_ctx *ctx)
+static bool cip_step_multi_part(const fs_ctx *ctx)
 {
     // From 2.6 M cells (round 5, two-part form: bc2 res 1600 5 630 -> 6 195 steps/s, with dye 2 737 -> 3 435; res 1200 56 against 58.5 us; res 800, on its
     // 2-row tiles, 37.6 against 35.3 us the other way).  The three-part form (FS_FUSE_K2=1) paid for its K2 launch below 8 M cells.
@@ -284,17 +284,17 @@ static bool cip_step_three_parts(const fs_ctx *ctx)
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
-    *ok = cip_step_three_parts(ctx) ? 1 : 0;
+    *ok = cip_step_multi_part(ctx) ? 1 : 0;
     return FS_OK;
 }
 
-// diagnostic (bench.py: the algorithmic bytes of each part): how many tiles of tile_rows x tile_cells cells each of the three parts of a whole-grid
-// fs_cip_step launch covers - the all-fluid tiles, the boundary tiles, the tiles K2 runs over as a kernel of its own (0 0 0: not this form)
+// diagnostic (bench.py: the algorithmic bytes of each part): how many tiles of tile_rows x tile_cells cells each part of a whole-grid fs_cip_step
+// launch covers - the all-fluid tiles, the boundary tiles, (FS_FUSE_K2=1) the tiles K2 runs over as a kernel of its own (0 0 0: not this form)
 int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *tile_rows, int *tile_cells)
 {
     FS_REQUIRE(ctx && plain && boundary && band && tile_rows && tile_cells, "null argument");
     *plain = *boundary = *band = 0; *tile_rows = 4; *tile_cells = 120;
-    if (!cip_step_three_parts(ctx) || ctx->capturing || ctx->tape_rec) return FS_OK;
+    if (!cip_step_multi_part(ctx) || ctx->capturing || ctx->tape_rec) return FS_OK;
     const OvGrid ogp = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 1, 2, 1);
     const OvGrid ogb = ov_grid_lanes(ctx, 0, ctx->rows, 4, 2, XCD_ADVECT, 2, true, 2, 2, 1);
     OvGrid ogk{};
@@ -310,9 +310,10 @@ int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *ti
 
 // K2 + K3 + K4 of the velocity (fs/solver.py:213-227) as ONE call: fs_cip_nonadv(fn <- fc, pc) followed by fs_cip_grad_advect(v_out, gx_out,
 // gy_out <- fn, fc, gxc, gyc) - with the one difference that the fluid cells of fn that nothing reads before the next kernel rewrites them
-// are NOT stored where the three-part launch below applies (large single-GPU f32 grids; fs_k234.h): K2 runs as a kernel of its own only over
-// the tiles within one tile of a boundary tile, the plain tiles evaluate it in registers on the way to K3 + K4, the boundary tiles run the
-// general K3 + K4 kernel on the same wave columns.  fs_cip_step_ok: the static conditions of that form (the kernel names of a profile say what ran).
+// are NOT stored where the multi-part launch below applies (f32 grids from 2.6 M cells; fs_k234.h): every tile evaluates K2 in registers on the way
+// to K3 + K4 - k_cip_step_plain over the tiles that see nothing but fluid, k_cip_step_bnd (masks; stores K2 on inflow / outflow cells) over the
+// others.  FS_FUSE_K2=1: the form before - K2 as a kernel of its own over the tiles within one tile of a boundary tile, the general K3 + K4 kernel
+// over the boundary tiles.  fs_cip_step_ok: the static conditions (the kernel names of a profile say what ran).
 int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
                 const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end)
 {
@@ -327,7 +328,7 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
     // (a slab - halo != 0, the two-part form only: any row range; K2 is then evaluated for the rows within 2 of the range from rows within 3 of it, which the
     //  caller keeps valid - fs/runtime.py cip_step - where the two calls would read what an earlier K2 launch left in fn.  Single GPU: the whole grid.)
     const bool slab = ctx->halo != 0;
-    if (cip_step_three_parts(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
+    if (cip_step_multi_part(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
         const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 1, 2, 1, 0, slab);      // plain tiles: one entry per tile, two waves each
         auto k = make_konst<T>(ctx, dt, dx, re);
         const int dm = dm_all(ctx, k);
@@ -391,9 +392,9 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
 }
 
 // K12 + K3 + K4 of the dye (fs/solver.py:385-401 _update_dye) as ONE call: fs_cip_nonadv_dye(fn <- fc) followed by fs_cip_grad_advect_dye - with the
-// three-part launch of fs_cip_step where that applies (same conditions, fs_cip_step_ok): K12 as a kernel only over the boundary tiles' rows, the
-// all-fluid tiles evaluate it in registers (fs_k234.h k_cip_dye_plain), the boundary tiles run the general K3 + K4 kernel.  The fluid cells
-// of fn that nothing reads before the next K12 rewrites them are then not stored.
+// multi-part launch of fs_cip_step where that applies (same conditions, fs_cip_step_ok): K12 in registers (fs_k234.h k_cip_dye_plain over the all-fluid
+// tiles, k_cip_dye_bnd over the others; FS_FUSE_K2=1: K12 as a kernel over the boundary tiles' rows and the general K3 + K4 kernel there).  The fluid
+// cells of fn that nothing reads before the next K12 rewrites them are then not stored.
 int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
                     const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v, int clamp01, int full, int row_begin, int row_end)
 {
@@ -406,7 +407,7 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
     using T = float;
     constexpr int RT = 4;
     const bool slab = ctx->halo != 0;      // (as fs_cip_step)
-    if (cip_step_three_parts(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
+    if (cip_step_multi_part(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
         const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 1, 2, 1, 0, slab);
         const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 2, 2, 1, 0, slab);
         OvGrid ogk{};

@@ -942,7 +942,7 @@ class Device(DeviceBase):
 
     def cip_step_tiles(self):
         """(all-fluid tiles, boundary tiles, tiles of the stand-alone K2 launch, rows per tile, cells per tile row) of a whole-grid fs_cip_step
-        launch in its three-part form (zeros otherwise) - bench.py prices each part against the bytes of its own tiles."""
+        launch in its multi-part form (zeros otherwise; the third count: FS_FUSE_K2=1 only) - bench.py prices each part against the bytes of its own tiles."""
         v = [ctypes.c_int() for _ in range(5)]
         _lib.call("fs_cip_step_tiles", self._ctx, *[ctypes.byref(x) for x in v])
         return tuple(x.value for x in v)

@@ -7,7 +7,7 @@ cp gpurun_out/prof_r5/trace/t_kernel_stats.csv profiles/r5_kernel_stats.csv
 cp gpurun_out/prof_r5/pmc_traffic.json profiles/pmc_traffic.json
 cp gpurun_out/prof_r5/bench_trace.json profiles/r5_bench_under_rocprof.json
 cp gpurun_out/pmc_r5/summary.txt profiles/r5_sq_wave_cycles.txt
-{ echo "tools/overlap_bench.py, round 5: middle slab (rank 3 of 8) of bc5 res 4096 on ONE MI355X, ghost-row exchanges through RCCL in loop-back (the rank is its own neighbour)."
+{ echo "tools/overlap_bench.py, round 5: one slab (rank 3 of 8; rank 1 of 4 / of 2) of bc5 res 4096 on ONE MI355X, ghost-row exchanges through RCCL in loop-back (the rank is its own neighbour)."
   echo "none = exchanges removed (compute only); blocking = in line on the compute stream; tape = the recorded period replayed from C++.  One box, one call (tools/r5_lease.sh)."
   cat gpurun_out/r5/loopback.txt; } > profiles/r5_loopback_slab_step.txt
 python3 - <<'PY' > profiles/r5_summary.txt
@@ -26,7 +26,7 @@ print(f"the library's own fs_box_rates (bench.py \"box\", 268 MB buffers): read 
 print("== rocprofv3 --kernel-trace --stats + PMC passes (FETCH_SIZE doubled per the gfx950 correction; Infinity-Cache hits count as fetches) of")
 print("   python3 bench.py --steps 20 --warmup 10 --no-cpu --no-graph --sweeps 40   (tools/profile.sh; profiles/r5_kernel_stats.csv, profiles/pmc_traffic.json)")
 print(open("gpurun_out/prof_r5/summary.txt").read().rstrip())
-print("\n== SQ wave-cycle split + instruction counts per wave + traffic, per kernel instantiation (tools/r3_pmc.sh; multi-part launches: k_cip_step_plain / k_rbsor_pair_stack = the all-fluid tiles, k_cip_grad_advect_n<.., false, .., 2> / k_rbsor_pair<.., 2, ..> = the boundary tiles, k_cip_nonadv_n<.., 2, true> = K2 over their rows)")
+print("\n== SQ wave-cycle split + instruction counts per wave + traffic, per kernel instantiation (tools/r3_pmc.sh; multi-part launches: k_cip_step_plain / k_rbsor_pair_stack = the all-fluid tiles, k_cip_step_bnd / k_rbsor_pair<.., 2, ..> = the boundary tiles, k_cip_nonadv_n<.., 2, true> = K2 over their rows)")
 print("   wait = parked on s_waitcnt, stall = ready but not issued, act = issuing; qc/wave = quad-cycles a wave is resident")
 print(open("gpurun_out/pmc_r5/summary.txt").read().rstrip())
 print("\n== steps/s of every BASELINE configuration on this box (profiles/r5_bench_*.json)")

@@ -15,7 +15,10 @@ run res1600_bc2_cip_vc     --bc 2 --res 1600 --steps 1200 --warmup 60 --sweeps 0
 run res1600_bc2_cip_vc_dye --bc 2 --res 1600 --dye --steps 600 --warmup 60 --sweeps 0 --no-cpu
 bash tools/profile.sh r5 > $OUT/profile.log 2>&1
 EXTRA_PMC="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" bash tools/r3_pmc.sh r5 > $OUT/pmc.log 2>&1
-{ echo "== defaults (halo 20, pair on)"; timeout 600 python3 tools/overlap_bench.py 16 20 2>&1 | tail -8; } > $OUT/loopback.txt 2>&1
+{ echo "== defaults (halo 20, pair on): middle slab of the 8-way cut"; timeout 600 python3 tools/overlap_bench.py 16 20 2>&1 | tail -8;
+  for w in "4 1" "2 1"; do set -- $w; echo "== slab $2 of the $1-way cut (none = compute only, tape = the recorded period with its exchanges)"; OB_MODES=none,tape OB_WORLD=$1 OB_RANK=$2 timeout 300 python3 tools/overlap_bench.py 20 2>&1 | tail -2; done
+  echo "== the 8- / 4- / 2-way cuts with fs_cip_step as its two calls (FS_FUSE_K2=0: K2 as a launch of its own, as before round 5 on slabs)"
+  for w in "8 3" "4 1" "2 1"; do set -- $w; OB_MODES=tape OB_WORLD=$1 OB_RANK=$2 FS_FUSE_K2=0 timeout 300 python3 tools/overlap_bench.py 20 2>&1 | tail -1 | sed "s/^/$1-way: /"; done; } > $OUT/loopback.txt 2>&1
 tools/membw.bin > $OUT/membw_after.txt 2>&1
 ls gpurun_out/bench_r5 gpurun_out/prof_r5 gpurun_out/pmc_r5 > $OUT/files.txt 2>&1
 tail -8 $OUT/bench_configs.log
