@@ -91,10 +91,7 @@ __device__ __forceinline__ void k234_phase2(const Grid &g, const Konst<float> &k
                                             float *out, float *gxo, float *gyo, unsigned *hot, const K234State<RT> &st, const v2f (*xch)[64])
 {
     const int lane = threadIdx.x & 63;
-    v2f A[RT + 2];
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) A[s] = xch[(1 - c) * (RT + 2) + s][lane];
-    cip_k34_pk_core<2, c, RT, DM, true, false>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, st.Nn, st.Fc, st.GX, st.GY, A, A, out, gxo, gyo, hot);
+    cip_k34_pk_core<2, c, RT, DM, true, false>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, st.Nn, st.Fc, st.GX, st.GY, AdvLds<RT>{xch + (1 - c) * (RT + 2), lane}, out, gxo, gyo, hot);
 }
 
 // one workgroup = 2 waves = the two velocity components of ONE listed tile (compact launch only: Grid::tiles, one entry per tile)
@@ -184,7 +181,7 @@ __device__ __forceinline__ void k234_bnd_phase1(const Grid &g, const Konst<float
                 const LV<T, N> O = unpk(st.Nn[t + 2]);
 #pragma unroll
                 for (int q = 0; q < N; ++q) raise_hot(hot_fn, ((sel >> q) & 1u) && hot1(O.a[q]));
-                lv_store_sel<T, N>(fn + idx<2, T>(g, c, i0, j0 + t), O, sel);
+                lv_store_row_sel<2, T, N>(fn, g, c, i0, j0 + t, O, sel);
             }
         }
     }
@@ -196,19 +193,16 @@ __device__ __forceinline__ void k234_bnd_phase1(const Grid &g, const Konst<float
 
 template <int c, int RT, int DM>
 __device__ __forceinline__ void k234_bnd_phase2(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
-                                                float *out, float *gxo, float *gyo, unsigned *hot, const K234State<RT> &st,
+                                                float *out, float *gxo, float *gyo, const float *gxc, const float *gyc, unsigned *hot, const K234State<RT> &st,
                                                 unsigned nwbits, unsigned flbits, const v2f (*xch)[64])
 {
     const int lane = threadIdx.x & 63;
-    v2f A[RT + 2];
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) A[s] = xch[(1 - c) * (RT + 2) + s][lane];
-    cip_k34_pk_core<2, c, RT, DM, false, false>(g, k, lm, i0, j0, je, MaskPacked{nwbits >> 2, flbits}, st.Nn, st.Fc, st.GX, st.GY, A, A, out, gxo, gyo, hot);
+    cip_k34_pk_core<2, c, RT, DM, false, false>(g, k, lm, i0, j0, je, MaskPacked{nwbits >> 2, flbits}, st.Nn, st.Fc, st.GX, st.GY, AdvLds<RT>{xch + (1 - c) * (RT + 2), lane}, out, gxo, gyo, hot, gxc, gyc);
 }
 
 // one workgroup = 2 waves = the two velocity components of ONE listed boundary tile (compact launch, class 2 list with one entry per tile)
 #ifndef FS_K234_BND_WAVES
-#define FS_K234_BND_WAVES 3
+#define FS_K234_BND_WAVES 4
 #endif
 template <int RT, int DM>
 __global__ __launch_bounds__(128, FS_K234_BND_WAVES) void k_cip_step_bnd(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
@@ -228,8 +222,44 @@ __global__ __launch_bounds__(128, FS_K234_BND_WAVES) void k_cip_step_bnd(Grid g,
     if (c == 0) k234_bnd_phase1<0, RT, DM>(g, k, lm, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, xch);
     else        k234_bnd_phase1<1, RT, DM>(g, k, lm, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, xch);
     __syncthreads();
-    if (c == 0) k234_bnd_phase2<0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, nwbits, flbits, xch);
-    else        k234_bnd_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, nwbits, flbits, xch);
+    if (c == 0) k234_bnd_phase2<0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, gxc, gyc, hot, st, nwbits, flbits, xch);
+    else        k234_bnd_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, gxc, gyc, hot, st, nwbits, flbits, xch);
+}
+
+// ... and both kinds of tile in ONE launch (class 0 list with the per-tile plain hint): the boundary tiles are a launch of 8 569 workgroups at bc5 res
+// 4096 - a few rounds of what the chip holds - and the all-fluid launch ends on a partly filled round too; in one launch the boundary tiles fill in as
+// others finish.  One register budget: the boundary body fits the all-fluid body's 128 VGPRs since the selective stores take the scalar row base, the
+// carried gradients are re-read and the sibling's rows come from LDS where they are used.
+template <int RT, int DM>
+__global__ __launch_bounds__(128, 4) void k_cip_step_all(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
+                                                         float *out, float *gxo, float *gyo, float *fn, const float *fc, const float *pc,
+                                                         const float *gxc, const float *gyc, unsigned *hot, unsigned *hot_fn)
+{
+    constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
+    __shared__ v2f xch[2 * (RT + 2)][64];
+    int wx, ty, cg;
+    unsigned cls = 0u;
+    if (!band_coords<1>(g, nbx, nby, wx, ty, cg, 0, &cls)) return;
+    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
+    const int c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm_in.i0, j0 = jb + ty * RT;
+    K234State<RT> st;
+    if (cls & 1u) {                                                             // (workgroup-uniform: the list's hint for this tile)
+        const LaneMapN<N> lm{lm_in.i0, lm_in.owner, false, false};
+        if (c == 0) k234_phase1<0, RT, DM>(g, k, lm, i0, j0, fc, pc, gxc, gyc, st, xch);
+        else        k234_phase1<1, RT, DM>(g, k, lm, i0, j0, fc, pc, gxc, gyc, st, xch);
+        __syncthreads();
+        if (c == 0) k234_phase2<0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, xch);
+        else        k234_phase2<1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, xch);
+    } else {
+        unsigned nwbits, flbits;
+        if (c == 0) k234_bnd_phase1<0, RT, DM>(g, k, lm_in, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, xch);
+        else        k234_bnd_phase1<1, RT, DM>(g, k, lm_in, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, xch);
+        __syncthreads();
+        if (c == 0) k234_bnd_phase2<0, RT, DM>(g, k, lm_in, i0, j0, je, out, gxo, gyo, gxc, gyc, hot, st, nwbits, flbits, xch);
+        else        k234_bnd_phase2<1, RT, DM>(g, k, lm_in, i0, j0, je, out, gxo, gyo, gxc, gyc, hot, st, nwbits, flbits, xch);
+    }
 }
 
 // ---- the dye: K12 + K3 + K4 (fs/solver.py:385-401 _update_dye) over the all-fluid tiles -----------------------------------------------
@@ -251,106 +281,108 @@ __device__ __forceinline__ v2f nonadv_dye_pk_row(const Konst<float> &k, const La
     return f1 + dif * k.dt;
 }
 
-template <int RT, int DM, bool CLAMP>
-__global__ __launch_bounds__(64) void k_cip_dye_plain(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
-                                                      float *out, float *gxo, float *gyo, const float *fc, const float *gxc, const float *gyc, const float *v)
+// one channel of one all-fluid tile
+template <int c, int RT, int DM, bool CLAMP>
+__device__ __forceinline__ void k234_dye_plain(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
+                                               float *out, float *gxo, float *gyo, const float *fc, const float *gxc, const float *gyc, const float *v)
 {
     using T = float;
-    constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
-    int wx, ty, cg;
-    if (!band_coords<3>(g, nbx, nby, wx, ty, cg)) return;
-    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
-    const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
-    const LaneMapN<N> lm{lm_in.i0, lm_in.owner, false, false};
-    const int i0 = lm.i0, j0 = jb + ty * RT;
-    auto body = [&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        v2f F[RT + 6], Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
+    constexpr int N = 2;
+    v2f F[RT + 6], Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
 #pragma unroll
-        for (int u = 0; u < RT + 6; ++u) F[u] = pk(lv_field<3, T, N>(fc, g, c, i0, clampy(g, j0 - 3 + u)));
+    for (int u = 0; u < RT + 6; ++u) F[u] = pk(lv_field<3, T, N>(fc, g, c, i0, clampy(g, j0 - 3 + u)));
 #pragma unroll
-        for (int s = 0; s < RT + 2; ++s) {
-            const int row = clampy(g, j0 - 1 + s);
-            GX[s] = pk(lv_field<3, T, N>(gxc, g, c, i0, row));
-            GY[s] = pk(lv_field<3, T, N>(gyc, g, c, i0, row));
-            AX[s] = pk(lv_field<2, T, N>(v, g, 0, i0, row));
-            AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
-        }
+    for (int s = 0; s < RT + 2; ++s) {
+        const int row = clampy(g, j0 - 1 + s);
+        GX[s] = pk(lv_field<3, T, N>(gxc, g, c, i0, row));
+        GY[s] = pk(lv_field<3, T, N>(gyc, g, c, i0, row));
+        AX[s] = pk(lv_field<2, T, N>(v, g, 0, i0, row));
+        AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
+    }
 #pragma unroll
-        for (int u = 0; u < RT + 4; ++u) {
-            Nn[u] = nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]);
-            Fc[u] = F[u + 1];
-        }
-        cip_k34_pk_core<3, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
-    };
-    if (cg == 0) body(std::integral_constant<int, 0>{});
-    else if (cg == 1) body(std::integral_constant<int, 1>{});
-    else body(std::integral_constant<int, 2>{});
+    for (int u = 0; u < RT + 4; ++u) {
+        Nn[u] = nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]);
+        Fc[u] = F[u + 1];
+    }
+    cip_k34_pk_core<3, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, Nn, Fc, GX, GY, AdvRows<RT>{AX, AY}, out, gxo, gyo, nullptr);
 }
 
-// ... and the boundary tiles of the dye's call: k_cip_step_bnd without the exchange (masks, K12 of the reference on the not-wall cells of the
-// window, what the buffer holds on wall cells, edge-row slots; the not-wall cells that are not fluid are stored)
-template <int RT, int DM, bool CLAMP>
-__global__ __launch_bounds__(64) void k_cip_dye_bnd(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
-                                                    float *out, float *gxo, float *gyo, float *fn, const float *fc, const float *gxc, const float *gyc, const float *v)
+// ... of a tile that is not all fluid: k234_bnd_phase1 / 2 without the exchange (masks, K12 of the reference on the not-wall cells of the window, what
+// the buffer holds on wall cells, edge-row slots; the not-wall cells that are not fluid are stored)
+template <int c, int RT, int DM, bool CLAMP>
+__device__ __forceinline__ void k234_dye_bnd(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
+                                             float *out, float *gxo, float *gyo, float *fn, const float *fc, const float *gxc, const float *gyc, const float *v)
 {
     using T = float;
+    constexpr int N = 2;
+    FS_PIN_LANE_OFFSET(i0);
+    unsigned nwbits = 0u, flbits = 0u;      // (as k234_bnd_phase1)
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + u));
+        nwbits |= lv_sel_nw<N>(m) << (2 * u);
+        if (u >= 2 && u < RT + 2 && j0 + u - 2 < je) flbits |= lv_sel_fluid<N>(m) << (2 * (u - 2));
+    }
+#define FS_NWK(u) ((nwbits >> (2 * (u))) & 3u)
+    v2f F[RT + 6], Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
+#pragma unroll
+    for (int u = 0; u < RT + 6; ++u) F[u] = pk(lv_field<3, T, N>(fc, g, c, i0, clampy(g, j0 - 3 + u)));
+#pragma unroll
+    for (int s = 0; s < RT + 2; ++s) {
+        const int row = clampy(g, j0 - 1 + s);
+        GX[s] = pk(lv_field<3, T, N>(gxc, g, c, i0, row));
+        GY[s] = pk(lv_field<3, T, N>(gyc, g, c, i0, row));
+        AX[s] = pk(lv_field<2, T, N>(v, g, 0, i0, row));
+        AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
+    }
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        Nn[u] = v2f{0.0f, 0.0f};
+        if (FS_NWK(u) != 3u) Nn[u] = pk(lv_field<3, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
+    }
+#pragma unroll
+    for (int u = 0; u < RT + 4; ++u) {
+        Nn[u] = sel2(FS_NWK(u), nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]), Nn[u]);
+        Fc[u] = F[u + 1];
+    }
+#pragma unroll
+    for (int u = RT + 2; u >= 0; --u) if (j0 - 2 + u < g.jlo) Nn[u] = Nn[u + 1];
+#pragma unroll
+    for (int u = 1; u < RT + 4; ++u) if (j0 - 2 + u > g.jhi) Nn[u] = Nn[u - 1];
+    if (lm.owner) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const unsigned sel = FS_NWK(t + 2) & ~(flbits >> (2 * t)) & 3u;
+            if (j0 + t < je && sel) lv_store_row_sel<3, T, N>(fn, g, c, i0, j0 + t, unpk(Nn[t + 2]), sel);
+        }
+    }
+    cip_k34_pk_core<3, c, RT, DM, false, CLAMP>(g, k, lm, i0, j0, je, MaskPacked{nwbits >> 2, flbits}, Nn, Fc, GX, GY, AdvRows<RT>{AX, AY}, out, gxo, gyo, nullptr, gxc, gyc);
+#undef FS_NWK
+}
+
+// one workgroup = one wave = one channel of one listed tile.  KIND: 1 - the all-fluid tiles (class 1 list), 2 - the others (class 2 list), 0 - both in ONE
+// launch (class 0 list: the entry's hint bit says which body; as k_cip_step_all)
+template <int RT, int DM, bool CLAMP, int KIND>
+__global__ __launch_bounds__(64, 4) void k_cip_dye(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
+                                                   float *out, float *gxo, float *gyo, float *fn, const float *fc, const float *gxc, const float *gyc, const float *v)
+{
     constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
     int wx, ty, cg;
-    if (!band_coords<3>(g, nbx, nby, wx, ty, cg)) return;
+    unsigned cls = 0u;
+    if (!band_coords<3>(g, nbx, nby, wx, ty, cg, 0, KIND == 0 ? &cls : nullptr)) return;
     if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
-    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
-    const int j0 = jb + ty * RT;
-    auto body = [&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        int i0 = lm.i0;
-        FS_PIN_LANE_OFFSET(i0);
-        unsigned nwbits = 0u, flbits = 0u;      // (as k234_bnd_phase1)
-#pragma unroll
-        for (int u = 0; u < RT + 4; ++u) {
-            const uint32_t m = lv_bytes<N>(g.mask, g, i0, clampy(g, j0 - 2 + u));
-            nwbits |= lv_sel_nw<N>(m) << (2 * u);
-            if (u >= 2 && u < RT + 2 && j0 + u - 2 < je) flbits |= lv_sel_fluid<N>(m) << (2 * (u - 2));
-        }
-#define FS_NWK(u) ((nwbits >> (2 * (u))) & 3u)
-        v2f F[RT + 6], Nn[RT + 4], Fc[RT + 4], GX[RT + 2], GY[RT + 2], AX[RT + 2], AY[RT + 2];
-#pragma unroll
-        for (int u = 0; u < RT + 6; ++u) F[u] = pk(lv_field<3, T, N>(fc, g, c, i0, clampy(g, j0 - 3 + u)));
-#pragma unroll
-        for (int s = 0; s < RT + 2; ++s) {
-            const int row = clampy(g, j0 - 1 + s);
-            GX[s] = pk(lv_field<3, T, N>(gxc, g, c, i0, row));
-            GY[s] = pk(lv_field<3, T, N>(gyc, g, c, i0, row));
-            AX[s] = pk(lv_field<2, T, N>(v, g, 0, i0, row));
-            AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
-        }
-#pragma unroll
-        for (int u = 0; u < RT + 4; ++u) {
-            Nn[u] = v2f{0.0f, 0.0f};
-            if (FS_NWK(u) != 3u) Nn[u] = pk(lv_field<3, T, N>(fn, g, c, i0, clampy(g, j0 - 2 + u)));
-        }
-#pragma unroll
-        for (int u = 0; u < RT + 4; ++u) {
-            Nn[u] = sel2(FS_NWK(u), nonadv_dye_pk_row<DM>(k, lm, F[u], F[u + 1], F[u + 2]), Nn[u]);
-            Fc[u] = F[u + 1];
-        }
-#pragma unroll
-        for (int u = RT + 2; u >= 0; --u) if (j0 - 2 + u < g.jlo) Nn[u] = Nn[u + 1];
-#pragma unroll
-        for (int u = 1; u < RT + 4; ++u) if (j0 - 2 + u > g.jhi) Nn[u] = Nn[u - 1];
-        if (lm.owner) {
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const unsigned sel = FS_NWK(t + 2) & ~(flbits >> (2 * t)) & 3u;
-                if (j0 + t < je && sel) lv_store_sel<T, N>(fn + idx<3, T>(g, c, i0, j0 + t), unpk(Nn[t + 2]), sel);
-            }
-        }
-        cip_k34_pk_core<3, c, RT, DM, false, CLAMP>(g, k, lm, i0, j0, je, MaskPacked{nwbits >> 2, flbits}, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, nullptr);
-#undef FS_NWK
-    };
-    if (cg == 0) body(std::integral_constant<int, 0>{});
-    else if (cg == 1) body(std::integral_constant<int, 1>{});
-    else body(std::integral_constant<int, 2>{});
+    const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
+    const int i0 = lm_in.i0, j0 = jb + ty * RT;
+    if (KIND == 1 || (KIND == 0 && (cls & 1u))) {
+        const LaneMapN<N> lm{lm_in.i0, lm_in.owner, false, false};
+        if (cg == 0) k234_dye_plain<0, RT, DM, CLAMP>(g, k, lm, i0, j0, je, out, gxo, gyo, fc, gxc, gyc, v);
+        else if (cg == 1) k234_dye_plain<1, RT, DM, CLAMP>(g, k, lm, i0, j0, je, out, gxo, gyo, fc, gxc, gyc, v);
+        else k234_dye_plain<2, RT, DM, CLAMP>(g, k, lm, i0, j0, je, out, gxo, gyo, fc, gxc, gyc, v);
+    } else {
+        if (cg == 0) k234_dye_bnd<0, RT, DM, CLAMP>(g, k, lm_in, i0, j0, je, out, gxo, gyo, fn, fc, gxc, gyc, v);
+        else if (cg == 1) k234_dye_bnd<1, RT, DM, CLAMP>(g, k, lm_in, i0, j0, je, out, gxo, gyo, fn, fc, gxc, gyc, v);
+        else k234_dye_bnd<2, RT, DM, CLAMP>(g, k, lm_in, i0, j0, je, out, gxo, gyo, fn, fc, gxc, gyc, v);
+    }
 }
 
 }  // namespace fs

@@ -235,10 +235,23 @@ struct MaskPlain {
     __device__ __forceinline__ unsigned nw(int) const { return 3u; }
     __device__ __forceinline__ unsigned fl(int t) const { return t < rows ? 3u : 0u; }
 };
-template <int C, int c, int RT, int DM, bool PLAIN, bool CLAMP, typename MK>
+// the advecting velocity of the core, rows j0-1 .. j0+RT (slot s): register rows (the two-kernel form and the dye), or the sibling wave's rows in LDS,
+// read where they are used (fs_k234.h: six rows held from the barrier on were 12 VGPRs at the register peak of the boundary body)
+template <int RT> struct AdvRows {
+    const v2f (&ax)[RT + 2]; const v2f (&ay)[RT + 2];
+    __device__ __forceinline__ v2f x(int s) const { return ax[s]; }
+    __device__ __forceinline__ v2f y(int s) const { return ay[s]; }
+};
+template <int RT> struct AdvLds {
+    const v2f (*rows)[64]; int lane;       // rows[s][lane]: the sibling component's row s
+    __device__ __forceinline__ v2f x(int s) const { return rows[s][lane]; }
+    __device__ __forceinline__ v2f y(int s) const { return rows[s][lane]; }
+};
+template <int C, int c, int RT, int DM, bool PLAIN, bool CLAMP, typename MK, typename AV>
 __device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je, const MK &mk,
                                                 const v2f (&Nn)[RT + 4], const v2f (&Fc)[RT + 4], const v2f (&GX)[RT + 2], const v2f (&GY)[RT + 2],
-                                                const v2f (&AX)[RT + 2], const v2f (&AY)[RT + 2], float *out, float *gxo, float *gyo, unsigned *hot)
+                                                const AV &adv, float *out, float *gxo, float *gyo, unsigned *hot,
+                                                const float *gxc = nullptr, const float *gyc = nullptr)      // (not PLAIN: the old gradients in memory, for the cells that carry them)
 {
     using T = float;
     constexpr int N = 2;
@@ -274,8 +287,9 @@ __device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float
         const int j = j0 + t;
         if (t < 0 || j >= je) continue;
         const v2f Nm = Nn[t + 1], Nc = Nn[t + 2], Np = Nn[t + 3];
-        const v2f VXm = SELF && c == 0 ? Nm : AX[t], VXr = SELF && c == 0 ? Nc : AX[t + 1], VXp = SELF && c == 0 ? Np : AX[t + 2];
-        const v2f VYm = SELF && c == 1 ? Nm : AY[t], VYr = SELF && c == 1 ? Nc : AY[t + 1], VYp = SELF && c == 1 ? Np : AY[t + 2];
+        v2f VXm, VXr, VXp, VYm, VYr, VYp;
+        if constexpr (SELF && c == 0) { VXm = Nm; VXr = Nc; VXp = Np; } else { VXm = adv.x(t); VXr = adv.x(t + 1); VXp = adv.x(t + 2); }
+        if constexpr (SELF && c == 1) { VYm = Nm; VYr = Nc; VYp = Np; } else { VYm = adv.y(t); VYr = adv.y(t + 1); VYp = adv.y(t + 2); }
         const T vxl = lv_left<T, N>(lm, unpk(VXr)), vxr = lv_right<T, N>(lm, unpk(VXr));
         const T vyl = lv_left<T, N>(lm, unpk(VYr)), vyr = lv_right<T, N>(lm, unpk(VYr));
         const T fl0 = lv_left<T, N>(lm, unpk(Nm)), fr0 = lv_right<T, N>(lm, unpk(Nm));
@@ -295,7 +309,9 @@ __device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float
         v2f of, ofx, ofy;
         cip_point<DM>(k, vx, vy, dxx, dxy, dyx, dyy, f00, f0m, fm0, fmm, fx00, fxm0, fx0m, fy00, fy0m, fym0, of, ofx, ofy);
         if (CLAMP) { of.x = tmin(tmax(of.x, 0.0f), 1.0f); of.y = tmin(tmax(of.y, 0.0f), 1.0f); }
-        const R OV = unpk(PLAIN ? of : sel2(mk.fl(t), of, Fc[t + 2])), OX = unpk(PLAIN ? ofx : sel2(mk.fl(t), ofx, GX[t + 1])), OY = unpk(PLAIN ? ofy : sel2(mk.fl(t), ofy, GY[t + 1]));
+        // (not PLAIN: the gradients of a not-wall cell that is not fluid - inflow / outflow - are carried from the old buffers; those cells are re-read below
+        //  instead of holding rows t+1 of GX / GY across K3 of the two rows above: 8 VGPRs of the boundary bodies)
+        const R OV = unpk(PLAIN ? of : sel2(mk.fl(t), of, Fc[t + 2])), OX = unpk(ofx), OY = unpk(ofy);
         if (lm.owner) {
             if (SELF && lv_hot1<T, N>(OV)) {
                 bool hf = false, hn = false;
@@ -310,10 +326,15 @@ __device__ __forceinline__ void cip_k34_pk_core(const Grid &g, const Konst<float
                 lv_store_row<C, T, N>(gxo, g, c, i0, j, OX);
                 lv_store_row<C, T, N>(gyo, g, c, i0, j, OY);
             } else {
-                lv_store<T, N>(out + idx<C, T>(g, c, i0, j), OV);
-                if (mk.nw(t + 1)) {
-                    lv_store_sel<T, N>(gxo + idx<C, T>(g, c, i0, j), OX, mk.nw(t + 1));
-                    lv_store_sel<T, N>(gyo + idx<C, T>(g, c, i0, j), OY, mk.nw(t + 1));
+                lv_store_row<C, T, N>(out, g, c, i0, j, OV);
+                if (mk.fl(t)) {
+                    lv_store_row_sel<C, T, N>(gxo, g, c, i0, j, OX, mk.fl(t));
+                    lv_store_row_sel<C, T, N>(gyo, g, c, i0, j, OY, mk.fl(t));
+                }
+                const unsigned carry = mk.nw(t + 1) & ~mk.fl(t) & 3u;
+                if (carry) {
+                    lv_store_row_sel<C, T, N>(gxo, g, c, i0, j, lv_field<C, T, N>(gxc, g, c, i0, j), carry);
+                    lv_store_row_sel<C, T, N>(gyo, g, c, i0, j, lv_field<C, T, N>(gyc, g, c, i0, j), carry);
                 }
             }
         }
@@ -391,8 +412,8 @@ __device__ __forceinline__ void cip_grad_advect_pk_body(const Grid &g, const Kon
             AY[s] = pk(lv_field<2, T, N>(v, g, 1, i0, row));
         }
     }
-    if constexpr (PLAIN) cip_k34_pk_core<C, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, hot);
-    else cip_k34_pk_core<C, c, RT, DM, false, CLAMP>(g, k, lm, i0, j0, je, mk, Nn, Fc, GX, GY, AX, AY, out, gxo, gyo, hot);
+    if constexpr (PLAIN) cip_k34_pk_core<C, c, RT, DM, true, CLAMP>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, Nn, Fc, GX, GY, AdvRows<RT>{AX, AY}, out, gxo, gyo, hot);
+    else cip_k34_pk_core<C, c, RT, DM, false, CLAMP>(g, k, lm, i0, j0, je, mk, Nn, Fc, GX, GY, AdvRows<RT>{AX, AY}, out, gxo, gyo, hot, gxc, gyc);
 }
 
 #ifndef FS_K34_PK

@@ -112,6 +112,31 @@ __device__ __forceinline__ void lv_store_row(T *f, const Grid &g, int c, int i0,
 #endif
 }
 
+// ... and the cells of the lane that `sel` names (bit k = cell k): the same addressing - no 64-bit address pair per store (round 5: the general bodies'
+// selective stores went through `dst + idx(...)`, a v_lshl_add_u64 and two VGPRs each)
+template <int C, typename T, int N>
+__device__ __forceinline__ void lv_store_row_sel(T *f, const Grid &g, int c, int i0, int j, const LV<T, N> &v, unsigned sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Q = typename LVec<T, N>::type;
+    asm volatile("" : "+v"(i0));
+    const fs_gptr row = (fs_gptr)uniform64((uint64_t)(f + ((size_t)j * C + c) * g.P));
+    const unsigned off = (unsigned)i0 * (unsigned)sizeof(T);
+    if (sel == (1u << N) - 1u) {
+        Q q;
+        if constexpr (N == 4) { q.x = v.a[0]; q.y = v.a[1]; q.z = v.a[2]; q.w = v.a[3]; }
+        else { q.x = v.a[0]; q.y = v.a[1]; }
+        *reinterpret_cast<__attribute__((address_space(1))) Q *>(row + off) = q;
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        if (sel & (1u << q)) *reinterpret_cast<__attribute__((address_space(1))) T *>(row + off + (unsigned)(q * sizeof(T))) = v.a[q];
+#else
+    lv_store_sel<T, N>(f + ((size_t)j * C + c) * g.P + i0, v, sel);
+#endif
+}
+
 // ---- the two cells of a lane as one packed operand (fs_device.h v2f) ----------------------------------------------------------------------
 __device__ __forceinline__ v2f pk(const LV<float, 2> &r) { v2f v; v.x = r.a[0]; v.y = r.a[1]; return v; }
 __device__ __forceinline__ LV<float, 2> unpk(v2f v) { LV<float, 2> r; r.a[0] = v.x; r.a[1] = v.y; return r; }

@@ -275,11 +275,12 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
 
 static bool cip_step_multi_part(const fs_ctx *ctx)
 {
-    // From 2.6 M cells (round 5, two-part form: bc2 res 1600 5 630 -> 6 195 steps/s, with dye 2 737 -> 3 435; res 1200 56 against 58.5 us; res 800, on its
-    // 2-row tiles, 37.6 against 35.3 us the other way).  The three-part form (FS_FUSE_K2=1) paid for its K2 launch below 8 M cells.
-    const size_t cells = (size_t)ctx->X * ctx->Y, from = ctx->fuse_k2 == 2 ? (size_t)5 << 19 : (size_t)1 << 23;
+    // From 1 M cells (late round 5, K2 in registers on every tile in ONE launch - FS_FUSE_K2=3: bc2 res 800 15.8 -> 16.2 k steps/s, with dye 9.2 -> 10.2 k; bc5 res 1024
+    // 13.9 -> 15.0 k; res 1200 10.35 -> 11.0 k; res 1600 6 150 -> 6 410; res 400, on its 2-row tiles, 29.0 -> 27.0 k the other way).  As two launches (2) the
+    // form paid from 2.6 M cells, as three (1: K2 as a kernel over the boundary tiles' rows) from 8 M.
+    const size_t cells = (size_t)ctx->X * ctx->Y, from = ctx->fuse_k2 >= 2 ? ctx->fuse_k2_cells : (size_t)1 << 23;
     const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && cells >= from);
-    return ctx->mask_set && ctx->fuse_k2 != 0 && big && (ctx->halo == 0 || ctx->fuse_k2 == 2) && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
+    return ctx->mask_set && ctx->fuse_k2 != 0 && big && (ctx->halo == 0 || ctx->fuse_k2 >= 2) && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
 }
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
 {
@@ -334,7 +335,18 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
         const int dm = dm_all(ctx, k);
 #define FS_K234(DM) hipLaunchKernelGGL((k_cip_step_plain<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
-        if (ctx->fuse_k2 == 2) {
+        if (ctx->fuse_k2 == 3) {
+            // one launch over both kinds of tile (fs_k234.h k_cip_step_all)
+            const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
+            if (oga.g.tiles)
+                return launch(ctx, "cip_step", [=] {
+                    const OvGrid og = oga;
+#define FS_K234A(DM) hipLaunchKernelGGL((k_cip_step_all<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
+                    FS_DMA(dm, FS_K234A);
+                });
+        }
+        if (ctx->fuse_k2 >= 2) {
             // two parts: K2 in registers on the boundary tiles as well (fs_k234.h k_cip_step_bnd)
             const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 2, 2, 1, 0, slab);  // boundary tiles: one entry per tile, two waves each
             if (ogp.g.tiles && ogb.g.tiles) {
@@ -408,32 +420,37 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
     constexpr int RT = 4;
     const bool slab = ctx->halo != 0;      // (as fs_cip_step)
     if (cip_step_multi_part(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
+        auto k = make_konst<T>(ctx, dt, dx, re);
+        const int dm = dm_all(ctx, k), dmx = dm_dx(ctx, k);
+        // k_cip_dye<RT, DM, CLAMP, KIND> over a list: KIND 1 - the all-fluid tiles, 2 - the others, 0 - both (class 0 list with the per-tile hint)
+#define FS_KD(DM, CL, KIND) hipLaunchKernelGGL((k_cip_dye<RT, DM, CL, KIND>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
+#define FS_KD_C0(DM) FS_KD(DM, true, 0)
+#define FS_KD_N0(DM) FS_KD(DM, false, 0)
+#define FS_KD_C1(DM) FS_KD(DM, true, 1)
+#define FS_KD_N1(DM) FS_KD(DM, false, 1)
+#define FS_KD_C2(DM) FS_KD(DM, true, 2)
+#define FS_KD_N2(DM) FS_KD(DM, false, 2)
+        if (ctx->fuse_k2 == 3) {
+            const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
+            if (oga.g.tiles) return launch(ctx, "cip_step_dye", [=] { const OvGrid og = oga; if (clamp01) FS_DMA(dm, FS_KD_C0); else FS_DMA(dm, FS_KD_N0); });
+        }
         const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 1, 2, 1, 0, slab);
         const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 2, 2, 1, 0, slab);
         OvGrid ogk{};
         if (ctx->fuse_k2 == 1) ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);
-        if (ogp.g.tiles && ogb.g.tiles && (ogk.g.tiles || ctx->fuse_k2 == 2)) {
-            auto k = make_konst<T>(ctx, dt, dx, re);
-            const int dm = dm_all(ctx, k), dmx = dm_dx(ctx, k);
+        if (ogp.g.tiles && ogb.g.tiles && (ogk.g.tiles || ctx->fuse_k2 >= 2)) {
 #define FS_K12B(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, RT, DM, T, 2, true>), ogk.grid, dim3(64), 0, ctx->stream, ogk.g, k, ogk.nbx, ogk.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d)
-#define FS_KD(DM, CL) hipLaunchKernelGGL((k_cip_dye_plain<RT, DM, CL>), ogp.grid, dim3(64), 0, ctx->stream, ogp.g, k, ogp.nbx, ogp.nby, row_begin, row_end, \
-        (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
-#define FS_KD_C(DM) FS_KD(DM, true)
-#define FS_KD_N(DM) FS_KD(DM, false)
 #define FS_K34DB(DM, CL) hipLaunchKernelGGL((k_cip_grad_advect_n<3, 2, RT, DM, false, CL, T, 2>), ogb.grid, dim3(64), 0, ctx->stream, ogb.g, k, ogb.nbx, ogb.nby, row_begin, row_end, \
         (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, d_out->hot, (const uint8_t *)ctx->d_bcmap, 0)
 #define FS_K34DB_C(DM) FS_K34DB(DM, true)
 #define FS_K34DB_N(DM) FS_K34DB(DM, false)
-#define FS_KDB(DM, CL) hipLaunchKernelGGL((k_cip_dye_bnd<RT, DM, CL>), ogb.grid, dim3(64), 0, ctx->stream, ogb.g, k, ogb.nbx, ogb.nby, row_begin, row_end, \
-        (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
-#define FS_KDB_C(DM) FS_KDB(DM, true)
-#define FS_KDB_N(DM) FS_KDB(DM, false)
             int rc = FS_OK;
             if (ctx->fuse_k2 == 1) rc = launch(ctx, "cip_step_dye_band", [=] { FS_DMA(dm, FS_K12B); });
             if (rc) return rc;
-            rc = launch(ctx, "cip_step_dye", [=] { if (clamp01) FS_DMA(dm, FS_KD_C); else FS_DMA(dm, FS_KD_N); });
+            rc = launch(ctx, "cip_step_dye", [=] { const OvGrid og = ogp; if (clamp01) FS_DMA(dm, FS_KD_C1); else FS_DMA(dm, FS_KD_N1); });
             if (rc) return rc;
-            if (ctx->fuse_k2 == 2) return launch(ctx, "cip_step_dye_bnd", [=] { if (clamp01) FS_DMA(dm, FS_KDB_C); else FS_DMA(dm, FS_KDB_N); });      // (K12 in registers there too)
+            if (ctx->fuse_k2 >= 2) return launch(ctx, "cip_step_dye_bnd", [=] { const OvGrid og = ogb; if (clamp01) FS_DMA(dm, FS_KD_C2); else FS_DMA(dm, FS_KD_N2); });      // (K12 in registers there too)
             return launch(ctx, "cip_step_dye_bnd", [=] { if (clamp01) FS_DMX(dmx, FS_K34DB_C); else FS_DMX(dmx, FS_K34DB_N); });
         }
     }

@@ -635,13 +635,15 @@ def main():
                                                                   "k_cip_step_plain + k_cip_grad_advect_n (boundary tiles) + k_cip_nonadv_n (K2 over their rows)",
                                                        "alg_bytes": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"], "frac": round(kd["GBps"] / HBM_PEAK_GBS, 4),
                                                        "traffic": pmc_traffic.get(dominant), "parts_us": kd.get("parts_us")}})
+        elif dominant == "cip_step":
+            out["roofline"]["kernel"] = "cip_step / k_cip_step_all (K2 + K3 + K4 of the velocity over every tile, one launch)"
         if "unfused_equiv_frac" in kd:
             out["roofline"]["note"] = (
                 "two Jacobi sweeps (and both pressure boundary passes) per launch, the first sweep's rows in registers: `frac` counts what "
                 "ONE pass has to move (p in, source pair in, p out); the reference's 2 x (K7 + sweep) move twice that"
                 if dominant == "jacobi_pair_lazy" else
-                ("K2 + K3 + K4 of the velocity as one logical launch (all-fluid tiles + boundary tiles, csrc/fs_k234.h): `frac` counts the bytes the step has to move through "
-                 "them (mask 1 + 28 read + 24 written = 53 B per fluid cell); the reference's three kernels move 119 B per fluid cell for the same result"
+                ("K2 + K3 + K4 of the velocity as one launch (csrc/fs_k234.h; FS_FUSE_K2=2 / 1: two / three): `frac` counts the bytes the step has to move through "
+                 "it (mask 1 + 28 read + 24 written = 53 B per fluid cell); the reference's three kernels move 119 B per fluid cell for the same result"
                  if dominant == "cip_step" else
                  "fused gradient-update + advection pass: `frac` counts the bytes the fused kernel has to move "
                  "(mask 1 + 32 read + 24 written = 57 B per fluid cell); the reference's two kernels move 98 B per fluid cell for the same result"))

@@ -88,11 +88,14 @@ def test_bench_gpus_2_as_one_command(single):
     assert d["box"]["copy_GBps"] > 100 and d["roofline"]["frac_of_box_copy"] > 0
 
 
-def test_bench_line_contract_with_the_multi_part_step(hip_lib):
-    """One rank, the large-grid launch forms forced onto a small grid: the line prices the dominant KERNEL (fs_cip_step's part over the all-fluid tiles)
-    on its own tiles next to the logical launch, times the graded Jacobi sweep as one event span, and carries the CPU oracle's in-run parity."""
+@pytest.mark.parametrize("mode", ["3", "2"])
+def test_bench_line_contract_with_the_large_grid_step(mode, hip_lib):
+    """One rank, the large-grid launch forms forced onto a small grid: the line prices the dominant kernel - fs_cip_step as ONE launch over every tile
+    (FS_FUSE_K2=3, the default), or (2) its part over the all-fluid tiles on its own tiles next to the logical launch -, times the graded Jacobi sweep as
+    one event span, and carries the CPU oracle's in-run parity."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["FS_RBPAIR_SPLIT"] = "2"
+    env["FS_FUSE_K2"] = mode
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--res", "512", "--bc", "2", "--steps", "12", "--warmup", "4", "--sweeps", "20",
                           "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -101,12 +104,15 @@ def test_bench_line_contract_with_the_multi_part_step(hip_lib):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["unit"] == "steps/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
     rf = d["roofline"]
-    assert "k_cip_step_plain" in rf["kernel"] and rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
-    assert rf["logical_launch"]["parts_us"].keys() == {"plain", "bnd"} and rf["logical_launch"]["avg_us"] > rf["avg_us"]
-    assert "k_cip_step_bnd" in rf["logical_launch"]["kernels"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
     assert rf["traffic"] is None                                      # (PMC numbers belong to the headline workload and to one build of the library)
     cs = d["kernels"]["cip_step"]
-    assert cs["plain_part"]["tiles"] > 0 and cs["plain_part"]["cells"] == cs["plain_part"]["tiles"] * 480
+    if mode == "3":
+        assert "k_cip_step_all" in rf["kernel"] and "parts_us" not in cs and rf["alg_bytes_per_launch"] > 0
+    else:
+        assert "k_cip_step_plain" in rf["kernel"] and "k_cip_step_bnd" in rf["logical_launch"]["kernels"]
+        assert rf["logical_launch"]["parts_us"].keys() == {"plain", "bnd"} and rf["logical_launch"]["avg_us"] > rf["avg_us"]
+        assert cs["plain_part"]["tiles"] > 0 and cs["plain_part"]["cells"] == cs["plain_part"]["tiles"] * 480
     jac = d["poisson_jacobi_sweep"]
     assert jac["timing"].startswith("one HIP-event pair") and jac["per_launch_avg_us"] > 0 and jac["frac"] > 0
     assert d["box"]["valu_pk_ginstr_per_simd"] > 0.8 * d["box"]["valu_ginstr_per_simd"]      # packed f32 issues at (about) the scalar rate

@@ -28,7 +28,8 @@ traffic, by_short = {}, {}
 NAMES = {"k_rbsor_pair": "rbsor_pair", "k_jacobi_quad": "jacobi_quad_lazy", "k_cip_grad_advect_dye": "cip_grad_advect_dye", "k_mac_update_n": "mac_update_kk",
          "k_cip_grad_advect_rt": "cip_grad_advect_rt", "k_cip_advect_quad": "cip_advect", "k_rbsor_iter_n": "rbsor_iteration", "k_cip_nonadv_grad_quad": "cip_nonadv_grad",
          "k_cip_nonadv_n": "cip_nonadv", "k_vort_n": "vort_confine", "k_limit": "limit_field", "k_limit_quad": "limit_field",
-         "k_jacobi_pair": "jacobi_pair_lazy", "k_jacobi_lazy": "jacobi_sweep_lazy"}
+         "k_jacobi_pair": "jacobi_pair_lazy", "k_jacobi_lazy": "jacobi_sweep_lazy",
+         "k_cip_step_all": "cip_step", "k_cip_dye": "cip_step_dye"}      # (late round 5: fs_cip_step / fs_cip_step_dye as ONE launch over every tile)
 print(f"{'kernel':28s} {'calls':>6s} {'avg_us':>9s} {'fetch_MB(x2)':>13s} {'write_MB':>9s} {'L2hit%':>7s} {'HBM GB/s':>9s}")
 for k, (calls, tot) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     avg = tot / calls / 1e3
@@ -87,6 +88,8 @@ for f in glob.glob(os.path.join(out, "pmc_valu", "**", "*counter_collection.csv"
 valu_per_launch = {k: sum(v) / len(v) for k, v in valu.items() if v}
 if all(k in valu_per_launch for k in parts3):
     valu_per_launch["cip_step"] = sum(valu_per_launch[k] for k in parts3)
+elif "k_cip_step_all" in valu_per_launch:
+    valu_per_launch["cip_step"] = valu_per_launch["k_cip_step_all"]
 if all(k in valu_per_launch for k in parts2):
     valu_per_launch["rbsor_pair"] = sum(valu_per_launch[k] for k in parts2)
 # the stamp: these numbers belong to ONE build of the library - bench.py quotes them only when the library it loaded has this hash
