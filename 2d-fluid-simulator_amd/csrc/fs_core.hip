@@ -152,26 +152,12 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                     for (int wx = wx0; wx < wx1 && !any; ++wx)
                         for (int j = j0; j < j1; ++j)
                             if (act[(size_t)wx * Y + j] & 1) { any = true; break; }
-                    if (any && cls && cls != 3) {
+                    if (any && cls) {
                         // plain: no non-fluid cell (bit 1 of the activity byte; halo lanes included) within `reach` rows of the tile - or, for the
                         // boundary list of a launch whose plain part runs on tiles of parent_rt rows, of the parent tile this tile lies in
                         int p0 = j0, p1 = j1;
                         if (parent_rt) { p0 = jb + (j0 - jb) / parent_rt * parent_rt; p1 = std::min(je, p0 + parent_rt); }
                         any = plain_box(wx0, wx1, p0, p1) == (cls == 1);
-                    }
-                    if (cls == 3) {
-                        // a BOUNDARY tile (active, not plain) of the same tiling, or the tile above / below one: the rows the general kernel of a
-                        // two-part launch reads around its own tiles (fs_transport.hip fs_cip_step: K2 where K3 + K4 read its result from memory;
-                        // that launch stores one lane beyond the owner lanes on either side, which is as far as K3 + K4 look sideways).
-                        // One-wave workgroups only (stacked or not: the same tiling).
-                        any = false;
-                        if (wgw == 1)
-                            for (int ty = std::max(0, by - 1); ty <= std::min(nby - 1, by + 1) && !any; ++ty) {
-                                const int t0 = jb + ty * rt, t1 = std::min(je, t0 + rt);
-                                bool act_t = false;
-                                for (int j = t0; j < t1 && !act_t; ++j) act_t = (act[(size_t)bx * Y + j] & 1) != 0;
-                                any = act_t && !plain_box(bx, bx + 1, t0, t1);
-                            }
                     }
                     uint32_t hints = 0u;
                     if (any && !cls && reach > 0 && wgw <= 4) {
@@ -612,7 +598,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
     if (const char *s = getenv("FS_TILE_BALANCE")) c->tile_balance = atoi(s) != 0;
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
-    if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = std::max(0, std::min(3, atoi(s)));
+    if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = std::max(0, std::min(2, atoi(s)));
     if (const char *s = getenv("FS_FUSE_K2_CELLS")) c->fuse_k2_cells = (size_t)atoll(s);
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_SMALL_CELLS")) c->small_cells = (size_t)atoll(s);

@@ -97,8 +97,8 @@ __device__ __forceinline__ void k234_phase2(const Grid &g, const Konst<float> &k
 // one workgroup = 2 waves = the two velocity components of ONE listed tile (compact launch only: Grid::tiles, one entry per tile)
 template <int RT, int DM>
 __global__ __launch_bounds__(128) void k_cip_step_plain(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
-                                                        float *out, float *gxo, float *gyo, const float *fc, const float *pc,
-                                                        const float *gxc, const float *gyc, unsigned *hot)
+                                                        float *out, float *gxo, float *gyo, float *, const float *fc, const float *pc,
+                                                        const float *gxc, const float *gyc, unsigned *hot, unsigned *)      // (the argument list of k_cip_step_bnd / _all)
 {
     constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
     __shared__ v2f xch[2 * (RT + 2)][64];

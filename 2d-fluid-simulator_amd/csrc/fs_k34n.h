@@ -475,9 +475,7 @@ __device__ __forceinline__ v2f nonadv_pk_row(const Konst<float> &k, const LaneMa
 // (The quad form with one row per tile, fs_march.h cip_nonadv_quad_tile, requests 9 16-byte rows per output row: 36 B per cell for 12 B
 // of input; 2 cells x 4 rows: 18 B per cell.)
 // ------------------------------------------------------------------------------------------------
-// WIDE (HL = 2): the lane next to the owner lanes on either side stores too - the launch that feeds the boundary tiles of fs_cip_step
-// (fs_k234.h), whose K3 + K4 look one lane sideways; neighbouring wave columns then store the same values into the same cells.
-template <int N, int RT, int DM, typename T, int HL = 1, bool WIDE = false>
+template <int N, int RT, int DM, typename T, int HL = 1>
 __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *fn, const T *fc, const T *pc, unsigned *hot, int clear3)
 {
     using R = LV<T, N>;
@@ -486,11 +484,7 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_n(Grid g, Konst<T> k, int nb
     int wx, ty;
     bool plain;
     if (!tile_coords_hint<N, HL>(g, nbx, nby, jb, je, RT, wx, ty, plain)) return;
-    LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
-    if (WIDE) {
-        const int lane = threadIdx.x & 63, q = wx * (64 - 2 * HL) - HL + lane;
-        lm.owner = lane >= 1 && lane < 63 && q >= 0 && q < g.X / N;
-    }
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[RT];
     if (plain) {                                    // (the list's hint: all fluid - the window is requested without waiting for the masks)
@@ -924,7 +918,7 @@ __global__ __launch_bounds__(256) void k_poisson_source_n(Grid g, Konst<T> k, in
 // K12  DyeCipMacSolver._non_advection_phase_dye (fs/solver.py:378-383) on lanes of N cells, tiles of RT rows: dn = dc + (lap(dc)/re) dt on
 // not-wall cells, the three channels one after the other.  One halo lane per side.
 // ------------------------------------------------------------------------------------------------
-template <int N, int RT, int DM, typename T, int HL = 1, bool WIDE = false>      // (HL, WIDE: as k_cip_nonadv_n)
+template <int N, int RT, int DM, typename T, int HL = 1>
 __global__ __launch_bounds__(256) void k_cip_nonadv_dye_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *dn, const T *dc)
 {
     using R = LV<T, N>;
@@ -932,11 +926,7 @@ __global__ __launch_bounds__(256) void k_cip_nonadv_dye_n(Grid g, Konst<T> k, in
     int wx, ty;
     bool plain;
     if (!tile_coords_hint<N, HL>(g, nbx, nby, jb, je, RT, wx, ty, plain)) return;
-    LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
-    if (WIDE) {
-        const int lane = threadIdx.x & 63, q = wx * (64 - 2 * HL) - HL + lane;
-        lm.owner = lane >= 1 && lane < 63 && q >= 0 && q < g.X / N;
-    }
+    const LaneMapN<N> lm = lane_map_n<N, HL>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned nw[RT];
     if (plain) {

@@ -275,12 +275,11 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
 
 static bool cip_step_multi_part(const fs_ctx *ctx)
 {
-    // From 1 M cells (late round 5, K2 in registers on every tile in ONE launch - FS_FUSE_K2=3: bc2 res 800 15.8 -> 16.2 k steps/s, with dye 9.2 -> 10.2 k; bc5 res 1024
-    // 13.9 -> 15.0 k; res 1200 10.35 -> 11.0 k; res 1600 6 150 -> 6 410; res 400, on its 2-row tiles, 29.0 -> 27.0 k the other way).  As two launches (2) the
-    // form paid from 2.6 M cells, as three (1: K2 as a kernel over the boundary tiles' rows) from 8 M.
-    const size_t cells = (size_t)ctx->X * ctx->Y, from = ctx->fuse_k2 >= 2 ? ctx->fuse_k2_cells : (size_t)1 << 23;
-    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && cells >= from);
-    return ctx->mask_set && ctx->fuse_k2 != 0 && big && (ctx->halo == 0 || ctx->fuse_k2 >= 2) && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
+    // From 1 M cells (late round 5, K2 in registers on every tile in ONE launch - FS_FUSE_K2=2: bc2 res 800 15.8 -> 16.2 k steps/s, with dye 9.2 -> 10.2 k; bc5 res 1024
+    // 13.9 -> 15.0 k; res 1200 10.35 -> 11.0 k; res 1600 6 150 -> 6 410; res 400, on its 2-row tiles, 29.0 -> 27.0 k the other way).  As two launches (1) the
+    // form paid from 2.6 M cells; with K2 as a third launch over the boundary tiles' rows and the general K3 + K4 kernel there (the round's first form) from 8 M.
+    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ctx->fuse_k2_cells);
+    return ctx->mask_set && ctx->fuse_k2 != 0 && big && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
 }
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
 {
@@ -289,32 +288,29 @@ int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
     return FS_OK;
 }
 
-// diagnostic (bench.py: the algorithmic bytes of each part): how many tiles of tile_rows x tile_cells cells each part of a whole-grid fs_cip_step
-// launch covers - the all-fluid tiles, the boundary tiles, (FS_FUSE_K2=1) the tiles K2 runs over as a kernel of its own (0 0 0: not this form)
+// diagnostic (bench.py: the algorithmic bytes of each part): how many tiles of tile_rows x tile_cells cells the two classes of a whole-grid fs_cip_step
+// launch hold - the all-fluid tiles, the others (`band`: 0 since the form with K2 as a kernel over the boundary tiles' rows is gone; 0 0 0: the two calls)
 int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *tile_rows, int *tile_cells)
 {
     FS_REQUIRE(ctx && plain && boundary && band && tile_rows && tile_cells, "null argument");
     *plain = *boundary = *band = 0; *tile_rows = 4; *tile_cells = 120;
     if (!cip_step_multi_part(ctx) || ctx->capturing || ctx->tape_rec) return FS_OK;
     const OvGrid ogp = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 1, 2, 1);
-    const OvGrid ogb = ov_grid_lanes(ctx, 0, ctx->rows, 4, 2, XCD_ADVECT, 2, true, 2, 2, 1);
-    OvGrid ogk{};
-    if (ctx->fuse_k2 == 1) ogk = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 3, 2, 1);      // (2: K2 in registers on every tile - no such part)
+    const OvGrid ogb = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 2, 2, 1);
     for (const auto &kv : ctx->tile_lists) {
         if (!kv.second.d) continue;
         if (kv.second.d == ogp.g.tiles) *plain = kv.second.count;
         if (kv.second.d == ogb.g.tiles) *boundary = kv.second.count;
-        if (ctx->fuse_k2 == 1 && kv.second.d == ogk.g.tiles) *band = kv.second.count;
     }
     return FS_OK;
 }
 
 // K2 + K3 + K4 of the velocity (fs/solver.py:213-227) as ONE call: fs_cip_nonadv(fn <- fc, pc) followed by fs_cip_grad_advect(v_out, gx_out,
 // gy_out <- fn, fc, gxc, gyc) - with the one difference that the fluid cells of fn that nothing reads before the next kernel rewrites them
-// are NOT stored where the multi-part launch below applies (f32 grids from 2.6 M cells; fs_k234.h): every tile evaluates K2 in registers on the way
-// to K3 + K4 - k_cip_step_plain over the tiles that see nothing but fluid, k_cip_step_bnd (masks; stores K2 on inflow / outflow cells) over the
-// others.  FS_FUSE_K2=1: the form before - K2 as a kernel of its own over the tiles within one tile of a boundary tile, the general K3 + K4 kernel
-// over the boundary tiles.  fs_cip_step_ok: the static conditions (the kernel names of a profile say what ran).
+// are NOT stored where the form below applies (f32 grids from 1 M cells; fs_k234.h): every tile evaluates K2 in registers on the way to K3 + K4 -
+// ONE launch over the list of all tiles, whose entries say which body a tile takes (k_cip_step_all: all fluid within reach / masks, K2 stored
+// on inflow / outflow cells).  FS_FUSE_K2=1: the two bodies as two launches over the two classes (k_cip_step_plain, k_cip_step_bnd: the form
+// of bench.py's per-part roofline).  fs_cip_step_ok: the static conditions (the kernel names of a profile say what ran).
 int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
                 const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end)
 {
@@ -326,59 +322,29 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
     if (ctx->dtype != 0) { set_error("the fused gradient+advection pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
     using T = float;
     constexpr int RT = 4;
-    // (a slab - halo != 0, the two-part form only: any row range; K2 is then evaluated for the rows within 2 of the range from rows within 3 of it, which the
-    //  caller keeps valid - fs/runtime.py cip_step - where the two calls would read what an earlier K2 launch left in fn.  Single GPU: the whole grid.)
+    // (a slab - halo != 0: any row range; K2 is then evaluated for the rows within 2 of the range from rows within 3 of it, which the caller keeps
+    //  valid - fs/runtime.py cip_step - where the two calls would read what an earlier K2 launch left in fn.  Single GPU: the whole grid.)
     const bool slab = ctx->halo != 0;
     if (cip_step_multi_part(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
-        const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 1, 2, 1, 0, slab);      // plain tiles: one entry per tile, two waves each
         auto k = make_konst<T>(ctx, dt, dx, re);
         const int dm = dm_all(ctx, k);
-#define FS_K234(DM) hipLaunchKernelGGL((k_cip_step_plain<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot)
-        if (ctx->fuse_k2 == 3) {
-            // one launch over both kinds of tile (fs_k234.h k_cip_step_all)
-            const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
-            if (oga.g.tiles)
-                return launch(ctx, "cip_step", [=] {
-                    const OvGrid og = oga;
-#define FS_K234A(DM) hipLaunchKernelGGL((k_cip_step_all<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K234(KERNEL, DM) hipLaunchKernelGGL((KERNEL<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
-                    FS_DMA(dm, FS_K234A);
-                });
-        }
+#define FS_K234A(DM) FS_K234(k_cip_step_all, DM)
+#define FS_K234P(DM) FS_K234(k_cip_step_plain, DM)
+#define FS_K234B(DM) FS_K234(k_cip_step_bnd, DM)
         if (ctx->fuse_k2 >= 2) {
-            // two parts: K2 in registers on the boundary tiles as well (fs_k234.h k_cip_step_bnd)
-            const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 2, 2, 1, 0, slab);  // boundary tiles: one entry per tile, two waves each
-            if (ogp.g.tiles && ogb.g.tiles) {
-                int rc = launch(ctx, "cip_step", [=] { const OvGrid og = ogp; FS_DMA(dm, FS_K234); });
-                if (rc) return rc;
-                return launch(ctx, "cip_step_bnd", [=] {
-                    const OvGrid og = ogb;
-#define FS_K234B(DM) hipLaunchKernelGGL((k_cip_step_bnd<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
-                    FS_DMA(dm, FS_K234B);
-                });
-            }
-        } else {
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 2, XCD_ADVECT, 2, true, 2, 2, 1);      // boundary tiles: one wave per tile and component
-        const OvGrid ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);      // K2: the boundary tiles and the tiles above / below them
-        if (ogp.g.tiles && ogb.g.tiles && ogk.g.tiles) {
-            int rc = launch(ctx, "cip_step_band", [=] {
-                const OvGrid og = ogk;
-#define FS_K2B(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, RT, DM, T, 2, true>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, 0)
-                FS_DMA(dm, FS_K2B);
-            });
-            if (rc) return rc;
-            rc = launch(ctx, "cip_step", [=] { const OvGrid og = ogp; FS_DMA(dm, FS_K234); });
-            if (rc) return rc;
-            const int dmx = dm_dx(ctx, k);
-            return launch(ctx, "cip_step_bnd", [=] {
-                const OvGrid og = ogb;
-#define FS_K34B(DM) hipLaunchKernelGGL((k_cip_grad_advect_n<2, 2, RT, DM, false, false, T, 2>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)nullptr, v_out->hot, (const uint8_t *)ctx->d_bcmap, 0)
-                FS_DMX(dmx, FS_K34B);
-            });
+            // one launch over both kinds of tile: the class 0 list, whose entries carry the per-tile "all fluid within reach" hint
+            const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
+            if (oga.g.tiles) return launch(ctx, "cip_step", [=] { const OvGrid og = oga; FS_DMA(dm, FS_K234A); });
         }
+        // two launches: the all-fluid tiles, the others (one entry per tile, two waves each)
+        const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 1, 2, 1, 0, slab);
+        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 2, 2, 1, 0, slab);
+        if (ogp.g.tiles && ogb.g.tiles) {
+            int rc = launch(ctx, "cip_step", [=] { const OvGrid og = ogp; FS_DMA(dm, FS_K234P); });
+            if (rc) return rc;
+            return launch(ctx, "cip_step_bnd", [=] { const OvGrid og = ogb; FS_DMA(dm, FS_K234B); });
         }
     }
     // (a slab: K2 also on the 2 rows either side that K3 + K4 read - the call's contract there, see above)
@@ -403,10 +369,9 @@ int fs_cip_grad_advect_dye(fs_ctx *ctx, double dt, double dx, fs_field *d_out, f
     return launch_k34<3, false>(ctx, "cip_grad_advect_dye", "cip_grad_advect_dye_bnd", dt, dx, d_out, gx_out, gy_out, fn, fc, gxc, gyc, v, full, row_begin, row_end);
 }
 
-// K12 + K3 + K4 of the dye (fs/solver.py:385-401 _update_dye) as ONE call: fs_cip_nonadv_dye(fn <- fc) followed by fs_cip_grad_advect_dye - with the
-// multi-part launch of fs_cip_step where that applies (same conditions, fs_cip_step_ok): K12 in registers (fs_k234.h k_cip_dye_plain over the all-fluid
-// tiles, k_cip_dye_bnd over the others; FS_FUSE_K2=1: K12 as a kernel over the boundary tiles' rows and the general K3 + K4 kernel there).  The fluid
-// cells of fn that nothing reads before the next K12 rewrites them are then not stored.
+// K12 + K3 + K4 of the dye (fs/solver.py:385-401 _update_dye) as ONE call: fs_cip_nonadv_dye(fn <- fc) followed by fs_cip_grad_advect_dye - in the form of
+// fs_cip_step where that applies (same conditions, fs_cip_step_ok): K12 in registers on every tile (fs_k234.h k_cip_dye: one launch over all tiles, or -
+// FS_FUSE_K2=1 - one per class).  The fluid cells of fn that nothing reads before the next K12 rewrites them are then not stored.
 int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
                     const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v, int clamp01, int full, int row_begin, int row_end)
 {
@@ -421,7 +386,7 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
     const bool slab = ctx->halo != 0;      // (as fs_cip_step)
     if (cip_step_multi_part(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
         auto k = make_konst<T>(ctx, dt, dx, re);
-        const int dm = dm_all(ctx, k), dmx = dm_dx(ctx, k);
+        const int dm = dm_all(ctx, k);
         // k_cip_dye<RT, DM, CLAMP, KIND> over a list: KIND 1 - the all-fluid tiles, 2 - the others, 0 - both (class 0 list with the per-tile hint)
 #define FS_KD(DM, CL, KIND) hipLaunchKernelGGL((k_cip_dye<RT, DM, CL, KIND>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
@@ -431,27 +396,16 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
 #define FS_KD_N1(DM) FS_KD(DM, false, 1)
 #define FS_KD_C2(DM) FS_KD(DM, true, 2)
 #define FS_KD_N2(DM) FS_KD(DM, false, 2)
-        if (ctx->fuse_k2 == 3) {
+        if (ctx->fuse_k2 >= 2) {
             const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
             if (oga.g.tiles) return launch(ctx, "cip_step_dye", [=] { const OvGrid og = oga; if (clamp01) FS_DMA(dm, FS_KD_C0); else FS_DMA(dm, FS_KD_N0); });
         }
         const OvGrid ogp = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 1, 2, 1, 0, slab);
         const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 2, 2, 1, 0, slab);
-        OvGrid ogk{};
-        if (ctx->fuse_k2 == 1) ogk = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 3, 2, 1);
-        if (ogp.g.tiles && ogb.g.tiles && (ogk.g.tiles || ctx->fuse_k2 >= 2)) {
-#define FS_K12B(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, RT, DM, T, 2, true>), ogk.grid, dim3(64), 0, ctx->stream, ogk.g, k, ogk.nbx, ogk.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d)
-#define FS_K34DB(DM, CL) hipLaunchKernelGGL((k_cip_grad_advect_n<3, 2, RT, DM, false, CL, T, 2>), ogb.grid, dim3(64), 0, ctx->stream, ogb.g, k, ogb.nbx, ogb.nby, row_begin, row_end, \
-        (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d, d_out->hot, (const uint8_t *)ctx->d_bcmap, 0)
-#define FS_K34DB_C(DM) FS_K34DB(DM, true)
-#define FS_K34DB_N(DM) FS_K34DB(DM, false)
-            int rc = FS_OK;
-            if (ctx->fuse_k2 == 1) rc = launch(ctx, "cip_step_dye_band", [=] { FS_DMA(dm, FS_K12B); });
+        if (ogp.g.tiles && ogb.g.tiles) {
+            int rc = launch(ctx, "cip_step_dye", [=] { const OvGrid og = ogp; if (clamp01) FS_DMA(dm, FS_KD_C1); else FS_DMA(dm, FS_KD_N1); });
             if (rc) return rc;
-            rc = launch(ctx, "cip_step_dye", [=] { const OvGrid og = ogp; if (clamp01) FS_DMA(dm, FS_KD_C1); else FS_DMA(dm, FS_KD_N1); });
-            if (rc) return rc;
-            if (ctx->fuse_k2 >= 2) return launch(ctx, "cip_step_dye_bnd", [=] { const OvGrid og = ogb; if (clamp01) FS_DMA(dm, FS_KD_C2); else FS_DMA(dm, FS_KD_N2); });      // (K12 in registers there too)
-            return launch(ctx, "cip_step_dye_bnd", [=] { if (clamp01) FS_DMX(dmx, FS_K34DB_C); else FS_DMX(dmx, FS_K34DB_N); });
+            return launch(ctx, "cip_step_dye_bnd", [=] { const OvGrid og = ogb; if (clamp01) FS_DMA(dm, FS_KD_C2); else FS_DMA(dm, FS_KD_N2); });
         }
     }
     int rc = fs_cip_nonadv_dye(ctx, dt, dx, re, fn, fc, slab ? std::max(row_begin - 2, 0) : row_begin, slab ? std::min(row_end + 2, ctx->rows) : row_end);

@@ -128,7 +128,7 @@ class CipMacSolver(Solver):
                                  and os.environ.get("FS_MARCH", "1") != "0")      # (f64: 256 VGPRs per tile - the two-kernel form)
         self._v_spare = self._dev.alloc(2) if self._fused_transport else None
         # ... and K2 in the same call (fs_cip_step; FS_FUSE_K2=0 / fused_k2=False: K2 as its own launch everywhere)
-        self._fused_k2 = self._fused_transport and (os.environ.get("FS_FUSE_K2", "3") != "0" if fused_k2 is None else bool(fused_k2)) and hasattr(self._dev, "cip_step")
+        self._fused_k2 = self._fused_transport and (os.environ.get("FS_FUSE_K2", "2") != "0" if fused_k2 is None else bool(fused_k2)) and hasattr(self._dev, "cip_step")
 
     def _flow_step(self):
         self._bc.set_velocity_boundary_condition(self.v.current)

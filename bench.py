@@ -625,14 +625,13 @@ def main():
                            "alg_bytes_per_launch": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"]}
         if dominant == "cip_step" and "plain_part" in kd:
             # the dominant KERNEL of the step is the part of fs_cip_step over the all-fluid tiles: its own bytes over its own duration; the logical
-            # launch (+ the kernel over the boundary tiles; FS_FUSE_K2=1: + K2 over their rows) stays next to it
+            # launch (+ the kernel over the other tiles) stays next to it (FS_FUSE_K2=1: the two-launch form)
             pp = kd["plain_part"]
             out["roofline"].update({"kernel": "cip_step / k_cip_step_plain (K2 + K3 + K4 over the all-fluid tiles)", "achieved": pp["GBps"], "frac": pp["frac"],
                                     "frac_of_box_copy": round(pp["GBps"] / box["copy_GBps"], 4) if box else None,
                                     "traffic": (pmc_traffic.get("cip_step_parts") or {}).get("k_cip_step_plain"),
                                     "alg_bytes_per_launch": int(pp["alg_MB"] * 1e6), "avg_us": pp["avg_us"],
-                                    "logical_launch": {"kernels": "k_cip_step_plain + k_cip_step_bnd (boundary tiles)" if pp.get("stand_alone_K2_tiles", 0) == 0 else
-                                                                  "k_cip_step_plain + k_cip_grad_advect_n (boundary tiles) + k_cip_nonadv_n (K2 over their rows)",
+                                    "logical_launch": {"kernels": "k_cip_step_plain + k_cip_step_bnd (the other tiles)",
                                                        "alg_bytes": int(abytes[dominant] * frac_rows), "avg_us": kd["avg_us"], "frac": round(kd["GBps"] / HBM_PEAK_GBS, 4),
                                                        "traffic": pmc_traffic.get(dominant), "parts_us": kd.get("parts_us")}})
         elif dominant == "cip_step":
@@ -642,7 +641,7 @@ def main():
                 "two Jacobi sweeps (and both pressure boundary passes) per launch, the first sweep's rows in registers: `frac` counts what "
                 "ONE pass has to move (p in, source pair in, p out); the reference's 2 x (K7 + sweep) move twice that"
                 if dominant == "jacobi_pair_lazy" else
-                ("K2 + K3 + K4 of the velocity as one launch (csrc/fs_k234.h; FS_FUSE_K2=2 / 1: two / three): `frac` counts the bytes the step has to move through "
+                ("K2 + K3 + K4 of the velocity as one launch (csrc/fs_k234.h; FS_FUSE_K2=1: one launch per kind of tile): `frac` counts the bytes the step has to move through "
                  "it (mask 1 + 28 read + 24 written = 53 B per fluid cell); the reference's three kernels move 119 B per fluid cell for the same result"
                  if dominant == "cip_step" else
                  "fused gradient-update + advection pass: `frac` counts the bytes the fused kernel has to move "

@@ -88,10 +88,10 @@ def test_bench_gpus_2_as_one_command(single):
     assert d["box"]["copy_GBps"] > 100 and d["roofline"]["frac_of_box_copy"] > 0
 
 
-@pytest.mark.parametrize("mode", ["3", "2"])
+@pytest.mark.parametrize("mode", ["2", "1"])
 def test_bench_line_contract_with_the_large_grid_step(mode, hip_lib):
     """One rank, the large-grid launch forms forced onto a small grid: the line prices the dominant kernel - fs_cip_step as ONE launch over every tile
-    (FS_FUSE_K2=3, the default), or (2) its part over the all-fluid tiles on its own tiles next to the logical launch -, times the graded Jacobi sweep as
+    (FS_FUSE_K2=2, the default), or (1) its part over the all-fluid tiles on its own tiles next to the logical launch -, times the graded Jacobi sweep as
     one event span, and carries the CPU oracle's in-run parity."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["FS_RBPAIR_SPLIT"] = "2"
@@ -107,7 +107,7 @@ def test_bench_line_contract_with_the_large_grid_step(mode, hip_lib):
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
     assert rf["traffic"] is None                                      # (PMC numbers belong to the headline workload and to one build of the library)
     cs = d["kernels"]["cip_step"]
-    if mode == "3":
+    if mode == "2":
         assert "k_cip_step_all" in rf["kernel"] and "parts_us" not in cs and rf["alg_bytes_per_launch"] > 0
     else:
         assert "k_cip_step_plain" in rf["kernel"] and "k_cip_step_bnd" in rf["logical_launch"]["kernels"]

@@ -53,9 +53,8 @@ def _build(case):
     return const, mask, res, case[-1]
 
 
-# FS_FUSE_K2: 3 (default) - K2 in registers on every tile, ONE launch over both kinds of tile; 2 - two launches; 1 - K2 as a kernel over the boundary
-# tiles' rows, three launches
-@pytest.mark.parametrize("mode", [3, 2, 1])
+# FS_FUSE_K2: 2 (default) - K2 in registers on every tile, ONE launch over both kinds of tile; 1 - one launch per kind
+@pytest.mark.parametrize("mode", [2, 1])
 @pytest.mark.parametrize("case", CASES)
 def test_one_call_equals_the_two_calls(case, mode, hip_lib, monkeypatch):
     import fs
@@ -89,7 +88,7 @@ def test_one_call_equals_the_two_calls(case, mode, hip_lib, monkeypatch):
             kernels = set(dev.profile_report())
             dev.profile(False)
             if form == "one":
-                assert "cip_step" in kernels and ("cip_step_bnd" in kernels) == (mode != 3) and ("cip_step_band" in kernels) == (mode == 1), kernels
+                assert "cip_step" in kernels and ("cip_step_bnd" in kernels) == (mode == 1) and "cip_step_band" not in kernels, kernels
             res_[form] = {n: f.to_numpy() for n, f in zip(names, (out, gxo, gyo, fn))}
         for n in ("out", "gxo", "gyo"):
             assert np.array_equal(res_["one"][n], res_["two"][n], equal_nan=True), n
@@ -104,8 +103,8 @@ def test_one_call_equals_the_two_calls(case, mode, hip_lib, monkeypatch):
         dev.close()
 
 
-@pytest.mark.parametrize("bc,res,vc,steps,mode", [(2, 512, 5.0, 8, 3), (2, 512, None, 8, 3), (1, 400, 5.0, 8, 3), (5, 512, 5.0, 6, 3), (3, 512, None, 6, 3), (4, 512, 5.0, 6, 3),
-                                                  (2, 512, 5.0, 8, 2), (1, 400, 5.0, 8, 2), (5, 512, 5.0, 6, 2), (3, 512, None, 6, 2), (5, 512, 5.0, 6, 1), (2, 512, None, 6, 1)])
+@pytest.mark.parametrize("bc,res,vc,steps,mode", [(2, 512, 5.0, 8, 2), (2, 512, None, 8, 2), (1, 400, 5.0, 8, 2), (5, 512, 5.0, 6, 2), (3, 512, None, 6, 2), (4, 512, 5.0, 6, 2),
+                                                  (2, 512, 5.0, 8, 1), (1, 400, 5.0, 8, 1), (5, 512, 5.0, 6, 1), (3, 512, None, 6, 1)])
 def test_trajectory_against_the_oracle(bc, res, vc, steps, mode, hip_lib, monkeypatch):
     import fs
     from oracle import oracle as O
@@ -163,7 +162,7 @@ def test_hipgraph_replay_of_the_three_part_step(hip_lib, monkeypatch):
         b._solver._bc.device.close()
 
 
-@pytest.mark.parametrize("bc,res,steps,mode", [(2, 512, 6, 3), (5, 512, 5, 3), (1, 400, 6, 3), (3, 512, 5, 3), (4, 512, 5, 3), (2, 512, 6, 2), (5, 512, 5, 2), (1, 400, 6, 2), (5, 512, 5, 1)])
+@pytest.mark.parametrize("bc,res,steps,mode", [(2, 512, 6, 2), (5, 512, 5, 2), (1, 400, 6, 2), (3, 512, 5, 2), (4, 512, 5, 2), (2, 512, 6, 1), (5, 512, 5, 1), (1, 400, 6, 1)])
 def test_dye_trajectory_against_the_oracle(bc, res, steps, mode, hip_lib, monkeypatch):
     """fs_cip_step_dye: K12 in registers on the all-fluid tiles of the dye's step (k_cip_dye_plain), one wave per tile and channel."""
     import fs
@@ -183,7 +182,7 @@ def test_dye_trajectory_against_the_oracle(bc, res, steps, mode, hip_lib, monkey
             sim.step()
             ref.update()
         rep = dev.profile_report()
-        assert "cip_step_dye" in rep and ("cip_step_dye_bnd" in rep) == (mode != 3) and "cip_nonadv_dye" not in rep and ("cip_step_dye_band" in rep) == (mode == 1), sorted(rep)
+        assert "cip_step_dye" in rep and ("cip_step_dye_bnd" in rep) == (mode == 1) and "cip_nonadv_dye" not in rep and "cip_step_dye_band" not in rep, sorted(rep)
         out = sim.field_to_numpy()
         for k, e in ref.fields().items():
             assert np.array_equal(out[k], e), k

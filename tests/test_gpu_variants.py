@@ -60,13 +60,13 @@ def test_jacobi_tile_variants(variant, hip_lib, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"FS_SMALL_CELLS": "0"}, {"FS_TILE_LIST": "0"},
                                  {"FS_RBPAIR_SPLIT": "2"}, {"FS_RBPAIR_SPLIT": "2", "FS_SMALL_CELLS": "0"}, {"FS_RBPAIR_SPLIT": "2", "FS_RBPAIR_PLAIN_RT": "4"},
-                                 {"FS_RBPAIR_SPLIT": "2", "FS_RBPAIR_PLAIN_RT": "8"}, {"FS_RBPAIR_SPLIT": "2", "FS_FUSE_K2": "0"}],
+                                 {"FS_RBPAIR_SPLIT": "2", "FS_RBPAIR_PLAIN_RT": "8"}, {"FS_RBPAIR_SPLIT": "2", "FS_FUSE_K2": "0"}, {"FS_RBPAIR_SPLIT": "2", "FS_FUSE_K2": "1"}],
                          ids=lambda e: "-".join(f"{k[3:]}{v}" for k, v in e.items()))
 def test_round4_tile_height_and_list_variants(env, hip_lib, monkeypatch):
     """Tile heights by grid size (this grid, 0.54 M cells, takes the small-grid heights by default), the per-wave plain hints of the launch
     lists (FS_TILE_LIST=0: dense launches without them), the two- and three-part launches forced onto a small grid - the pair pass's plain part
-    as two stacked waves per 16-row tile (default), on mirrored 8-row tiles, on 4-row tiles; fs_cip_step with K2 in registers (default) and
-    as its own launch: the same bits as the one-cell-per-lane kernels."""
+    as two stacked waves per 16-row tile (default), on mirrored 8-row tiles, on 4-row tiles; fs_cip_step with K2 in registers (one launch: default;
+    one launch per kind of tile) and as its own launch: the same bits as the one-cell-per-lane kernels."""
     ref = _run(monkeypatch, {"FS_MARCH": "0"}, "step")
     got = _run(monkeypatch, env, "step")
     for k in ref:

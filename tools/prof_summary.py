@@ -64,9 +64,8 @@ for form, key in (("V", "jacobi_sweep"), ("SRC", "jacobi_sweep_src")):
     wr = [v for n, fo, v in rows if n == "WRITE_SIZE" and fo == form]
     if fe and wr:
         traffic[key] = int((2 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024)
-# fs_cip_step = two kernels per logical launch (csrc/fs_k234.h): the all-fluid tiles, the boundary tiles (FS_FUSE_K2=1, the form before: three -
-# the general K3 + K4 kernel over the boundary tiles behind K2 over their rows)
-parts3 = ("k_cip_step_plain", "k_cip_step_bnd") if "k_cip_step_bnd" in by_short else ("k_cip_step_plain", "k_cip_grad_advect_rt", "k_cip_nonadv_n")
+# fs_cip_step: ONE kernel (k_cip_step_all); FS_FUSE_K2=1: two kernels per logical launch (csrc/fs_k234.h: the all-fluid tiles, the others)
+parts3 = ("k_cip_step_plain", "k_cip_step_bnd")
 if all(k in by_short for k in parts3):
     traffic["cip_step"] = sum(by_short[k] for k in parts3)
     traffic["cip_step_parts"] = {k: by_short[k] for k in parts3}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Historical: FS_FUSE_K2 numbering of the time - 1 = the three-part form, since removed; 2 = two launches, today's 1.)
 # Run ON THE GPU BOX: parity of fs_cip_step with K2 in registers on the boundary tiles too (FS_FUSE_K2=2), then A/B against the three-part form
 set -u
 mkdir -p gpurun_out

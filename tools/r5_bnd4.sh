@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Historical: FS_FUSE_K2 numbering of the time - 2 = two launches (today's 1), 3 = one launch (today's 2, the default).)
 # Run ON THE GPU BOX: the dye's step as two launches (FS_FUSE_K2=2) against one launch over both kinds of tile (3); parity of all three forms first
 set -u
 mkdir -p gpurun_out
