@@ -16,9 +16,9 @@
 // Same expression trees, same operation order, one rounding per operation: the bits of the three-kernel sequence (tests compare at
 // tolerance 0).  What is NOT the same is the content of the intermediate buffer: the post-K2 velocity of these tiles never reaches HBM.
 // Nothing reads it there - the reference's own sequence overwrites every fluid cell of that buffer (K2 of the next step, or the vorticity
-// confinement of this one) before anything looks at it.  The tiles that are NOT all fluid take the same route with the masks
-// (k_cip_step_bnd below; the host launches the two kernels over the two classes of its tile lists, fs_transport.hip fs_cip_step).  Until late
-// in round 5 they ran the general K3 + K4 kernel of fs_k34n.h behind a K2 launch over their rows (FS_FUSE_K2=1: that three-part form).
+// confinement of this one) before anything looks at it.  The tiles that are NOT all fluid take the same route with the masks (k234_bnd_phase1 / 2
+// below), and ONE launch covers both kinds (k_cip_step_all: the list entry's hint picks the body; fs_transport.hip fs_cip_step).  Until late in
+// round 5 the other tiles ran the general K3 + K4 kernel of fs_k34n.h behind a K2 launch over their rows.
 // Plain tile: every cell within 2 rows and within the halo lanes is fluid and inside the domain (fs_core.hip tile_list) - K2's own reads
 // one cell further out take whatever the buffers hold there, as the reference's K2 does.
 #pragma once
@@ -264,8 +264,7 @@ __global__ __launch_bounds__(128, 4) void k_cip_step_all(Grid g, Konst<float> k,
 
 // ---- the dye: K12 + K3 + K4 (fs/solver.py:385-401 _update_dye) over the all-fluid tiles -----------------------------------------------
 // K12 (_non_advection_phase_dye :378-383: dn = dc + (lap(dc) / re) dt, no pressure term) of one channel needs nothing from the others, and
-// the advecting velocity is the finished flow step's - read from memory: one wave per tile and channel, no exchange.  The launch of
-// fs_cip_step_dye is the velocity's (fs_transport.hip): this kernel over the all-fluid tiles, k_cip_dye_bnd over the others.
+// the advecting velocity is the finished flow step's - read from memory: one wave per tile and channel, no exchange (k_cip_dye below).
 // K12 for one row of one channel on packed operands: dn = dc + (lap(dc) / re) dt
 template <int DM>
 __device__ __forceinline__ v2f nonadv_dye_pk_row(const Konst<float> &k, const LaneMapN<2> &lm, v2f fm, v2f f1, v2f fp)

@@ -140,20 +140,20 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
                        int full, int row_begin, int row_end);
 /* CipMacSolver._update_velocities (fs/solver.py:213-227) as ONE call: _non_advection_phase (:229-240; fn <- fc, pc on the not-wall cells)
  * followed by the fused pass above.  Same results in v_out / gx_out / gy_out and in every cell of fn that anything reads before it is
- * rewritten.  On f32 grids of 2.6 M cells and more the post-K2 velocity is evaluated in registers on the way (csrc/fs_k234.h: one launch over
- * the tiles that see nothing but fluid, one over the others) and stored only on the not-wall cells that are not fluid (inflow / outflow):
- * the fluid cells of fn keep their old content - which the reference's own sequence overwrites (K2 of the next step, or this step's
- * vorticity confinement) before reading it.  fs_cip_step_ok: whether calls take that form (f32, FS_FUSE_K2 != 0, the size; one GPU: calls over
- * the whole grid; a slab context: any row range - K2 is then evaluated for the rows within 2 of the range from rows within 3 of it, which the
- * caller keeps valid, where the two calls would read what an earlier K2 launch left in fn); otherwise the call is exactly fs_cip_nonadv +
- * fs_cip_grad_advect (on a slab: fs_cip_nonadv over the range widened by 2 rows).                                                    */
+ * rewritten.  On f32 grids of 1 M cells and more the post-K2 velocity is evaluated in registers on the way (csrc/fs_k234.h: one launch over every
+ * tile - FS_FUSE_K2=1: one over the tiles that see nothing but fluid, one over the others) and stored only on the not-wall cells that are not
+ * fluid (inflow / outflow): the fluid cells of fn keep their old content - which the reference's own sequence overwrites (K2 of the next step,
+ * or this step's vorticity confinement) before reading it.  fs_cip_step_ok: whether calls take that form (f32, FS_FUSE_K2 != 0, the size; one GPU:
+ * calls over the whole grid; a slab context: any row range - K2 is then evaluated for the rows within 2 of the range from rows within 3 of it,
+ * which the caller keeps valid, where the two calls would read what an earlier K2 launch left in fn); otherwise the call is exactly
+ * fs_cip_nonadv + fs_cip_grad_advect (on a slab: fs_cip_nonadv over the range widened by 2 rows).                                    */
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok);
 /* The same for the dye: DyeCipMacSolver._update_dye (fs/solver.py:385-401) as ONE call = fs_cip_nonadv_dye(fn <- fc) + fs_cip_grad_advect_dye, with
- * K12 evaluated in registers under the conditions of fs_cip_step_ok (csrc/fs_k234.h k_cip_dye_plain / k_cip_dye_bnd). */
+ * K12 evaluated in registers under the conditions of fs_cip_step_ok (csrc/fs_k234.h k_cip_dye). */
 int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
                     const fs_field *fc, const fs_field *gxc, const fs_field *gyc, const fs_field *v, int clamp01, int full, int row_begin, int row_end);
-/* diagnostic: the tiles (tile_rows x tile_cells cells each) of the parts of a whole-grid fs_cip_step launch - all-fluid tiles, boundary
- * tiles, and (FS_FUSE_K2=1, the three-part form) the tiles K2 runs over as a kernel of its own; 0 0 0 where the call takes the two-call form. */
+/* diagnostic: the tiles (tile_rows x tile_cells cells each) of the two classes of a whole-grid fs_cip_step launch - all-fluid tiles, the others
+ * (`band`: always 0 since ABI 8's three-part form is gone); 0 0 0 where the call takes the two-call form. */
 int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *tile_rows, int *tile_cells);
 int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, fs_field *gx_out, fs_field *gy_out, fs_field *fn,
                 const fs_field *fc, const fs_field *pc, const fs_field *gxc, const fs_field *gyc, int full, int row_begin, int row_end);
