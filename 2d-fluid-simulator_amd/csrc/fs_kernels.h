@@ -175,26 +175,28 @@ __device__ __forceinline__ void cip_point(const Konst<S> &k, V vx, V vy, V dxx, 
     const V tmp1 = ((f00 - f0m) - fm0) + fmm;
     const V tmp2 = fm0 - f00;
     const V tmp3 = f0m - f00;
-    const V na = (is * (fxm0 + fx00)) * k.dx - (S)2.0 * (-tmp2), nb = (js * (fy0m + fy00)) * k.dx - (S)2.0 * (-tmp3);
-    const V nc = (-tmp1) - (is * (fx0m - fx00)) * k.dx, nd = (-tmp1) - (js * (fym0 - fy00)) * k.dx;
     V a, b, cc, d, gq;
-    if constexpr ((DM & DM_F64) != 0 && (DM & DM_P2) == 0) {
+    // (power-of-two dx: x * (+-1/d) is exact either way and the per-lane signed reciprocals are three register pairs - measured: no difference)
+    constexpr bool SIGN_AFTER = (DM & DM_F64) != 0 && (DM & DM_P2) == 0;
+    if constexpr (SIGN_AFTER) {
         // x / (+-d) through the f64 multiplication by the UNSIGNED reciprocal (a scalar register pair instead of a per-lane double per divisor: 12
         // VGPRs of the packed bodies) and the sign put on afterwards: (float)((double)x * -r) == -(float)((double)x * r), rounding is symmetric
-        const V qa = xdiv<DM>(na, k.dx3_fold, k.inv_dx3_fold, k.r_dx3_fold), qb = xdiv<DM>(nb, k.dx3_fold, k.inv_dx3_fold, k.r_dx3_fold);
-        const V qc = xdiv<DM>(nc, k.dx3_fold, k.inv_dx3_fold, k.r_dx3_fold), qd = xdiv<DM>(nd, k.dx3_fold, k.inv_dx3_fold, k.r_dx3_fold);
+        const V qa = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (S)2.0 * (-tmp2), k.dx3_fold, k.inv_dx3_fold, k.r_dx3_fold);
+        const V qb = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (S)2.0 * (-tmp3), k.dx3_fold, k.inv_dx3_fold, k.r_dx3_fold);
+        const V qc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, k.dx3_fold, k.inv_dx3_fold, k.r_dx3_fold);
+        const V qd = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, k.dx3_fold, k.inv_dx3_fold, k.r_dx3_fold);
         a = sel_neg(vx, -qa, qa); b = sel_neg(vy, -qb, qb); cc = sel_neg(vy, -qc, qc); d = sel_neg(vx, -qd, qd);
         const V qg = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, k.dx, k.inv_dx, k.r_dx);
         gq = sel_neg(vx, -qg, qg);
     } else {
-        a = xdiv<DM>(na, i_s_denom, i_s_inv, i_s_r);
-        b = xdiv<DM>(nb, j_s_denom, j_s_inv, j_s_r);
-        cc = xdiv<DM>(nc, j_s_denom, j_s_inv, j_s_r);
-        d = xdiv<DM>(nd, i_s_denom, i_s_inv, i_s_r);
-        gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, is_dx_r);
+        a = xdiv<DM>((is * (fxm0 + fx00)) * k.dx - (S)2.0 * (-tmp2), i_s_denom, i_s_inv, i_s_r);
+        b = xdiv<DM>((js * (fy0m + fy00)) * k.dx - (S)2.0 * (-tmp3), j_s_denom, j_s_inv, j_s_r);
+        cc = xdiv<DM>((-tmp1) - (is * (fx0m - fx00)) * k.dx, j_s_denom, j_s_inv, j_s_r);
+        d = xdiv<DM>((-tmp1) - (js * (fym0 - fy00)) * k.dx, i_s_denom, i_s_inv, i_s_r);
     }
     const V e = xdiv<DM>((S)3.0 * tmp2 + (is * (fxm0 + (S)2.0 * fx00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold);
     const V f = xdiv<DM>((S)3.0 * tmp3 + (js * (fy0m + (S)2.0 * fy00)) * k.dx, k.dx2_fold, k.inv_dx2_fold, k.r_dx2_fold);
+    if constexpr (!SIGN_AFTER) gq = xdiv<DM>((-(fym0 - fy00)) + cc * k.dx2_fold, is_dx, is_dx_inv, is_dx_r);
     out_f = (((((a * Xd + cc * Yd) + e) * Xd + gq * Yd) + fx00) * Xd + (((b * Yd + d * Xd) + f) * Yd + fy00) * Yd) + f00;
     const V Fx = ((((S)3.0 * a) * Xd + ((S)2.0 * cc) * Yd) + (S)2.0 * e) * Xd + (d * Yd + gq) * Yd + fx00;
     const V Fy = ((((S)3.0 * b) * Yd + ((S)2.0 * d) * Xd) + (S)2.0 * f) * Yd + (cc * Xd + gq) * Xd + fy00;
