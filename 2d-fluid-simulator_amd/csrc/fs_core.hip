@@ -599,7 +599,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (const char *s = getenv("FS_TILE_BALANCE")) c->tile_balance = atoi(s) != 0;
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = std::max(0, std::min(2, atoi(s)));
-    if (const char *s = getenv("FS_FUSE_K2_CELLS")) c->fuse_k2_cells = c->fuse_k2_cells_vel = (size_t)atoll(s);
+    if (const char *s = getenv("FS_FUSE_K2_CELLS")) c->fuse_k2_cells = (size_t)atoll(s);
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_SMALL_CELLS")) c->small_cells = (size_t)atoll(s);
     if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8 || v == 16) c->rbpair_plain_rt = v; }

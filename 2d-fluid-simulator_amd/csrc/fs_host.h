@@ -117,8 +117,7 @@ struct fs_ctx {
     bool use_pairs = true;     // lanes of 2 cells: even widths (every `res`); use_march: the quad kernels, X % 4 == 0
     bool use_f64div = true;    // env FS_F64DIV=0: IEEE division for the loop-invariant divisors of f32 runs (A/B; the results are the same)
     bool tile_balance = true;  // env FS_TILE_BALANCE=0: compact launch lists as the geometry deals them to the XCDs (A/B; fs_core.hip tile_list)
-    size_t fuse_k2_cells = (size_t)1 << 20;      // from how many cells fs_cip_step_dye / fs_cip_step evaluate K12 / K2 in registers (fs_transport.hip cip_step_multi_part;
-    size_t fuse_k2_cells_vel = 0;                // env FS_FUSE_K2_CELLS sets both): the velocity's form has 2-row tiles for small grids, the dye's not
+    size_t fuse_k2_cells = 0;  // env FS_FUSE_K2_CELLS: from how many cells fs_cip_step / fs_cip_step_dye evaluate K2 / K12 in registers (wherever launch lists exist)
     int fuse_k2 = 2;           // env FS_FUSE_K2: 0 - fs_cip_step as its two calls, K2 then the fused K3 + K4 pass; 1 - K2 in registers on every tile, two launches
                                // (all-fluid tiles, the others); 2 - the same in ONE launch over both kinds of tile.  Same observable results.
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)

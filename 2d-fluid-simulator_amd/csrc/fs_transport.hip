@@ -273,13 +273,13 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
     return launch_k34<2, false>(ctx, "cip_grad_advect_rt", "cip_grad_advect_rt_bnd", dt, dx, v_out, gx_out, gy_out, fn, fc, gxc, gyc, nullptr, full, row_begin, row_end);
 }
 
-static bool cip_step_multi_part(const fs_ctx *ctx, bool dye = false)
+static bool cip_step_multi_part(const fs_ctx *ctx)
 {
-    // The velocity: wherever the launch lists exist (late round 5, K2 in registers on every tile in ONE launch - 2-row tiles below FS_SMALL_CELLS: bc2 res 400 28.6 ->
-    // 29.4 k steps/s, bc5 res 512 27.2 -> 29.0 k, bc2 res 800 16.1 -> 17.1 k; 4-row tiles: bc5 res 1024 13.9 -> 14.9 k, res 1200 10.35 -> 11.0 k, res 1600 6 150 ->
-    // 6 700).  The dye (4-row tiles only): from 1 M cells (res 800 9.2 -> 10.2 k; res 400 17.7 -> 17.6 k).  As two launches the form paid from 2.6 M cells; with K2 as
-    // a third launch over the boundary tiles' rows and the general K3 + K4 kernel there (the round's first form) from 8 M.
-    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= (dye ? ctx->fuse_k2_cells : ctx->fuse_k2_cells_vel));
+    // Wherever the launch lists exist (late round 5, K2 / K12 in registers on every tile in ONE launch - 2-row tiles below FS_SMALL_CELLS: bc2 res 400 28.6 -> 29.4 k
+    // steps/s, with dye 18.0 -> 19.2 k; bc5 res 512 27.2 -> 29.0 k, with dye 16.6 -> 18.1 k; bc2 res 800 16.1 -> 17.1 k; 4-row tiles: bc5 res 1024 13.9 -> 14.9 k, res
+    // 1200 10.35 -> 11.0 k, res 1600 6 150 -> 6 700).  As two launches the form paid from 2.6 M cells; with K2 as a third launch over the boundary tiles' rows and
+    // the general K3 + K4 kernel there (the round's first form) from 8 M.
+    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ctx->fuse_k2_cells);
     return ctx->mask_set && ctx->fuse_k2 != 0 && big && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
 }
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
@@ -392,7 +392,7 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
     using T = float;
     constexpr int RT = 4;
     const bool slab = ctx->halo != 0;      // (as fs_cip_step)
-    if (cip_step_multi_part(ctx, true) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
+    if (cip_step_multi_part(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
         auto k = make_konst<T>(ctx, dt, dx, re);
         const int dm = dm_all(ctx, k);
         // k_cip_dye<RT, DM, CLAMP, KIND> over a list: KIND 1 - the all-fluid tiles, 2 - the others, 0 - both (class 0 list with the per-tile hint)
@@ -405,6 +405,14 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
 #define FS_KD_C2(DM) FS_KD(DM, true, 2)
 #define FS_KD_N2(DM) FS_KD(DM, false, 2)
         if (ctx->fuse_k2 >= 2) {
+            if (small_tiles(ctx)) {      // (2-row tiles, as fs_cip_step)
+                const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, 2, 3, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
+#define FS_KD2(DM, CL) hipLaunchKernelGGL((k_cip_dye<2, DM, CL, 0>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+        (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
+#define FS_KD2_C(DM) FS_KD2(DM, true)
+#define FS_KD2_N(DM) FS_KD2(DM, false)
+                if (oga.g.tiles) return launch(ctx, "cip_step_dye", [=] { const OvGrid og = oga; if (clamp01) FS_DMA(dm, FS_KD2_C); else FS_DMA(dm, FS_KD2_N); });
+            }
             const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, RT, 3, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
             if (oga.g.tiles) return launch(ctx, "cip_step_dye", [=] { const OvGrid og = oga; if (clamp01) FS_DMA(dm, FS_KD_C0); else FS_DMA(dm, FS_KD_N0); });
         }

@@ -140,7 +140,7 @@ int fs_cip_grad_advect(fs_ctx *ctx, double dt, double dx, fs_field *v_out, fs_fi
                        int full, int row_begin, int row_end);
 /* CipMacSolver._update_velocities (fs/solver.py:213-227) as ONE call: _non_advection_phase (:229-240; fn <- fc, pc on the not-wall cells)
  * followed by the fused pass above.  Same results in v_out / gx_out / gy_out and in every cell of fn that anything reads before it is
- * rewritten.  On f32 grids of 1 M cells and more the post-K2 velocity is evaluated in registers on the way (csrc/fs_k234.h: one launch over every
+ * rewritten.  On f32 grids of even width (wherever the compact launch lists exist) the post-K2 velocity is evaluated in registers on the way (csrc/fs_k234.h: one launch over every
  * tile - FS_FUSE_K2=1: one over the tiles that see nothing but fluid, one over the others) and stored only on the not-wall cells that are not
  * fluid (inflow / outflow): the fluid cells of fn keep their old content - which the reference's own sequence overwrites (K2 of the next step,
  * or this step's vorticity confinement) before reading it.  fs_cip_step_ok: whether calls take that form (f32, FS_FUSE_K2 != 0, the size; one GPU:
