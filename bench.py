@@ -122,6 +122,44 @@ def merge_parts(rep, parts=None):
     return rep
 
 
+def cip_step_by_kind(args, res, dt, dx, re, vc, esize, box, steps=12):
+    """fs_cip_step as one launch per kind of tile (FS_FUSE_K2=1: k_cip_step_plain over the tiles that see nothing but fluid, k_cip_step_bnd over the
+    others) on a second context of the same scene: per-launch HIP-event brackets of `steps` eager steps."""
+    import fs
+    saved = os.environ.get("FS_FUSE_K2")
+    os.environ["FS_FUSE_K2"] = "1"
+    sim2 = None
+    try:
+        sim2 = fs.FluidSimulator.create(args.bc, res, dt, dx, re, vc, args.scheme, pressure_updater=("jacobi", args.jacobi) if args.jacobi else None)
+        dev2 = sim2._solver._bc.device
+        for _ in range(3):
+            sim2.step()
+        dev2.profile(True)
+        dev2.profile_reset()
+        for _ in range(steps):
+            sim2.step()
+        parts = {}
+        merge_parts(dev2.profile_report(), parts)
+        dev2.profile(False)
+        n_plain, n_bnd, _, t_rows, t_cells = dev2.cip_step_tiles()
+        if "cip_step" not in parts or n_plain <= 0:
+            return None
+        us = {k: v[1] / max(v[0], 1) * 1e3 for k, v in parts["cip_step"].items()}
+        pl_bytes = n_plain * t_rows * t_cells * 13 * esize
+        gbps = pl_bytes / (us["plain"] * 1e-6) / 1e9
+        return {"form": "FS_FUSE_K2=1: k_cip_step_plain over the all-fluid tiles + k_cip_step_bnd over the others, a second context of the same scene, "
+                        f"{steps} eager steps", "all_fluid_tiles": n_plain, "other_tiles": n_bnd, "all_fluid_us": round(us["plain"], 2), "others_us": round(us.get("bnd", 0.0), 2),
+                "all_fluid_alg_MB": round(pl_bytes / 1e6, 2), "all_fluid_GBps": round(gbps, 1), "all_fluid_frac": round(gbps / HBM_PEAK_GBS, 4),
+                "all_fluid_frac_of_box_copy": round(gbps / box["copy_GBps"], 4) if box else None}
+    finally:
+        if saved is None:
+            os.environ.pop("FS_FUSE_K2", None)
+        else:
+            os.environ["FS_FUSE_K2"] = saved
+        if sim2 is not None:
+            sim2._solver._bc.device.close()
+
+
 def usable_cores():
     """Host threads this process can really run on: the affinity mask, capped by the cgroup CPU quota (a container that sees 256
     logical CPUs under a quota of a few cores makes an OpenMP team of 256 spin on its barriers: round 2's 0.7 steps/s)."""
@@ -636,6 +674,13 @@ def main():
                                                        "traffic": pmc_traffic.get(dominant), "parts_us": kd.get("parts_us")}})
         elif dominant == "cip_step":
             out["roofline"]["kernel"] = "cip_step / k_cip_step_all (K2 + K3 + K4 of the velocity over every tile, one launch)"
+            if world == 1 and not args.dye and args.dtype == "f32" and hasattr(dev, "cip_step_tiles"):
+                # diagnostic: the same step with one launch per KIND of tile (FS_FUSE_K2=1) on a second context - what the all-fluid body reaches on the bytes
+                # of its own tiles (52 B per cell: it reads no mask), and what the masked body costs; `frac` above stays the one launch's
+                try:
+                    out["roofline"]["by_kind_of_tile"] = cip_step_by_kind(args, res, dt, dx, re, vc, esize, box)
+                except Exception as e:      # (a diagnostic must not cost the line)
+                    out["roofline"]["by_kind_of_tile"] = {"error": repr(e)[:200]}
         if "unfused_equiv_frac" in kd:
             out["roofline"]["note"] = (
                 "two Jacobi sweeps (and both pressure boundary passes) per launch, the first sweep's rows in registers: `frac` counts what "

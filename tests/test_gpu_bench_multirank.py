@@ -109,6 +109,8 @@ def test_bench_line_contract_with_the_large_grid_step(mode, hip_lib):
     cs = d["kernels"]["cip_step"]
     if mode == "2":
         assert "k_cip_step_all" in rf["kernel"] and "parts_us" not in cs and rf["alg_bytes_per_launch"] > 0
+        bk = rf["by_kind_of_tile"]      # diagnostic on a second context: one launch per kind of tile, the all-fluid body on the bytes of its own tiles
+        assert bk["all_fluid_tiles"] > 0 and bk["all_fluid_us"] > 0 and 0 < bk["all_fluid_frac"] < 1, bk
     else:
         assert "k_cip_step_plain" in rf["kernel"] and "k_cip_step_bnd" in rf["logical_launch"]["kernels"]
         assert rf["logical_launch"]["parts_us"].keys() == {"plain", "bnd"} and rf["logical_launch"]["avg_us"] > rf["avg_us"]
