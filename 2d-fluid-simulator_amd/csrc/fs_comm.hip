@@ -143,6 +143,15 @@ using namespace fs;
 
 extern "C" {
 
+// librccl can be loaded and has every entry point the exchange uses (no GPU call, no communicator): what an N > 1 job checks on every rank
+// BEFORE any rank blocks in ncclCommInitRank (bench.py preflight).  *ok = 0 leaves the reason in fs_last_error().
+int fs_comm_available(int *ok)
+{
+    FS_REQUIRE(ok, "null argument");
+    *ok = load_rccl() == FS_OK ? 1 : 0;
+    return FS_OK;
+}
+
 int fs_comm_unique_id(void *out_128_bytes)
 {
     FS_REQUIRE(out_128_bytes, "null argument");
@@ -263,11 +272,11 @@ static int exchange_direct(fs_ctx *ctx, hipStream_t xs, fs_field *const *fields,
         if (f->C != 2 || v >= depth) continue;
         const dim3 gridv((ctx->X + 255) / 256, depth - v);
         if (ctx->dtype == 0) {
-            if (lower >= 0) hipLaunchKernelGGL(k_scan_hot<float>, gridv, dim3(256), 0, xs, ctx->grid(), H - depth, (const float *)f->d, f->hot);
-            if (upper >= 0) hipLaunchKernelGGL(k_scan_hot<float>, gridv, dim3(256), 0, xs, ctx->grid(), H + n + v, (const float *)f->d, f->hot);
+            if (lower >= 0) FS_KLAUNCH(k_scan_hot<float>, gridv, dim3(256), 0, xs, ctx->grid(), H - depth, (const float *)f->d, f->hot);
+            if (upper >= 0) FS_KLAUNCH(k_scan_hot<float>, gridv, dim3(256), 0, xs, ctx->grid(), H + n + v, (const float *)f->d, f->hot);
         } else {
-            if (lower >= 0) hipLaunchKernelGGL(k_scan_hot<double>, gridv, dim3(256), 0, xs, ctx->grid(), H - depth, (const double *)f->d, f->hot);
-            if (upper >= 0) hipLaunchKernelGGL(k_scan_hot<double>, gridv, dim3(256), 0, xs, ctx->grid(), H + n + v, (const double *)f->d, f->hot);
+            if (lower >= 0) FS_KLAUNCH(k_scan_hot<double>, gridv, dim3(256), 0, xs, ctx->grid(), H - depth, (const double *)f->d, f->hot);
+            if (upper >= 0) FS_KLAUNCH(k_scan_hot<double>, gridv, dim3(256), 0, xs, ctx->grid(), H + n + v, (const double *)f->d, f->hot);
         }
     }
     FS_HIP(hipGetLastError());
@@ -308,7 +317,7 @@ static int exchange_packed(fs_ctx *ctx, hipStream_t xs, fs_field *const *fields,
     }
     char *send_lo = cm->stage, *send_hi = cm->stage + cm->stage_part, *recv_lo = cm->stage + 2 * cm->stage_part, *recv_hi = cm->stage + 3 * cm->stage_part;
     const dim3 grid(64, 2 * nfields);
-    hipLaunchKernelGGL(k_halo_pack<true>, grid, dim3(256), 0, xs, own, send_lo, send_hi);
+    FS_KLAUNCH(k_halo_pack<true>, grid, dim3(256), 0, xs, own, send_lo, send_hi);
     FS_NCCL(g_rccl.GroupStart());
     if (lower >= 0) {
         FS_NCCL(g_rccl.Send(send_lo, total, ncclUint8, lower, cm->comm, xs));
@@ -319,7 +328,7 @@ static int exchange_packed(fs_ctx *ctx, hipStream_t xs, fs_field *const *fields,
         FS_NCCL(g_rccl.Recv(recv_hi, total, ncclUint8, upper, cm->comm, xs));
     }
     FS_NCCL(g_rccl.GroupEnd());
-    hipLaunchKernelGGL(k_halo_pack<false>, grid, dim3(256), 0, xs, ghost, recv_lo, recv_hi);
+    FS_KLAUNCH(k_halo_pack<false>, grid, dim3(256), 0, xs, ghost, recv_lo, recv_hi);
     FS_HIP(hipGetLastError());
     return FS_OK;
 }

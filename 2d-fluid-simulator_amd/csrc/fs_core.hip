@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cxxabi.h>
 #include <mutex>
 #include <numeric>
 #include <type_traits>
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) static void k_verify_f64div(float d, double rd
 }
 
 // ---- launch helper: optional HIP-event pair around every launch (fs_prof_*) --------------------
+thread_local KernelNotes kernel_notes = {{nullptr, nullptr, nullptr, nullptr}, 0};
 hipEvent_t prof_event(fs_ctx *c)
 {
     hipEvent_t e;
@@ -73,6 +75,7 @@ ProfRec prof_span_begin(fs_ctx *c, const char *name, hipStream_t stream)
         c->prof_names.push_back(name);
         c->prof_launches.push_back(0);
         c->prof_ms.push_back(0.0);
+        c->prof_kernels.emplace_back();
     }
     rec.name_id = it->second;
     rec.start = prof_event(c);
@@ -155,9 +158,11 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                     if (any && cls) {
                         // plain: no non-fluid cell (bit 1 of the activity byte; halo lanes included) within `reach` rows of the tile - or, for the
                         // boundary list of a launch whose plain part runs on tiles of parent_rt rows, of the parent tile this tile lies in
-                        int p0 = j0, p1 = j1;
-                        if (parent_rt) { p0 = jb + (j0 - jb) / parent_rt * parent_rt; p1 = std::min(je, p0 + parent_rt); }
-                        any = plain_box(wx0, wx1, p0, p1) == (cls == 1);
+                        // A tile (or parent tile) the row range cuts short is never plain: the plain kernels may store every row of their tile
+                        // (the stacked red-black pair does - ADVICE r5: rows past row_end of a slab range), the kernels with masks guard `je`.
+                        int p0 = j0, p1 = j1, full_rows = (stacked ? wgw : 1) * rt;
+                        if (parent_rt) { p0 = jb + (j0 - jb) / parent_rt * parent_rt; p1 = std::min(je, p0 + parent_rt); full_rows = parent_rt; }
+                        any = (p1 - p0 == full_rows && plain_box(wx0, wx1, p0, p1)) == (cls == 1);
                     }
                     uint32_t hints = 0u;
                     if (any && !cls && reach > 0 && wgw <= 4) {
@@ -678,9 +683,9 @@ static int upload_window(fs_ctx *ctx, void *dev, int C, size_t esize, const void
     FS_HIP(hipMemcpyAsync(ctx->d_stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     const int Q = nrows * C;
     dim3 grid((ctx->X + 63) / 64, (Q + 63) / 64);
-    if (esize == 1) hipLaunchKernelGGL(k_to_device<uint8_t>, grid, dim3(256), 0, ctx->stream, (const uint8_t *)ctx->d_stage, (uint8_t *)dev, ctx->X, Q, pitch, row_begin * C);
-    else if (esize == 4) hipLaunchKernelGGL(k_to_device<float>, grid, dim3(256), 0, ctx->stream, (const float *)ctx->d_stage, (float *)dev, ctx->X, Q, pitch, row_begin * C);
-    else hipLaunchKernelGGL(k_to_device<double>, grid, dim3(256), 0, ctx->stream, (const double *)ctx->d_stage, (double *)dev, ctx->X, Q, pitch, row_begin * C);
+    if (esize == 1) FS_KLAUNCH(k_to_device<uint8_t>, grid, dim3(256), 0, ctx->stream, (const uint8_t *)ctx->d_stage, (uint8_t *)dev, ctx->X, Q, pitch, row_begin * C);
+    else if (esize == 4) FS_KLAUNCH(k_to_device<float>, grid, dim3(256), 0, ctx->stream, (const float *)ctx->d_stage, (float *)dev, ctx->X, Q, pitch, row_begin * C);
+    else FS_KLAUNCH(k_to_device<double>, grid, dim3(256), 0, ctx->stream, (const double *)ctx->d_stage, (double *)dev, ctx->X, Q, pitch, row_begin * C);
     FS_HIP(hipGetLastError());
     FS_HIP(hipStreamSynchronize(ctx->stream));
     return FS_OK;
@@ -755,14 +760,14 @@ int fs_upload_mask(fs_ctx *ctx, const uint8_t *mask_xy)
     std::vector<uint8_t>().swap(ctx->h_bcmap);
     if (rc) return rc;
     if (ctx->X % 4 == 0) {      // per-tile flags of the lazy pressure BC
-        hipLaunchKernelGGL(k_lazy_flags, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_bcmap, ctx->d_lazyflags);
+        FS_KLAUNCH(k_lazy_flags, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, ctx->d_bcmap, ctx->d_lazyflags);
         FS_HIP(hipGetLastError());
         // the rows the two-sweep kernel hands to its general path: list + count (read back once per mask)
         const size_t cap = (size_t)ctx->nwx * ctx->rows;
         if (!ctx->d_pairlist) FS_HIP(hipMalloc(&ctx->d_pairlist, (2 * cap + 2) * sizeof(uint32_t)));
         unsigned *d_count = (unsigned *)(ctx->d_pairlist + 2 * cap);
         FS_HIP(hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned), ctx->stream));
-        hipLaunchKernelGGL(k_pair_list, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, (uint8_t *)ctx->d_lazyflags,
+        FS_KLAUNCH(k_pair_list, dim3((ctx->nwx * ctx->rows + 3) / 4), dim3(256), 0, ctx->stream, ctx->grid(), ctx->nwx, (uint8_t *)ctx->d_lazyflags,
                            ctx->d_pairlist, ctx->d_pairlist + cap, d_count);
         FS_HIP(hipGetLastError());
         unsigned n[2] = {0, 0};
@@ -848,8 +853,8 @@ int fs_field_fill(fs_field *f, double value)
     const unsigned hot = 2.0 * value * value > 0.999 * (double)FS_HOT_SQ ? 1u : 0u;      // every channel takes `value` (the margin: x * x + y * y is evaluated in the field type on the device)
     FS_DISPATCH(ctx, {
         return launch(ctx, "fill", [=] {
-            hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value);
-            hipLaunchKernelGGL(k_fill<unsigned>, dim3(1), dim3(64), 0, ctx->stream, f->hot, (size_t)4, hot);
+            FS_KLAUNCH(k_fill<T>, dim3(2048), dim3(256), 0, ctx->stream, (T *)f->d, n, (T)value);
+            FS_KLAUNCH(k_fill<unsigned>, dim3(1), dim3(64), 0, ctx->stream, f->hot, (size_t)4, hot);
         });
     })
 }
@@ -862,7 +867,7 @@ int fs_field_upload(fs_field *f, const void *host_xrc, int row_begin, int nrows)
     int rc = upload_window(ctx, f->d, f->C, ctx->esize, host_xrc, row_begin, nrows, ctx->P);
     if (rc || f->C != 2 || nrows == 0) return rc;
     FS_DISPATCH(ctx, {      // what came in may exceed the speed the limit_field gate assumes: look at it (fs_device.h "hot" flag)
-        hipLaunchKernelGGL(k_scan_hot<T>, cells_grid(ctx, row_begin, row_begin + nrows), dim3(256), 0, ctx->stream, ctx->grid(), row_begin, (const T *)f->d, f->hot);
+        FS_KLAUNCH(k_scan_hot<T>, cells_grid(ctx, row_begin, row_begin + nrows), dim3(256), 0, ctx->stream, ctx->grid(), row_begin, (const T *)f->d, f->hot);
     })
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -882,7 +887,7 @@ int fs_field_download(const fs_field *f, void *host_xrc, int row_begin, int nrow
     const int Q = nrows * f->C;
     dim3 grid((ctx->X + 63) / 64, (Q + 63) / 64);
     FS_DISPATCH(ctx, {
-        hipLaunchKernelGGL(k_to_host<T>, grid, dim3(256), 0, ctx->stream, (T *)ctx->d_stage, (const T *)f->d, ctx->X, Q, ctx->P, row_begin * f->C);
+        FS_KLAUNCH(k_to_host<T>, grid, dim3(256), 0, ctx->stream, (T *)ctx->d_stage, (const T *)f->d, ctx->X, Q, ctx->P, row_begin * f->C);
     })
     FS_HIP(hipGetLastError());
     FS_HIP(hipMemcpyAsync(host_xrc, ctx->d_stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -915,7 +920,7 @@ int fs_field_copy(fs_field *dst, const fs_field *src)
 {
     FS_REQUIRE(dst && src && dst->ctx == src->ctx && dst->C == src->C, "copy needs two fields of one context and shape");
     FS_HIP(hipMemcpyAsync(dst->d, src->d, src->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
-    hipLaunchKernelGGL(k_hot_fold, dim3(1), dim3(64), 0, dst->ctx->stream, dst->hot, (const unsigned *)src->hot);      // (one word: the copy starts a new parity sequence)
+    FS_KLAUNCH(k_hot_fold, dim3(1), dim3(64), 0, dst->ctx->stream, dst->hot, (const unsigned *)src->hot);      // (one word: the copy starts a new parity sequence)
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -948,7 +953,7 @@ int fs_velocity_bc(fs_ctx *ctx, fs_field *v, int row_begin, int row_end)
     if (ctx->ops_vel.lanes() == 0) return FS_OK;
     FS_DISPATCH(ctx, {
         return launch(ctx, "velocity_bc", [=] {
-            hipLaunchKernelGGL(k_velocity_bc<T>, dim3((ctx->ops_vel.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+            FS_KLAUNCH(k_velocity_bc<T>, dim3((ctx->ops_vel.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, (T *)v->d, (const T *)ctx->d_bc_const, v->hot);
         });
     })
@@ -981,7 +986,7 @@ int fs_velocity_bc_limit(fs_ctx *ctx, double limit, fs_field *v, int parity, int
         return launch(ctx, "velocity_bc", [=] {
             // (at least one workgroup per row of the limit pass, up to 64 (the barrier costs ~40 ns per workgroup): with the flag up - a run that has once exceeded a speed of 8 keeps it
             //  up - the pass is shared by the launch's workgroups; the extra ones find no op and cost nothing while the flag is down)
-            hipLaunchKernelGGL(k_velocity_bc_limit<T>, dim3(std::max((ctx->ops_vel.lanes() + 255) / 256, std::min(64, limit_end - limit_begin))), dim3(256), 0, ctx->stream,
+            FS_KLAUNCH(k_velocity_bc_limit<T>, dim3(std::max((ctx->ops_vel.lanes() + 255) / 256, std::min(64, limit_end - limit_begin))), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_vel.view(), row_begin, row_end, limit_begin, limit_end, (T)limit, (T *)v->d, (const T *)ctx->d_bc_const, v->hot, ctx->d_sync, parity);
         });
     })
@@ -996,7 +1001,7 @@ int fs_pressure_bc(fs_ctx *ctx, fs_field *p, int row_begin, int row_end)
     if (ctx->ops_prs.lanes() == 0) return FS_OK;
     FS_DISPATCH(ctx, {
         return launch(ctx, "pressure_bc", [=] {
-            hipLaunchKernelGGL(k_pressure_bc<T>, dim3((ctx->ops_prs.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+            FS_KLAUNCH(k_pressure_bc<T>, dim3((ctx->ops_prs.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_prs.view(), row_begin, row_end, (T *)p->d);
         });
     })
@@ -1011,7 +1016,7 @@ int fs_dye_bc(fs_ctx *ctx, fs_field *dye, int row_begin, int row_end)
     if (ctx->ops_dye.lanes() == 0) return FS_OK;
     FS_DISPATCH(ctx, {
         return launch(ctx, "dye_bc", [=] {
-            hipLaunchKernelGGL(k_dye_bc<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+            FS_KLAUNCH(k_dye_bc<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T *)dye->d, (const T *)ctx->d_bc_dye);
         });
     })
@@ -1036,7 +1041,7 @@ int fs_dye_bc_limit(fs_ctx *ctx, double limit, fs_field *v, fs_field *dye, int l
     if (!ok || !((float)limit * (float)limit > FS_HOT_GATE_SQ)) { set_error("fs_dye_bc_limit is not available for this context / limit (fs_dye_bc_limit_ok)"); return FS_ERR_UNSUPPORTED; }
     FS_DISPATCH(ctx, {
         return launch(ctx, "dye_bc", [=] {
-            hipLaunchKernelGGL(k_dye_bc_limit<T>, dim3(std::max((ctx->ops_dye.lanes() + 255) / 256, std::min(64, limit_end - limit_begin))), dim3(256), 0, ctx->stream,
+            FS_KLAUNCH(k_dye_bc_limit<T>, dim3(std::max((ctx->ops_dye.lanes() + 255) / 256, std::min(64, limit_end - limit_begin))), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, limit_begin, limit_end, (T)limit, (T *)v->d, v->hot, ctx->d_sync,
                                (T *)dye->d, (const T *)ctx->d_bc_dye);
         });
@@ -1056,7 +1061,7 @@ int fs_selftest_f64div(fs_ctx *ctx, double divisor, int *mismatches)
     FS_HIP(hipMalloc(&flag, sizeof(unsigned)));
     hipError_t e = hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_verify_f64div, dim3(1u << 15, 10 + 2), dim3(256), 0, ctx->stream, d, 1.0 / (double)d, tie_free((double)d) ? 0 : 1, flag);   // the form the library uses for this divisor
+        FS_KLAUNCH(k_verify_f64div, dim3(1u << 15, 10 + 2), dim3(256), 0, ctx->stream, d, 1.0 / (double)d, tie_free((double)d) ? 0 : 1, flag);   // the form the library uses for this divisor
         e = hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1151,8 +1156,8 @@ static int box_valu_rate(fs_ctx *ctx, double budget_ms, double *ginstr_per_simd,
     for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
         (void)hipEventRecord(e0, ctx->stream);
         for (int r = 0; r < reps; ++r) {
-            if (packed) hipLaunchKernelGGL(k_box_valu_pk, dim3(cus * 4), dim3(256), 0, ctx->stream, sink, 1.0000001f, 1e-9f, iters);
-            else hipLaunchKernelGGL(k_box_valu, dim3(cus * 4), dim3(256), 0, ctx->stream, sink, 1.0000001f, 1e-9f, iters);
+            if (packed) FS_KLAUNCH(k_box_valu_pk, dim3(cus * 4), dim3(256), 0, ctx->stream, sink, 1.0000001f, 1e-9f, iters);
+            else FS_KLAUNCH(k_box_valu, dim3(cus * 4), dim3(256), 0, ctx->stream, sink, 1.0000001f, 1e-9f, iters);
         }
         (void)hipEventRecord(e1, ctx->stream);
         e = hipEventSynchronize(e1);
@@ -1210,7 +1215,7 @@ int fs_box_mixed_rate(fs_ctx *ctx, size_t bytes, double budget_ms, double *GBps)
     int reps = 1;
     for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
         (void)hipEventRecord(e0, ctx->stream);
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_box_mixed, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, a, b, n, 1.0000001f, 1e-9f);
+        for (int r = 0; r < reps; ++r) FS_KLAUNCH(k_box_mixed, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, a, b, n, 1.0000001f, 1e-9f);
         (void)hipEventRecord(e1, ctx->stream);
         e = hipEventSynchronize(e1);
         float ms = 0.f;
@@ -1252,8 +1257,8 @@ int fs_box_rates(fs_ctx *ctx, size_t bytes, double budget_ms, double *read_GBps,
         for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
             (void)hipEventRecord(e0, ctx->stream);
             for (int r = 0; r < reps; ++r) {
-                if (copy) hipLaunchKernelGGL(k_box_copy, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, a, b, n);
-                else hipLaunchKernelGGL(k_box_read, dim3(2048), dim3(256), 0, ctx->stream, a, sink, n);
+                if (copy) FS_KLAUNCH(k_box_copy, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, a, b, n);
+                else FS_KLAUNCH(k_box_read, dim3(2048), dim3(256), 0, ctx->stream, a, sink, n);
             }
             (void)hipEventRecord(e1, ctx->stream);
             e = hipEventSynchronize(e1);
@@ -1288,7 +1293,7 @@ int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int ro
             const int gated = (T)limit * (T)limit > (T)FS_HOT_GATE_SQ && ctx->limit_gate ? 1 : 0;
             const int lanes = std::min(row_end - row_begin, 256);
             return launch(ctx, "limit_field", [=] {
-                hipLaunchKernelGGL((k_limit_quad<T>), dim3((ctx->X / 4 + 255) / 256, lanes), dim3(256), 0, ctx->stream,
+                FS_KLAUNCH((k_limit_quad<T>), dim3((ctx->X / 4 + 255) / 256, lanes), dim3(256), 0, ctx->stream,
                                    ctx->grid(), row_begin, row_end, (T)limit, (T *)v->d, v->hot, gated);
             });
         }
@@ -1318,10 +1323,10 @@ static int visualize(fs_ctx *ctx, int mode, double dx, fs_field *rgb, const fs_f
         const T *pa = (const T *)a->d, *pb = b ? (const T *)b->d : nullptr;
         return launch(ctx, names[mode], [=] {
             const dim3 grid = cells_grid(ctx, row_begin, row_end);
-            if (mode == 0) hipLaunchKernelGGL((k_visualize<0, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
-            else if (mode == 1) hipLaunchKernelGGL((k_visualize<1, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
-            else if (mode == 2) hipLaunchKernelGGL((k_visualize<2, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
-            else hipLaunchKernelGGL((k_visualize<3, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
+            if (mode == 0) FS_KLAUNCH((k_visualize<0, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
+            else if (mode == 1) FS_KLAUNCH((k_visualize<1, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
+            else if (mode == 2) FS_KLAUNCH((k_visualize<2, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
+            else FS_KLAUNCH((k_visualize<3, T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, (T *)rgb->d, pa, pb);
         });
     })
 }
@@ -1521,6 +1526,39 @@ int fs_prof_get(fs_ctx *ctx, int idx, char *name, int name_cap, int *launches, d
     if (name && name_cap > 0) { strncpy(name, ctx->prof_names[idx].c_str(), name_cap - 1); name[name_cap - 1] = 0; }
     if (launches) *launches = ctx->prof_launches[idx];
     if (total_ms) *total_ms = ctx->prof_ms[idx];
+    return FS_OK;
+}
+
+// The __global__ functions launched under profile name `name` since profiling was enabled, demangled, one per line (the names a
+// rocprofv3 --kernel-trace of the same run shows).  Returns the number of kernels in *n; `out` may be null.
+int fs_prof_kernels(fs_ctx *ctx, const char *name, char *out, int capacity, int *n)
+{
+    FS_REQUIRE(ctx && name && n, "null argument");
+    *n = 0;
+    if (out && capacity > 0) out[0] = 0;
+    auto it = ctx->prof_ids.find(name);
+    if (it == ctx->prof_ids.end()) return FS_OK;
+    std::string all;
+    for (const void *fn : ctx->prof_kernels[it->second]) {
+        const char *mangled = hipKernelNameRefByPtr(fn, ctx->stream);
+        if (!mangled) continue;
+        int status = 0;
+        char *dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+        std::string s = status == 0 && dem ? dem : mangled;
+        free(dem);
+        // (the signature is noise: "void fs::k_x<4, 0>(fs::Grid, ...)" -> "fs::k_x<4, 0>")
+        if (s.rfind("void ", 0) == 0) s = s.substr(5);
+        int depth = 0;
+        for (size_t i = 0; i < s.size(); ++i) {
+            if (s[i] == '<') ++depth;
+            else if (s[i] == '>') --depth;
+            else if (s[i] == '(' && depth == 0) { s.resize(i); break; }
+        }
+        if (!all.empty()) all += "\n";
+        all += s;
+        ++*n;
+    }
+    if (out && capacity > 0) { strncpy(out, all.c_str(), capacity - 1); out[capacity - 1] = 0; }
     return FS_OK;
 }
 

@@ -47,6 +47,17 @@ struct BcOpsDev {
     BcOps view() const { return BcOps{nsimple, simple, npair, pair, ncomp, comp_begin, comp_rlo, comp_rhi, kind, tgt, s1, s2, row, srow}; }
 };
 
+// Which __global__ functions a profiled launch name stands for (fs_prof_kernels: bench.py quotes the demangled symbols instead of string
+// literals).  Every kernel launch of the library is written FS_KLAUNCH(kernel, grid, block, lds, stream, args...): the host stub's address
+// is noted per thread, and fs::launch() (fs_launch.h) files the notes of the callable it just ran under the launch's profile name.
+struct KernelNotes { const void *fn[4]; int n; };
+extern thread_local KernelNotes kernel_notes;      // fs_core.hip
+#define FS_KLAUNCH(kern, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                       \
+        if (fs::kernel_notes.n < 4) fs::kernel_notes.fn[fs::kernel_notes.n++] = (const void *)(kern);           \
+        hipLaunchKernelGGLInternal((kern), (grid), (block), (lds), (stream), __VA_ARGS__);                     \
+    } while (0)
+
 struct ProfRec {
     int name_id;
     hipEvent_t start, stop;
@@ -107,6 +118,7 @@ struct fs_ctx {
     std::vector<hipEvent_t> prof_pool;
     std::vector<int> prof_launches;
     std::vector<double> prof_ms;
+    std::vector<std::vector<const void *>> prof_kernels;      // per name: the host stubs of the __global__ functions launched under it (fs_prof_kernels)
     hipEvent_t span_ev[2] = {nullptr, nullptr};      // fs_span_begin / fs_span_end
     // comm
     fs::Comm *comm = nullptr;

@@ -15,6 +15,7 @@ namespace fs {
 
 hipEvent_t prof_event(fs_ctx *c);      // fs_core.hip
 
+
 // Every kernel launch of the library goes through here.  The callable captures its arguments BY VALUE: while a tape is being
 // recorded (fs_tape_begin) a copy is kept and re-issued by fs_tape_replay without going back through the caller.
 template <typename F>
@@ -37,16 +38,21 @@ inline int launch(fs_ctx *c, const char *name, F &&f)
             c->prof_names.push_back(name);
             c->prof_launches.push_back(0);
             c->prof_ms.push_back(0.0);
+            c->prof_kernels.emplace_back();
         }
         rec.name_id = it->second;
         rec.start = prof_event(c);
         rec.stop = prof_event(c);
         (void)hipEventRecord(rec.start, c->stream);
     }
+    kernel_notes.n = 0;
     f();
     if (prof) {
         (void)hipEventRecord(rec.stop, c->stream);
         c->prof_recs.push_back(rec);
+        auto &ks = c->prof_kernels[rec.name_id];
+        for (int i = 0; i < kernel_notes.n; ++i)
+            if (std::find(ks.begin(), ks.end(), kernel_notes.fn[i]) == ks.end()) ks.push_back(kernel_notes.fn[i]);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, name, __FILE__, __LINE__);
@@ -145,7 +151,7 @@ int ensure_stage(fs_ctx *c, size_t bytes);
 
 #define FS_LAUNCH_CELLS(name, kern, ...)                                                                   \
     return launch(ctx, name, [=] {                                                                         \
-        hipLaunchKernelGGL(kern, cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, __VA_ARGS__); \
+        FS_KLAUNCH(kern, cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, __VA_ARGS__); \
     });
 
 }  // namespace fs

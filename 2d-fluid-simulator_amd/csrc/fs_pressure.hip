@@ -4,7 +4,7 @@
 
 using namespace fs;
 
-#define FS_PAIR(RT) hipLaunchKernelGGL((k_jacobi_pair<RT, SW, HV, T>), grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
+#define FS_PAIR(RT) FS_KLAUNCH((k_jacobi_pair<RT, SW, HV, T>), grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, list, nlist, zoff, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
 template <bool SW, bool HV, typename T>
 static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, int row_end, fs_field *pn, const fs_field *pc, const fs_field *src)
@@ -29,7 +29,7 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
         if (ctx->jacobi_variant == 0 && ctx->use_pairs) {
             const OvGrid og = ov_grid_lanes(ctx, jb, je, 4, 1, XCD_JACOBI, 3, true, 0, 1);      // (reach 1: the hints)
             const int dm = dm_const(ctx, k);
-#define FS_JAC2(DM) hipLaunchKernelGGL((k_jacobi_ov2<4, DM>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs)
+#define FS_JAC2(DM) FS_KLAUNCH((k_jacobi_ov2<4, DM>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs)
             return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC2); });
         }
     }
@@ -37,10 +37,10 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
     const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
     const int dm = SRC ? 0 : dm_const(ctx, k);           // the source-pair form divides nothing
 #define FS_JAC(DM) do { \
-        if (rt == 2) hipLaunchKernelGGL((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else if (rt == 3) hipLaunchKernelGGL((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else if (rt == 4) hipLaunchKernelGGL((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else hipLaunchKernelGGL((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
+        if (rt == 2) FS_KLAUNCH((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else if (rt == 3) FS_KLAUNCH((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else if (rt == 4) FS_KLAUNCH((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
+        else FS_KLAUNCH((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
     return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC); });
 }
 
@@ -103,7 +103,7 @@ int fs_jacobi_sweep_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs
     const OvGrid og = ov_grid(ctx, row_begin, row_end, 1, 1, XCD_JACOBI);
     FS_DISPATCH(ctx, {
         return launch(ctx, "jacobi_sweep_lazy", [=] {
-            hipLaunchKernelGGL((k_jacobi_lazy<T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
+            FS_KLAUNCH((k_jacobi_lazy<T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
                                (const uint8_t *)ctx->d_bcmap, (const uint8_t *)ctx->d_lazyflags, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
         });
     })
@@ -145,7 +145,7 @@ int fs_rbsor_halfsweep(fs_ctx *ctx, double dt, double dx, double omega, int pari
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
         return launch(ctx, parity ? "rbsor_odd" : "rbsor_even", [=] {
-            hipLaunchKernelGGL((k_rbsor<false, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
+            FS_KLAUNCH((k_rbsor<false, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
                                row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
         });
     })
@@ -168,7 +168,7 @@ int fs_rbsor_iteration(fs_ctx *ctx, double dt, double dx, double omega, fs_field
     const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 3, false);
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-#define FS_RBN4(DM) hipLaunchKernelGGL((k_rbsor_iter_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBN4(DM) FS_KLAUNCH((k_rbsor_iter_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
         return launch(ctx, "rbsor_iteration", [=] { FS_DMC(dm_const(ctx, k), FS_RBN4); });
     })
@@ -192,7 +192,7 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     using T = float;
     // lanes of 2 cells (116 VGPRs = 4 waves per SIMD at 4 rows; quads: 182 = 2 waves, 44.9 against 34.3 us per pass at bc2 res 1600)
     constexpr int rt = 4;
-#define FS_JQ(RT, PATH) hipLaunchKernelGGL((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
+#define FS_JQ(RT, PATH) FS_KLAUNCH((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
     // plain and boundary workgroups as two compact launches (as fs_rbsor_pair) - on large grids: a second launch costs ~5 us, which a
     // cache-resident grid does not earn back (bc2 res 1600: 18.1 + 21.3 against 34.6 us; bc5 res 4096: 81.4 + 49.8 against 137.5)
@@ -223,7 +223,7 @@ int fs_jacobi_finish(fs_ctx *ctx, fs_field *pc_out, fs_field *pn, const fs_field
     using T = float;
     const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2, true, 0, 2);      // (per-wave plain hints: two sweeps reach 2 rows)
     return launch(ctx, "jacobi_finish", [=] {
-        hipLaunchKernelGGL((k_jacobi_finish<2, 4, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
+        FS_KLAUNCH((k_jacobi_finish<2, 4, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
                            (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
     });
 }
@@ -256,7 +256,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
         // iteration) at 137 VGPRs that is still one pass over p and v instead of two.
         using T = double;
         auto k = make_konst<T>(ctx, dt, dx, 1.0, 0.0, omega);
-#define FS_RBPD_K(RT, PAR, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, 0, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBPD_K(RT, PAR, PATH, FULL) FS_KLAUNCH((k_rbsor_pair<2, RT, PAR, 0, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBPD(RT, PATH, FULL) do { if (par0) FS_RBPD_K(RT, 1, PATH, FULL); else FS_RBPD_K(RT, 0, PATH, FULL); } while (0)
         if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
@@ -279,7 +279,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     // (grids below 1 M cells: 2-row tiles - fewer waves than SIMDs there, the pass takes as long as ONE wave's chain of loads and stages:
     //  res 200 12.1 -> 9.2 us per launch, BASELINE configs[0] 53.3 -> 62.8 k steps/s; res 1600: 4 rows, 5602 against 5435 steps/s)
     const int rt = full || !small_tiles(ctx) ? 4 : 2;
-#define FS_RBP_K(RT, PAR, DM, PATH, FULL) hipLaunchKernelGGL((k_rbsor_pair<2, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBP_K(RT, PAR, DM, PATH, FULL) FS_KLAUNCH((k_rbsor_pair<2, RT, PAR, DM, PATH, FULL, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBP_PAR(RT, DM, PATH, FULL) do { if (par0) FS_RBP_K(RT, 1, DM, PATH, FULL); else FS_RBP_K(RT, 0, DM, PATH, FULL); } while (0)
 #define FS_RBP_DM(RT, PATH) do { if (dm & DM_F64) FS_RBP_PAR(RT, 4, PATH, false); else FS_RBP_PAR(RT, 0, PATH, false); } while (0)
@@ -295,7 +295,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
         const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, 1, 0, slab);
         const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, 1, prt, slab);
         if (og.g.tiles && ogb.g.tiles) {
-#define FS_RBS_K(PAR, DM) hipLaunchKernelGGL((k_rbsor_pair_stack<2, 8, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_RBS_K(PAR, DM) FS_KLAUNCH((k_rbsor_pair_stack<2, 8, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBS_PAR(DM) do { if (par0) FS_RBS_K(1, DM); else FS_RBS_K(0, DM); } while (0)
             int rc = launch(ctx, "rbsor_pair", [=] {
@@ -326,7 +326,7 @@ int fs_rbsor_halfsweep_src(fs_ctx *ctx, double omega, int parity, fs_field *pn, 
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, 1.0, 1.0, 1.0, 0.0, omega);
         return launch(ctx, parity ? "rbsor_odd_src" : "rbsor_even_src", [=] {
-            hipLaunchKernelGGL((k_rbsor<true, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
+            FS_KLAUNCH((k_rbsor<true, T>), rb_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k,
                                row_begin, parity, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
         });
     })
@@ -342,7 +342,7 @@ int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
         if (ctx->use_pairs && !getenv("FS_SRC_CELLS")) {
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_JACOBI, 3);      // (deep-wall workgroups skipped: nobody reads the source there)
-#define FS_PSN(DM) hipLaunchKernelGGL((k_poisson_source_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)src->d, (const T *)vc->d)
+#define FS_PSN(DM) FS_KLAUNCH((k_poisson_source_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)src->d, (const T *)vc->d)
             return launch(ctx, "poisson_source", [=] { FS_DMC(dm_const(ctx, k), FS_PSN); });
         }
         FS_LAUNCH_CELLS("poisson_source", (k_poisson_source<T>), ctx->grid(), k, row_begin, (T *)src->d, (const T *)vc->d)
@@ -367,9 +367,9 @@ int fs_poisson_residual(fs_ctx *ctx, double dt, double dx, const fs_field *p, co
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
         rc = launch(ctx, "poisson_residual", [=] {
-            hipLaunchKernelGGL((k_residual<T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end,
+            FS_KLAUNCH((k_residual<T>), grid, dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, row_end,
                                (const T *)p->d, (const T *)vc->d, ctx->d_partial);
-            hipLaunchKernelGGL((k_residual_final<double>), dim3(1), dim3(1024), 0, ctx->stream, (const double *)ctx->d_partial, (int)nblocks, ctx->d_acc);
+            FS_KLAUNCH((k_residual_final<double>), dim3(1), dim3(1024), 0, ctx->stream, (const double *)ctx->d_partial, (int)nblocks, ctx->d_acc);
         });
     })
     if (rc) return rc;

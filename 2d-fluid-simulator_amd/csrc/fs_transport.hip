@@ -25,7 +25,7 @@ static int launch_k34(fs_ctx *ctx, const char *name, const char *name_bnd, doubl
     // (below 1 M cells: 1-row tiles for the dye's three channels - a launch is one wave's chain there, fs_ctx::small_tiles; res 400: 17.6 against
     //  17.1 k steps/s with the dye; the velocity's pass stays on 2 rows: 29.0 against 28.1 k)
     const int RT = N == 4 ? 2 : (cells >= ((size_t)1 << 23) ? 4 : (small_tiles(ctx) && !full && C == 3 ? 1 : 2)), geo = N == 2 ? 3 : 4;
-#define FS_K34(NN, R, DM, PL) hipLaunchKernelGGL((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
+#define FS_K34(NN, R, DM, PL) FS_KLAUNCH((k_cip_grad_advect_n<C, NN, R, DM, PL, CLAMP, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, \
         (T *)f_out->d, (T *)gx_out->d, (T *)gy_out->d, (const T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, v ? (const T *)v->d : (const T *)nullptr, \
         f_out->hot, (const uint8_t *)ctx->d_bcmap, full)
 #define FS_K34_24(DM) FS_K34(2, 4, DM, false)
@@ -71,7 +71,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
             const int rt = sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2;
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_NONADV, 3, true, 0, 2);      // (reach: per-wave plain hints in the list)
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
-#define FS_K2MN(SS, RR, PP) hipLaunchKernelGGL((k_mac_update_n<SS, 2, RR, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K2MN(SS, RR, PP) FS_KLAUNCH((k_mac_update_n<SS, 2, RR, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
             (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot)
 #define FS_K2MN_UP4(DM) FS_K2MN(0, 4, DM)
 #define FS_K2MN_KK4(DM) FS_K2MN(1, 4, DM)
@@ -132,8 +132,8 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3, true, 0, 1);      // (reach 1: per-wave plain hints)
             const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
             return launch(ctx, "cip_nonadv", [=] {
-#define FS_K2N4(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
-#define FS_K2N2(DM) hipLaunchKernelGGL((k_cip_nonadv_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
+#define FS_K2N4(DM) FS_KLAUNCH((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
+#define FS_K2N2(DM) FS_KLAUNCH((k_cip_nonadv_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
                 if (small) FS_DMA(dm_all(ctx, k), FS_K2N2); else FS_DMA(dm_all(ctx, k), FS_K2N4);
             });
         }
@@ -155,8 +155,8 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
             const bool small = small_tiles(ctx);       // (2-row tiles, see fs_cip_nonadv)
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3, true, 0, 1);
             return launch(ctx, "cip_nonadv_dye", [=] {
-#define FS_K12N(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
-#define FS_K12N2(DM) hipLaunchKernelGGL((k_cip_nonadv_dye_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
+#define FS_K12N(DM) FS_KLAUNCH((k_cip_nonadv_dye_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
+#define FS_K12N2(DM) FS_KLAUNCH((k_cip_nonadv_dye_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
                 if (small) FS_DMA(dm_all(ctx, k), FS_K12N2); else FS_DMA(dm_all(ctx, k), FS_K12N);
             });
         }
@@ -164,7 +164,7 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
     })
 }
 
-#define FS_K3Q(CC, NC, PP) hipLaunchKernelGGL((k_cip_nonadv_grad_quad<CC, NC, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K3Q(CC, NC, PP) FS_KLAUNCH((k_cip_nonadv_grad_quad<CC, NC, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
             (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d)
 #define FS_K3(CC, PP, NAME) { FS_LAUNCH_CELLS(NAME, (k_cip_nonadv_grad<CC, PP, T>), ctx->grid(), k, row_begin, (T *)fxn->d, (T *)fyn->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)fc->d, (const T *)fn->d) }
 int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, const fs_field *fxc, const fs_field *fyc,
@@ -192,11 +192,11 @@ int fs_cip_nonadv_grad(fs_ctx *ctx, double dx, fs_field *fxn, fs_field *fyn, con
     })
 }
 
-#define FS_K4Q(CC, NC, SELF, PP) hipLaunchKernelGGL((k_cip_advect_quad<CC, NC, SELF, PP, false, T>), qgrid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K4Q(CC, NC, SELF, PP) FS_KLAUNCH((k_cip_advect_quad<CC, NC, SELF, PP, false, T>), qgrid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-#define FS_K4D(PP) hipLaunchKernelGGL((k_cip_advect_dye<PP, false, T>), qgrid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K4D(PP) FS_KLAUNCH((k_cip_advect_dye<PP, false, T>), qgrid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
-#define FS_K4N(CC, PP) hipLaunchKernelGGL((k_cip_advect<CC, PP, T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, \
+#define FS_K4N(CC, PP) FS_KLAUNCH((k_cip_advect<CC, PP, T>), cells_grid(ctx, row_begin, row_end), dim3(256), 0, ctx->stream, ctx->grid(), k, row_begin, \
         (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
 int fs_cip_advect(fs_ctx *ctx, double dt, double dx, fs_field *fn, fs_field *fxn, fs_field *fyn, const fs_field *fc,
                   const fs_field *fxc, const fs_field *fyc, const fs_field *v, int row_begin, int row_end)
@@ -239,7 +239,7 @@ int fs_cip_advect_dye_clamped(fs_ctx *ctx, double dt, double dx, fs_field *fn, f
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
         return launch(ctx, "cip_advect_c3_clamped", [=] {
-#define FS_K4DC(DM) hipLaunchKernelGGL((k_cip_advect_dye<DM, true, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K4DC(DM) FS_KLAUNCH((k_cip_advect_dye<DM, true, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                          (T *)fn->d, (T *)fxn->d, (T *)fyn->d, (const T *)fc->d, (const T *)fxc->d, (const T *)fyc->d, (const T *)v->d, fn->hot)
             FS_DMX(dm_dx(ctx, k), FS_K4DC);
         });
@@ -255,7 +255,7 @@ int fs_clamp_inflow(fs_ctx *ctx, double low, double high, fs_field *dye, int row
     if (ctx->ops_dye.lanes() == 0) return FS_OK;
     FS_DISPATCH(ctx, {
         return launch(ctx, "clamp_inflow", [=] {
-            hipLaunchKernelGGL(k_clamp_inflow<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
+            FS_KLAUNCH(k_clamp_inflow<T>, dim3((ctx->ops_dye.lanes() + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->grid(), ctx->ops_dye.view(), row_begin, row_end, (T)low, (T)high, (T *)dye->d);
         });
     })
@@ -294,10 +294,12 @@ int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
 int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *tile_rows, int *tile_cells)
 {
     FS_REQUIRE(ctx && plain && boundary && band && tile_rows && tile_cells, "null argument");
+    // (the one-launch form runs 2-row tiles below FS_SMALL_CELLS; the per-kind lists counted here are those of the two-launch form: 4-row tiles everywhere)
     *plain = *boundary = *band = 0; *tile_rows = 4; *tile_cells = 120;
     if (!cip_step_multi_part(ctx) || ctx->capturing || ctx->tape_rec) return FS_OK;
-    const OvGrid ogp = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 1, 2, 1);
-    const OvGrid ogb = ov_grid_lanes(ctx, 0, ctx->rows, 4, 1, XCD_ADVECT, 2, true, 2, 2, 1);
+    if (ctx->fuse_k2 >= 2 && small_tiles(ctx)) *tile_rows = 2;
+    const OvGrid ogp = ov_grid_lanes(ctx, 0, ctx->rows, *tile_rows, 1, XCD_ADVECT, 2, true, 1, 2, 1);
+    const OvGrid ogb = ov_grid_lanes(ctx, 0, ctx->rows, *tile_rows, 1, XCD_ADVECT, 2, true, 2, 2, 1);
     for (const auto &kv : ctx->tile_lists) {
         if (!kv.second.d) continue;
         if (kv.second.d == ogp.g.tiles) *plain = kv.second.count;
@@ -308,7 +310,8 @@ int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *ti
 
 // K2 + K3 + K4 of the velocity (fs/solver.py:213-227) as ONE call: fs_cip_nonadv(fn <- fc, pc) followed by fs_cip_grad_advect(v_out, gx_out,
 // gy_out <- fn, fc, gxc, gyc) - with the one difference that the fluid cells of fn that nothing reads before the next kernel rewrites them
-// are NOT stored where the form below applies (f32 grids from 1 M cells; fs_k234.h): every tile evaluates K2 in registers on the way to K3 + K4 -
+// are NOT stored where the form below applies (f32, even X, wherever the launch lists exist - cip_step_multi_part above: every grid size unless
+// FS_FUSE_K2_CELLS raises the threshold; fs_k234.h): every tile evaluates K2 in registers on the way to K3 + K4 -
 // ONE launch over the list of all tiles, whose entries say which body a tile takes (k_cip_step_all: all fluid within reach / masks, K2 stored
 // on inflow / outflow cells).  FS_FUSE_K2=1: the two bodies as two launches over the two classes (k_cip_step_plain, k_cip_step_bnd: the form
 // of bench.py's per-part roofline).  fs_cip_step_ok: the static conditions (the kernel names of a profile say what ran).
@@ -326,10 +329,13 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
     // (a slab - halo != 0: any row range; K2 is then evaluated for the rows within 2 of the range from rows within 3 of it, which the caller keeps
     //  valid - fs/runtime.py cip_step - where the two calls would read what an earlier K2 launch left in fn.  Single GPU: the whole grid.)
     const bool slab = ctx->halo != 0;
-    if (cip_step_multi_part(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
+    // (K2 in registers reads rows row_begin - 3 .. row_end + 2 of fc and pc through clampy(), which clamps to the DOMAIN's edge rows, not to the
+    //  slab buffer: a range closer than 3 rows to the buffer's end that is not the domain's edge takes the two-call form below, whose K2 launch has its own range)
+    const bool rows_ok = !slab || ((row_begin >= 3 || ctx->y0 - ctx->halo + row_begin <= 0) && (row_end + 3 <= ctx->rows || ctx->y0 - ctx->halo + row_end >= ctx->Y));
+    if (cip_step_multi_part(ctx) && !full && rows_ok && (slab || (row_begin == 0 && row_end == ctx->rows))) {
         auto k = make_konst<T>(ctx, dt, dx, re);
         const int dm = dm_all(ctx, k);
-#define FS_K234(KERNEL, DM) hipLaunchKernelGGL((KERNEL<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K234(KERNEL, DM) FS_KLAUNCH((KERNEL<RT, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
 #define FS_K234A(DM) FS_K234(k_cip_step_all, DM)
 #define FS_K234P(DM) FS_K234(k_cip_step_plain, DM)
@@ -339,7 +345,7 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
             // (grids below FS_SMALL_CELLS: 2-row tiles - a launch there lasts as long as one wave's chain, fs_launch.h small_tiles)
             if (small_tiles(ctx)) {
                 const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
-#define FS_K234A2(DM) hipLaunchKernelGGL((k_cip_step_all<2, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K234A2(DM) FS_KLAUNCH((k_cip_step_all<2, DM>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
                 if (oga.g.tiles) return launch(ctx, "cip_step", [=] { const OvGrid og = oga; FS_DMA(dm, FS_K234A2); });
             }
@@ -391,12 +397,13 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
     if (ctx->dtype != 0) { set_error("the fused dye pass exists for f32 (f64: the two-kernel form)"); return FS_ERR_UNSUPPORTED; }
     using T = float;
     constexpr int RT = 4;
-    const bool slab = ctx->halo != 0;      // (as fs_cip_step)
-    if (cip_step_multi_part(ctx) && !full && (slab || (row_begin == 0 && row_end == ctx->rows))) {
+    const bool slab = ctx->halo != 0;      // (as fs_cip_step, its row condition included)
+    const bool rows_ok = !slab || ((row_begin >= 3 || ctx->y0 - ctx->halo + row_begin <= 0) && (row_end + 3 <= ctx->rows || ctx->y0 - ctx->halo + row_end >= ctx->Y));
+    if (cip_step_multi_part(ctx) && !full && rows_ok && (slab || (row_begin == 0 && row_end == ctx->rows))) {
         auto k = make_konst<T>(ctx, dt, dx, re);
         const int dm = dm_all(ctx, k);
         // k_cip_dye<RT, DM, CLAMP, KIND> over a list: KIND 1 - the all-fluid tiles, 2 - the others, 0 - both (class 0 list with the per-tile hint)
-#define FS_KD(DM, CL, KIND) hipLaunchKernelGGL((k_cip_dye<RT, DM, CL, KIND>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_KD(DM, CL, KIND) FS_KLAUNCH((k_cip_dye<RT, DM, CL, KIND>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
 #define FS_KD_C0(DM) FS_KD(DM, true, 0)
 #define FS_KD_N0(DM) FS_KD(DM, false, 0)
@@ -407,7 +414,7 @@ int fs_cip_step_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *d_ou
         if (ctx->fuse_k2 >= 2) {
             if (small_tiles(ctx)) {      // (2-row tiles, as fs_cip_step)
                 const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, 2, 3, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
-#define FS_KD2(DM, CL) hipLaunchKernelGGL((k_cip_dye<2, DM, CL, 0>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_KD2(DM, CL) FS_KLAUNCH((k_cip_dye<2, DM, CL, 0>), og.grid, dim3(64), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
         (T *)d_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)gxc->d, (const T *)gyc->d, (const T *)v->d)
 #define FS_KD2_C(DM) FS_KD2(DM, true)
 #define FS_KD2_N(DM) FS_KD2(DM, false)
@@ -477,10 +484,10 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
         const int dm = dm_dx(ctx, k);
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
         const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
-#define FS_VORTN(DM, ST) hipLaunchKernelGGL((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
+#define FS_VORTN(DM, ST) FS_KLAUNCH((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
 #define FS_VORTN_S(DM) FS_VORTN(DM, true)
 #define FS_VORTN_N(DM) FS_VORTN(DM, false)
-#define FS_VORTN_2(DM) hipLaunchKernelGGL((k_vort_n<2, 2, DM, false, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
+#define FS_VORTN_2(DM) FS_KLAUNCH((k_vort_n<2, 2, DM, false, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
         return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORTN_S); else if (small) FS_DMX(dm, FS_VORTN_2); else FS_DMX(dm, FS_VORTN_N); });
     })
 }

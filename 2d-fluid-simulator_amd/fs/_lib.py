@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libfs_hip.so")     # FS_LIB: A/B builds (tools/)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -84,6 +84,7 @@ _PROTOS = {
     "fs_vis_pressure": [_c_vp, _c_vp, _c_vp] + _ROWS,
     "fs_vis_vorticity": [_c_vp, _c_dbl, _c_vp, _c_vp] + _ROWS,
     "fs_vis_dye": [_c_vp, _c_vp, _c_vp] + _ROWS,
+    "fs_comm_available": [_P(_c_int)],
     "fs_comm_unique_id": [_c_vp],
     "fs_comm_init": [_c_vp, _c_int, _c_int, _c_vp],
     "fs_comm_destroy": [_c_vp],
@@ -117,6 +118,7 @@ _PROTOS = {
     "fs_prof_reset": [_c_vp],
     "fs_prof_count": [_c_vp, _P(_c_int)],
     "fs_prof_get": [_c_vp, _c_int, ctypes.c_char_p, _c_int, _P(_c_int), _P(_c_dbl)],
+    "fs_prof_kernels": [_c_vp, ctypes.c_char_p, ctypes.c_char_p, _c_int, _P(_c_int)],
 }
 EXPORTS = sorted(list(_PROTOS) + ["fs_last_error"])
 

@@ -92,7 +92,40 @@ class FileRendezvous:
         with open(path, "rb") as f:
             return f.read()
 
+    def preflight(self, ok, message="", timeout=None):
+        """Every rank reports whether it can run (its GPU is visible, librccl loads, ...) BEFORE anything blocks in ncclCommInitRank: a
+        status file per rank next to the rendezvous files; every rank waits for all of them and gets the list of failure messages (empty =
+        go).  A rank that never reports counts as failed after `timeout` seconds (default: the rendezvous timeout)."""
+        timeout = self.timeout if timeout is None else timeout
+        mine = f"{self.base.replace('fs_rdzv_', 'fs_pre_', 1)}_{self.rank}"
+        self._pre = mine
+        tmp = mine + ".tmp"
+        with open(tmp, "w") as f:
+            f.write("ok" if ok else (message or "failed"))
+        os.replace(tmp, mine)
+        failures, t0 = [], time.time()
+        for r in range(self.world):
+            path = f"{self.base.replace('fs_rdzv_', 'fs_pre_', 1)}_{r}"
+            while True:
+                try:
+                    if os.path.getmtime(path) >= self.t_valid:
+                        txt = open(path).read()
+                        if txt != "ok":
+                            failures.append(txt)
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout:
+                    failures.append(f"rank {r} did not report within {timeout:.0f} s")
+                    break
+                time.sleep(0.01)
+        return failures
+
     def cleanup(self):
+        try:
+            os.remove(getattr(self, "_pre", ""))
+        except OSError:
+            pass
         if self.rank == 0:
             for k in range(self.calls):
                 try:

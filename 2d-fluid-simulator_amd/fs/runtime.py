@@ -1118,6 +1118,13 @@ class Device(DeviceBase):
             out[name.value.decode()] = (launches.value, ms.value)
         return out
 
+    def profile_kernels(self, name):
+        """The __global__ functions launched under profile name `name` since profiling was switched on, demangled without their signature
+        ("fs::k_jacobi_ov2<4, 4>"): the names a rocprofv3 --kernel-trace of the same run shows (fs_prof_kernels)."""
+        buf, n = ctypes.create_string_buffer(4096), ctypes.c_int()
+        _lib.call("fs_prof_kernels", self._ctx, name.encode(), buf, 4096, ctypes.byref(n))
+        return [l for l in buf.value.decode().split("\n") if l]
+
     def close(self):
         if self._ctx is not None:
             ctx, self._ctx = self._ctx, None

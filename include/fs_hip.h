@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 8
+#define FS_ABI_VERSION 9
 
 typedef struct fs_ctx fs_ctx;
 typedef struct fs_field fs_field;
@@ -277,6 +277,9 @@ int fs_vis_dye(fs_ctx *ctx, fs_field *rgb, const fs_field *dye, int row_begin, i
 
 /* ---- multi-GPU: y-slab halo exchange over RCCL (new; the reference is single-device) ---------- */
 #define FS_UNIQUE_ID_BYTES 128
+/* librccl loads and exports what the exchange needs (*ok; no GPU call): the pre-flight check of an N > 1 job, before any rank can block in
+ * ncclCommInitRank.  *ok = 0: the reason is in fs_last_error(). */
+int fs_comm_available(int *ok);
 int fs_comm_unique_id(void *out_128_bytes);
 int fs_comm_init(fs_ctx *ctx, int rank, int nranks, const void *unique_id_128_bytes);
 int fs_comm_destroy(fs_ctx *ctx);
@@ -296,10 +299,10 @@ int fs_halo_exchange_begin_partial(fs_ctx *ctx, fs_field *const *fields, const i
 int fs_halo_exchange_wait(fs_ctx *ctx);
 /* Optional, before begin(): the exchange will depend on the compute stream as of NOW - kernels launched between mark() and
  * begin() (same restrictions as above) are already running while the host still issues the exchange.                     */
+int fs_halo_exchange_mark(fs_ctx *ctx);
 /* Exchanges in line on the compute stream (0, default) or on the communication stream (1: overlappable; FS_OVERLAP=1 at fs_comm_init).  Same
  * bits either way; a tape recorded under one setting is replayed under it. */
 int fs_comm_set_overlap(fs_ctx *ctx, int on);
-int fs_halo_exchange_mark(fs_ctx *ctx);
 /* Loop-back self-test on a 1-rank communicator: the rank is its own lower and upper neighbour, so afterwards
  * lower ghost rows == first owned rows and upper ghost rows == last owned rows (single-GPU check of the RCCL leg).
  * fs_comm_loopback(ctx, 1) makes every later exchange of a 1-rank communicator behave that way.                          */
@@ -348,6 +351,10 @@ int fs_span_end(fs_ctx *ctx, double *ms);
 int fs_prof_reset(fs_ctx *ctx);
 int fs_prof_count(fs_ctx *ctx, int *n);           /* number of distinct kernels seen (syncs)       */
 int fs_prof_get(fs_ctx *ctx, int idx, char *name, int name_cap, int *launches, double *total_ms);
+/* The __global__ functions launched under profile name `name` since fs_prof_enable, demangled ("fs::k_jacobi_ov2<4, 4>"), one per line in
+ * `out` (may be null), their number in *n: what a rocprofv3 --kernel-trace of the same run lists.  bench.py names the kernels it prices
+ * from here instead of from string literals. */
+int fs_prof_kernels(fs_ctx *ctx, const char *name, char *out, int capacity, int *n);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the GPU suite (the driver runs `pytest -m gpu -x -q`: the first failure ends the run).  Parity evidence first, in the
+# order of SURVEY.md 8c's chain - per-kernel golden vectors, golden trajectories, the fast launch forms against each other and the oracle,
+# the BASELINE sizes, fuzzing, slabs / RCCL - and LAST the tests that start bench.py / the CLI as subprocesses (slow, and about the format of
+# a report rather than about a value a kernel computed).  Unlisted modules keep their alphabetical place in the middle.
+_ORDER = ["test_gpu_kernels", "test_gpu_traj", "test_gpu_cip_step", "test_gpu_rbpair", "test_gpu_jquad", "test_gpu_variants",
+          "test_gpu_limit_gate", "test_gpu_lazy_bc", "test_gpu_odd_res", "test_gpu_random_masks", "test_vis", "test_f64div",
+          "test_gpu_errors", "test_gpu_graph", "test_deferred_passes", "test_gpu_fullsize", "test_gpu_fuzz",
+          "test_gpu_slab_threads", "test_gpu_rccl_loopback", "test_gpu_rccl_overlap"]
+_LAST = ["test_cli", "test_gpu_bench_multirank"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if mod in _ORDER:
+            return _ORDER.index(mod)
+        if mod in _LAST:
+            return 1000 + _LAST.index(mod)
+        return 500
+    items.sort(key=rank)      # (stable: the order inside a module stays)
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name))
 

@@ -123,3 +123,59 @@ def run_default_halo(rank, world, port, res, out_dir):
             f.write(f"{len(bad)} {sorted(set(h for h, _ in halos))} {sorted(set(n for _, n in halos))}\n")
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_scene(rank, world, port, bc, res, scheme, vc, updater, halo, steps, tape, out_dir):
+    """A reference scene at (bc, res) cut into `world` slabs (halo None: the default depth), `steps` steps eagerly - or, with `tape`, a logged
+    period replayed as bench.py's N > 1 timed loop does - against the single-domain ORACLE run (no golden file needed: the 4- and 8-way cuts
+    of BASELINE configs[3]'s scene, bc2 CIP + VC, at res 64 / 128)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    here = os.path.dirname(os.path.abspath(__file__))
+    repo = os.path.dirname(here)
+    for p in (repo, os.path.join(repo, "2d-fluid-simulator_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fs
+    from fs.boundary_condition import create_scene_arrays
+    from oracle import oracle as O
+    from oracle_device import OracleSlabDevice
+
+    def allgather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    dt, dx, re = 0.05 / res, 1.0 / res, 1.0e6
+    fs.runtime.init(dtype="f32", rank=rank, nranks=world, halo=halo, allgather=allgather, device_cls=OracleSlabDevice)
+    sim = fs.FluidSimulator.create(bc, res, dt, dx, re, vc, scheme, pressure_updater=updater)
+    dev = sim._solver._bc.device
+    total = 0
+    period = 0
+    if tape:
+        done = [0]
+
+        def counted():
+            sim.step()
+            done[0] += 1
+        t = dev.tape_period(counted, nsteps=2)
+        assert t is not None, "no steady period found"
+        period = t["nsteps"]
+        dev.replay_tape(t, 2)
+        total = done[0] + 2 * t["nsteps"]
+    for _ in range(steps):
+        sim.step()
+    total += steps
+    out = sim.field_to_numpy()
+    geo = allgather((dev.halo, dev.nyl))
+    if rank == 0:
+        const, mask, _ = create_scene_arrays(bc, res)
+        ref = O.make_simulator(const, mask, None, scheme=scheme, dt=dt, dx=dx, re=re, vor_eps=vc, updater=updater or ("rbsor", 1.3, 2))
+        for _ in range(total):
+            ref.update()
+        bad = [k for k, e in ref.fields().items() if not np.array_equal(out[k], e, equal_nan=True)]
+        with open(os.path.join(out_dir, "result.txt"), "w") as f:
+            f.write(f"{len(bad)} {total} {period} {dev.n_exchanges / total:.2f} {sorted(set(h for h, _ in geo))} {sorted(set(n for _, n in geo))}\n")
+    dist.barrier()
+    dist.destroy_process_group()

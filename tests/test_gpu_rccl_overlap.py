@@ -115,8 +115,7 @@ def test_tape_replay_equals_eager(res, halo, scheme, updater, hip_lib):
 
 def test_the_run_chooses_its_exchange_mode(hip_lib):
     """bench.py's N > 1 start (DeviceBase.choose_exchange_mode): the period is recorded and replayed in line and on the communication stream,
-    the faster mode stays - in loop-back, where the RCCL kernel competes with the compute kernels for the same CUs, that is the in-line form -
-    and the state afterwards is the state of eager stepping through the same number of steps."""
+    one of the two modes stays (the timing decides; either is correct) and the state afterwards is the state of eager stepping through the same number of steps."""
     import fs
     from fs.boundary_condition import BoundaryCondition, create_scene_arrays
     res, halo = 1024, 16
@@ -136,8 +135,11 @@ def test_the_run_chooses_its_exchange_mode(hip_lib):
         done[0] += 1
     tape, rep = dev.choose_exchange_mode(counted, record_tries=20, trial_steps=48)
     assert tape is not None and rep["in_line_us_per_step"] and rep["overlapped_us_per_step"], rep
-    assert rep["chosen"].startswith("in line"), rep          # (loop-back: measured 119 against 139 us per step at the headline size)
-    assert not dev.overlap and not dev.overlap_stream
+    # WHICH mode wins is a measurement (loop-back: 119 against 139 us per step at the headline size), not a property of the code: the test
+    # asserts only that one of the two was kept and that the device's settings are those of the mode the report names
+    mode = rep["chosen"].split()[0]
+    assert mode in ("in", "overlapped"), rep
+    assert bool(dev.overlap) == bool(dev.overlap_stream) == (mode == "overlapped"), (rep, dev.overlap, dev.overlap_stream)
     dev.replay_tape(tape, 2)
     steps = done[0] + rep["replayed_steps"] + 2 * tape["nsteps"]
     got = {n: getattr(solver, n).current.local_window() for n in ("v", "p", "vx", "vy")}

@@ -142,3 +142,50 @@ def test_bench_starts_its_own_ranks(tmp_path, monkeypatch, capfd):
     monkeypatch.setenv("FS_BENCH_TIMEOUT", "2")
     t0 = time.time()
     assert bench.spawn_ranks(2) == 124 and time.time() - t0 < 30
+
+
+def _preflight_rank(rank, world, key, ok, q):
+    from fs.rendezvous import FileRendezvous
+    r = FileRendezvous(rank, world, key=key, timeout=30)
+    q.put((rank, r.preflight(ok, "" if ok else f"rank {rank}: LOCAL_RANK {rank} but 1 GPU(s) visible", timeout=20)))
+    # (no cleanup here: a rank's status file must outlive the slowest reader - bench.py removes it at the end of a run, after the barriers)
+
+
+def test_preflight_every_rank_learns_every_verdict(tmp_path, monkeypatch):
+    """bench.py --gpus N, before ncclCommInitRank: each rank reports whether its GPU exists and librccl loads; every rank gets the
+    list of failures (empty = go) - nobody is left waiting for a peer that already gave up.  A rank that never reports is a failure too."""
+    import multiprocessing as mp
+    monkeypatch.setenv("FS_RDZV_DIR", str(tmp_path))
+    os.chmod(tmp_path, 0o700)
+    ctx = mp.get_context("fork")
+    for verdicts in ([True, True, True], [True, False, True]):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_preflight_rank, args=(r, 3, f"pf{sum(verdicts)}", verdicts[r], q)) for r in range(3)]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=60) for _ in procs)
+        for p in procs:
+            p.join(timeout=30)
+        expect = [] if all(verdicts) else ["rank 1: LOCAL_RANK 1 but 1 GPU(s) visible"]
+        assert all(got[r] == expect for r in range(3)), got
+    from fs.rendezvous import FileRendezvous
+    lone = FileRendezvous(0, 2, key="pf_lone", timeout=30)
+    failures = lone.preflight(True, timeout=0.5)
+    assert len(failures) == 1 and failures[0].startswith("rank 1 did not report"), failures
+    lone.cleanup()
+
+
+def test_bench_parent_refuses_more_ranks_than_gpus(monkeypatch, capfd):
+    """`python bench.py --gpus N` on a node with fewer GPUs: rc != 0 and ONE stderr line, no rank started (the GPUs are counted from the
+    KFD topology - the parent never makes a HIP call)."""
+    import sys
+    bench = _bench_module()
+    monkeypatch.delenv("FS_BENCH_LOCAL_RANK", raising=False)
+    monkeypatch.setattr(bench, "visible_gpus_without_hip", lambda: 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    assert bench.spawn_ranks(8) == 2
+    err = capfd.readouterr().err.strip().splitlines()
+    assert len(err) == 1 and "--gpus 8 but 1 GPU(s) visible" in err[0]
+    assert bench.visible_gpus_without_hip.__name__ == "<lambda>"
+    n = _bench_module().visible_gpus_without_hip()       # the real counter: None without a KFD topology (this container), else a count >= 1
+    assert n is None or n >= 1
