@@ -97,7 +97,9 @@ class FileRendezvous:
         status file per rank next to the rendezvous files; every rank waits for all of them and gets the list of failure messages (empty =
         go).  A rank that never reports counts as failed after `timeout` seconds (default: the rendezvous timeout)."""
         timeout = self.timeout if timeout is None else timeout
-        mine = f"{self.base.replace('fs_rdzv_', 'fs_pre_', 1)}_{self.rank}"
+        d, b = os.path.split(self.base)
+        pre = os.path.join(d, "fs_pre_" + b[len("fs_rdzv_"):])      # (next to the rendezvous files, outside the pattern rank 0 clears at start-up)
+        mine = f"{pre}_{self.rank}"
         self._pre = mine
         tmp = mine + ".tmp"
         with open(tmp, "w") as f:
@@ -105,7 +107,7 @@ class FileRendezvous:
         os.replace(tmp, mine)
         failures, t0 = [], time.time()
         for r in range(self.world):
-            path = f"{self.base.replace('fs_rdzv_', 'fs_pre_', 1)}_{r}"
+            path = f"{pre}_{r}"
             while True:
                 try:
                     if os.path.getmtime(path) >= self.t_valid:

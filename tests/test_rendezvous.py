@@ -189,3 +189,15 @@ def test_bench_parent_refuses_more_ranks_than_gpus(monkeypatch, capfd):
     assert bench.visible_gpus_without_hip.__name__ == "<lambda>"
     n = _bench_module().visible_gpus_without_hip()       # the real counter: None without a KFD topology (this container), else a count >= 1
     assert n is None or n >= 1
+
+
+def test_preflight_files_live_next_to_the_rendezvous_files(monkeypatch):
+    """Round 6, first GPU lease: the status file's name was derived by replacing 'fs_rdzv_' in the whole PATH - with the default directory
+    /tmp/fs_rdzv_<uid> that renamed the directory.  Default directory, one rank."""
+    from fs.rendezvous import FileRendezvous
+    monkeypatch.delenv("FS_RDZV_DIR", raising=False)
+    r = FileRendezvous(0, 1, key="pf_default_dir")
+    assert r.preflight(True, timeout=5) == []
+    assert os.path.dirname(r._pre) == os.path.dirname(r.base) and os.path.basename(r._pre).startswith("fs_pre_") and os.path.exists(r._pre)
+    r.cleanup()
+    assert not os.path.exists(r._pre)
