@@ -966,7 +966,8 @@ int fs_velocity_bc_limit_ok(const fs_ctx *ctx, int *ok)
     FS_REQUIRE(ctx && ok, "null argument");
     const int wgs = (ctx->ops_vel.lanes() + 255) / 256;
     // every workgroup resident (the grid barrier of the rare path): the launch has max(wgs, <= 64) workgroups, the device holds barrier_wgs at once
-    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && ctx->d_bc_const && wgs >= 1 && std::max(wgs, 64) <= ctx->barrier_wgs ? 1 : 0;
+    // (use_pairs: every `res` - the limit pass walks the rows in quads and stops at the row's width, fs_march.h limit_pass_and_barrier)
+    *ok = ctx->mask_set && ctx->use_pairs && ctx->limit_gate && ctx->d_sync && ctx->d_bc_const && wgs >= 1 && std::max(wgs, 64) <= ctx->barrier_wgs ? 1 : 0;
     return FS_OK;
 }
 
@@ -1026,7 +1027,7 @@ int fs_dye_bc_limit_ok(const fs_ctx *ctx, int *ok)
 {
     FS_REQUIRE(ctx && ok, "null argument");
     const int wgs = (ctx->ops_dye.lanes() + 255) / 256;
-    *ok = ctx->mask_set && ctx->use_march && ctx->limit_gate && ctx->d_sync && ctx->d_bc_dye && wgs >= 1 && std::max(wgs, 64) <= ctx->barrier_wgs ? 1 : 0;
+    *ok = ctx->mask_set && ctx->use_pairs && ctx->limit_gate && ctx->d_sync && ctx->d_bc_dye && wgs >= 1 && std::max(wgs, 64) <= ctx->barrier_wgs ? 1 : 0;
     return FS_OK;
 }
 
@@ -1288,12 +1289,12 @@ int fs_limit_field(fs_ctx *ctx, double limit, fs_field *v, int row_begin, int ro
     FS_FIELD(v, 2);
     FS_ROWS();
     FS_DISPATCH(ctx, {
-        if (ctx->use_march) {
+        if (ctx->use_pairs) {      // (any even width: the quads stop at the row's width)
             // gated by the buffer's "hot" flag (fs_device.h): while no writer has stored a speed above 9.95 the pass has nothing to do
             const int gated = (T)limit * (T)limit > (T)FS_HOT_GATE_SQ && ctx->limit_gate ? 1 : 0;
             const int lanes = std::min(row_end - row_begin, 256);
             return launch(ctx, "limit_field", [=] {
-                FS_KLAUNCH((k_limit_quad<T>), dim3((ctx->X / 4 + 255) / 256, lanes), dim3(256), 0, ctx->stream,
+                FS_KLAUNCH((k_limit_quad<T>), dim3(((ctx->X + 3) / 4 + 255) / 256, lanes), dim3(256), 0, ctx->stream,
                                    ctx->grid(), row_begin, row_end, (T)limit, (T *)v->d, v->hot, gated);
             });
         }

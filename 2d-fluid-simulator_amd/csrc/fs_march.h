@@ -855,6 +855,7 @@ __global__ __launch_bounds__(256) void k_limit_quad(Grid g, int jb, int je, T li
         const Q4<T> X(*reinterpret_cast<const typename Quad<T>::type *>(px)), Y(*reinterpret_cast<const typename Quad<T>::type *>(py));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (i0 + q >= g.X) break;        // (odd res: the last quad of a row ends in the row's padding)
             const T x = X.a[q], y = Y.a[q];
             const T nrm = tsqrt(x * x + y * y);
             if (nrm > lim) {
@@ -893,6 +894,7 @@ __device__ __forceinline__ void limit_pass_and_barrier(const Grid &g, int lb, in
             const Q4<T> X(*reinterpret_cast<const typename Quad<T>::type *>(px)), Y(*reinterpret_cast<const typename Quad<T>::type *>(py));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (i0 + q >= g.X) break;            // (X = 2 res: a multiple of 4 for even res; at odd res the last quad of a row holds 2 cells + 2 of the row's padding)
                 const T x = X.a[q], y = Y.a[q];
                 const T nrm = tsqrt(x * x + y * y);
                 if (nrm > lim) {

@@ -54,7 +54,9 @@ int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_fi
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        if (ctx->use_march) return launch_jacobi<false, T>(ctx, "jacobi_sweep", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
+        // (odd res - X = 2 res not a multiple of 4: the f32 sweep on packed lanes of 2 cells needs an even width only, fs_jquad.h k_jacobi_ov2)
+        if (ctx->use_march || (ctx->use_pairs && std::is_same<T, float>::value && ctx->jacobi_variant == 0))
+            return launch_jacobi<false, T>(ctx, "jacobi_sweep", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
         FS_LAUNCH_CELLS("jacobi_sweep", (k_jacobi<false, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
     })
 }
