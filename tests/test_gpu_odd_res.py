@@ -89,17 +89,16 @@ def test_odd_resolution_literal_jacobi_sweeps_on_pair_lanes(res, hip_lib):
     ref = O.make_simulator(const, mask, None, scheme="cip", dt=dt, dx=dx, re=re, vor_eps=vc, updater=("jacobi", 4))
     try:
         dev.profile(True)
-        for step in range(6):
+        for step in range(6):      # (no download in between: a download makes a deferred limit pass run as its own launch first)
             sim.step()
             ref.update()
-            out = sim.field_to_numpy()
-            for name, e in ref.fields().items():
-                assert np.array_equal(out[name], e, equal_nan=True), f"res {res} step {step + 1} {name}"
         names = set(dev.profile_report())
         ks = dev.profile_kernels("jacobi_sweep")
         assert ks and all(k.startswith("fs::k_jacobi_ov2<") for k in ks), ks
-        assert "limit_field" not in names or dev.profile_report()["limit_field"][0] <= 6, names      # (field_to_numpy flushes a deferred pass: one per download at most)
-        assert "fs::k_velocity_bc_limit<float>" in dev.profile_kernels("velocity_bc"), dev.profile_kernels("velocity_bc")
+        assert "limit_field" not in names and "fs::k_velocity_bc_limit<float>" in dev.profile_kernels("velocity_bc"), (names, dev.profile_kernels("velocity_bc"))
+        out = sim.field_to_numpy()
+        for name, e in ref.fields().items():
+            assert np.array_equal(out[name], e, equal_nan=True), f"res {res} after 6 steps: {name}"
     finally:
         dev.close()
 
