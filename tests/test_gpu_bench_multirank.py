@@ -95,6 +95,7 @@ def test_bench_line_contract_with_the_large_grid_step(hip_lib):
     parity incl. the graded sweep's values.  Structure and membership only: no assertion here compares two measured times."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["FS_RBPAIR_SPLIT"] = "2"
+    env["FS_SMALL_CELLS"] = "0"          # (below 2 M cells the pair and fs_cip_step run 2-row tiles in one launch: the big grids' tile heights here)
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--res", "512", "--bc", "2", "--steps", "12", "--warmup", "4", "--sweeps", "20",
                           "--cpu-seconds", "2", "--roofline-kernel", "cip_step"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
