@@ -130,6 +130,7 @@ __device__ __forceinline__ v2f f64div(v2f x, v2d rd) { return __builtin_convertv
 template <int DM> __device__ __forceinline__ v2f xdiv(v2f x, v2f d, v2f inv_d, v2d rd) { return (DM & DM_P2) ? x * inv_d : ((DM & DM_F64) ? f64div(x, rd) : x / d); }
 template <int DM> __device__ __forceinline__ v2f xdiv(v2f x, float d, float inv_d, double rd)
 { return (DM & DM_P2) ? x * inv_d : ((DM & DM_F64) ? f64div(x, (v2d)rd) : x / d); }
+template <int DM> __device__ __forceinline__ v2f cdiv(v2f x, float d, double rd) { return (DM & DM_F64) ? f64div(x, (v2d)rd) : x / d; }
 
 template <typename T> __device__ __forceinline__ T tmin(T a, T b);
 template <typename T> __device__ __forceinline__ T tmax(T a, T b);

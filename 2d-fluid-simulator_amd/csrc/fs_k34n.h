@@ -679,6 +679,109 @@ __global__ __launch_bounds__(256) void k_vort_n(Grid g, Konst<T> k, int nbx, int
 // K2'  MacSolver._update_velocities (fs/solver.py:94-107) on lanes of N cells, tiles of RT rows: upwind (fs/advection.py:12-24, +-1
 // stencil) or Kawamura-Kuwahara (fs/advection.py:27-60, +-2 stencil: two DPP hops give the two cells left / right of the lane's).
 // ------------------------------------------------------------------------------------------------
+#ifndef FS_MAC_PK
+#define FS_MAC_PK 1        // f32 lanes of 2 cells: the packed body below (0: the scalar body; A/B)
+#endif
+// The same update with the lane's two cells as ONE packed operand (round 6; f32, N = 2): every mul / add / sub of the advection sums, the Laplacian
+// and the pressure gradient is one v_pk_* for both cells; the Kawamura-Kuwahara weights are chosen per cell by the sign of the advecting component
+// ONCE per row for both velocity components (five selects per direction and cell instead of per component); the division by Re stays per half.
+// Same expression tree and operation order per cell as the scalar body (fs/advection.py:12-24, 27-60; fs/solver.py:94-107): the same bits.
+template <int SCHEME, int RT, int DM>
+__device__ __forceinline__ void mac_update_pk_tile(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je, const unsigned (&fl)[RT],
+                                                   float *vn, const float *vc, const float *pc, unsigned *hot)
+{
+    using T = float;
+    constexpr int N = 2, R = SCHEME == 0 ? 1 : 2;
+    v2f V[2][RT + 2 * R], P[RT + 2];                // slot u of V <-> row j0 - R + u, slot u of P <-> row j0 - 1 + u
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int u = 0; u < RT + 2 * R; ++u) V[c][u] = pk(lv_field<2, T, N>(vc, g, c, i0, clampy(g, j0 - R + u)));
+#pragma unroll
+    for (int u = 0; u < RT + 2; ++u) P[u] = pk(lv_field<1, T, N>(pc, g, 0, i0, clampy(g, j0 - 1 + u)));
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int j = j0 + t;
+        if (j >= je) break;
+        const v2f ux = V[0][t + R], uy = V[1][t + R];
+        const T pl = lv_left<T, N>(lm, unpk(P[t + 1])), pr = lv_right<T, N>(lm, unpk(P[t + 1]));
+        v2f fE[2], fW[2], adv[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            // the cells left / right of the lane's (sample()-clamped at the domain edge)
+            const LV<T, N> row = unpk(V[c][t + R]);
+            fE[c] = east(V[c][t + R], lv_right<T, N>(lm, row));
+            fW[c] = west(lv_left<T, N>(lm, row), V[c][t + R]);
+        }
+        if (SCHEME == 0) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const v2f f0 = V[c][t + R];
+                const v2f ax = ux * xdiv<DM>(sel_neg(ux, fE[c] - f0, f0 - fW[c]), k.dx, k.inv_dx, k.r_dx);
+                const v2f ay = uy * xdiv<DM>(sel_neg(uy, V[c][t + R + 1] - f0, f0 - V[c][t + R - 1]), k.dx, k.inv_dx, k.r_dx);
+                adv[c] = ax + ay;
+            }
+        } else {
+            // weights by the sign of the advecting component (fs/advection.py:36-44, 50-58): the x-sums of both components, then the y-sums - ten weights live at a time
+            const v2f wn[5] = {v2f{-2.f, -2.f}, v2f{10.f, 10.f}, v2f{-9.f, -9.f}, v2f{2.f, 2.f}, v2f{-1.f, -1.f}};
+            const v2f wp[5] = {v2f{1.f, 1.f}, v2f{-2.f, -2.f}, v2f{9.f, 9.f}, v2f{-10.f, -10.f}, v2f{2.f, 2.f}};
+            v2f a[2], b[2];
+            {
+                v2f w[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) w[i] = sel_neg(ux, wn[i], wp[i]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const LV<T, N> row = unpk(V[c][t + R]);
+                    // two cells out: BOTH clamped onto the edge cell at the domain's first / last column
+                    T l2 = lane_prev(row.a[0]); if (lm.at_lo) l2 = row.a[0];
+                    T r2 = lane_next(row.a[1]); if (lm.at_hi) r2 = row.a[1];
+                    const v2f fEE = v2f{fE[c].y, r2}, fWW = v2f{l2, fW[c].x};
+                    v2f acc = fEE * w[0];
+                    acc = acc + fE[c] * w[1]; acc = acc + V[c][t + R] * w[2]; acc = acc + fW[c] * w[3]; acc = acc + fWW * w[4];
+                    a[c] = cdiv<DM>(acc, k.six_dx, k.r_six_dx);
+                }
+            }
+            {
+                v2f w[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) w[i] = sel_neg(uy, wn[i], wp[i]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    v2f acc = V[c][t + 2 * R] * w[0];
+                    acc = acc + V[c][t + R + 1] * w[1]; acc = acc + V[c][t + R] * w[2]; acc = acc + V[c][t + R - 1] * w[3]; acc = acc + V[c][t] * w[4];
+                    b[c] = cdiv<DM>(acc, k.six_dx, k.r_six_dx);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) adv[c] = ux * a[c] + uy * b[c];
+        }
+        v2f O[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const v2f f0 = V[c][t + R], fN = V[c][t + R + 1], fS = V[c][t + R - 1];
+            v2f gp;
+            if (c == 0) gp = xdiv<DM>(0.5f * ew_diff(P[t + 1], pl, pr), k.dx, k.inv_dx, k.r_dx);
+            else gp = xdiv<DM>(0.5f * (P[t + 2] - P[t]), k.dx, k.inv_dx, k.r_dx);
+            const v2f two_f = 2.0f * f0;
+            const v2f d2x = xdiv<DM>((fE[c] - two_f) + fW[c], k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const v2f d2y = xdiv<DM>((fN - two_f) + fS, k.dx_sq, k.inv_dx_sq, k.r_dx_sq);
+            const v2f sum = d2x + d2y;
+            v2f lap;
+            lap.x = rdiv<DM>(sum.x, k.re, k.r_re);
+            lap.y = rdiv<DM>(sum.y, k.re, k.r_re);
+            O[c] = f0 + k.dt * (((-adv[c]) - gp) + lap);
+        }
+        if (lm.owner && fl[t]) {
+            const LV<T, N> O0 = unpk(O[0]), O1 = unpk(O[1]);
+#pragma unroll
+            for (int q = 0; q < N; ++q) raise_hot(hot, ((fl[t] >> q) & 1u) && hot2(O0.a[q], O1.a[q]));
+            lv_store_row_sel<2, T, N>(vn, g, 0, i0, j, O0, fl[t]);
+            lv_store_row_sel<2, T, N>(vn, g, 1, i0, j, O1, fl[t]);
+        }
+    }
+}
+
 template <int SCHEME, int N, int RT, int DM, typename T>
 __global__ __launch_bounds__(256) void k_mac_update_n(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *vn, const T *vc, const T *pc, unsigned *hot)
 {
@@ -702,6 +805,10 @@ __global__ __launch_bounds__(256) void k_mac_update_n(Grid g, Konst<T> k, int nb
             any = any || (lm.owner && fl[t] != 0u);
         }
         if (!__any(any)) return;
+    }
+    if constexpr (FS_MAC_PK && N == 2 && sizeof(T) == 4) {
+        mac_update_pk_tile<SCHEME, RT, DM>(g, k, lm, i0, j0, je, fl, vn, vc, pc, hot);
+        return;
     }
     Rw V[2][RT + 2 * R], P[RT + 2];                 // slot u of V <-> row j0 - R + u, slot u of P <-> row j0 - 1 + u
 #pragma unroll

@@ -68,6 +68,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
         if (ctx->use_pairs) {
             // lanes of 2 cells (fs_k34n.h k_mac_update_n), tiles of 4 rows on large f32 grids (KK at bc3 res 4096: 178 -> 162 us against the one-row quad
             // form it replaces; f64: 424 -> 306 with 2-row tiles), 2 rows on small grids (more workgroups) and for f64 (registers)
+            // (round 6, packed body: 6-row tiles 144.7-151.1 against 154.2 us, 8-row tiles 157.8-158.9 (111 VGPRs = 4 waves): left at 4)
             const int rt = sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2;
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_NONADV, 3, true, 0, 2);      // (reach: per-wave plain hints in the list)
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
