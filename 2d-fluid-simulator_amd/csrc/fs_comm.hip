@@ -340,7 +340,7 @@ static int exchange_packed(fs_ctx *ctx, hipStream_t xs, fs_field *const *fields,
 // (a ghost-row block is contiguous in the [row][channel][x] layout); several fields travel as one packed message.
 static int exchange(fs_ctx *ctx, hipStream_t xs, fs_field *const *fields, const int *valid, int nfields, int depth, int lower, int upper)
 {
-    if (nfields >= 2 && nfields <= MAX_PACK && ctx->pack_halo) return exchange_packed(ctx, xs, fields, valid, nfields, depth, lower, upper);
+    if (nfields >= 2 && nfields <= MAX_PACK) return exchange_packed(ctx, xs, fields, valid, nfields, depth, lower, upper);
     return exchange_direct(ctx, xs, fields, valid, nfields, depth, lower, upper);
 }
 

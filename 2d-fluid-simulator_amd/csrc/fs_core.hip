@@ -121,8 +121,9 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
     const fs_ctx::TileKey key{{lanes, rt, stacked ? 1 : 0, group, cls, reach, wgw, parent_rt, jb, je}};      // (slab launches cover varying row ranges: one list per range)
     auto it = c->tile_lists.find(key);
     if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
-    if (c->capturing || c->tape_rec) return nullptr;      // (building one synchronises the stream: not inside a capture - the dense grid then)
-    if (c->tile_lists.size() >= 512) return nullptr;      // (slab launches over ever new row ranges: the dense grid from here on, not one allocation per range)
+    // (building one allocates and synchronises the stream: not inside a capture or a tape recording - the dense grid then; and slab launches over ever new
+    //  row ranges stop at 512 lists.  Both cases are counted: fs_tile_list_stats - a run whose warm-up covered its period reports none)
+    if (c->capturing || c->tape_rec || c->tile_lists.size() >= 512) { ++c->tile_list_misses; return nullptr; }
     const std::vector<uint8_t> &act = lanes == 4 ? c->h_act4 : (lanes == 2 ? c->h_act2 : c->h_act2w);
     const int ow = geo_owners(lanes), waves = (c->X / geo_cells(lanes) + ow - 1) / ow, Y = c->rows;       // (activity maps are indexed by LOCAL row)
     std::vector<uint32_t> per[8];
@@ -188,7 +189,7 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
             }
     size_t K = 0, total = 0;
     for (auto &v : per) total += v.size();
-    if (c->tile_balance && total >= 64) {
+    if (total >= 64) {
         // The geometry deals a class of tiles unevenly (bc5 res 4096: the boundary tiles of the red-black pair 1003 .. 1365 per XCD) and a compact
         // launch lasts as long as its fullest XCD.  An entry names its tile, so any XCD may run it: the surplus of an XCD - the END of its list, whole
         // runs of vertically adjacent tiles - goes to the end of the emptiest lists.  Those tiles read their halo rows through another L2; they are
@@ -205,9 +206,6 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
             }
     }
     for (auto &v : per) K = std::max(K, v.size());
-    if (getenv("FS_TILE_LIST_DEBUG"))      // how evenly the geometry deals a class of tiles to the 8 XCDs (a compact launch takes max-per-XCD rounds)
-        fprintf(stderr, "tile_list lanes=%d rt=%d cls=%d reach=%d wgw=%d parent=%d: %zu entries, per XCD %zu %zu %zu %zu %zu %zu %zu %zu\n", lanes, rt, cls, reach, wgw, parent_rt,
-                total, per[0].size(), per[1].size(), per[2].size(), per[3].size(), per[4].size(), per[5].size(), per[6].size(), per[7].size());
     fs_ctx::TileList tl;
     if (K > 0 && (cls || any_hint || total < (size_t)nbx * nby)) {        // (nothing to skip, no hint to give: the dense grid needs no list)
         std::vector<uint32_t> h(K * 8, 0xffffffffu);
@@ -555,6 +553,17 @@ extern "C" {
 int fs_abi_version(void) { return FS_ABI_VERSION; }
 const char *fs_last_error(void) { return g_err.c_str(); }
 
+// Launch lists of this context (fs_core.hip tile_list): how many were built so far (each costs one hipMalloc + a stream synchronisation at the first
+// launch of its geometry / row range), and how many launches wanted one they could not build - inside a hipGraph capture or a tape recording, or beyond the
+// cap of 512 - and ran (or were recorded) as dense grids instead.  bench.py samples this around its timed region: 0 built, 0 misses.
+int fs_tile_list_stats(const fs_ctx *ctx, int *built, int *misses)
+{
+    FS_REQUIRE(ctx && built && misses, "null argument");
+    *built = (int)ctx->tile_lists.size();
+    *misses = ctx->tile_list_misses;
+    return FS_OK;
+}
+
 int fs_device_count(int *count)
 {
     FS_REQUIRE(count, "count is null");
@@ -599,17 +608,11 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     c->nwx = (nx / 4 + 61) / 62;
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
-    if (const char *s = getenv("FS_F64DIV")) c->use_f64div = atoi(s) != 0;
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
-    if (const char *s = getenv("FS_TILE_BALANCE")) c->tile_balance = atoi(s) != 0;
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = std::max(0, std::min(2, atoi(s)));
-    if (const char *s = getenv("FS_FUSE_K2_CELLS")) c->fuse_k2_cells = (size_t)atoll(s);
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);
     if (const char *s = getenv("FS_SMALL_CELLS")) c->small_cells = (size_t)atoll(s);
-    if (const char *s = getenv("FS_RBPAIR_PLAIN_RT")) { const int v = atoi(s); if (v == 4 || v == 8 || v == 16) c->rbpair_plain_rt = v; }
-    if (const char *s = getenv("FS_JACOBI")) c->jacobi_variant = atoi(s);
-    if (const char *s = getenv("FS_PACK_HALO")) c->pack_halo = atoi(s) != 0;
     c->stack_mask = XCD_RBSOR | XCD_ADVECT | XCD_GRAD;      // measured per family: K4 313 -> 301 us, K3 246 -> 243, RB-SOR 129 -> 127.5; the others lose 1 %
     c->use_pairs = c->use_march && nx % 2 == 0;   // the kernels on lanes of 2 cells (fs_k34n.h, fs_rbpair.h, fs_jquad.h): any even width, i.e. any `res`
     if (nx % 4 != 0) c->use_march = false;        // quads need 16-byte aligned rows

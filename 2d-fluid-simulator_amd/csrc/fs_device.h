@@ -54,7 +54,7 @@ struct Konst {
 // the kernels' DM template parameter:
 //   bit 0 (DM_P2):  the dx-derived divisors are powers of two (res 1024, 4096, 8192 ...) -> x * (1/d) is exact
 //   bit 2 (DM_F64): every other loop-invariant divisor through ONE f64 multiplication (f32 fields only), see f64div
-// DM_IEEE = neither: the plain division (f64 fields; FS_F64DIV=0 for the A/B).
+// DM_IEEE = neither: the plain division (f64 fields, and f32 divisors that admit a tie).
 // (Round 2's reciprocal-FMA sequence with its range guard, redo path and exhaustive per-divisor check - bit 1 - is gone: the f64
 //  multiplication is shorter, needs no guard and measured faster everywhere, MAC update included: 176 against 208 / 194 us.)
 constexpr int DM_IEEE = 0, DM_P2 = 1, DM_F64 = 4;

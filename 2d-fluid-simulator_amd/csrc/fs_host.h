@@ -88,7 +88,6 @@ struct fs_ctx {
     int rbpair_split = 1;                    // plain and boundary workgroups of that pass (and of the four-sweep Jacobi pass) as two compact
                                              // launches: env FS_RBPAIR_SPLIT = 0 never, 1 on grids of 8 M cells or more, 2 always
     size_t small_cells = (size_t)1 << 21;    // 2-row tiles on grids below this many cells (env FS_SMALL_CELLS; 0: never): res 800 +4.7 %, res 1024 (2 M cells) +0.3 %
-    int rbpair_plain_rt = 16;                // env FS_RBPAIR_PLAIN_RT = 4 / 8 / 16: rows per tile of the pair pass's PLAIN part (two-part launch; 16: two stacked waves per workgroup, fs_rbpair.h)
     uint32_t *d_pairlist = nullptr; int n_pairlist[2] = {0, 0};   // wave-tile rows of the two-sweep kernel's general path, without / with its
                                                                    // vertical-recipe tile path (fs_march.h k_pair_list): [2][nwx * rows] + 2 counters
     int nwx = 0;                   // wave columns of 62 quads across a row
@@ -118,6 +117,7 @@ struct fs_ctx {
     std::vector<hipEvent_t> prof_pool;
     std::vector<int> prof_launches;
     std::vector<double> prof_ms;
+    int tile_list_misses = 0;     // launches that wanted a launch list and could not build one (capture / tape recording / cap): fs_tile_list_stats
     std::vector<std::vector<const void *>> prof_kernels;      // per name: the host stubs of the __global__ functions launched under it (fs_prof_kernels)
     hipEvent_t span_ev[2] = {nullptr, nullptr};      // fs_span_begin / fs_span_end
     // comm
@@ -127,15 +127,10 @@ struct fs_ctx {
     // tuning knobs (env FS_MARCH=0: one-cell-per-lane kernels only)
     bool use_march = true;
     bool use_pairs = true;     // lanes of 2 cells: even widths (every `res`); use_march: the quad kernels, X % 4 == 0
-    bool use_f64div = true;    // env FS_F64DIV=0: IEEE division for the loop-invariant divisors of f32 runs (A/B; the results are the same)
-    bool tile_balance = true;  // env FS_TILE_BALANCE=0: compact launch lists as the geometry deals them to the XCDs (A/B; fs_core.hip tile_list)
-    size_t fuse_k2_cells = 0;  // env FS_FUSE_K2_CELLS: from how many cells fs_cip_step / fs_cip_step_dye evaluate K2 / K12 in registers (wherever launch lists exist)
     int fuse_k2 = 2;           // env FS_FUSE_K2: 0 - fs_cip_step as its two calls, K2 then the fused K3 + K4 pass; 1 - K2 in registers on every tile, two launches
                                // (all-fluid tiles, the others); 2 - the same in ONE launch over both kinds of tile.  Same observable results.
     bool limit_gate = true;    // env FS_LIMIT_GATE=0: limit_field always reads the whole field (A/B; the results are the same)
     int stack_mask = 0;       // kernel families (XCD_* bits) launched with stacked workgroups (fs_create)
-    bool pack_halo = true;    // env FS_PACK_HALO=0: one ncclSend/ncclRecv per field instead of one packed message per neighbour
-    int jacobi_variant = 0;   // env FS_JACOBI: 0 = per-form default (the literal f32 sweep: packed pairs, fs_jquad.h k_jacobi_ov2), 21 / 22 / 23 / 24 = quad tiles of 1 - 4 rows
 
     // compact launches (fs_device.h Grid::tiles): per-cell activity of the scene on the host (bit 0: some cell of wave column wx - 248
     // cells - in row j is not deep wall, bit 1: the same for the 120-cell wave columns of the 2-cell-lane kernels), and the lists built from
@@ -223,7 +218,7 @@ inline bool tie_free(double d)
 template <typename T> inline int f64_mode(const fs_ctx *c, const Konst<T> &k)      // f32 fields: the f64-multiply division, if every dx- / dt-derived divisor is tie-free
 {
     const bool ok = tie_free(k.dx) && tie_free(k.two_dx) && tie_free(k.dx_sq) && tie_free(k.dx2_fold) && tie_free(k.dx3_fold) && tie_free(k.six_dx) && tie_free(k.eight_dt);
-    return sizeof(T) == 4 && c->use_f64div && ok ? DM_F64 : DM_IEEE;
+    return sizeof(T) == 4 && ok ? DM_F64 : DM_IEEE;
 }
 template <typename T> inline int dm_all(const fs_ctx *c, const Konst<T> &k) { return (k.p2 ? DM_P2 : 0) | f64_mode<T>(c, k); }   // dx-derived AND other divisors
 template <typename T> inline int dm_dx(const fs_ctx *c, const Konst<T> &k) { return k.p2 ? DM_P2 : f64_mode<T>(c, k); }          // dx-derived divisors only

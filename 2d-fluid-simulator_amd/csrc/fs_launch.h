@@ -117,7 +117,7 @@ template <int N>
 static OvGrid ov_grid_n(fs_ctx *c, int jb, int je, int rt) { return ov_grid_lanes(c, jb, je, rt, 1, XCD_RBSOR, N); }
 
 // Division-mode dispatch (fs_device.h DM_*): CALL(DM) is expanded for the modes a kernel family distinguishes.  f32 fields divide by their
-// loop-invariant divisors through the f64 multiplication (modes 4 / 5; FS_F64DIV=0: IEEE division, modes 0 / 1); power-of-two dx-derived
+// loop-invariant divisors through the f64 multiplication (modes 4 / 5; divisors that admit a tie: IEEE division, modes 0 / 1); power-of-two dx-derived
 // divisors by exact multiplication (bit 0).
 #define FS_F32_ONLY(dm, bits, CALL, MODE) if constexpr (std::is_same<T, float>::value) { if (((dm) & 7) == (bits)) { CALL(MODE); break; } }
 #define FS_DMC(dm, CALL)      /* modes 0 / 4 : no dx-derived divisor                */ \

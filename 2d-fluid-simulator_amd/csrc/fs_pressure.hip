@@ -20,27 +20,22 @@ static void launch_pair(fs_ctx *ctx, const OvGrid &og, int rt, int row_begin, in
 template <bool SRC, typename T>
 static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int jb, int je, T *pn, const T *pc, const T *vs)
 {
-    // overlapped-wave register tiles of 1 - 4 rows (FS_JACOBI=21 .. 24).  Default (0): the source-pair
-    // form streams best with 1-row tiles at 8 waves/SIMD (76 vs 79 us), the v-reading form with 2-row tiles (89 vs 95 us)
-    const int v = ctx->jacobi_variant ? ctx->jacobi_variant : (SRC ? 21 : 24);      // (round 4, after the DPP diet: 4-row tiles for the v-reading form: 84.7 against 85.9-86.4 us)
     if constexpr (!SRC && std::is_same<T, float>::value) {
-        // default (FS_JACOBI unset): the literal sweep on packed lanes of 2 cells, 4-row tiles, per-wave plain hints in the launch list (fs_jquad.h
-        // k_jacobi_ov2; round 5: 74.5-75.6 against 81.6 us for the quad form below - 8-row tiles 86, 2-row tiles 84, without the hints 79-80)
-        if (ctx->jacobi_variant == 0 && ctx->use_pairs) {
+        // the literal f32 sweep on packed lanes of 2 cells, 4-row tiles, per-wave plain hints in the launch list (fs_jquad.h k_jacobi_ov2; round 5:
+        // 74.5-75.6 against 81.6 us for the quad form below - 8-row tiles 86, 2-row tiles 84, without the hints 79-80)
+        if (ctx->use_pairs) {
             const OvGrid og = ov_grid_lanes(ctx, jb, je, 4, 1, XCD_JACOBI, 3, true, 0, 1);      // (reach 1: the hints)
             const int dm = dm_const(ctx, k);
 #define FS_JAC2(DM) FS_KLAUNCH((k_jacobi_ov2<4, DM>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs)
             return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC2); });
         }
     }
-    const int rt = v == 24 ? 4 : (v == 21 ? 1 : (v == 23 ? 3 : 2));
-    const OvGrid og = ov_grid(ctx, jb, je, rt, 1, XCD_JACOBI);
+    // overlapped-wave register tiles of quads: the source-pair form streams best with 1-row tiles at 8 waves/SIMD (76 vs 79 us), the v-reading form (f64)
+    // with 4-row tiles (round 4: 84.7 against 85.9-86.4 us; the tile heights 2 and 3 of rounds 2 - 4 went with their switch in round 6)
+    constexpr int RT = SRC ? 1 : 4;
+    const OvGrid og = ov_grid(ctx, jb, je, RT, 1, XCD_JACOBI);
     const int dm = SRC ? 0 : dm_const(ctx, k);           // the source-pair form divides nothing
-#define FS_JAC(DM) do { \
-        if (rt == 2) FS_KLAUNCH((k_jacobi_ov<SRC, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else if (rt == 3) FS_KLAUNCH((k_jacobi_ov<SRC, 3, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else if (rt == 4) FS_KLAUNCH((k_jacobi_ov<SRC, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); \
-        else FS_KLAUNCH((k_jacobi_ov<SRC, 1, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs); } while (0)
+#define FS_JAC(DM) FS_KLAUNCH((k_jacobi_ov<SRC, RT, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs)
     return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC); });
 }
 
@@ -55,7 +50,7 @@ int fs_jacobi_sweep(fs_ctx *ctx, double dt, double dx, fs_field *pn, const fs_fi
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
         // (odd res - X = 2 res not a multiple of 4: the f32 sweep on packed lanes of 2 cells needs an even width only, fs_jquad.h k_jacobi_ov2)
-        if (ctx->use_march || (ctx->use_pairs && std::is_same<T, float>::value && ctx->jacobi_variant == 0))
+        if (ctx->use_march || (ctx->use_pairs && std::is_same<T, float>::value))
             return launch_jacobi<false, T>(ctx, "jacobi_sweep", k, row_begin, row_end, (T *)pn->d, (const T *)pc->d, (const T *)vc->d);
         FS_LAUNCH_CELLS("jacobi_sweep", (k_jacobi<false, T>), ctx->grid(), k, row_begin, (T *)pn->d, (const T *)pc->d, (const T *)vc->d)
     })
@@ -291,8 +286,8 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
         // the plain part on tiles of 8 rows (round 4: 125 VGPRs, still 4 waves per SIMD, since the DPP shifts lost their init moves - 2 rows
         // of window per output row instead of 3), the boundary part on tiles of 4 rows that lie in no plain 8-row tile; one wave per workgroup
         // (round 5: the plain part as workgroups of TWO stacked waves on tiles of 16 rows that exchange their edge rows through LDS instead of
-        //  recomputing them - rbsor_pair_stack_tile, FS_RBPAIR_PLAIN_RT=16, the default)
-        const int prt = ctx->rbpair_plain_rt >= 8 ? ctx->rbpair_plain_rt : rt;
+        //  recomputing them - rbsor_pair_stack_tile)
+        constexpr int prt = 16;      // (FS_RBPAIR_PLAIN_RT = 8 / 4 - one wave per mirrored 8-row tile: 117 against 109 us; 4-row tiles - went with their switch in round 6)
         const bool slab = ctx->halo != 0;      // (a slab's row ranges too: lists per range, fs_core.hip tile_list)
         const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, 1, 0, slab);
         const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, 1, prt, slab);
@@ -300,11 +295,7 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
 #define FS_RBS_K(PAR, DM) FS_KLAUNCH((k_rbsor_pair_stack<2, 8, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBS_PAR(DM) do { if (par0) FS_RBS_K(1, DM); else FS_RBS_K(0, DM); } while (0)
-            int rc = launch(ctx, "rbsor_pair", [=] {
-                if (prt == 16) { if (dm & DM_F64) FS_RBS_PAR(4); else FS_RBS_PAR(0); }
-                else if (prt == 8) FS_RBP_DM(8, 3);
-                else FS_RBP_DM(4, 3);      // (12-row tiles: 151 VGPRs = 3 waves, 188 against 177 us)
-            });
+            int rc = launch(ctx, "rbsor_pair", [=] { if (dm & DM_F64) FS_RBS_PAR(4); else FS_RBS_PAR(0); });
             if (rc) return rc;
             { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_DM(4, 2); }); }
         }
@@ -342,7 +333,7 @@ int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs
     FS_ROWS();
     FS_DISPATCH(ctx, {
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
-        if (ctx->use_pairs && !getenv("FS_SRC_CELLS")) {
+        if (ctx->use_pairs) {
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_JACOBI, 3);      // (deep-wall workgroups skipped: nobody reads the source there)
 #define FS_PSN(DM) FS_KLAUNCH((k_poisson_source_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)src->d, (const T *)vc->d)
             return launch(ctx, "poisson_source", [=] { FS_DMC(dm_const(ctx, k), FS_PSN); });

@@ -280,7 +280,7 @@ static bool cip_step_multi_part(const fs_ctx *ctx)
     // steps/s, with dye 18.0 -> 19.2 k; bc5 res 512 27.2 -> 29.0 k, with dye 16.6 -> 18.1 k; bc2 res 800 16.1 -> 17.1 k; 4-row tiles: bc5 res 1024 13.9 -> 14.9 k, res
     // 1200 10.35 -> 11.0 k, res 1600 6 150 -> 6 700).  As two launches the form paid from 2.6 M cells; with K2 as a third launch over the boundary tiles' rows and
     // the general K3 + K4 kernel there (the round's first form) from 8 M.
-    const bool big = ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ctx->fuse_k2_cells);
+    const bool big = ctx->rbpair_split == 2 || ctx->rbpair_split == 1;
     return ctx->mask_set && ctx->fuse_k2 != 0 && big && ctx->dtype == 0 && ctx->use_pairs && !ctx->h_act2.empty() && (ctx->tile_list_mask & XCD_ADVECT);
 }
 int fs_cip_step_ok(const fs_ctx *ctx, int *ok)
@@ -311,8 +311,8 @@ int fs_cip_step_tiles(fs_ctx *ctx, int *plain, int *boundary, int *band, int *ti
 
 // K2 + K3 + K4 of the velocity (fs/solver.py:213-227) as ONE call: fs_cip_nonadv(fn <- fc, pc) followed by fs_cip_grad_advect(v_out, gx_out,
 // gy_out <- fn, fc, gxc, gyc) - with the one difference that the fluid cells of fn that nothing reads before the next kernel rewrites them
-// are NOT stored where the form below applies (f32, even X, wherever the launch lists exist - cip_step_multi_part above: every grid size unless
-// FS_FUSE_K2_CELLS raises the threshold; fs_k234.h): every tile evaluates K2 in registers on the way to K3 + K4 -
+// are NOT stored where the form below applies (f32, even X, wherever the launch lists exist - cip_step_multi_part above: every grid size;
+// fs_k234.h): every tile evaluates K2 in registers on the way to K3 + K4 -
 // ONE launch over the list of all tiles, whose entries say which body a tile takes (k_cip_step_all: all fluid within reach / masks, K2 stored
 // on inflow / outflow cells).  FS_FUSE_K2=1: the two bodies as two launches over the two classes (k_cip_step_plain, k_cip_step_bnd: the form
 // of bench.py's per-part roofline).  fs_cip_step_ok: the static conditions (the kernel names of a profile say what ran).

@@ -20,6 +20,7 @@ _ROWS = [_c_int, _c_int]
 _PROTOS = {
     "fs_abi_version": [],
     "fs_device_count": [_P(_c_int)],
+    "fs_tile_list_stats": [_c_vp, _P(_c_int), _P(_c_int)],
     "fs_create": [_P(_c_vp), _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
     "fs_destroy": [_c_vp],
     "fs_sync": [_c_vp],

@@ -203,7 +203,7 @@ class DeviceBase:
         self.overlap = nranks > 1 and os.environ.get("FS_OVERLAP", "0") == "1"
         self.overlap_stream = self.overlap      # the exchanges run on a communication stream of their own (tape_period switches `overlap`
                                                 # off while it logs - this remembers what the context was created with)
-        self.partial = os.environ.get("FS_PARTIAL_HALO", "1") != "0"     # send only the ghost rows beyond a field's validity
+        self.partial = True           # send only the ghost rows beyond a field's validity (tests flip the attribute; its switch went in round 6)
         # "refresh everything": when an exchange is due anyway, every ghost-read field below full depth travels with it (see _run).
         # Loop-back, middle slab of the 8-way cut of bc5 res 4096, halo 16: 1.0 -> 0.67 grouped exchanges per step, 141.8 -> 133.0 us per
         # step (compute alone 116); the price is +47 % bytes per step and neighbour (4.05 instead of 2.77 MB) - exchange_all = False for a
@@ -1117,6 +1117,12 @@ class Device(DeviceBase):
             _lib.call("fs_prof_get", self._ctx, k, name, 64, ctypes.byref(launches), ctypes.byref(ms))
             out[name.value.decode()] = (launches.value, ms.value)
         return out
+
+    def tile_list_stats(self):
+        """(launch lists built so far, launches that wanted one and ran dense): fs_tile_list_stats."""
+        built, misses = ctypes.c_int(), ctypes.c_int()
+        _lib.call("fs_tile_list_stats", self._ctx, ctypes.byref(built), ctypes.byref(misses))
+        return built.value, misses.value
 
     def profile_kernels(self, name):
         """The __global__ functions launched under profile name `name` since profiling was switched on, demangled without their signature

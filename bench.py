@@ -454,6 +454,7 @@ def main():
             nsteps %= glong[1]
         dev.replay(graph, nsteps // gperiod)
 
+    lists_before = dev.tile_list_stats() if hasattr(dev, "tile_list_stats") else None
     dev.barrier()                      # device sync + all ranks arrived
     t0 = time.perf_counter()
     if graph is not None:
@@ -470,6 +471,7 @@ def main():
     dev.barrier()
     elapsed = max(dev.allgather_scalars(time.perf_counter() - t0))      # max over ranks
     steps_per_s = args.steps / elapsed
+    lists_after = dev.tile_list_stats() if lists_before else None
 
     # Short timed regions (the driver's --steps 20 is 16 ms of work) say little about the spread: for K < 120 another 120 steps follow in
     # blocks of the whole replay periods of K, each timed like the first, and min / median / max per step are reported NEXT TO the
@@ -704,6 +706,10 @@ def main():
                    "cells": counts["cells"], "fluid_cells": counts["fluid"], "parallelism": f"y-slab x{world}",
                    "launch": launch},
         "box": box,
+        # compact launch lists (one hipMalloc + stream sync each, at the first launch of a geometry / slab row range): all built during the warm-up -
+        # none inside the timed region, and no launch of the captured / taped period had to fall back to its dense grid
+        "launch_lists": None if not lists_before else {"built_before_timed_region": lists_before[0], "built_in_timed_region": lists_after[0] - lists_before[0],
+                                                       "dense_fallbacks": max(dev.allgather_scalars(float(lists_after[1])))},
         "state_checksum": checksum,
         "poisson_residual": residual,
         "exchange_model": exchange_model,

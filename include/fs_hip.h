@@ -49,6 +49,9 @@ enum fs_scheme { FS_UPWIND = 0, FS_KK = 1 };   /* fs/advection.py:12-24 / :27-60
 int fs_abi_version(void);
 const char *fs_last_error(void);
 int fs_device_count(int *count);
+/* Compact launch lists of this context: how many exist (one hipMalloc + stream synchronisation each, at the first launch of a geometry / slab row
+ * range), and how many launches wanted one they could not build (inside a hipGraph capture / tape recording, or beyond 512 lists) and ran dense. */
+int fs_tile_list_stats(const fs_ctx *ctx, int *built, int *misses);
 
 /* ---- context -------------------------------------------------------------------------------- */
 /* replaces ti.init(...) + Taichi's field allocator (main.py:65-69). */

@@ -44,6 +44,6 @@ def test_random_slab_cuts_match_the_oracle(hip_lib, monkeypatch):
             if r:
                 failures.append(r)
     finally:
-        for k in ("FS_FUSE_TRANSPORT", "FS_OVERLAP", "FS_PARTIAL_HALO"):
+        for k in ("FS_FUSE_TRANSPORT", "FS_OVERLAP"):
             os.environ.pop(k, None)
     assert not failures, "\n".join(failures[:10])

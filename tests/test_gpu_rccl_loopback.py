@@ -10,11 +10,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("packed", ["1", "0"], ids=["packed", "per-field"])
 @pytest.mark.parametrize("dtype,depth,halo", [(np.float32, 8, 8), (np.float32, 3, 8), (np.float64, 2, 4)])
-def test_self_exchange_fills_ghost_rows(hip_lib, dtype, depth, halo, packed, monkeypatch):
+def test_self_exchange_fills_ghost_rows(hip_lib, dtype, depth, halo):
     from fs import _lib
-    monkeypatch.setenv("FS_PACK_HALO", packed)      # one packed message per neighbour (default) / one send+recv per field
     nx, ny = 200, 24
     ctx = ctypes.c_void_p()
     _lib.call("fs_create", ctypes.byref(ctx), 0, nx, ny, 0 if dtype == np.float32 else 1, 0, ny, halo)

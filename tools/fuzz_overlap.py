@@ -53,9 +53,7 @@ def one_case(seed):
     vc = float(rng.choice([0.0, 5.0]))
     res = float(rng.choice([64, 256, 300]))
     steps = int(rng.integers(2, 8))
-    os.environ["FS_PACK_HALO"] = "1" if rng.random() < 0.8 else "0"
-    os.environ["FS_PARTIAL_HALO"] = "1" if rng.random() < 0.8 else "0"
-    desc = f"seed {seed}: {X}x{Y} (slab {nyl} rows) halo={halo} {scheme} {updater} vc={vc} steps={steps} pack={os.environ['FS_PACK_HALO']} partial={os.environ['FS_PARTIAL_HALO']}"
+    desc = f"seed {seed}: {X}x{Y} (slab {nyl} rows) halo={halo} {scheme} {updater} vc={vc} steps={steps}"
     try:
         a, (na, oa) = run(const, mask, halo, False, scheme, updater, vc, res, steps)
         b, (nb, ob) = run(const, mask, halo, True, scheme, updater, vc, res, steps)

@@ -37,9 +37,8 @@ def one_case(seed):
     res = float(rng.choice([2 ** rng.integers(3, 10), rng.integers(10, 900)]))
     os.environ["FS_FUSE_TRANSPORT"] = "1" if rng.random() < 0.2 else "0"
     os.environ["FS_OVERLAP"] = "1" if rng.random() < 0.7 else "0"
-    os.environ["FS_PARTIAL_HALO"] = "1" if rng.random() < 0.8 else "0"
     steps = int(rng.integers(2, 7))
-    for k in ("FS_FUSE_TRANSPORT", "FS_OVERLAP", "FS_PARTIAL_HALO"):          # FORCE_<knob>=0/1 overrides the drawn value (diagnosis)
+    for k in ("FS_FUSE_TRANSPORT", "FS_OVERLAP"):          # FORCE_<knob>=0/1 overrides the drawn value (diagnosis)
         if os.environ.get("FORCE_" + k):
             os.environ[k] = os.environ["FORCE_" + k]
     if os.environ.get("FORCE_HALO"):
@@ -47,7 +46,7 @@ def one_case(seed):
     cfg = dict(bc=0, res=res, dt=0.05 / res, dx=1.0 / res, re=float(rng.choice([100.0, 1e6])), vor_eps=vc, scheme=scheme, updater=updater,
                dye=with_dye, fp64=f64, snaps=[steps])
     desc = (f"seed {seed}: {X}x{Y} world={world} halo={halo} {np.dtype(dtype).name} {scheme} vc={vc} {updater} dye={with_dye} steps={steps} "
-            f"fuse={os.environ['FS_FUSE_TRANSPORT']} overlap={os.environ['FS_OVERLAP']} partial={os.environ['FS_PARTIAL_HALO']}")
+            f"fuse={os.environ['FS_FUSE_TRANSPORT']} overlap={os.environ['FS_OVERLAP']}")
     g = {"bc_const": const.astype(dtype), "bc_mask": mask, "bc_dye": dye.astype(dtype)}
     try:
         results = T._run_slabs(g, cfg, world, halo)
