@@ -65,6 +65,9 @@ def test_bench_as_n_ranks_matches_single_rank(world, halo, single):
     assert d["halo_exchanges_per_step"]["grouped_launches"] > 0
     assert d["roofline"]["frac"] > 0 and d["poisson_jacobi_sweep"]["frac"] > 0 and d["roofline"]["kernel"] in d["kernels"]
     assert "cpu_baseline" not in d and single["value"] > 0
+    # every launch list was built during the warm-up: none inside the timed region, and no launch of the taped period fell back to its dense grid
+    assert d["launch_lists"]["built_in_timed_region"] == 0 and d["launch_lists"]["dense_fallbacks"] == 0, d["launch_lists"]
+    assert single["launch_lists"]["built_in_timed_region"] == 0 and single["launch_lists"]["dense_fallbacks"] == 0, single["launch_lists"]
     # the run timed its period with the exchanges in line and on the communication stream and kept one of the two (same bits: the checksum above)
     tr = d["exchange_mode_trial"]
     assert tr and tr["in_line_us_per_step"] > 0 and tr["overlapped_us_per_step"] > 0 and tr["chosen"].split()[0] in ("in", "overlapped"), tr
