@@ -117,7 +117,8 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
     if (c->h_act4.empty() || nbx > 0xfff || nby > 0xffff || lanes > 4 || c->rows > 0xffff) return nullptr;      // (entry: class hints << 28 | by << 12 | bx)
     if (je < 0) je = c->rows;
     if (parent_rt == rt) parent_rt = 0;
-    if (parent_rt && (wgw != 1 || parent_rt % rt != 0 || parent_rt > 64)) return nullptr;      // (a coarser plain tiling is defined for one-wave workgroups)
+    if (parent_rt && (wgw != 1 || parent_rt % rt != 0 || parent_rt > 64)) return nullptr;
+    if (cls == 3 && !(rt == 8 && parent_rt == 16 && wgw == 1 && lanes == 2)) return nullptr;      // (a coarser plain tiling is defined for one-wave workgroups)
     const fs_ctx::TileKey key{{lanes, rt, stacked ? 1 : 0, group, cls, reach, wgw, parent_rt, jb, je}};      // (slab launches cover varying row ranges: one list per range)
     auto it = c->tile_lists.find(key);
     if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
@@ -156,6 +157,23 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                     for (int wx = wx0; wx < wx1 && !any; ++wx)
                         for (int j = j0; j < j1; ++j)
                             if (act[(size_t)wx * Y + j] & 1) { any = true; break; }
+                    if (cls == 3) {
+                        // mixed list of the one-launch red-black pair (fs_rbpair.h k_rbsor_pair_all): units of rt = 8 rows; an all-fluid parent tile of
+                        // parent_rt = 16 rows is ONE entry at its lower unit (hint bit 0), any other unit with work an entry with the per-4-row-tile
+                        // "fluid in its own rows" bits (1, 2)
+                        const int p0 = jb + (j0 - jb) / parent_rt * parent_rt, p1 = std::min(je, p0 + parent_rt);
+                        if (p1 - p0 == parent_rt && plain_box(wx0, wx1, p0, p1)) {
+                            if (j0 == p0) per[xcd].push_back((1u << 28) | ((uint32_t)by << 12) | (uint32_t)bx);
+                        } else if (any) {
+                            uint32_t h = 0u;
+                            for (int s = 0; s < 2; ++s)
+                                for (int j = j0 + 4 * s; j < std::min(j1, j0 + 4 * s + 4); ++j)
+                                    if (act[(size_t)bx * Y + j] & 4) { h |= 2u << s; break; }
+                            per[xcd].push_back((h << 28) | ((uint32_t)by << 12) | (uint32_t)bx);
+                        }
+                        any_hint = true;
+                        continue;
+                    }
                     if (any && cls) {
                         // plain: no non-fluid cell (bit 1 of the activity byte; halo lanes included) within `reach` rows of the tile - or, for the
                         // boundary list of a launch whose plain part runs on tiles of parent_rt rows, of the parent tile this tile lies in
@@ -187,6 +205,11 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                     if (any) per[xcd].push_back((hints << 28) | ((uint32_t)by << 12) | (uint32_t)bx);
                 }
             }
+    if ((!cls || cls == 3) && any_hint && wgw == 1) {
+        // one launch over both kinds of tile (fs_cip_step): the tiles that take the longer, masked body go FIRST in each XCD's list - the all-fluid tiles fill in
+        // behind them and the launch does not end on the slow ones (round 6: 281.5-282.7 -> 279.1-280.7 us; the other way round 283.6-284.6)
+        for (auto &v : per) std::stable_partition(v.begin(), v.end(), [](uint32_t e) { return ((e >> 28) & 1u) == 0u; });
+    }
     size_t K = 0, total = 0;
     for (auto &v : per) total += v.size();
     if (total >= 64) {
@@ -609,6 +632,7 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
+    if (const char *s = getenv("FS_RBPAIR_ONE")) c->rbpair_one = atoi(s) != 0;
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = std::max(0, std::min(2, atoi(s)));
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);

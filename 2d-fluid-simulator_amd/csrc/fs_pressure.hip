@@ -283,6 +283,16 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
     // Compact launch in two parts where the lists exist (single GPU, whole grid): the workgroups that see nothing but fluid within reach run
     // the plain path as its own kernel (PATH 3: no mask loads, 126 VGPRs = 4 waves per SIMD), the others the kernel with both paths.
     if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
+        // round 6: ONE launch over both kinds of tile (fs_rbpair.h k_rbsor_pair_all; FS_RBPAIR_ONE=0: the two launches below)
+        if (ctx->rbpair_one) {
+            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 8, 1, XCD_RBSOR, 2, true, 3, 4, 1, 16, ctx->halo != 0);
+            if (og.g.tiles) {
+#define FS_RBA_K(PAR, DM) FS_KLAUNCH((k_rbsor_pair_all<2, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+                               (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
+#define FS_RBA_PAR(DM) do { if (par0) FS_RBA_K(1, DM); else FS_RBA_K(0, DM); } while (0)
+                return launch(ctx, "rbsor_pair", [=] { if (dm & DM_F64) FS_RBA_PAR(4); else FS_RBA_PAR(0); });
+            }
+        }
         // the plain part on tiles of 8 rows (round 4: 125 VGPRs, still 4 waves per SIMD, since the DPP shifts lost their init moves - 2 rows
         // of window per output row instead of 3), the boundary part on tiles of 4 rows that lie in no plain 8-row tile; one wave per workgroup
         // (round 5: the plain part as workgroups of TWO stacked waves on tiles of 16 rows that exchange their edge rows through LDS instead of

@@ -488,13 +488,10 @@ __global__ __launch_bounds__(128, 5) void k_rbsor_pair_stack(Grid g, Konst<T> k,
 // of the workgroups the host found to be plain: its own kernel, so its own register budget - 126 VGPRs = 4 waves per SIMD, where the
 // boundary path with its recipe bytes and views needs 156); 0 / 1 - classify and run only the plain / only the boundary tiles (A/B).
 template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
-__device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
-                                                const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
+__device__ __forceinline__ void rbsor_pair_wave_at(const Grid &g, const Konst<T> &k, int wx, int ty, bool hint, bool bnd_fluid, int jb, int je,
+                                                   const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
 {
     constexpr int W = RT + 8;
-    int wx, ty;
-    bool hint = false, bnd_fluid = false;
-    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty, PATH == 2 && !FULL ? &hint : nullptr, PATH == 2 && !FULL ? &bnd_fluid : nullptr)) return;
     const LaneMapN<N> lm = lane_map_n<N>(g, wx);
     const int i0 = lm.i0, j0 = jb + ty * RT;
     unsigned fl[W];
@@ -532,6 +529,47 @@ __device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k
         return;
     }
     if constexpr (PATH != 0 && PATH != 3) rbsor_pair_tile<N, RT, PAR0, DM, true, FULL, T>(g, k, lm, i0, j0, je, fl, bcmap, C, D, A, B, v);
+}
+
+template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>
+__device__ __forceinline__ void rbsor_pair_wave(const Grid &g, const Konst<T> &k, int nbx, int nby, int jb, int je,
+                                                const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
+{
+    int wx, ty;
+    bool hint = false, bnd_fluid = false;
+    if (!tile_coords_n<N>(g, nbx, nby, jb, je, RT, wx, ty, PATH == 2 && !FULL ? &hint : nullptr, PATH == 2 && !FULL ? &bnd_fluid : nullptr)) return;
+    rbsor_pair_wave_at<N, RT, PAR0, DM, PATH, FULL, T>(g, k, wx, ty, hint, bnd_fluid, jb, je, bcmap, C, D, A, B, v);
+}
+
+// ---- both kinds of tile in ONE launch (round 6) -----------------------------------------------------------------------------------------
+// The two-part launch ends twice on a partly filled chip: 10 422 stacked workgroups are 4.07 rounds of what the chip holds, the 9 425 boundary
+// waves 3.07 rounds of long-lived waves at 3 per SIMD.  Measured (round 6): the stacked plain part does not care about its occupancy - 113.9 /
+// 113.5 / 112.9 us at 5 / 3 / 2.5 waves per SIMD (dynamic LDS holding it down) - so both bodies fit ONE kernel at the boundary body's register
+// budget, and the boundary tiles, listed first, fill in while the all-fluid ones stream (what k_cip_step_all did for fs_cip_step).
+// The list (fs_core.hip tile_list, class 3) is over units of 8 rows: an all-fluid 16-row parent tile is ONE entry at its lower unit (hint bit 0) and
+// runs the two stacked waves; a unit of any other parent is an entry whose two waves take its two 4-row tiles with the masked body (hint bits
+// 1 / 2: fluid in the rows of tile 0 / 1 - the window is then requested with the masks, not behind them).
+template <int N, int PAR0, int DM, typename T>
+__global__ __launch_bounds__(128) void k_rbsor_pair_all(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, const uint8_t *bcmap, T *C, T *D, const T *A, const T *B, const T *v)
+{
+    constexpr int RT = 8;
+    __shared__ typename LVec<T, N>::type xch[3][2][64];
+    constexpr int OW = 64 - 2 * (4 / N);
+    int wx, ty, cg;
+    unsigned cls = 0u;
+    if (!band_coords<1>(g, nbx, nby, wx, ty, cg, 0, &cls)) return;              // (workgroup-uniform)
+    if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (cls & 1u) {
+        const LaneMapN<N> lm = lane_map_n<N>(g, wx);
+        const int j0 = jb + ty * RT;
+        if (w == 0) rbsor_pair_stack_tile<N, RT, PAR0, DM, false, T>(g, k, lm, lm.i0, j0, C, D, A, B, v, xch, 0);
+        else        rbsor_pair_stack_tile<N, RT, PAR0, DM, true, T>(g, k, lm, lm.i0, j0 + RT, C, D, A, B, v, xch, 1);
+    } else {
+        const int t4 = ty * 2 + w;                                              // this wave's 4-row tile
+        if (jb + t4 * 4 >= je) return;                                          // (no barrier on this path)
+        rbsor_pair_wave_at<N, 4, PAR0, DM, 2, false, T>(g, k, wx, t4, false, ((cls >> (1 + w)) & 1u) != 0u, jb, je, bcmap, C, D, A, B, v);
+    }
 }
 
 template <int N, int RT, int PAR0, int DM, int PATH, bool FULL, typename T>

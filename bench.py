@@ -439,6 +439,13 @@ def main():
             done[0] += exchange_trial["replayed_steps"]
         else:
             tape = record()
+        if tape is not None:
+            # One whole period EAGERLY in the mode the timed region runs in (it ends where it began: at the start of a period).  The timed K steps are
+            # replays + K mod period eager steps; with the exchanges on the communication stream an eager kernel is split into interior rows and edge
+            # strips - row ranges no launch has had yet while the period was logged (the log runs with blocking exchanges).  Their launch lists
+            # (one hipMalloc + stream sync each) are built HERE, not inside the timed region (`launch_lists` in the line).
+            for _ in range(tape["nsteps"]):
+                counted()
         later = settle - done[0]
         if tape is not None:
             launch = f"tape replay of {tape['nsteps']}-step periods ({len(tape['ops'])} operations, C++ loop)"

@@ -54,9 +54,14 @@ def single(hip_lib):
     return _single()
 
 
-@pytest.mark.parametrize("world,halo", [(2, None), (3, "4"), (4, "16")])
-def test_bench_as_n_ranks_matches_single_rank(world, halo, single):
-    d = _multi(world, {"FS_HALO": halo} if halo else None)
+@pytest.mark.parametrize("world,halo,overlap", [(2, None, None), (3, "4", None), (4, "16", None), (2, None, "1")])
+def test_bench_as_n_ranks_matches_single_rank(world, halo, overlap, single):
+    """(overlap "1": FS_OVERLAP=1 - the exchanges on the communication stream without a trial; otherwise the run's own timing picks the mode, and
+    whichever it picks must satisfy every assertion below)"""
+    env = {"FS_HALO": halo} if halo else {}
+    if overlap:
+        env["FS_OVERLAP"] = overlap
+    d = _multi(world, env or None)
     assert d["n_gpus"] == world and d["steps"] == 10 and d["warmup"] == 4 and d["scaling"] == "strong"
     assert d["config"]["parallelism"] == f"y-slab x{world}"
     assert d["state_checksum"] == single["state_checksum"]
@@ -70,7 +75,10 @@ def test_bench_as_n_ranks_matches_single_rank(world, halo, single):
     assert single["launch_lists"]["built_in_timed_region"] == 0 and single["launch_lists"]["dense_fallbacks"] == 0, single["launch_lists"]
     # the run timed its period with the exchanges in line and on the communication stream and kept one of the two (same bits: the checksum above)
     tr = d["exchange_mode_trial"]
-    assert tr and tr["in_line_us_per_step"] > 0 and tr["overlapped_us_per_step"] > 0 and tr["chosen"].split()[0] in ("in", "overlapped"), tr
+    if overlap:
+        assert tr is None and d["halo_exchanges_per_step"]["overlapped_fraction"] >= 0
+    else:
+        assert tr and tr["in_line_us_per_step"] > 0 and tr["overlapped_us_per_step"] > 0 and tr["chosen"].split()[0] in ("in", "overlapped"), tr
     assert single["exchange_mode_trial"] is None
 
 
