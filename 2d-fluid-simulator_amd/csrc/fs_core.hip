@@ -632,7 +632,6 @@ int fs_create(fs_ctx **out, int device, int nx, int ny, int dtype, int y0, int n
     if (e != hipSuccess) { fs_destroy(c); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
     if (const char *s = getenv("FS_MARCH")) c->use_march = atoi(s) != 0;
     if (const char *s = getenv("FS_TILE_LIST")) c->tile_list_mask = atoi(s);
-    if (const char *s = getenv("FS_RBPAIR_ONE")) c->rbpair_one = atoi(s) != 0;
     if (const char *s = getenv("FS_LIMIT_GATE")) c->limit_gate = atoi(s) != 0;
     if (const char *s = getenv("FS_FUSE_K2")) c->fuse_k2 = std::max(0, std::min(2, atoi(s)));
     if (const char *s = getenv("FS_RBPAIR_SPLIT")) c->rbpair_split = atoi(s);

@@ -117,7 +117,6 @@ struct fs_ctx {
     std::vector<hipEvent_t> prof_pool;
     std::vector<int> prof_launches;
     std::vector<double> prof_ms;
-    bool rbpair_one = true;       // env FS_RBPAIR_ONE=0: the red-black pair's all-fluid and boundary tiles as two launches (round 5) instead of one (A/B, tests)
     int tile_list_misses = 0;     // launches that wanted a launch list and could not build one (capture / tape recording / cap): fs_tile_list_stats
     std::vector<std::vector<const void *>> prof_kernels;      // per name: the host stubs of the __global__ functions launched under it (fs_prof_kernels)
     hipEvent_t span_ev[2] = {nullptr, nullptr};      // fs_span_begin / fs_span_end

@@ -282,32 +282,17 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
 #define FS_RBP_DM(RT, PATH) do { if (dm & DM_F64) FS_RBP_PAR(RT, 4, PATH, false); else FS_RBP_PAR(RT, 0, PATH, false); } while (0)
     // Compact launch in two parts where the lists exist (single GPU, whole grid): the workgroups that see nothing but fluid within reach run
     // the plain path as its own kernel (PATH 3: no mask loads, 126 VGPRs = 4 waves per SIMD), the others the kernel with both paths.
-    if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23))) && rt == 4) {
-        // round 6: ONE launch over both kinds of tile (fs_rbpair.h k_rbsor_pair_all; FS_RBPAIR_ONE=0: the two launches below)
-        if (ctx->rbpair_one) {
-            const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 8, 1, XCD_RBSOR, 2, true, 3, 4, 1, 16, ctx->halo != 0);
-            if (og.g.tiles) {
+    // Round 6: ONE launch over both kinds of tile (fs_rbpair.h k_rbsor_pair_all: all-fluid 16-row tiles as two stacked waves, the others as two 4-row
+    // tiles with masks, boundary entries first) from 1 M cells - bc5 res 4096: 161 -> 139.5 us; bc2 res 1600 45.8 -> 36.4, res 1200 26.2 -> 20.2, res 1024
+    // 23.0 -> 19.0, res 800 20.0 -> 16.7; res 512 14.5 -> 14.9 and res 400 12.6 -> 14.0 (the 2-row tiles of small grids stay there).  Round 5's two
+    // launches over the two kinds of tile (k_rbsor_pair_stack, then the masked kernel: from 8 M cells) went with it.
+    if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20)))) {
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 8, 1, XCD_RBSOR, 2, true, 3, 4, 1, 16, ctx->halo != 0);
+        if (og.g.tiles) {
 #define FS_RBA_K(PAR, DM) FS_KLAUNCH((k_rbsor_pair_all<2, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBA_PAR(DM) do { if (par0) FS_RBA_K(1, DM); else FS_RBA_K(0, DM); } while (0)
-                return launch(ctx, "rbsor_pair", [=] { if (dm & DM_F64) FS_RBA_PAR(4); else FS_RBA_PAR(0); });
-            }
-        }
-        // the plain part on tiles of 8 rows (round 4: 125 VGPRs, still 4 waves per SIMD, since the DPP shifts lost their init moves - 2 rows
-        // of window per output row instead of 3), the boundary part on tiles of 4 rows that lie in no plain 8-row tile; one wave per workgroup
-        // (round 5: the plain part as workgroups of TWO stacked waves on tiles of 16 rows that exchange their edge rows through LDS instead of
-        //  recomputing them - rbsor_pair_stack_tile)
-        constexpr int prt = 16;      // (FS_RBPAIR_PLAIN_RT = 8 / 4 - one wave per mirrored 8-row tile: 117 against 109 us; 4-row tiles - went with their switch in round 6)
-        const bool slab = ctx->halo != 0;      // (a slab's row ranges too: lists per range, fs_core.hip tile_list)
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, prt, 1, XCD_RBSOR, 2, true, 1, 4, 1, 0, slab);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, 1, prt, slab);
-        if (og.g.tiles && ogb.g.tiles) {
-#define FS_RBS_K(PAR, DM) FS_KLAUNCH((k_rbsor_pair_stack<2, 8, PAR, DM, T>), og.grid, dim3(128), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-                               (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
-#define FS_RBS_PAR(DM) do { if (par0) FS_RBS_K(1, DM); else FS_RBS_K(0, DM); } while (0)
-            int rc = launch(ctx, "rbsor_pair", [=] { if (dm & DM_F64) FS_RBS_PAR(4); else FS_RBS_PAR(0); });
-            if (rc) return rc;
-            { const OvGrid og = ogb; return launch(ctx, "rbsor_pair_bnd", [=] { FS_RBP_DM(4, 2); }); }
+            return launch(ctx, "rbsor_pair", [=] { if (dm & DM_F64) FS_RBA_PAR(4); else FS_RBA_PAR(0); });
         }
     }
     // (one launch: the list's entries carry a per-wave "plain" hint - a wave that sees nothing but fluid within 4 rows skips its mask loads)

@@ -466,24 +466,6 @@ __device__ __forceinline__ void rbsor_pair_stack_tile(const Grid &g, const Konst
 #undef FS_ROW
 }
 
-// one workgroup = 2 waves = one listed tile of 2 RT rows (compact launch only)
-template <int N, int RT, int PAR0, int DM, typename T>
-// (5 waves per SIMD: 97 VGPRs unbounded - one over; held to 96 nothing spills)
-__global__ __launch_bounds__(128, 5) void k_rbsor_pair_stack(Grid g, Konst<T> k, int nbx, int nby, int jb, int je, T *C, T *D, const T *A, const T *B, const T *v)
-{
-    static_assert(RT % 2 == 0, "the row parity of a tile is a launch constant only for even tile heights");
-    __shared__ typename LVec<T, N>::type xch[3][2][64];
-    constexpr int OW = 64 - 2 * (4 / N);
-    int wx, ty, cg;
-    if (!band_coords<1>(g, nbx, nby, wx, ty, cg)) return;                       // (workgroup-uniform)
-    if (!(wx * OW < g.X / N && jb + ty * 2 * RT < je)) return;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const LaneMapN<N> lm = lane_map_n<N>(g, wx);
-    const int j0 = jb + ty * 2 * RT;
-    if (w == 0) rbsor_pair_stack_tile<N, RT, PAR0, DM, false, T>(g, k, lm, lm.i0, j0, C, D, A, B, v, xch, 0);
-    else        rbsor_pair_stack_tile<N, RT, PAR0, DM, true, T>(g, k, lm, lm.i0, j0 + RT, C, D, A, B, v, xch, 1);
-}
-
 // PATH: 2 - classify the tile here (mask loads) and take the plain or the boundary path; 3 - the plain path without looking (compact launch
 // of the workgroups the host found to be plain: its own kernel, so its own register budget - 126 VGPRs = 4 waves per SIMD, where the
 // boundary path with its recipe bytes and views needs 156); 0 / 1 - classify and run only the plain / only the boundary tiles (A/B).

@@ -123,8 +123,8 @@ def test_bench_line_contract_with_the_large_grid_step(hip_lib):
     assert "parts_us" not in cs                                        # one launch over both kinds of tile
     bk = rf["by_kind_of_tile"]      # diagnostic on a second context: one launch per kind of tile, the all-fluid body on the bytes of its own tiles
     assert bk["all_fluid_tiles"] > 0 and bk["all_fluid_us"] > 0 and bk["all_fluid_frac"] > 0, bk
-    pair = d["kernels"]["rbsor_pair"]      # FS_RBPAIR_SPLIT=2: the stacked plain part + the boundary part, two launches under one name
-    assert set(pair["parts_us"]) == {"plain", "bnd"} and any(k.startswith("fs::k_rbsor_pair_stack<") for k in pair["gpu_kernels"]), pair
+    pair = d["kernels"]["rbsor_pair"]      # FS_RBPAIR_SPLIT=2: the large grids' form - ONE launch over the all-fluid (stacked) and the other tiles
+    assert "parts_us" not in pair and len(pair["gpu_kernels"]) == 1 and pair["gpu_kernels"][0].startswith("fs::k_rbsor_pair_all<"), pair
     jac = d["poisson_jacobi_sweep"]
     assert jac["timing"].startswith("one HIP-event pair") and jac["per_launch_avg_us"] > 0 and jac["frac"] > 0
     assert jac["gpu_kernels"] == [k for k in jac["gpu_kernels"] if k.startswith("fs::k_jacobi_ov2<")] and len(jac["gpu_kernels"]) == 1, jac["gpu_kernels"]
