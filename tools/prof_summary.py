@@ -22,14 +22,14 @@ for sub in ("pmc_fetch", "pmc_write"):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             full[short(r["Kernel_Name"])][r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # kernels launched in two compact parts per logical launch (workgroups that see nothing but fluid / the others: two instantiations)
-SPLIT = {"k_cip_grad_advect_dye", "k_rbsor_pair", "k_jacobi_quad"} | ({"k_cip_grad_advect_rt"} if "k_cip_step_plain" not in stats else set())
+SPLIT = {"k_cip_grad_advect_dye", "k_jacobi_quad"}      # (round 6: the red-black pair is ONE launch over both kinds of tile - k_rbsor_pair_all) | ({"k_cip_grad_advect_rt"} if "k_cip_step_plain" not in stats else set())
 import json
 traffic, by_short = {}, {}
 NAMES = {"k_rbsor_pair": "rbsor_pair", "k_jacobi_quad": "jacobi_quad_lazy", "k_cip_grad_advect_dye": "cip_grad_advect_dye", "k_mac_update_n": "mac_update_kk",
          "k_cip_grad_advect_rt": "cip_grad_advect_rt", "k_cip_advect_quad": "cip_advect", "k_rbsor_iter_n": "rbsor_iteration", "k_cip_nonadv_grad_quad": "cip_nonadv_grad",
          "k_cip_nonadv_n": "cip_nonadv", "k_vort_n": "vort_confine", "k_limit": "limit_field", "k_limit_quad": "limit_field",
          "k_jacobi_pair": "jacobi_pair_lazy", "k_jacobi_lazy": "jacobi_sweep_lazy",
-         "k_cip_step_all": "cip_step", "k_cip_dye": "cip_step_dye"}      # (late round 5: fs_cip_step / fs_cip_step_dye as ONE launch over every tile)
+         "k_cip_step_all": "cip_step", "k_cip_dye": "cip_step_dye", "k_rbsor_pair_all": "rbsor_pair"}      # (late round 5: fs_cip_step / fs_cip_step_dye as ONE launch over every tile)
 print(f"{'kernel':28s} {'calls':>6s} {'avg_us':>9s} {'fetch_MB(x2)':>13s} {'write_MB':>9s} {'L2hit%':>7s} {'HBM GB/s':>9s}")
 for k, (calls, tot) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     avg = tot / calls / 1e3
