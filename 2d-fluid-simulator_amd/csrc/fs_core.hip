@@ -118,8 +118,7 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
     if (je < 0) je = c->rows;
     if (parent_rt == rt) parent_rt = 0;
     if (parent_rt && (wgw != 1 || parent_rt % rt != 0 || parent_rt > 64)) return nullptr;
-    if (cls == 3 && !(rt == 8 && parent_rt == 16 && wgw == 1 && lanes == 2)) return nullptr;
-    if (cls == 4 && !(rt % 2 == 0 && parent_rt == 0 && wgw == 1 && lanes == 2)) return nullptr;      // (a coarser plain tiling is defined for one-wave workgroups)
+    if (cls == 3 && !(rt == 8 && parent_rt == 16 && wgw == 1 && lanes == 2)) return nullptr;      // (a coarser plain tiling is defined for one-wave workgroups)
     const fs_ctx::TileKey key{{lanes, rt, stacked ? 1 : 0, group, cls, reach, wgw, parent_rt, jb, je}};      // (slab launches cover varying row ranges: one list per range)
     auto it = c->tile_lists.find(key);
     if (it != c->tile_lists.end()) return it->second.d ? &it->second : nullptr;
@@ -158,19 +157,6 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                     for (int wx = wx0; wx < wx1 && !any; ++wx)
                         for (int j = j0; j < j1; ++j)
                             if (act[(size_t)wx * Y + j] & 1) { any = true; break; }
-                    if (cls == 4) {
-                        // list of the stacked fs_cip_step (fs_k234.h k_cip_step_stack): units of rt = 2 x 4 rows, four waves each; hint bit 0 = the whole
-                        // unit sees nothing but fluid within reach (the waves then share K2's rows), bits 1 / 2 = its lower / upper 4-row tile has work
-                        uint32_t h = 0u;
-                        for (int s = 0; s < 2; ++s)
-                            for (int j = j0 + (rt / 2) * s; j < std::min(j1, j0 + (rt / 2) * (s + 1)); ++j)
-                                if (act[(size_t)bx * Y + j] & 1) { h |= 2u << s; break; }
-                        if (!h) continue;
-                        if (j1 - j0 == rt && plain_box(wx0, wx1, j0, j1)) h |= 1u;
-                        per[xcd].push_back((h << 28) | ((uint32_t)by << 12) | (uint32_t)bx);
-                        any_hint = true;
-                        continue;
-                    }
                     if (cls == 3) {
                         // mixed list of the one-launch red-black pair (fs_rbpair.h k_rbsor_pair_all): units of rt = 8 rows; an all-fluid parent tile of
                         // parent_rt = 16 rows is ONE entry at its lower unit (hint bit 0), any other unit with work an entry with the per-4-row-tile
@@ -219,7 +205,7 @@ const fs_ctx::TileList *tile_list(fs_ctx *c, int lanes, int rt, bool stacked, in
                     if (any) per[xcd].push_back((hints << 28) | ((uint32_t)by << 12) | (uint32_t)bx);
                 }
             }
-    if ((!cls || cls == 3 || cls == 4) && any_hint && wgw == 1) {
+    if ((!cls || cls == 3) && any_hint && wgw == 1) {
         // one launch over both kinds of tile (fs_cip_step): the tiles that take the longer, masked body go FIRST in each XCD's list - the all-fluid tiles fill in
         // behind them and the launch does not end on the slow ones (round 6: 281.5-282.7 -> 279.1-280.7 us; the other way round 283.6-284.6)
         for (auto &v : per) std::stable_partition(v.begin(), v.end(), [](uint32_t e) { return ((e >> 28) & 1u) == 0u; });

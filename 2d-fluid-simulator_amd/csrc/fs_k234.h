@@ -262,112 +262,6 @@ __global__ __launch_bounds__(128, 4) void k_cip_step_all(Grid g, Konst<float> k,
     }
 }
 
-// ---- two vertically stacked tiles per workgroup (round 6) -------------------------------------------------------------------------------
-// K2 is evaluated on RT + 4 rows for RT output rows: two of every eight K2 rows of a 4-row tile are rows the tile above / below evaluates as well.  Here a
-// workgroup is FOUR waves on a unit of 2 RT rows - (component c, half h): h = 0 the lower tile, h = 1 the upper one - and, on units that see nothing but
-// fluid, a wave evaluates K2 only on the RT + 2 rows on ITS side of the unit: the lower wave rows j0-2 .. j0+RT-1, the upper wave rows j0+RT .. j0+2RT+1.
-// Every wave writes its rows into the component's column in LDS (rows j0-2 .. j0+2RT+1), one barrier, and reads the two rows of its window that the
-// partner evaluated, and the sibling component's rows as before.  Per wave: 6 K2 rows instead of 8, one row of v.current and two rows of p less to load.
-// Same expression per cell - the partner's K2 row IS the row this wave would have computed (same inputs, same code).
-// Units that are not all fluid: the two tiles take the masked body independently (k234_bnd_phase1 / 2, one barrier as well).
-template <int c, int H, int RT, int DM>
-__device__ __forceinline__ void k234_stack_phase1(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0,       // j0: the wave's OWN tile
-                                                  const float *fc, const float *pc, const float *gxc, const float *gyc, K234State<RT> &st, v2f (*col)[64])
-{
-    using T = float;
-    constexpr int N = 2;
-    constexpr int U0 = H == 0 ? 0 : 2, U1 = H == 0 ? RT + 2 : RT + 4;      // K2 slots this wave evaluates (slot u <-> row j0-2+u)
-    FS_PIN_LANE_OFFSET(i0);
-#pragma unroll
-    for (int s = 0; s < RT + 2; ++s) {
-        const int row = clampy(g, j0 - 1 + s);
-        st.GX[s] = pk(lv_field<2, T, N>(gxc, g, c, i0, row));
-        st.GY[s] = pk(lv_field<2, T, N>(gyc, g, c, i0, row));
-    }
-    v2f F[RT + 6], P[RT + 6];                    // F[u] <-> row j0-3+u: K2 of slot u reads F[u .. u+2]; Fc of slot u is F[u+1]
-#pragma unroll
-    for (int u = 0; u < RT + 6; ++u) {
-        const int row = clampy(g, j0 - 3 + u);
-        const bool f_k2 = u >= U0 && u <= U1 + 1, f_fc = u >= 1 && u <= RT + 4;
-        if (f_k2 || f_fc) F[u] = pk(lv_field<2, T, N>(fc, g, c, i0, row));
-        const bool p_need = c == 0 ? (u >= U0 + 1 && u <= U1) : (u >= U0 && u <= U1 + 1);
-        if (p_need) P[u] = pk(lv_field<1, T, N>(pc, g, 0, i0, row));
-    }
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int u = 0; u < RT + 4; ++u) {
-        st.Fc[u] = F[u + 1];
-        if (u >= U0 && u < U1) {
-            st.Nn[u] = nonadv_pk_row<c, DM>(k, lm, F[u], F[u + 1], F[u + 2], P[u + 1], P[c == 0 ? u + 1 : u], P[c == 0 ? u + 1 : u + 2]);
-            col[c * (2 * RT + 4) + H * RT + u][lane] = st.Nn[u];             // column index = row - (unit's j0 - 2)
-        }
-    }
-}
-
-template <int c, int H, int RT, int DM>
-__device__ __forceinline__ void k234_stack_phase2(const Grid &g, const Konst<float> &k, const LaneMapN<2> &lm, int i0, int j0, int je,
-                                                  float *out, float *gxo, float *gyo, unsigned *hot, K234State<RT> &st, const v2f (*col)[64])
-{
-    const int lane = threadIdx.x & 63;
-    // the two rows of the window the partner evaluated
-    if (H == 0) { st.Nn[RT + 2] = col[c * (2 * RT + 4) + RT + 2][lane]; st.Nn[RT + 3] = col[c * (2 * RT + 4) + RT + 3][lane]; }
-    else        { st.Nn[0] = col[c * (2 * RT + 4) + RT][lane];          st.Nn[1] = col[c * (2 * RT + 4) + RT + 1][lane]; }
-    // the sibling component's rows j0-1 .. j0+RT of this tile: column indices H RT + 1 ..
-    cip_k34_pk_core<2, c, RT, DM, true, false>(g, k, lm, i0, j0, je, MaskPlain{je - j0}, st.Nn, st.Fc, st.GX, st.GY,
-                                               AdvLds<RT>{col + (1 - c) * (2 * RT + 4) + H * RT + 1, lane}, out, gxo, gyo, hot);
-}
-
-// one workgroup = 4 waves = (component, half) of ONE listed unit of 2 RT rows (class-4 list: hint bit 0 = the unit sees nothing but fluid, bits 1 / 2 = its
-// lower / upper tile has work)
-template <int RT, int DM>
-__global__ __launch_bounds__(256, 4) void k_cip_step_stack(Grid g, Konst<float> k, int nbx, int nby, int jb, int je,
-                                                           float *out, float *gxo, float *gyo, float *fn, const float *fc, const float *pc,
-                                                           const float *gxc, const float *gyc, unsigned *hot, unsigned *hot_fn)
-{
-    constexpr int N = 2, HL = 2, OW = 64 - 2 * HL;
-    __shared__ v2f col[2 * (2 * RT + 4)][64];
-    int wx, ty, cg;
-    unsigned cls = 0u;
-    if (!band_coords<1>(g, nbx, nby, wx, ty, cg, 0, &cls)) return;              // (workgroup-uniform)
-    if (!(wx * OW < g.X / N && jb + ty * 2 * RT < je)) return;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int c = w & 1, h = w >> 1;
-    const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
-    const int i0 = lm_in.i0, j0 = jb + ty * 2 * RT + h * RT;                    // this wave's own tile
-    K234State<RT> st;
-    if (cls & 1u) {
-        const LaneMapN<N> lm{lm_in.i0, lm_in.owner, false, false};
-        if (h == 0) { if (c == 0) k234_stack_phase1<0, 0, RT, DM>(g, k, lm, i0, j0, fc, pc, gxc, gyc, st, col); else k234_stack_phase1<1, 0, RT, DM>(g, k, lm, i0, j0, fc, pc, gxc, gyc, st, col); }
-        else        { if (c == 0) k234_stack_phase1<0, 1, RT, DM>(g, k, lm, i0, j0, fc, pc, gxc, gyc, st, col); else k234_stack_phase1<1, 1, RT, DM>(g, k, lm, i0, j0, fc, pc, gxc, gyc, st, col); }
-        __syncthreads();
-        if (h == 0) { if (c == 0) k234_stack_phase2<0, 0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, col); else k234_stack_phase2<1, 0, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, col); }
-        else        { if (c == 0) k234_stack_phase2<0, 1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, col); else k234_stack_phase2<1, 1, RT, DM>(g, k, lm, i0, j0, je, out, gxo, gyo, hot, st, col); }
-    } else {
-        // the masked body, each tile by itself: its two component waves exchange through their own RT + 2 rows of the column array
-        const bool active = ((cls >> (1 + h)) & 1u) != 0u && j0 < je;
-        unsigned nwbits = 0u, flbits = 0u;
-        if (active) {
-            if (h == 0) {
-                if (c == 0) k234_bnd_phase1<0, RT, DM>(g, k, lm_in, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, col);
-                else        k234_bnd_phase1<1, RT, DM>(g, k, lm_in, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, col);
-            } else {
-                if (c == 0) k234_bnd_phase1<0, RT, DM>(g, k, lm_in, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, col + 2 * (RT + 2));
-                else        k234_bnd_phase1<1, RT, DM>(g, k, lm_in, i0, j0, je, fn, fc, pc, gxc, gyc, hot_fn, st, nwbits, flbits, col + 2 * (RT + 2));
-            }
-        }
-        __syncthreads();
-        if (active) {
-            if (h == 0) {
-                if (c == 0) k234_bnd_phase2<0, RT, DM>(g, k, lm_in, i0, j0, je, out, gxo, gyo, gxc, gyc, hot, st, nwbits, flbits, col);
-                else        k234_bnd_phase2<1, RT, DM>(g, k, lm_in, i0, j0, je, out, gxo, gyo, gxc, gyc, hot, st, nwbits, flbits, col);
-            } else {
-                if (c == 0) k234_bnd_phase2<0, RT, DM>(g, k, lm_in, i0, j0, je, out, gxo, gyo, gxc, gyc, hot, st, nwbits, flbits, col + 2 * (RT + 2));
-                else        k234_bnd_phase2<1, RT, DM>(g, k, lm_in, i0, j0, je, out, gxo, gyo, gxc, gyc, hot, st, nwbits, flbits, col + 2 * (RT + 2));
-            }
-        }
-    }
-}
-
 // ---- the dye: K12 + K3 + K4 (fs/solver.py:385-401 _update_dye) over the all-fluid tiles -----------------------------------------------
 // K12 (_non_advection_phase_dye :378-383: dn = dc + (lap(dc) / re) dt, no pressure term) of one channel needs nothing from the others, and
 // the advecting velocity is the finished flow step's - read from memory: one wave per tile and channel, no exchange (k_cip_dye below).

@@ -350,13 +350,6 @@ int fs_cip_step(fs_ctx *ctx, double dt, double dx, double re, fs_field *v_out, f
         (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
                 if (oga.g.tiles) return launch(ctx, "cip_step", [=] { const OvGrid og = oga; FS_DMA(dm, FS_K234A2); });
             }
-            static const bool exp_stack = getenv("FS_EXP_STACK") != nullptr;      // EXPERIMENT: two stacked tiles per workgroup, K2's rows shared through LDS
-            if (exp_stack) {
-                const OvGrid ogs = ov_grid_lanes(ctx, row_begin, row_end, 2 * RT, 1, XCD_ADVECT, 2, true, 4, 2, 1, 0, slab);
-#define FS_K234S(DM) FS_KLAUNCH((k_cip_step_stack<RT, DM>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
-        (T *)v_out->d, (T *)gx_out->d, (T *)gy_out->d, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, (const T *)gxc->d, (const T *)gyc->d, v_out->hot, fn->hot)
-                if (ogs.g.tiles) return launch(ctx, "cip_step", [=] { const OvGrid og = ogs; FS_DMA(dm, FS_K234S); });
-            }
             const OvGrid oga = ov_grid_lanes(ctx, row_begin, row_end, RT, 1, XCD_ADVECT, 2, true, 0, 2, 1, 0, slab);
             if (oga.g.tiles) return launch(ctx, "cip_step", [=] { const OvGrid og = oga; FS_DMA(dm, FS_K234A); });
         }
