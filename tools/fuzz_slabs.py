@@ -43,6 +43,8 @@ def one_case(seed):
             os.environ[k] = os.environ["FORCE_" + k]
     if os.environ.get("FORCE_HALO"):
         halo = int(os.environ["FORCE_HALO"])
+        if Y // world < halo:               # (a forced depth the drawn grid cannot carry: not a case)
+            return None
     cfg = dict(bc=0, res=res, dt=0.05 / res, dx=1.0 / res, re=float(rng.choice([100.0, 1e6])), vor_eps=vc, scheme=scheme, updater=updater,
                dye=with_dye, fp64=f64, snaps=[steps])
     desc = (f"seed {seed}: {X}x{Y} world={world} halo={halo} {np.dtype(dtype).name} {scheme} vc={vc} {updater} dye={with_dye} steps={steps} "
