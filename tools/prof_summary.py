@@ -91,6 +91,10 @@ elif "k_cip_step_all" in valu_per_launch:
     valu_per_launch["cip_step"] = valu_per_launch["k_cip_step_all"]
 if all(k in valu_per_launch for k in parts2):
     valu_per_launch["rbsor_pair"] = sum(valu_per_launch[k] for k in parts2)
+elif "k_rbsor_pair_all" in valu_per_launch:      # round 6: one launch over both kinds of tile
+    valu_per_launch["rbsor_pair"] = valu_per_launch["k_rbsor_pair_all"]
+if "k_vort_n" in valu_per_launch:
+    valu_per_launch["vort_confine"] = valu_per_launch["k_vort_n"]
 # the stamp: these numbers belong to ONE build of the library - bench.py quotes them only when the library it loaded has this hash
 import hashlib
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2d-fluid-simulator_amd", "csrc", "libfs_hip.so")
