@@ -429,6 +429,19 @@ static int upload_ops(fs_ctx *c, const std::vector<HostOp> &ops, BcOpsDev &out, 
         }
         pos = end;
     }
+    // The components are independent of each other (no cell in common), so the flat records may run in any order: sorted by (target row, position
+    // in the row) the lanes of a wave walk ALONG the rows of the field layout - the targets and sources of a horizontal wall share cache lines - where
+    // the reference's serial (i-major) order hands consecutive lanes cells 2 P elements apart (round 6).
+#ifndef FS_BC_UNSORTED      // (A/B build flavour: the serial order of round 5)
+    {
+        auto key = [](const int4 &r) { return ((long long)(r.w >> 2) << 32) | (unsigned)r.x; };
+        std::sort(h_simple.begin(), h_simple.end(), [&](const int4 &a, const int4 &b) { return key(a) < key(b); });
+        std::vector<std::pair<int4, int4>> pr;
+        for (size_t q = 0; q + 1 < h_pair.size(); q += 2) pr.emplace_back(h_pair[q], h_pair[q + 1]);
+        std::sort(pr.begin(), pr.end(), [&](const std::pair<int4, int4> &a, const std::pair<int4, int4> &b) { return key(a.first) < key(b.first); });
+        for (size_t q = 0; q < pr.size(); ++q) { h_pair[2 * q] = pr[q].first; h_pair[2 * q + 1] = pr[q].second; }
+    }
+#endif
     h_begin.push_back((int)h_kind.size());
     out.ncomp = (int)h_rlo.size();
     out.nops = (int)h_kind.size();
