@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step as a hipGraph (N=1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--trial-steps", type=int, default=120,
+                    help="N > 1 with FS_OVERLAP unset: steps replayed per exchange mode in the trial that picks one (part of the untimed step budget of every N)")
     ap.add_argument("--roofline-kernel", default="cip_step",
                     help="profile name (a key of `kernels`) of the kernel the `roofline` object prices: fixed by name, not by which launch happened to be "
                          "slowest.  Default: cip_step, the headline workload's dominant kernel; a workload that never launches it (upwind / KK / f64 / "
@@ -413,7 +415,7 @@ def main():
     #   by 15 %; on xGMI a transfer is ~40 us of a ~100 us step).  So the run measures: the period is recorded and replayed for TRIAL steps in
     #   each mode, the max-over-ranks times decide (every rank sees the same numbers), a tie within 2 % keeps the simpler in-line form, and the
     #   tape of the chosen mode is the one the timed region replays.  Both timings go into exchange_model.
-    SETTLE, TRIAL = 40, 120
+    SETTLE, TRIAL = 40, max(int(args.trial_steps), 2)
     settle = 3 * SETTLE + 2 * TRIAL     # (every N takes the same budget - state_checksum is compared across --gpus 1/2/4/8 - and `after_steps` says how many)
     later = 0
     exchange_trial = None

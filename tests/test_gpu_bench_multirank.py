@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ["--res", "256", "--steps", "10", "--warmup", "4", "--sweeps", "20", "--no-cpu"]
+ARGS = ["--res", "256", "--steps", "10", "--warmup", "4", "--sweeps", "20", "--no-cpu", "--trial-steps", "24"]      # (the trial's default of 120 steps per mode is for real links)
 
 
 def _single():
