@@ -196,3 +196,32 @@ def test_pair_pass_in_f64(X, Y, n_iter, split, hip_lib, monkeypatch):
     finally:
         a._dev.close()
         b._dev.close()
+
+
+@pytest.mark.parametrize("res,one_launch", [(800, True), (400, False)])
+def test_launch_form_of_the_pair_by_grid_size(res, one_launch, hip_lib, monkeypatch):
+    """Round 6: from 1 M cells the two iterations run as ONE launch over the all-fluid (stacked) and the masked tiles (k_rbsor_pair_all); below, the 2-row
+    tiles of small grids in one kernel with per-wave hints.  The kernel that ran is read back from the library (fs_prof_kernels); values against the oracle."""
+    import fs
+    from fs.boundary_condition import create_scene_arrays
+    from oracle import oracle as O
+    for k in ("FS_RBPAIR_SPLIT", "FS_SMALL_CELLS", "FS_TILE_LIST"):
+        monkeypatch.delenv(k, raising=False)
+    dt, dx, re, vc = 0.05 / res, 1.0 / res, 1.0e6, 5.0
+    fs.runtime.init(gpu=0, dtype="f32")
+    sim = fs.FluidSimulator.create(5, res, dt, dx, re, vc, "cip")
+    dev = sim._solver._bc.device
+    const, mask, _ = create_scene_arrays(5, res)
+    ref = O.make_simulator(const, mask, None, scheme="cip", dt=dt, dx=dx, re=re, vor_eps=vc)
+    try:
+        dev.profile(True)
+        for _ in range(3):
+            sim.step()
+            ref.update()
+        ks = dev.profile_kernels("rbsor_pair")
+        assert len(ks) == 1 and ks[0].startswith("fs::k_rbsor_pair_all<" if one_launch else "fs::k_rbsor_pair<2, 2, "), ks
+        out = sim.field_to_numpy()
+        for name, e in ref.fields().items():
+            assert np.array_equal(out[name], e, equal_nan=True), (res, name)
+    finally:
+        dev.close()
