@@ -191,16 +191,13 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     constexpr int rt = 4;
 #define FS_JQ(RT, PATH) FS_KLAUNCH((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
-    // plain and boundary workgroups as two compact launches (as fs_rbsor_pair) - on large grids: a second launch costs ~5 us, which a
-    // cache-resident grid does not earn back (bc2 res 1600: 18.1 + 21.3 against 34.6 us; bc5 res 4096: 81.4 + 49.8 against 137.5)
+    // Large grids (from 8 M cells; FS_RBPAIR_SPLIT=2: always): ONE launch of one-wave workgroups whose list entry says which body the tile takes, masked tiles
+    // first (round 6, as fs_rbsor_pair / fs_cip_step: bc5 res 4096 122.5 -> 108.7 us per pass, Jacobi(50) there 500 -> 540 steps/s; rounds 4 - 5 ran the
+    // all-fluid and the other workgroups as two compact launches: 81.4 + 49.8 against 137.5 dense).  Mid grids keep the 4-wave workgroups with per-wave
+    // hints below (bc2 res 1600: 30.6 us; a cache-resident grid does not earn a second form back).
     if ((ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 1, 4, 1);
-        const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 2, 4, 1);
-        if (og.g.tiles && ogb.g.tiles) {
-            int rc = launch(ctx, "jacobi_quad_lazy", [=] { FS_JQ(4, 3); });
-            if (rc) return rc;
-            { const OvGrid og = ogb; return launch(ctx, "jacobi_quad_lazy_bnd", [=] { FS_JQ(4, 2); }); }
-        }
+        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 0, 4, 1);
+        if (og.g.tiles) return launch(ctx, "jacobi_quad_lazy", [=] { FS_JQ(4, 2); });
     }
     const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 0, 4);      // (per-wave plain hints in the list, as fs_rbsor_pair)
     return launch(ctx, "jacobi_quad_lazy", [=] {
@@ -257,6 +254,8 @@ int fs_rbsor_pair(fs_ctx *ctx, double dt, double dx, double omega, fs_field *pc_
                                (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn_out->d, (const T *)pc->d, (const T *)pn->d, (const T *)vc->d)
 #define FS_RBPD(RT, PATH, FULL) do { if (par0) FS_RBPD_K(RT, 1, PATH, FULL); else FS_RBPD_K(RT, 0, PATH, FULL); } while (0)
         if (!full && (ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
+            // (round 6: ONE launch of one-wave workgroups over both kinds of tile, as the f32 pass has it, loses here - 514-527 against 424 us at bc3 res 4096:
+            //  the double2 bodies hold 220-256 VGPRs, and the masked one then sets the occupancy of the all-fluid tiles too)
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2, true, 1, 4, 1);
             const OvGrid ogb = ov_grid_lanes(ctx, row_begin, row_end, 2, 1, XCD_RBSOR, 2, true, 2, 4, 1, 4);
             if (og.g.tiles && ogb.g.tiles) {
