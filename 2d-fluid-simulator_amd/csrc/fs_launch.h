@@ -88,9 +88,15 @@ static inline OvGrid ov_grid_lanes(fs_ctx *c, int jb, int je, int rt, int zgroup
 {
     OvGrid o;
     o.g = c->grid();
+    // Round 6: the hinted single-launch kernels of the pressure families run as ONE-wave workgroups - a list entry is then one tile, and the entries whose tile
+    // takes the masked body stand first in every XCD's list (fs_core.hip tile_list), the all-fluid tiles fill in behind them: the four-sweep Jacobi pass at bc2 res
+    // 1600 30.2 -> 23.9 us (configs[1] 2 057 -> 2 472 steps/s), the finishing pass 24.2 -> 21.2, the small grids' red-black pair 12.7 -> 12.0 (res 400) / 12.3 ->
+    // 11.6 (configs[0]: 59.6 -> 62.0 k steps/s), the graded literal sweep 73.6 -> 72.1 (three A/B rounds).  Vorticity confinement and K2' measured no gain
+    // (85.5 against 84.9; 155.4 against 154.8) and keep their 4-wave workgroups (column-by-column locality).
+    if (c->dtype == 0 && (family & (XCD_RBSOR | XCD_JACOBI)) && wgw == 4 && cls == 0 && reach > 0 && allow_list) wgw = 1;      // (f32: the f64 bodies were not measured)
     const int ow = geo_owners(lanes);
     const int nu = c->X / geo_cells(lanes), waves = (nu + ow - 1) / ow, tiles = (je - jb + rt - 1) / rt;
-    const bool stacked = (c->stack_mask & family) != 0;    // the 4 waves of a workgroup: 4 tile rows of one wave column
+    const bool stacked = (c->stack_mask & family) != 0 && wgw > 1;    // the 4 waves of a workgroup: 4 tile rows of one wave column
     o.threads = 64 * wgw;
     o.nbx = stacked ? waves : (waves + wgw - 1) / wgw;
     o.nby = stacked ? (tiles + wgw - 1) / wgw : tiles;

@@ -26,7 +26,7 @@ static int launch_jacobi(fs_ctx *ctx, const char *name, const Konst<T> &k, int j
         if (ctx->use_pairs) {
             const OvGrid og = ov_grid_lanes(ctx, jb, je, 4, 1, XCD_JACOBI, 3, true, 0, 1);      // (reach 1: the hints)
             const int dm = dm_const(ctx, k);
-#define FS_JAC2(DM) FS_KLAUNCH((k_jacobi_ov2<4, DM>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs)
+#define FS_JAC2(DM) FS_KLAUNCH((k_jacobi_ov2<4, DM>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, jb, je, pn, pc, vs)
             return launch(ctx, name, [=] { FS_DMC(dm, FS_JAC2); });
         }
     }
@@ -191,15 +191,10 @@ int fs_jacobi_quad_lazy(fs_ctx *ctx, fs_field *pn, const fs_field *pc, const fs_
     constexpr int rt = 4;
 #define FS_JQ(RT, PATH) FS_KLAUNCH((k_jacobi_quad<2, RT, PATH, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end, \
                                (const uint8_t *)ctx->d_bcmap, (T *)pn->d, (const T *)pc->d, (const T *)src->d)
-    // Large grids (from 8 M cells; FS_RBPAIR_SPLIT=2: always): ONE launch of one-wave workgroups whose list entry says which body the tile takes, masked tiles
-    // first (round 6, as fs_rbsor_pair / fs_cip_step: bc5 res 4096 122.5 -> 108.7 us per pass, Jacobi(50) there 500 -> 540 steps/s; rounds 4 - 5 ran the
-    // all-fluid and the other workgroups as two compact launches: 81.4 + 49.8 against 137.5 dense).  Mid grids keep the 4-wave workgroups with per-wave
-    // hints below (bc2 res 1600: 30.6 us; a cache-resident grid does not earn a second form back).
-    if ((ctx->rbpair_split == 2 || (ctx->rbpair_split == 1 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 23)))) {
-        const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 0, 4, 1);
-        if (og.g.tiles) return launch(ctx, "jacobi_quad_lazy", [=] { FS_JQ(4, 2); });
-    }
-    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 0, 4);      // (per-wave plain hints in the list, as fs_rbsor_pair)
+    // ONE launch of one-wave workgroups whose list entry says which body the tile takes, masked tiles first (round 6; fs_launch.h ov_grid_lanes: the hinted
+    // launches of the pressure families) - bc5 res 4096 122.5 -> 108.7 us per pass against rounds 4 - 5's two compact launches over the all-fluid and the other
+    // workgroups (81.4 + 49.8; 137.5 dense), bc2 res 1600 30.2 -> 23.9 against the 4-wave workgroups with per-wave hints
+    const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_RBSOR, 2, true, 0, 4);      // (reach 4: the hints)
     return launch(ctx, "jacobi_quad_lazy", [=] {
         FS_JQ(4, 2);
     });
@@ -217,7 +212,7 @@ int fs_jacobi_finish(fs_ctx *ctx, fs_field *pc_out, fs_field *pn, const fs_field
     using T = float;
     const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_RBSOR, 2, true, 0, 2);      // (per-wave plain hints: two sweeps reach 2 rows)
     return launch(ctx, "jacobi_finish", [=] {
-        FS_KLAUNCH((k_jacobi_finish<2, 4, T>), og.grid, dim3(256), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
+        FS_KLAUNCH((k_jacobi_finish<2, 4, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, og.nbx, og.nby, row_begin, row_end,
                            (const uint8_t *)ctx->d_bcmap, (T *)pc_out->d, (T *)pn->d, (const T *)pc->d, (const T *)src->d);
     });
 }
@@ -329,7 +324,7 @@ int fs_poisson_source(fs_ctx *ctx, double dt, double dx, fs_field *src, const fs
         auto k = make_konst<T>(ctx, dt, dx, 1.0);
         if (ctx->use_pairs) {
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, 4, 1, XCD_JACOBI, 3);      // (deep-wall workgroups skipped: nobody reads the source there)
-#define FS_PSN(DM) FS_KLAUNCH((k_poisson_source_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)src->d, (const T *)vc->d)
+#define FS_PSN(DM) FS_KLAUNCH((k_poisson_source_n<2, 4, DM, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)src->d, (const T *)vc->d)
             return launch(ctx, "poisson_source", [=] { FS_DMC(dm_const(ctx, k), FS_PSN); });
         }
         FS_LAUNCH_CELLS("poisson_source", (k_poisson_source<T>), ctx->grid(), k, row_begin, (T *)src->d, (const T *)vc->d)

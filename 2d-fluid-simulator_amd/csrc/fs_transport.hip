@@ -72,7 +72,7 @@ int fs_mac_update(fs_ctx *ctx, int scheme, double dt, double dx, double re, fs_f
             const int rt = sizeof(T) == 4 && (size_t)ctx->X * ctx->Y >= ((size_t)1 << 20) ? 4 : 2;
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, rt, 1, XCD_NONADV, 3, true, 0, 2);      // (reach: per-wave plain hints in the list)
             return launch(ctx, scheme == FS_UPWIND ? "mac_update_upwind" : "mac_update_kk", [=] {
-#define FS_K2MN(SS, RR, PP) FS_KLAUNCH((k_mac_update_n<SS, 2, RR, PP, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
+#define FS_K2MN(SS, RR, PP) FS_KLAUNCH((k_mac_update_n<SS, 2, RR, PP, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, \
             (T *)vn->d, (const T *)vc->d, (const T *)pc->d, vn->hot)
 #define FS_K2MN_UP4(DM) FS_K2MN(0, 4, DM)
 #define FS_K2MN_KK4(DM) FS_K2MN(1, 4, DM)
@@ -133,8 +133,8 @@ int fs_cip_nonadv(fs_ctx *ctx, double dt, double dx, double re, fs_field *fn, co
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3, true, 0, 1);      // (reach 1: per-wave plain hints)
             const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
             return launch(ctx, "cip_nonadv", [=] {
-#define FS_K2N4(DM) FS_KLAUNCH((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
-#define FS_K2N2(DM) FS_KLAUNCH((k_cip_nonadv_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
+#define FS_K2N4(DM) FS_KLAUNCH((k_cip_nonadv_n<2, 4, DM, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
+#define FS_K2N2(DM) FS_KLAUNCH((k_cip_nonadv_n<2, 2, DM, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)fn->d, (const T *)fc->d, (const T *)pc->d, fn->hot, clear3)
                 if (small) FS_DMA(dm_all(ctx, k), FS_K2N2); else FS_DMA(dm_all(ctx, k), FS_K2N4);
             });
         }
@@ -156,8 +156,8 @@ int fs_cip_nonadv_dye(fs_ctx *ctx, double dt, double dx, double re, fs_field *dn
             const bool small = small_tiles(ctx);       // (2-row tiles, see fs_cip_nonadv)
             const OvGrid og = ov_grid_lanes(ctx, row_begin, row_end, small ? 2 : 4, 1, XCD_NONADV, 3, true, 0, 1);
             return launch(ctx, "cip_nonadv_dye", [=] {
-#define FS_K12N(DM) FS_KLAUNCH((k_cip_nonadv_dye_n<2, 4, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
-#define FS_K12N2(DM) FS_KLAUNCH((k_cip_nonadv_dye_n<2, 2, DM, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
+#define FS_K12N(DM) FS_KLAUNCH((k_cip_nonadv_dye_n<2, 4, DM, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
+#define FS_K12N2(DM) FS_KLAUNCH((k_cip_nonadv_dye_n<2, 2, DM, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)dn->d, (const T *)dc->d)
                 if (small) FS_DMA(dm_all(ctx, k), FS_K12N2); else FS_DMA(dm_all(ctx, k), FS_K12N);
             });
         }
@@ -485,10 +485,10 @@ int fs_vort_confine(fs_ctx *ctx, double dt, double dx, double weight, fs_field *
         const int dm = dm_dx(ctx, k);
         T *w = vort ? (T *)vort->d : nullptr; T *wa = vort_abs ? (T *)vort_abs->d : nullptr;
         const int clear3 = whole_grid(ctx, row_begin, row_end);      // (fs_device.h "hot" word [3])
-#define FS_VORTN(DM, ST) FS_KLAUNCH((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
+#define FS_VORTN(DM, ST) FS_KLAUNCH((k_vort_n<2, 4, DM, ST, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
 #define FS_VORTN_S(DM) FS_VORTN(DM, true)
 #define FS_VORTN_N(DM) FS_VORTN(DM, false)
-#define FS_VORTN_2(DM) FS_KLAUNCH((k_vort_n<2, 2, DM, false, T>), og.grid, dim3(256), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
+#define FS_VORTN_2(DM) FS_KLAUNCH((k_vort_n<2, 2, DM, false, T>), og.grid, dim3(og.threads), 0, ctx->stream, og.g, k, og.nbx, og.nby, row_begin, row_end, (T *)vn->d, (const T *)vc->d, w, wa, vn->hot, clear3)
         return launch(ctx, "vort_confine", [=] { if (vort) FS_DMX(dm, FS_VORTN_S); else if (small) FS_DMX(dm, FS_VORTN_2); else FS_DMX(dm, FS_VORTN_N); });
     })
 }
