@@ -372,15 +372,15 @@ __global__ __launch_bounds__(64, 4) void k_cip_dye(Grid g, Konst<float> k, int n
     if (!(wx * OW < g.X / N && jb + ty * RT < je)) return;
     const LaneMapN<N> lm_in = lane_map_n<N, HL>(g, wx);
     const int i0 = lm_in.i0, j0 = jb + ty * RT;
+    // The three channels run ONE body (round 6): channel cg of a 3-channel field at (row, i) is element ((row 3 + cg) P + i) - the bodies are instantiated for
+    // channel 0 and handed the planes of channel cg (every pointer moved by cg P; workgroup-uniform).  A third of the code: the kernel was 74 KB (f64-multiply
+    // divisions) to 139 KB (IEEE) against an instruction cache of 64 KB per two CUs.
+    const size_t co = (size_t)cg * (size_t)g.P;
     if (KIND == 1 || (KIND == 0 && (cls & 1u))) {
         const LaneMapN<N> lm{lm_in.i0, lm_in.owner, false, false};
-        if (cg == 0) k234_dye_plain<0, RT, DM, CLAMP>(g, k, lm, i0, j0, je, out, gxo, gyo, fc, gxc, gyc, v);
-        else if (cg == 1) k234_dye_plain<1, RT, DM, CLAMP>(g, k, lm, i0, j0, je, out, gxo, gyo, fc, gxc, gyc, v);
-        else k234_dye_plain<2, RT, DM, CLAMP>(g, k, lm, i0, j0, je, out, gxo, gyo, fc, gxc, gyc, v);
+        k234_dye_plain<0, RT, DM, CLAMP>(g, k, lm, i0, j0, je, out + co, gxo + co, gyo + co, fc + co, gxc + co, gyc + co, v);
     } else {
-        if (cg == 0) k234_dye_bnd<0, RT, DM, CLAMP>(g, k, lm_in, i0, j0, je, out, gxo, gyo, fn, fc, gxc, gyc, v);
-        else if (cg == 1) k234_dye_bnd<1, RT, DM, CLAMP>(g, k, lm_in, i0, j0, je, out, gxo, gyo, fn, fc, gxc, gyc, v);
-        else k234_dye_bnd<2, RT, DM, CLAMP>(g, k, lm_in, i0, j0, je, out, gxo, gyo, fn, fc, gxc, gyc, v);
+        k234_dye_bnd<0, RT, DM, CLAMP>(g, k, lm_in, i0, j0, je, out + co, gxo + co, gyo + co, fn + co, fc + co, gxc + co, gyc + co, v);
     }
 }
 
